@@ -1,0 +1,165 @@
+"""Deterministic synthetic inputs of the BASELINE.json shapes.
+
+Model: molecules = ceil(N/4); family size 1 + Geometric(mean 3); every emitted
+base substituted with p_sub (1e-3) and called 'N' with p_n (1e-4); records
+globally shuffled.  `synth_words` produces the packed words the hot path
+consumes (the first `word_nt` bases that src/fastq.cc:116-161 would take);
+`synth_fastq` writes small full FastQ files for the CLI end-to-end tests.
+
+No external data: numpy PCG64 seeded with 1000 + config number.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+__all__ = ["synth_words", "synth_fastq", "CONFIG_SEEDS", "pack_bases"]
+
+CONFIG_SEEDS = {1: 1001, 2: 1002, 3: 1003, 4: 1004, 5: 1005}
+
+_COMP = np.array([3, 2, 1, 0], dtype=np.uint8)
+
+
+def _family_of_read(rng, n_reads):
+    """molecule index per read, families 1+Geom(mean 3), truncated so sum == n_reads."""
+    m = max(1, -(-n_reads // 4))
+    sizes = rng.geometric(0.25, size=m).astype(np.int64)
+    tot = int(sizes.sum())
+    while tot < n_reads:  # top up with more molecules
+        extra = rng.geometric(0.25, size=max(16, (n_reads - tot) // 4 + 16)).astype(np.int64)
+        sizes = np.concatenate([sizes, extra])
+        tot = int(sizes.sum())
+    mol = np.repeat(np.arange(len(sizes), dtype=np.int64), sizes)[:n_reads]
+    n_mol = int(mol[-1]) + 1 if n_reads else 0
+    return mol, n_mol
+
+
+def pack_bases(bases: np.ndarray) -> np.ndarray:
+    """[N, n] codes 0..3 -> uint64 words, first nucleotide most significant."""
+    n = bases.shape[1]
+    w = np.zeros(bases.shape[0], dtype=np.uint64)
+    for i in range(n):
+        w = (w << np.uint64(2)) | bases[:, i].astype(np.uint64)
+    return w
+
+
+def synth_words(n_reads: int, seed: int, word_nt: int = 24, p_sub: float = 1e-3,
+                p_n: float = 1e-4, mode: str = "umi", genome_bp: int = 4_000_000,
+                shuffle: bool = True):
+    """Packed words + filtered flags for `n_reads` reads.
+
+    mode "umi": every word base iid uniform per molecule (configs 1-4: UMI + read
+    prefixes of random inserts).  mode "genome": no UMI, word = first word_nt/2
+    bases of each mate of a fragment drawn from a random `genome_bp` genome
+    (config 5: prefixes collide, d=2 satellites fan out).
+    """
+    if not (1 <= word_nt <= 32):
+        raise ValueError("word_nt must be 1..32")
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mol, n_mol = _family_of_read(rng, n_reads)
+    if mode == "umi":
+        hi = 1 << (2 * word_nt)
+        if word_nt == 32:
+            mw = rng.integers(0, 1 << 63, size=n_mol, dtype=np.uint64) * np.uint64(2) + \
+                rng.integers(0, 2, size=n_mol, dtype=np.uint64)
+        else:
+            mw = rng.integers(0, hi, size=n_mol, dtype=np.uint64)
+    elif mode == "genome":
+        h1 = word_nt // 2
+        h2 = word_nt - h1
+        genome = rng.integers(0, 4, size=genome_bp, dtype=np.uint8)
+        start = rng.integers(0, genome_bp - 600, size=n_mol)
+        flen = rng.integers(200, 500, size=n_mol)
+        a = np.stack([genome[start + i] for i in range(h1)], axis=1)
+        end = start + flen
+        b = np.stack([_COMP[genome[end - 1 - i]] for i in range(h2)], axis=1)
+        mw = pack_bases(np.concatenate([a, b], axis=1))
+    else:
+        raise ValueError("mode")
+    words = mw[mol]
+    total_bases = n_reads * word_nt
+    # substitutions
+    k = int(rng.binomial(total_bases, p_sub)) if total_bases else 0
+    if k:
+        idx = rng.integers(0, total_bases, size=k)
+        rd = idx // word_nt
+        pos = idx % word_nt
+        delta = rng.integers(1, 4, size=k).astype(np.uint64)
+        shift = (2 * (word_nt - 1 - pos)).astype(np.uint64)
+        old = (words[rd] >> shift) & np.uint64(3)
+        new = (old + delta) & np.uint64(3)
+        np.bitwise_xor.at(words, rd, (old ^ new) << shift)
+    filtered = np.zeros(n_reads, dtype=np.uint8)
+    k2 = int(rng.binomial(total_bases, p_n)) if total_bases else 0
+    if k2:
+        idx = rng.integers(0, total_bases, size=k2)
+        rd = idx // word_nt
+        pos = idx % word_nt
+        filtered[rd] = 1
+        # the reference pushes the code of 'G' for an unknown base (src/fastq.cc:156)
+        shift = (2 * (word_nt - 1 - pos)).astype(np.uint64)
+        for r, s in zip(rd.tolist(), shift.tolist()):
+            words[r] = (int(words[r]) & ~(3 << s)) | (2 << s)
+    if shuffle and n_reads:
+        perm = rng.permutation(n_reads)
+        words = words[perm]
+        filtered = filtered[perm]
+    return np.ascontiguousarray(words), np.ascontiguousarray(filtered)
+
+
+_ALPHA = np.frombuffer(b"ACGTN", dtype=np.uint8)
+
+
+def synth_fastq(out_dir: str, n_reads: int, seed: int, n_files: int = 1, umi_len: int = 8,
+                umi_in_header: bool = True, umi_file: bool = False, read_len: int = 150,
+                p_sub: float = 1e-3, p_n: float = 1e-4, short_frac: float = 0.0,
+                header_style: str = "_", prefix: str = "syn"):
+    """Write small synthetic FastQ files; returns the list of file names.
+
+    n_files counts the read files (1 = SE, 2 = PE); umi_file adds a further file of
+    `umi_len`-nt reads (config 3).  header_style "_" -> "@r<idx>_<UMI>",
+    ":" -> "@r<idx>:<UMI>" (BCL Convert style).  short_frac: fraction of reads cut
+    to < 8 nt (exercises 'N' padding, src/fastq.cc:135-136).
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mol, n_mol = _family_of_read(rng, n_reads)
+    os.makedirs(out_dir, exist_ok=True)
+
+    def noisy(clean):  # clean: [n_mol, L] codes -> per read with errors
+        x = clean[mol].copy()
+        sub = rng.random(x.shape) < p_sub
+        x[sub] = (x[sub] + rng.integers(1, 4, size=int(sub.sum()))) & 3
+        x[rng.random(x.shape) < p_n] = 4
+        return x
+
+    umi = noisy(rng.integers(0, 4, size=(n_mol, umi_len), dtype=np.uint8)) if umi_len else None
+    mates = [noisy(rng.integers(0, 4, size=(n_mol, read_len), dtype=np.uint8))
+             for _ in range(n_files)]
+    perm = rng.permutation(n_reads)
+    lens = np.full(n_reads, read_len)
+    if short_frac > 0:
+        short = rng.random(n_reads) < short_frac
+        lens[short] = rng.integers(0, 8, size=int(short.sum()))
+    names = []
+    qual_full = "I" * read_len
+    for f in range(n_files):
+        name = os.path.join(out_dir, "%s_R%d.fastq" % (prefix, f + 1))
+        names.append(name)
+        with open(name, "w") as fh:
+            for j, r in enumerate(perm.tolist()):
+                hdr = "@r%d" % j
+                if f == 0 and umi_in_header and umi is not None:
+                    hdr += header_style + _ALPHA[umi[r]].tobytes().decode()
+                    hdr += " 1:N:0"
+                L = int(lens[j])
+                seq = _ALPHA[mates[f][r][:L]].tobytes().decode()
+                fh.write("%s\n%s\n+\n%s\n" % (hdr, seq, qual_full[:L]))
+    if umi_file and umi is not None:
+        name = os.path.join(out_dir, "%s_UMI.fastq" % prefix)
+        names.append(name)
+        with open(name, "w") as fh:
+            for j, r in enumerate(perm.tolist()):
+                seq = _ALPHA[umi[r]].tobytes().decode()
+                fh.write("@r%d\n%s\n+\n%s\n" % (j, seq, "I" * umi_len))
+    return names

@@ -1,0 +1,120 @@
+"""Second, independent CPU checker for SMALL cases (pure numpy / Python loops).
+
+It shares no code with oracle/humid_oracle.c: unique words come from np.unique,
+neighbours from an all-pairs nucleotide Hamming matrix, clustering from literal
+Python recursion over src/cluster.cc:10-87.  Used to cross-check the C oracle's
+trie search and explicit-stack traversals.
+"""
+import sys
+
+import numpy as np
+
+M55 = np.uint64(0x5555555555555555)
+
+
+def nt_hamming(a, b):
+    """nucleotide mismatches between packed words (a, b uint64 arrays, broadcast)."""
+    x = np.bitwise_xor(a, b)
+    y = (x | (x >> np.uint64(1))) & M55
+    # popcount
+    y = y.astype(np.uint64)
+    cnt = np.zeros(np.broadcast(a, b).shape, dtype=np.int64)
+    for s in range(0, 64, 2):
+        cnt += ((y >> np.uint64(s)) & np.uint64(1)).astype(np.int64)
+    return cnt
+
+
+def unique_counts(words, filtered):
+    w = np.asarray(words, dtype=np.uint64)[np.asarray(filtered) == 0]
+    return np.unique(w, return_counts=True)
+
+
+def adjacency(uw, distance):
+    """ascending neighbour lists (H1+H2): list of lists of ranks."""
+    u = len(uw)
+    out = []
+    if u == 0:
+        return out
+    d = nt_hamming(uw[:, None], uw[None, :])
+    for i in range(u):
+        nb = np.nonzero((d[i] <= distance) & (np.arange(u) != i))[0]
+        out.append(nb.tolist())
+    return out
+
+
+def cluster(counts, nbrs, maximum=False, order=None):
+    """findClusters (src/humid.cc:176-189) + src/cluster.cc, literal recursion."""
+    sys.setrecursionlimit(max(10000, 4 * len(counts) + 100))
+    u = len(counts)
+    cl = [0] * u
+    info = {}  # id -> dict(size, maxCount, maxLeaf)
+
+    def assign_leaf(l, c):
+        cl[l] = c
+        info[c]["size"] += int(counts[l])
+
+    def update_max(l, c):
+        if int(counts[l]) > info[c]["maxCount"]:
+            info[c]["maxLeaf"] = l
+            info[c]["maxCount"] = int(counts[l])
+
+    def max_neighbour(l):
+        i = 0
+        while i < len(nbrs[l]):
+            nb = nbrs[l][i]
+            i += 1
+            if cl[nb] == 0 and int(counts[nb]) >= 2 * int(counts[l]):
+                l = nb
+                i = 0
+        return l
+
+    def assign_dir(l, c):
+        assign_leaf(l, c)
+        for nb in nbrs[l]:
+            if cl[nb] == 0 and int(counts[l]) >= 2 * int(counts[nb]):
+                assign_dir(nb, c)
+
+    def assign_max(l, c):
+        assign_leaf(l, c)
+        update_max(l, c)
+        for nb in nbrs[l]:
+            if cl[nb] == 0:
+                assign_max(nb, c)
+
+    cid = 1
+    for l in (order if order is not None else range(u)):
+        if cl[l] == 0:
+            info[cid] = dict(size=0, maxCount=0, maxLeaf=-1)
+            if maximum:
+                assign_max(l, cid)
+            else:
+                node = max_neighbour(l)
+                update_max(node, cid)
+                assign_dir(node, cid)
+            cid += 1
+    return cl, info
+
+
+def dedup(words, filtered, distance=1, maximum=False):
+    """(cluster_id[N], keep[N], detail) for a small read set."""
+    words = np.asarray(words, dtype=np.uint64)
+    filtered = np.asarray(filtered, dtype=np.uint8)
+    uw, cnt = unique_counts(words, filtered)
+    nbrs = adjacency(uw, distance)
+    cl, info = cluster(cnt, nbrs, maximum)
+    rank = {int(w): i for i, w in enumerate(uw.tolist())}
+    n = len(words)
+    cid = np.zeros(n, dtype=np.uint32)
+    keep = np.zeros(n, dtype=np.uint8)
+    visited = set()
+    for r in range(n):
+        if filtered[r]:
+            continue
+        l = rank[int(words[r])]
+        c = cl[l]
+        cid[r] = c
+        if c not in visited and info[c]["maxLeaf"] == l:
+            keep[r] = 1
+            visited.add(c)
+    detail = dict(unique=uw, count=cnt, nbrs=nbrs, leaf_cluster=cl, info=info)
+    return cid, keep, detail

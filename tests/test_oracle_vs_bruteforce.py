@@ -1,0 +1,92 @@
+"""C oracle (trie + explicit stacks) against the independent numpy/Python checker."""
+import numpy as np
+import pytest
+
+import bruteforce as bf
+from humid_amd.synth import synth_words
+from oracle import pyoracle as orc
+
+
+def run_oracle(words, filt, n, d, maximum):
+    p = orc.Pipeline(n)
+    p.read_data(words, filt)
+    p.find_hamming_neighbours(d)
+    p.find_clusters(maximum)
+    cid, keep = p.map_reads()
+    return p, cid, keep
+
+
+def dense_words(rng, n_reads, n, alphabet_positions=4):
+    """words confined to a small sub-space so that neighbours and ties are common"""
+    base = rng.integers(0, 4 ** n, dtype=np.uint64)
+    w = np.full(n_reads, base, dtype=np.uint64)
+    for _ in range(alphabet_positions):
+        pos = int(rng.integers(0, n))
+        sh = np.uint64(2 * pos)
+        v = rng.integers(0, 4, size=n_reads).astype(np.uint64)
+        w = (w & ~(np.uint64(3) << sh)) | (v << sh)
+    return w
+
+
+@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("d", [1, 2])
+@pytest.mark.parametrize("maximum", [False, True])
+def test_dense_small(seed, d, maximum):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(4, 13))
+    n_reads = int(rng.integers(1, 400))
+    words = dense_words(rng, n_reads, n, alphabet_positions=int(rng.integers(1, 5)))
+    filt = (rng.random(n_reads) < 0.05).astype(np.uint8)
+    p, cid, keep = run_oracle(words, filt, n, d, maximum)
+    bcid, bkeep, det = bf.dedup(words, filt, d, maximum)
+    lv = p.leaves()
+    assert np.array_equal(lv["word"], det["unique"])
+    assert np.array_equal(lv["count"], det["count"].astype(np.uint64))
+    off, idx = p.adjacency()
+    for u in range(p.unique):
+        assert idx[int(off[u]):int(off[u + 1])].tolist() == det["nbrs"][u]
+    assert lv["cluster_id"].tolist() == det["leaf_cluster"]
+    assert np.array_equal(cid, bcid)
+    assert np.array_equal(keep, bkeep)
+
+
+@pytest.mark.parametrize("cfg", [(2000, 24, 1, "umi"), (1500, 24, 2, "genome"), (800, 32, 1, "umi"),
+                                 (500, 1, 1, "umi"), (700, 3, 2, "umi")])
+def test_synth(cfg):
+    n_reads, n, d, mode = cfg
+    words, filt = synth_words(n_reads, 7, n, p_sub=0.01, p_n=0.002, mode=mode,
+                              genome_bp=5000 if mode == "genome" else 0)
+    p, cid, keep = run_oracle(words, filt, n, d, False)
+    bcid, bkeep, det = bf.dedup(words, filt, d, False)
+    assert np.array_equal(cid, bcid)
+    assert np.array_equal(keep, bkeep)
+    assert p.unique == len(det["unique"])
+
+
+def test_empty_and_all_filtered():
+    p, cid, keep = run_oracle(np.zeros(0, np.uint64), np.zeros(0, np.uint8), 24, 1, False)
+    assert p.unique == 0 and len(cid) == 0
+    w = np.arange(5, dtype=np.uint64)
+    p, cid, keep = run_oracle(w, np.ones(5, np.uint8), 24, 1, False)
+    assert p.unique == 0 and cid.tolist() == [0] * 5 and keep.tolist() == [0] * 5
+
+
+def test_keep_is_first_read_of_max_leaf():
+    # family: centre x5 (reads 1,3,4,5,6), satellite x1 first in file
+    c = orc.pack_word([0, 1, 2, 3])
+    s = orc.pack_word([0, 1, 2, 0])
+    words = np.array([s, c, s ^ s ^ s, c, c, c, c], dtype=np.uint64)
+    words[2] = s
+    filt = np.zeros(7, np.uint8)
+    p, cid, keep = run_oracle(words, filt, 4, 1, False)
+    assert cid.tolist() == [1] * 7
+    assert keep.tolist() == [0, 1, 0, 0, 0, 0, 0]
+
+
+def test_deep_chain_no_stack_overflow():
+    # counts halve along a long path graph: the reference recursion would be U deep
+    n = 200000
+    g = orc.Graph([1] * n)
+    for i in range(n - 1):
+        g.link(i, i + 1)
+    assert g.find_clusters(True) == 1
