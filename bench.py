@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/sec deduplicated on the BASELINE.json metric workload.
+
+A "step" is one pass of the whole hot path (exact counts -> neighbours -> clusters ->
+per-read cluster id + duplicate flag) over one batch of synthetic packed words that is already
+resident in HBM when the timed region starts.  One process per GPU; for N > 1 the driver
+launches this file under torch.distributed.run and the read set is sharded over the ranks
+(humid_amd.sharded).  Rank 0 prints ONE JSON line.
+
+The oracle (oracle/) is used here ONLY for the cpu_baseline leg; it is never the thing timed
+as `value`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BYTES_PER_READ = 13         # 8 B word read + 4 B cluster id + 1 B keep written
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--word-nt", type=int, default=24)
+    ap.add_argument("--distance", type=int, default=1)
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000,
+                    help="reads of the same workload the CPU oracle is timed on (0 = skip)")
+    ap.add_argument("--traffic-json", default=None,
+                    help="optional JSON with PMC-derived HBM bytes per launch of the dominant kernel")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import torch
+    import humid_amd
+    from humid_amd.synth import synth_words
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if rank == 0 and world > 1:
+            print("warning: WORLD_SIZE %d != --gpus %d; using WORLD_SIZE" % (world, a.gpus), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    n_local = a.reads
+    seed = 1002                                   # metric config (1000 + config#)
+    # weak scaling: every rank holds its own n_local-read shard of ONE read set of world*n_local
+    # reads (shards differ by seed but share the molecule model); deduplication is global.
+    words, filt = synth_words(n_local, seed + 7919 * rank, a.word_nt)
+    d_w = torch.from_numpy(words.view(np.int64)).to(dev)
+    d_f = torch.from_numpy(filt).to(dev)
+    d_cid = torch.zeros(n_local, dtype=torch.int32, device=dev)
+    d_keep = torch.zeros(n_local, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    if world == 1:
+        dd = humid_amd.Dedup(device=local_rank)
+
+        def step():
+            return dd.run_device(d_w.data_ptr(), d_f.data_ptr(), d_cid.data_ptr(), d_keep.data_ptr(),
+                                 n_local, a.word_nt, a.distance, humid_amd.DIRECTIONAL)
+    else:
+        from humid_amd.sharded import ShardedDedup
+        sd = ShardedDedup(device=local_rank, word_nt=a.word_nt, distance=a.distance)
+
+        def step():
+            return sd.run(d_w, d_f, d_cid, d_keep)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    ks = {"ms_k_insert": 0.0, "ms_k_pairs": 0.0, "ms_k_cluster": 0.0, "ms_k_map": 0.0,
+          "ms_count": 0.0, "ms_neighbours": 0.0, "ms_cluster": 0.0, "ms_map": 0.0, "ms_total": 0.0}
+    last = None
+    for _ in range(a.steps):
+        last = step()
+        for k in ks:
+            ks[k] += float(last.get(k, 0.0))
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    for k in ks:
+        ks[k] /= max(a.steps, 1)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    total_reads = n_local * world
+    ms_per_step = 1e3 * dt / a.steps
+    value = total_reads * a.steps / dt
+
+    # ---- roofline of the dominant kernel (HIP events around its launch, live) ----
+    kern = {"k_hash_insert": ks["ms_k_insert"], "k_read_map": ks["ms_k_map"],
+            "k_pairs": ks["ms_k_pairs"], "k_cluster_components": ks["ms_k_cluster"]}
+    dom = max(kern, key=lambda k: kern[k])
+    dom_ms = kern[dom]
+    achieved = (BYTES_PER_READ * n_local / (dom_ms * 1e-3)) / 1e9 if dom_ms > 0 else 0.0
+    traffic = None
+    if a.traffic_json and os.path.exists(a.traffic_json):
+        traffic = json.load(open(a.traffic_json)).get(dom)
+    roofline = {"bound": "hbm", "kernel": dom, "kernel_ms": round(dom_ms, 4),
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                "alg_bytes_per_read": BYTES_PER_READ, "reads_per_launch": n_local}
+
+    # ---- CPU baseline: the oracle, 1 thread, bounded sample of the same workload ----
+    cpu = None
+    if a.cpu_sample > 0:
+        from oracle import pyoracle as orc
+        ns = min(a.cpu_sample, n_local)
+        t1 = time.perf_counter()
+        _, _, osum, phases = orc.dedup_run(words[:ns], filt[:ns], a.word_nt, a.distance, 0)
+        cdt = time.perf_counter() - t1
+        cpu = {"value": round(ns / cdt, 1), "unit": "reads/s", "cores": 1, "kind": "port",
+               "sample": "first %d reads of the same synthetic workload, oracle/humid_oracle.c "
+                         "(trie restatement), 1 thread, %.1f s" % (ns, cdt),
+               "host_cores_available": os.cpu_count(),
+               "phase_seconds": {"read+count": round(phases[0], 3), "neighbours": round(phases[1], 3),
+                                 "clusters": round(phases[2], 3), "map": round(phases[3], 3)}}
+
+    out = {
+        "metric": "reads/sec deduplicated, 10M PE150 UMI=8 d=1",
+        "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "%d reads/GPU x %d GPU, PE150 UMI=8 in header -> %d-nt packed words "
+                               "(8+8+8), d=%d, directional clustering; synthetic molecules=N/4, "
+                               "family 1+Geom(3), p_sub=1e-3, p_N=1e-4, shuffled"
+                               % (n_local, world, a.word_nt, a.distance),
+                   "reads_per_gpu": n_local, "word_nt": a.word_nt, "distance": a.distance,
+                   "method": "directional",
+                   "sharding": "single GPU" if world == 1 else "reads sharded, RCCL all-gather of packed words"},
+        "summary": {k: int(last[k]) for k in ("total", "usable", "unique", "clusters", "edges") if k in last},
+        "device_ms": {k: round(v, 4) for k, v in ks.items()},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

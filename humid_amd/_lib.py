@@ -1,0 +1,90 @@
+"""ctypes loader of libhumid_hip.so (include/humid_hip.h).
+
+Fails loudly: there is no CPU fallback.  torch is imported first so that this library binds to
+the HIP runtime torch already loaded (same soname libamdhip64.so.7) and device pointers /
+streams are shared."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libhumid_hip.so")
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+
+
+class HumidSummary(C.Structure):
+    _fields_ = [("total", C.c_uint64), ("usable", C.c_uint64), ("unique", C.c_uint64),
+                ("clusters", C.c_uint64), ("edges", C.c_uint64), ("nonsingle", C.c_uint64),
+                ("ms_count", C.c_float), ("ms_neighbours", C.c_float), ("ms_cluster", C.c_float),
+                ("ms_map", C.c_float), ("ms_total", C.c_float), ("ms_h2d", C.c_float),
+                ("ms_d2h", C.c_float), ("ms_k_insert", C.c_float), ("ms_k_pairs", C.c_float),
+                ("ms_k_cluster", C.c_float), ("ms_k_map", C.c_float)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/humid_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "humid_abi_version": (C.c_uint32, []),
+    "humid_device_count": (C.c_int, []),
+    "humid_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
+    "humid_ctx_destroy": (None, [C.c_void_p]),
+    "humid_last_error": (C.c_char_p, [C.c_void_p]),
+    "humid_dedup_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                  C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                  C.POINTER(HumidSummary)]),
+    "humid_dedup_run_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                         C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                         C.c_void_p, C.POINTER(HumidSummary)]),
+    "humid_get_leaves": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6),
+    "humid_get_adjacency": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "humid_get_clusters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "humid_get_histogram": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                      C.c_uint64, u64p]),
+    "humid_cluster_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, u32p]),
+    "humid_at_least_double": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_int)]),
+}
+
+_LIB = None
+
+
+class HumidLibraryError(RuntimeError):
+    pass
+
+
+def load(import_torch: bool = True):
+    """dlopen the HIP library and bind every C-ABI symbol.  Raises if it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if import_torch:
+        try:
+            import torch  # noqa: F401  (loads libamdhip64.so.7 first; see module docstring)
+        except Exception:  # torch absent: the library still works with the system runtime
+            pass
+    if not os.path.exists(SO_PATH):
+        raise HumidLibraryError(
+            "%s not found: build it with `python -m humid_amd.build` (hipcc, gfx950). "
+            "humid_amd has no CPU fallback." % SO_PATH)
+    try:
+        lib = C.CDLL(SO_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:
+        raise HumidLibraryError("cannot load %s: %s" % (SO_PATH, e)) from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HumidLibraryError("%s does not export %s" % (SO_PATH, name)) from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.humid_abi_version() != 1:
+        raise HumidLibraryError("ABI version mismatch")
+    _LIB = lib
+    return lib

@@ -1,0 +1,46 @@
+"""Builds libhumid_hip.so (hipcc, gfx950) in-tree.  No torch involvement: the library is a
+plain C-ABI shared object (include/humid_hip.h)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "humid_hip.hip")
+HDR = os.path.join(ROOT, "include", "humid_hip.h")
+SO = os.path.join(HERE, "libhumid_hip.so")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+
+
+def _sources():
+    out = [HDR]
+    for d, _, fs in os.walk(os.path.join(HERE, "csrc")):
+        if os.sep + "host" in d:
+            continue
+        out += [os.path.join(d, f) for f in fs if f.endswith((".hip", ".h", ".hpp"))]
+    return out
+
+
+def is_stale() -> bool:
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    return any(os.path.getmtime(p) > t for p in _sources())
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return SO
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", SO, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=ROOT)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build_hip(force=True, verbose=True))

@@ -1,0 +1,1035 @@
+// humid_hip.hip -- HUMID's neighbour-search-and-cluster hot path for MI355X (gfx950).
+//
+// Pipeline (all device-side; integer/bit work, HBM/latency bound, no MFMA):
+//   1. k_hash_insert      exact counts: open-address table of 2-bit-packed words in HBM
+//                         (replaces Trie::add, call site /root/reference/src/humid.cc:95)
+//   2. unique sort        radix sort of the U unique words -> Trie::walk() order
+//   3. k_pairs            pigeonhole radix buckets (d+1 segments), nucleotide Hamming by
+//                         popcount, both directions appended -> CSR with ascending lists
+//                         (replaces walk x asymmetricHamming, src/humid.cc:113-130)
+//   4. union-find CC      components of the neighbour graph (independent clustering units)
+//   5. k_cluster          per component: the findClusters loop + src/cluster.cc, order-exact
+//   6. ids + k_read_map   cluster ids in creator order; per read (cluster_id, keep)
+//                         (replaces trie.find()->leaf->cluster, src/humid.cc:223-231,276-277)
+//
+// No CPU fallback lives here: every entry point either runs on the GPU or fails.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "../../include/humid_hip.h"
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+typedef unsigned long long ull;
+
+#define EMPTY_KEY 0xffffffffffffffffull
+#define NOSLOT 0xffffffffu
+#define NONE32 0xffffffffu
+
+enum { CTR_UNIQUE = 0, CTR_USABLE, CTR_EDGES, CTR_NONSINGLE, CTR_MEMBERS, CTR_SPECIAL,
+       CTR_CLUSTERS, CTR_N = 16 };
+
+// --------------------------------------------------------------------------------
+// device helpers
+// --------------------------------------------------------------------------------
+__device__ __forceinline__ u64 mix64(u64 x) {
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+  x ^= x >> 27; x *= 0x94d049bb133111ebull;
+  x ^= x >> 31;
+  return x;
+}
+
+// nucleotide (not bit) mismatches between two packed words
+__device__ __forceinline__ u32 nt_mismatch(u64 x) {
+  return (u32)__popcll((x | (x >> 1)) & 0x5555555555555555ull);
+}
+
+__device__ __forceinline__ u32 ld_agent(const u32 *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// /root/reference/src/cluster.cc:31-33 atLeastDouble_
+__device__ __forceinline__ bool at_least_double(u64 a, u64 b) { return a >= 2 * b; }
+
+// --------------------------------------------------------------------------------
+// 1. exact counts: open-address hash of packed words
+// --------------------------------------------------------------------------------
+// keys[cap+1] (slot cap is reserved for the word that equals EMPTY_KEY, i.e. n=32 all-T),
+// cnt/first[cap+1].  One read per thread iteration; the claiming thread registers the slot
+// in uniq_slot (arbitrary order; sorted afterwards).
+__global__ void __launch_bounds__(256)
+k_hash_insert(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n_reads,
+              u64 *keys, u32 *cnt, u32 *first, u32 cap_log2, u32 *__restrict__ slot_of_read,
+              u32 *__restrict__ uniq_slot, ull *ctr) {
+  const u32 mask = (1u << cap_log2) - 1u;
+  const u32 cap = 1u << cap_log2;
+  u32 usable = 0;
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
+    if (filtered[r]) { slot_of_read[r] = NOSLOT; continue; }
+    usable++;
+    const u64 w = words[r];
+    u32 s;
+    if (w == EMPTY_KEY) {
+      s = cap;
+      if (atomicCAS((ull *)&ctr[CTR_SPECIAL], 0ull, 1ull) == 0ull) {
+        u32 uid = (u32)atomicAdd(&ctr[CTR_UNIQUE], 1ull);
+        uniq_slot[uid] = s;
+      }
+    } else {
+      s = (u32)(mix64(w) >> (64 - cap_log2)) & mask;
+      while (true) {
+        u64 k = keys[s];
+        if (k == EMPTY_KEY) {
+          k = atomicCAS((ull *)&keys[s], EMPTY_KEY, (ull)w);
+          if (k == EMPTY_KEY) {
+            u32 uid = (u32)atomicAdd(&ctr[CTR_UNIQUE], 1ull);
+            uniq_slot[uid] = s;
+            break;
+          }
+        }
+        if (k == w) break;
+        s = (s + 1) & mask;
+      }
+    }
+    atomicAdd(&cnt[s], 1u);
+    atomicMin(&first[s], r);
+    slot_of_read[r] = s;
+  }
+  if (usable) atomicAdd(&ctr[CTR_USABLE], (ull)usable);
+}
+
+__global__ void k_gather_words(const u64 *__restrict__ keys, const u32 *__restrict__ uniq_slot,
+                               u32 n, u64 *__restrict__ out) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = keys[uniq_slot[i]];
+}
+
+// after the sort: per rank i gather count / first read, and record slot -> rank
+__global__ void k_post_sort(const u32 *__restrict__ s_slot, const u32 *__restrict__ cnt,
+                            const u32 *__restrict__ first, u32 n, u32 *__restrict__ s_cnt,
+                            u32 *__restrict__ s_first) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    u32 s = s_slot[i];
+    s_cnt[i] = cnt[s];
+    s_first[i] = first[s];
+  }
+}
+
+// --------------------------------------------------------------------------------
+// 3. neighbour search: pigeonhole segments
+// --------------------------------------------------------------------------------
+struct SegPlan {
+  u32 nseg;
+  u32 shift[33];
+  u64 mask[33];
+};
+
+__global__ void k_seg_keys(const u64 *__restrict__ s_word, u32 n, u32 shift, u64 mask,
+                           u32 *__restrict__ key, u32 *__restrict__ val) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    key[i] = (u32)((s_word[i] >> shift) & mask);
+    val[i] = i;
+  }
+}
+
+// One thread per position i of the bucket-sorted order; compares with the following
+// elements of its bucket.  Ranks ascend inside a bucket, so (ri < rj) always.  A pair is
+// emitted only from the FIRST segment it agrees on (earlier segments must all differ).
+template <bool PASS0>
+__global__ void __launch_bounds__(256)
+k_pairs(const u64 *__restrict__ s_word, const u32 *__restrict__ K, const u32 *__restrict__ V,
+        u32 n, SegPlan plan, u32 seg, u32 distance, u32 *deg, u64 *ekeys, u64 ecap, ull *ctr) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 shift = plan.shift[seg];
+  const u64 mask = plan.mask[seg];
+  u32 ri;
+  u64 wi;
+  u64 ki;
+  if (PASS0) { ri = i; wi = s_word[i]; ki = (wi >> shift) & mask; }
+  else { ri = V[i]; wi = s_word[ri]; ki = K[i]; }
+  for (u32 j = i + 1; j < n; j++) {
+    u32 rj;
+    u64 wj;
+    if (PASS0) {
+      rj = j; wj = s_word[j];
+      if (((wj >> shift) & mask) != ki) break;
+    } else {
+      if ((u64)K[j] != ki) break;
+      rj = V[j]; wj = s_word[rj];
+    }
+    const u64 x = wi ^ wj;
+    if (nt_mismatch(x) > distance) continue;
+    bool firstseg = true;
+    for (u32 t = 0; t < seg; t++)
+      if (((x >> plan.shift[t]) & plan.mask[t]) == 0) { firstseg = false; break; }
+    if (!firstseg) continue;
+    ull e = atomicAdd(&ctr[CTR_EDGES], 1ull);
+    if (2 * e + 1 < ecap) {
+      ekeys[2 * e] = ((u64)ri << 32) | rj;
+      ekeys[2 * e + 1] = ((u64)rj << 32) | ri;
+    }
+    if (atomicAdd(&deg[ri], 1u) == 0) atomicAdd(&ctr[CTR_NONSINGLE], 1ull);
+    if (atomicAdd(&deg[rj], 1u) == 0) atomicAdd(&ctr[CTR_NONSINGLE], 1ull);
+  }
+}
+
+__global__ void k_low32(const u64 *__restrict__ in, u64 n, u32 *__restrict__ out) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (u32)in[i];
+}
+
+// --------------------------------------------------------------------------------
+// 4. connected components (lock-free union-find, smaller index wins => root = min rank)
+// --------------------------------------------------------------------------------
+__device__ __forceinline__ u32 uf_find(const u32 *P, u32 x) {
+  u32 p = ld_agent(&P[x]);
+  while (p != x) { x = p; p = ld_agent(&P[x]); }
+  return x;
+}
+
+__device__ __forceinline__ void uf_union(u32 *P, u32 a, u32 b) {
+  while (true) {
+    a = uf_find(P, a);
+    b = uf_find(P, b);
+    if (a == b) return;
+    if (a > b) { u32 t = a; a = b; b = t; }
+    if (atomicCAS(&P[b], b, a) == b) return;
+  }
+}
+
+__global__ void k_iota(u32 *p, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
+// undirected edges are the even entries of the (unsorted) directed key buffer
+__global__ void k_union_edges(const u64 *__restrict__ ekeys, u64 n_edges, u32 *P) {
+  u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  u64 k = ekeys[2 * e];
+  uf_union(P, (u32)(k >> 32), (u32)k);
+}
+
+// explicit-graph entry point: union every CSR entry (u, nbr)
+__global__ void k_union_csr(const u32 *__restrict__ off, const u32 *__restrict__ idx, u32 n, u32 *P) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  for (u32 k = off[u]; k < off[u + 1]; k++)
+    if (idx[k] != u) uf_union(P, u, idx[k]);
+}
+
+// members = nodes with >= 1 neighbour, keyed (root << 32 | rank)
+__global__ void k_member_keys(const u32 *__restrict__ deg, u32 *P, u32 n, u64 *mkeys, ull *ctr) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  if (deg[u] == 0) return;
+  u32 root = uf_find(P, u);
+  ull pos = atomicAdd(&ctr[CTR_MEMBERS], 1ull);
+  mkeys[pos] = ((u64)root << 32) | u;
+}
+
+// --------------------------------------------------------------------------------
+// 5. clustering
+// --------------------------------------------------------------------------------
+// singletons (no neighbours): the leaf creates its own cluster (src/humid.cc:179-187 with an
+// empty neighbour list: maxNeighbour_ returns the leaf, cluster.cc:39-51)
+__global__ void k_cluster_singletons(const u32 *__restrict__ deg, const u32 *__restrict__ cnt, u32 n,
+                                     u32 *cl_of, u32 *maxleaf, u64 *cl_size) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  if (deg[u] == 0) {
+    cl_of[u] = u + 1;
+    maxleaf[u] = u;
+    cl_size[u] = cnt[u];
+  } else {
+    cl_of[u] = 0;
+  }
+}
+
+// One thread per connected component (the head of its run in the sorted member keys).
+// Literal restatement, per component, of
+//   findClusters loop            /root/reference/src/humid.cc:176-189  (members ascending)
+//   maxNeighbour_                src/cluster.cc:39-51  (first qualifying neighbour, restart)
+//   assignDirectionalCluster_    src/cluster.cc:58-69  (pre-order flood, explicit stack)
+//   assignMaxCluster             src/cluster.cc:72-80
+// A cluster is named by its creating leaf (cl_of = creator rank + 1); ids come later from a
+// prefix sum over creators, which reproduces `id++` in walk order.
+template <bool MAXIMUM>
+__global__ void __launch_bounds__(64)
+k_cluster_components(const u64 *__restrict__ mkeys, u32 n_members, const u32 *__restrict__ cnt,
+                     const u32 *__restrict__ off, const u32 *__restrict__ idx, u32 *cl_of,
+                     u32 *maxleaf, u64 *cl_size, u32 *stk) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_members) return;
+  const u32 root = (u32)(mkeys[i] >> 32);
+  if (i > 0 && (u32)(mkeys[i - 1] >> 32) == root) return;   // not a component head
+  u32 *st = stk + 2 * (u64)i;
+  for (u32 m = i; m < n_members; m++) {
+    const u64 mk = mkeys[m];
+    if ((u32)(mk >> 32) != root) break;
+    const u32 u = (u32)mk;
+    if (cl_of[u] != 0) continue;                  // src/humid.cc:179
+    const u32 label = u + 1;                      // new Cluster, creator u
+    u32 start = u;
+    u32 best = u;
+    u32 bestc = 0;
+    if (!MAXIMUM) {
+      // maxNeighbour_
+      u32 leaf = u;
+      u32 k = off[leaf], kend = off[leaf + 1];
+      u64 lc = cnt[leaf];
+      while (k < kend) {
+        u32 nb = idx[k++];
+        if (cl_of[nb] == 0 && at_least_double(cnt[nb], lc)) {
+          leaf = nb; lc = cnt[leaf];
+          k = off[leaf]; kend = off[leaf + 1];
+        }
+      }
+      start = leaf;
+      best = leaf;                                // updateMaxCount_ once, cluster.cc:85
+    }
+    u64 size = 0;
+    u32 depth = 0;
+    // assignLeaf_(start)
+    cl_of[start] = label;
+    size += cnt[start];
+    if (MAXIMUM) { bestc = cnt[start]; best = start; }
+    st[0] = start; st[1] = off[start]; depth = 1;
+    while (depth) {
+      const u32 cur = st[2 * (depth - 1)];
+      u32 k = st[2 * (depth - 1) + 1];
+      const u32 kend = off[cur + 1];
+      const u64 cc = cnt[cur];
+      bool descended = false;
+      while (k < kend) {
+        const u32 nb = idx[k++];
+        if (cl_of[nb] != 0) continue;
+        if (!MAXIMUM && !at_least_double(cc, cnt[nb])) continue;
+        cl_of[nb] = label;
+        const u32 nc = cnt[nb];
+        size += nc;
+        if (MAXIMUM && nc > bestc) { bestc = nc; best = nb; }   // updateMaxCount_ strict >
+        st[2 * (depth - 1) + 1] = k;
+        st[2 * depth] = nb; st[2 * depth + 1] = off[nb];
+        depth++;
+        descended = true;
+        break;
+      }
+      if (!descended) depth--;
+    }
+    maxleaf[u] = best;
+    cl_size[u] = size;
+  }
+}
+
+__global__ void k_creator_flags(const u32 *__restrict__ cl_of, u32 n, u32 *flag) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < n) flag[u] = (cl_of[u] == u + 1) ? 1u : 0u;
+}
+
+// per node: final cluster id, maxLeaf flag; per hash slot: (cluster id, read to keep)
+__global__ void k_finalize_nodes(const u32 *__restrict__ cl_of, const u32 *__restrict__ pos,
+                                 const u32 *__restrict__ maxleaf, const u32 *__restrict__ s_first,
+                                 const u32 *__restrict__ s_slot, u32 n, u32 *__restrict__ cid,
+                                 u8 *__restrict__ ismax, u64 *__restrict__ slot_out) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  const u32 creator = cl_of[u] - 1;
+  const u32 c = pos[creator] + 1;
+  const bool mx = maxleaf[creator] == u;
+  cid[u] = c;
+  ismax[u] = mx ? 1 : 0;
+  if (slot_out) slot_out[s_slot[u]] = ((u64)(mx ? s_first[u] : NONE32) << 32) | c;
+}
+
+__global__ void k_export_clusters(const u32 *__restrict__ flag, const u32 *__restrict__ pos,
+                                  const u32 *__restrict__ maxleaf, const u64 *__restrict__ cl_size,
+                                  const u32 *__restrict__ cnt, u32 n, u64 *o_size, u32 *o_maxcount,
+                                  u32 *o_maxleaf) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n || !flag[u]) return;
+  const u32 c = pos[u];
+  if (o_size) o_size[c] = cl_size[u];
+  if (o_maxleaf) o_maxleaf[c] = maxleaf[u];
+  if (o_maxcount) o_maxcount[c] = cnt[maxleaf[u]];
+}
+
+// --------------------------------------------------------------------------------
+// 6. per-read map: cluster id and the duplicate flag
+// --------------------------------------------------------------------------------
+// keep = this read is the first (input order) whose word is its cluster's maxLeaf
+// (/root/reference/src/humid.cc:224-231); cluster 0 for filtered reads (:272).
+__global__ void __launch_bounds__(256)
+k_read_map(const u32 *__restrict__ slot_of_read, const u64 *__restrict__ slot_out, u32 n_reads,
+           u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
+    const u32 s = slot_of_read[r];
+    u32 c = 0;
+    u8 k = 0;
+    if (s != NOSLOT) {
+      const u64 o = slot_out[s];
+      c = (u32)o;
+      k = ((u32)(o >> 32) == r) ? 1 : 0;
+    }
+    cluster_id[r] = c;
+    keep[r] = k;
+  }
+}
+
+__global__ void k_widen32(const u32 *__restrict__ in, u32 n, u64 *__restrict__ out) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+
+__global__ void k_creator_sizes(const u32 *__restrict__ flag, const u32 *__restrict__ pos,
+                                const u64 *__restrict__ cl_size, u32 n, u64 *__restrict__ out) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < n && flag[u]) out[pos[u]] = cl_size[u];
+}
+
+__global__ void k_at_least_double(u64 a, u64 b, int *out) { *out = at_least_double(a, b) ? 1 : 0; }
+
+// --------------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------------
+struct DBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return e; }
+    cap = want;
+    return hipSuccess;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return (T *)p; }
+};
+
+struct humid_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  ull *d_ctr = nullptr;
+  ull *h_ctr = nullptr;   // pinned mirror
+  DBuf in_words, in_filt, out_cid, out_keep;                 // host entry point staging
+  DBuf keys, cnt, first, slot_out, slot_of_read, uniq_slot;  // table (cap+1) and per-read
+  DBuf uniq_word, s_word, s_slot, s_cnt, s_first;            // unique words (walk order)
+  DBuf deg, nbr_off, nbr_idx, seg_k0, seg_k1, seg_v0, seg_v1, ek0, ek1;
+  DBuf parent, mk0, mk1, cl_of, maxleaf, cl_size, flag, pos, cid, ismax, stk, tmp, scratch;
+  hipEvent_t ev[6] = {};
+  hipEvent_t kev[40] = {};   // per-kernel timing: [0,1] insert, [2,3] cluster, [4..] pairs per segment
+  bool have_run = false;
+  bool graph_mode = false;
+  u64 N = 0, U = 0, E = 0, M = 0, C = 0, usable = 0;
+  u32 word_nt = 0, distance = 0, method = 0;
+};
+
+static std::string g_err;
+
+static int fail(humid_ctx *c, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess)                                                                   \
+      return fail(c, _e == hipErrorOutOfMemory ? HUMID_E_NOMEM : HUMID_E_HIP, "%s: %s (%s:%d)", \
+                  #expr, hipGetErrorString(_e), __FILE__, __LINE__);                        \
+  } while (0)
+
+#define ENSURE(buf, bytes) HIPCHK((buf).ensure(bytes))
+
+static inline u32 blocks_for(u64 n, u32 bs = 256) { return (u32)((n + bs - 1) / bs); }
+static inline u32 grid_stride_blocks(u64 n, u32 bs = 256) {
+  u64 b = (n + bs - 1) / bs;
+  if (b > 256 * 8) b = 256 * 8;
+  if (b == 0) b = 1;
+  return (u32)b;
+}
+static inline u32 bits_for(u64 n) {  // bits needed to represent values < n
+  u32 b = 0;
+  while (b < 64 && ((u64)1 << b) < n) b++;
+  return b ? b : 1;
+}
+
+// ---- rocPRIM wrappers (temp storage grown on demand) ---------------------------------
+template <class K, class V>
+static int sort_pairs(humid_ctx *c, const K *kin, K *kout, const V *vin, V *vout, u64 n, u32 b0, u32 b1) {
+  size_t bytes = 0;
+  HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (size_t)n, b0, b1, c->stream));
+  ENSURE(c->tmp, bytes);
+  HIPCHK(rocprim::radix_sort_pairs(c->tmp.p, bytes, kin, kout, vin, vout, (size_t)n, b0, b1, c->stream));
+  return HUMID_OK;
+}
+template <class K>
+static int sort_keys(humid_ctx *c, const K *kin, K *kout, u64 n, u32 b0, u32 b1) {
+  size_t bytes = 0;
+  HIPCHK(rocprim::radix_sort_keys(nullptr, bytes, kin, kout, (size_t)n, b0, b1, c->stream));
+  ENSURE(c->tmp, bytes);
+  HIPCHK(rocprim::radix_sort_keys(c->tmp.p, bytes, kin, kout, (size_t)n, b0, b1, c->stream));
+  return HUMID_OK;
+}
+static int exscan_u32(humid_ctx *c, const u32 *in, u32 *out, u64 n) {
+  size_t bytes = 0;
+  HIPCHK(rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, (size_t)n, rocprim::plus<u32>(), c->stream));
+  ENSURE(c->tmp, bytes);
+  HIPCHK(rocprim::exclusive_scan(c->tmp.p, bytes, in, out, 0u, (size_t)n, rocprim::plus<u32>(), c->stream));
+  return HUMID_OK;
+}
+
+static int read_counters(humid_ctx *c) {
+  HIPCHK(hipMemcpyAsync(c->h_ctr, c->d_ctr, CTR_N * sizeof(ull), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return HUMID_OK;
+}
+
+#define TRY(...) do { int _rc = (__VA_ARGS__); if (_rc != HUMID_OK) return _rc; } while (0)
+
+// segments for the pigeonhole search: d+1 segments over n nucleotides (first segment = most
+// significant nucleotides, so its buckets are runs of the sorted unique array).  d >= n: one
+// zero-width segment (every pair is compared).
+static SegPlan make_plan(u32 n, u32 d) {
+  SegPlan p;
+  memset(&p, 0, sizeof p);
+  if (d + 1 > n) { p.nseg = 1; p.shift[0] = 0; p.mask[0] = 0; return p; }
+  p.nseg = d + 1;
+  u32 base = n / p.nseg, rem = n % p.nseg, pos = 0;
+  for (u32 s = 0; s < p.nseg; s++) {
+    u32 len = base + (s < rem ? 1 : 0);
+    u32 end = pos + len;               // nucleotides [pos, end) from the most significant
+    p.shift[s] = 2 * (n - end);
+    p.mask[s] = (len >= 32) ? ~0ull : (((u64)1 << (2 * len)) - 1);
+    pos = end;
+  }
+  return p;
+}
+
+// ---- cluster stage shared by the full pipeline and the explicit-graph entry point ------
+// needs: s_cnt[U], deg[U], nbr_off[U+1], nbr_idx, parent[U] (components already unioned),
+// M = number of nodes with deg > 0.
+static int cluster_stage(humid_ctx *c, u32 U, u64 M, u32 method) {
+  hipStream_t st = c->stream;
+  ENSURE(c->cl_of, (size_t)U * 4);
+  ENSURE(c->maxleaf, (size_t)U * 4);
+  ENSURE(c->cl_size, (size_t)U * 8);
+  ENSURE(c->flag, (size_t)U * 4);
+  ENSURE(c->pos, (size_t)(U + 1) * 4);
+  ENSURE(c->cid, (size_t)U * 4);
+  ENSURE(c->ismax, (size_t)U);
+  hipLaunchKernelGGL(k_cluster_singletons, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
+                     c->s_cnt.as<u32>(), U, c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
+  if (M > 0) {
+    ENSURE(c->mk0, (size_t)M * 8);
+    ENSURE(c->mk1, (size_t)M * 8);
+    ENSURE(c->stk, (size_t)M * 8);
+    HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_MEMBERS], 0, sizeof(ull), st));
+    hipLaunchKernelGGL(k_member_keys, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
+                       c->parent.as<u32>(), U, c->mk0.as<u64>(), c->d_ctr);
+    TRY(sort_keys<u64>(c, c->mk0.as<u64>(), c->mk1.as<u64>(), M, 0, 32 + bits_for(U)));
+    HIPCHK(hipEventRecord(c->kev[2], st));
+    if (method == HUMID_METHOD_MAXIMUM)
+      hipLaunchKernelGGL(k_cluster_components<true>, dim3(blocks_for(M, 64)), dim3(64), 0, st,
+                         c->mk1.as<u64>(), (u32)M, c->s_cnt.as<u32>(), c->nbr_off.as<u32>(),
+                         c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(),
+                         c->cl_size.as<u64>(), c->stk.as<u32>());
+    else
+      hipLaunchKernelGGL(k_cluster_components<false>, dim3(blocks_for(M, 64)), dim3(64), 0, st,
+                         c->mk1.as<u64>(), (u32)M, c->s_cnt.as<u32>(), c->nbr_off.as<u32>(),
+                         c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(),
+                         c->cl_size.as<u64>(), c->stk.as<u32>());
+    HIPCHK(hipEventRecord(c->kev[3], st));
+  }
+  hipLaunchKernelGGL(k_creator_flags, dim3(blocks_for(U)), dim3(256), 0, st, c->cl_of.as<u32>(), U,
+                     c->flag.as<u32>());
+  TRY(exscan_u32(c, c->flag.as<u32>(), c->pos.as<u32>(), U));
+  HIPCHK(hipGetLastError());
+  return HUMID_OK;
+}
+
+static int n_clusters_from_scan(humid_ctx *c, u32 U, u64 *out) {
+  u32 last_pos = 0, last_flag = 0;
+  HIPCHK(hipMemcpyAsync(&last_pos, c->pos.as<u32>() + (U - 1), 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(&last_flag, c->flag.as<u32>() + (U - 1), 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *out = (u64)last_pos + last_flag;
+  return HUMID_OK;
+}
+
+// ---- the full pipeline on device buffers ---------------------------------------------
+static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_reads, u32 word_nt,
+                      u32 distance, u32 method, u32 *d_cid, u8 *d_keep, humid_summary *sum) {
+  if (!c) return HUMID_E_INVALID;
+  c->have_run = false;
+  c->graph_mode = false;
+  if (word_nt == 0) return fail(c, HUMID_E_INVALID, "word_nt must be >= 1");
+  if (word_nt > 32) return fail(c, HUMID_E_UNSUPPORTED, "word_nt %u > 32 is not supported by the HIP path", word_nt);
+  if (method > 1) return fail(c, HUMID_E_INVALID, "method must be 0 (directional) or 1 (maximum)");
+  if (n_reads > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "n_reads %llu exceeds 2^31-1", (ull)n_reads);
+  if (n_reads && (!d_words || !d_filt || !d_cid || !d_keep)) return fail(c, HUMID_E_INVALID, "null buffer");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const u32 N = (u32)n_reads;
+  humid_summary s;
+  memset(&s, 0, sizeof s);
+  s.total = n_reads;
+  c->N = n_reads; c->U = c->E = c->M = c->C = c->usable = 0;
+  c->word_nt = word_nt; c->distance = distance; c->method = method;
+  if (N == 0) { if (sum) *sum = s; c->have_run = true; return HUMID_OK; }
+
+  // ---------------- 1. exact counts -----------------
+  u32 cap_log2 = 10;
+  while (((u64)1 << cap_log2) < (u64)N + N / 2) cap_log2++;
+  const u64 cap = (u64)1 << cap_log2;
+  ENSURE(c->keys, (cap + 1) * 8);
+  ENSURE(c->cnt, (cap + 1) * 4);
+  ENSURE(c->first, (cap + 1) * 4);
+  ENSURE(c->slot_out, (cap + 1) * 8);
+  ENSURE(c->slot_of_read, (size_t)N * 4);
+  ENSURE(c->uniq_slot, (size_t)N * 4);
+  HIPCHK(hipEventRecord(c->ev[0], st));
+  HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_N * sizeof(ull), st));
+  HIPCHK(hipMemsetAsync(c->keys.p, 0xff, (cap + 1) * 8, st));
+  HIPCHK(hipMemsetAsync(c->cnt.p, 0, (cap + 1) * 4, st));
+  HIPCHK(hipMemsetAsync(c->first.p, 0xff, (cap + 1) * 4, st));
+  HIPCHK(hipEventRecord(c->kev[0], st));
+  hipLaunchKernelGGL(k_hash_insert, dim3(grid_stride_blocks(N)), dim3(256), 0, st, d_words, d_filt, N,
+                     c->keys.as<u64>(), c->cnt.as<u32>(), c->first.as<u32>(), cap_log2,
+                     c->slot_of_read.as<u32>(), c->uniq_slot.as<u32>(), c->d_ctr);
+  HIPCHK(hipEventRecord(c->kev[1], st));
+  HIPCHK(hipGetLastError());
+  TRY(read_counters(c));
+  const u32 U = (u32)c->h_ctr[CTR_UNIQUE];
+  s.usable = c->usable = c->h_ctr[CTR_USABLE];
+  s.unique = c->U = U;
+
+  if (U == 0) {   // everything filtered
+    HIPCHK(hipMemsetAsync(d_cid, 0, (size_t)N * 4, st));
+    HIPCHK(hipMemsetAsync(d_keep, 0, (size_t)N, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (sum) *sum = s;
+    c->have_run = true;
+    return HUMID_OK;
+  }
+
+  // ---------------- 2. walk order -----------------
+  ENSURE(c->uniq_word, (size_t)U * 8);
+  ENSURE(c->s_word, (size_t)U * 8);
+  ENSURE(c->s_slot, (size_t)U * 4);
+  ENSURE(c->s_cnt, (size_t)U * 4);
+  ENSURE(c->s_first, (size_t)U * 4);
+  hipLaunchKernelGGL(k_gather_words, dim3(blocks_for(U)), dim3(256), 0, st, c->keys.as<u64>(),
+                     c->uniq_slot.as<u32>(), U, c->uniq_word.as<u64>());
+  TRY(sort_pairs<u64, u32>(c, c->uniq_word.as<u64>(), c->s_word.as<u64>(), c->uniq_slot.as<u32>(),
+                           c->s_slot.as<u32>(), U, 0, 2 * word_nt));
+  hipLaunchKernelGGL(k_post_sort, dim3(blocks_for(U)), dim3(256), 0, st, c->s_slot.as<u32>(),
+                     c->cnt.as<u32>(), c->first.as<u32>(), U, c->s_cnt.as<u32>(), c->s_first.as<u32>());
+  HIPCHK(hipEventRecord(c->ev[1], st));
+
+  // ---------------- 3. neighbours -----------------
+  ENSURE(c->deg, (size_t)U * 4);
+  ENSURE(c->nbr_off, (size_t)(U + 1) * 4);
+  u64 E = 0, M = 0;
+  u32 n_pair_segs = 0;
+  if (distance > 0 && U > 1) {
+    SegPlan plan = make_plan(word_nt, distance);
+    if (plan.nseg > 1) {
+      ENSURE(c->seg_k0, (size_t)U * 4); ENSURE(c->seg_k1, (size_t)U * 4);
+      ENSURE(c->seg_v0, (size_t)U * 4); ENSURE(c->seg_v1, (size_t)U * 4);
+    }
+    u64 ecap = c->ek0.cap / 8;
+    if (ecap < 2ull * 1024 * 1024) ecap = 2ull * 1024 * 1024;
+    if (ecap < (u64)U) ecap = U;
+    for (int attempt = 0; attempt < 2; attempt++) {
+      ENSURE(c->ek0, ecap * 8);
+      ecap = c->ek0.cap / 8;
+      HIPCHK(hipMemsetAsync(c->deg.p, 0, (size_t)U * 4, st));
+      HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_EDGES], 0, 2 * sizeof(ull), st));   // EDGES, NONSINGLE
+      for (u32 seg = 0; seg < plan.nseg; seg++) {
+        if (seg == 0) {
+          if (seg < 16) HIPCHK(hipEventRecord(c->kev[4 + 2 * seg], st));
+          hipLaunchKernelGGL(k_pairs<true>, dim3(blocks_for(U)), dim3(256), 0, st, c->s_word.as<u64>(),
+                             (const u32 *)nullptr, (const u32 *)nullptr, U, plan, seg, distance,
+                             c->deg.as<u32>(), c->ek0.as<u64>(), ecap, c->d_ctr);
+        } else {
+          u32 width = 0;
+          while (width < 64 && (plan.mask[seg] >> width)) width++;
+          hipLaunchKernelGGL(k_seg_keys, dim3(blocks_for(U)), dim3(256), 0, st, c->s_word.as<u64>(), U,
+                             plan.shift[seg], plan.mask[seg], c->seg_k0.as<u32>(), c->seg_v0.as<u32>());
+          TRY(sort_pairs<u32, u32>(c, c->seg_k0.as<u32>(), c->seg_k1.as<u32>(), c->seg_v0.as<u32>(),
+                                   c->seg_v1.as<u32>(), U, 0, width ? width : 1));
+          if (seg < 16) HIPCHK(hipEventRecord(c->kev[4 + 2 * seg], st));
+          hipLaunchKernelGGL(k_pairs<false>, dim3(blocks_for(U)), dim3(256), 0, st, c->s_word.as<u64>(),
+                             c->seg_k1.as<u32>(), c->seg_v1.as<u32>(), U, plan, seg, distance,
+                             c->deg.as<u32>(), c->ek0.as<u64>(), ecap, c->d_ctr);
+        }
+        if (seg < 16) HIPCHK(hipEventRecord(c->kev[5 + 2 * seg], st));
+        n_pair_segs = seg + 1 < 16 ? seg + 1 : 16;
+      }
+      HIPCHK(hipGetLastError());
+      TRY(read_counters(c));
+      E = c->h_ctr[CTR_EDGES];
+      M = c->h_ctr[CTR_NONSINGLE];
+      if (2 * E <= ecap) break;
+      if (attempt == 1) return fail(c, HUMID_E_HIP, "edge buffer overflow after regrow");
+      ecap = 2 * E;
+    }
+    if (2 * E >= 0xffffffffull) return fail(c, HUMID_E_OVERFLOW, "2*edges = %llu exceeds 32 bits", (ull)(2 * E));
+  } else {
+    HIPCHK(hipMemsetAsync(c->deg.p, 0, (size_t)U * 4, st));
+  }
+  s.edges = c->E = E;
+  s.nonsingle = c->M = M;
+  TRY(exscan_u32(c, c->deg.as<u32>(), c->nbr_off.as<u32>(), U));
+  {
+    u32 twoE = (u32)(2 * E);
+    HIPCHK(hipMemcpyAsync(c->nbr_off.as<u32>() + U, &twoE, 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));   // twoE is a stack variable
+  }
+  ENSURE(c->nbr_idx, (size_t)(2 * E + 1) * 4);
+  ENSURE(c->parent, (size_t)U * 4);
+  if (E > 0) {
+    ENSURE(c->ek1, (size_t)2 * E * 8);
+    // CSR lists ascending: sort the directed (src, dst) keys
+    TRY(sort_keys<u64>(c, c->ek0.as<u64>(), c->ek1.as<u64>(), 2 * E, 0, 32 + bits_for(U)));
+    hipLaunchKernelGGL(k_low32, dim3(blocks_for(2 * E)), dim3(256), 0, st, c->ek1.as<u64>(), 2 * E,
+                       c->nbr_idx.as<u32>());
+  }
+  HIPCHK(hipEventRecord(c->ev[2], st));
+
+  // ---------------- 4+5. components and clusters -----------------
+  hipLaunchKernelGGL(k_iota, dim3(blocks_for(U)), dim3(256), 0, st, c->parent.as<u32>(), U);
+  if (E > 0)
+    hipLaunchKernelGGL(k_union_edges, dim3(blocks_for(E)), dim3(256), 0, st, c->ek0.as<u64>(), E,
+                       c->parent.as<u32>());
+  TRY(cluster_stage(c, U, M, method));
+  hipLaunchKernelGGL(k_finalize_nodes, dim3(blocks_for(U)), dim3(256), 0, st, c->cl_of.as<u32>(),
+                     c->pos.as<u32>(), c->maxleaf.as<u32>(), c->s_first.as<u32>(), c->s_slot.as<u32>(), U,
+                     c->cid.as<u32>(), c->ismax.as<u8>(), c->slot_out.as<u64>());
+  HIPCHK(hipEventRecord(c->ev[3], st));
+
+  // ---------------- 6. per-read map -----------------
+  hipLaunchKernelGGL(k_read_map, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->slot_of_read.as<u32>(),
+                     c->slot_out.as<u64>(), N, d_cid, d_keep);
+  HIPCHK(hipEventRecord(c->ev[4], st));
+  HIPCHK(hipGetLastError());
+  TRY(n_clusters_from_scan(c, U, &c->C));
+  s.clusters = c->C;
+  HIPCHK(hipEventElapsedTime(&s.ms_count, c->ev[0], c->ev[1]));
+  HIPCHK(hipEventElapsedTime(&s.ms_neighbours, c->ev[1], c->ev[2]));
+  HIPCHK(hipEventElapsedTime(&s.ms_cluster, c->ev[2], c->ev[3]));
+  HIPCHK(hipEventElapsedTime(&s.ms_map, c->ev[3], c->ev[4]));
+  HIPCHK(hipEventElapsedTime(&s.ms_total, c->ev[0], c->ev[4]));
+  HIPCHK(hipEventElapsedTime(&s.ms_k_insert, c->kev[0], c->kev[1]));
+  s.ms_k_map = s.ms_map;   // ev[3]..ev[4] bracket exactly the k_read_map launch
+  if (M > 0) HIPCHK(hipEventElapsedTime(&s.ms_k_cluster, c->kev[2], c->kev[3]));
+  for (u32 g = 0; g < n_pair_segs; g++) {
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, c->kev[4 + 2 * g], c->kev[5 + 2 * g]));
+    s.ms_k_pairs += t;
+  }
+  if (sum) *sum = s;
+  c->have_run = true;
+  return HUMID_OK;
+}
+
+// --------------------------------------------------------------------------------
+// C ABI
+// --------------------------------------------------------------------------------
+extern "C" {
+
+uint32_t humid_abi_version(void) { return HUMID_ABI_VERSION; }
+
+int humid_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *humid_last_error(const humid_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int humid_ctx_create(humid_ctx **out, int device, void *stream) {
+  humid_ctx *c = nullptr;
+  if (!out) return fail(nullptr, HUMID_E_INVALID, "out is null");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, HUMID_E_HIP, "no HIP device available (%s); this library has no CPU fallback",
+                hipGetErrorString(e));
+  if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+  if (device >= ndev) return fail(nullptr, HUMID_E_INVALID, "device %d out of range (%d devices)", device, ndev);
+  c = new (std::nothrow) humid_ctx();
+  if (!c) return fail(nullptr, HUMID_E_NOMEM, "host allocation failed");
+  c->device = device;
+  auto bail = [&](hipError_t err, const char *what) {
+    int rc = fail(nullptr, HUMID_E_HIP, "%s: %s", what, hipGetErrorString(err));
+    humid_ctx_destroy(c);
+    return rc;
+  };
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+  if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+  else {
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    c->own_stream = true;
+  }
+  if ((e = hipMalloc((void **)&c->d_ctr, CTR_N * sizeof(ull))) != hipSuccess) return bail(e, "hipMalloc");
+  if ((e = hipHostMalloc((void **)&c->h_ctr, CTR_N * sizeof(ull), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+  for (auto &ev : c->ev)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
+  for (auto &ev : c->kev)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
+  *out = c;
+  return HUMID_OK;
+}
+
+void humid_ctx_destroy(humid_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->keys, &c->cnt, &c->first,
+                  &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
+                  &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_k1,
+                  &c->seg_v0, &c->seg_v1, &c->ek0, &c->ek1, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
+                  &c->maxleaf, &c->cl_size, &c->flag, &c->pos, &c->cid, &c->ismax, &c->stk, &c->tmp,
+                  &c->scratch};
+  for (DBuf *b : bufs) b->release();
+  if (c->d_ctr) (void)hipFree(c->d_ctr);
+  if (c->h_ctr) (void)hipHostFree(c->h_ctr);
+  for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+  for (auto &ev : c->kev) if (ev) (void)hipEventDestroy(ev);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int humid_dedup_run_device(humid_ctx *c, const uint64_t *d_words, const uint8_t *d_filtered,
+                           uint64_t n_reads, uint32_t word_nt, uint32_t distance, uint32_t method,
+                           uint32_t *d_cluster_id, uint8_t *d_keep, humid_summary *summary) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  return run_device(c, d_words, d_filtered, n_reads, word_nt, distance, method, d_cluster_id, d_keep, summary);
+}
+
+int humid_dedup_run(humid_ctx *c, const uint64_t *words, const uint8_t *filtered, uint64_t n_reads,
+                    uint32_t word_nt, uint32_t distance, uint32_t method, uint32_t *cluster_id,
+                    uint8_t *keep, humid_summary *summary) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (n_reads && (!words || !filtered || !cluster_id || !keep)) return fail(c, HUMID_E_INVALID, "null buffer");
+  if (n_reads > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "n_reads %llu exceeds 2^31-1", (ull)n_reads);
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  humid_summary s;
+  memset(&s, 0, sizeof s);
+  hipEvent_t e0 = c->ev[5];
+  hipEvent_t e1, e2, e3;
+  HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2)); HIPCHK(hipEventCreate(&e3));
+  size_t n = (size_t)n_reads;
+  ENSURE(c->in_words, n * 8 + 8);
+  ENSURE(c->in_filt, n + 8);
+  ENSURE(c->out_cid, n * 4 + 8);
+  ENSURE(c->out_keep, n + 8);
+  HIPCHK(hipEventRecord(e0, st));
+  if (n) {
+    HIPCHK(hipMemcpyAsync(c->in_words.p, words, n * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->in_filt.p, filtered, n, hipMemcpyHostToDevice, st));
+  }
+  HIPCHK(hipEventRecord(e1, st));
+  int rc = run_device(c, c->in_words.as<u64>(), c->in_filt.as<u8>(), n_reads, word_nt, distance, method,
+                      c->out_cid.as<u32>(), c->out_keep.as<u8>(), &s);
+  if (rc == HUMID_OK) {
+    hipError_t he = hipEventRecord(e2, st);
+    if (he == hipSuccess && n) he = hipMemcpyAsync(cluster_id, c->out_cid.p, n * 4, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess && n) he = hipMemcpyAsync(keep, c->out_keep.p, n, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipEventRecord(e3, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    if (he == hipSuccess) he = hipEventElapsedTime(&s.ms_h2d, e0, e1);
+    if (he == hipSuccess) he = hipEventElapsedTime(&s.ms_d2h, e2, e3);
+    if (he != hipSuccess) rc = fail(c, HUMID_E_HIP, "copy back: %s", hipGetErrorString(he));
+  }
+  (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
+  if (rc == HUMID_OK && summary) *summary = s;
+  return rc;
+}
+
+#define NEED_RUN()                                                                            \
+  do {                                                                                        \
+    if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");                             \
+    if (!c->have_run || c->graph_mode) return fail(c, HUMID_E_STATE, "no completed dedup run in this context"); \
+    HIPCHK(hipSetDevice(c->device));                                                          \
+  } while (0)
+
+#define D2H(dst, src, bytes)                                                                  \
+  do { if ((dst) && (bytes)) HIPCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, c->stream)); } while (0)
+
+int humid_get_leaves(humid_ctx *c, uint64_t *word, uint32_t *count, uint32_t *first_read,
+                     uint32_t *degree, uint32_t *cluster_id, uint8_t *is_max_leaf) {
+  NEED_RUN();
+  size_t U = (size_t)c->U;
+  if (U == 0) return HUMID_OK;
+  D2H(word, c->s_word.p, U * 8);
+  D2H(count, c->s_cnt.p, U * 4);
+  D2H(first_read, c->s_first.p, U * 4);
+  D2H(degree, c->deg.p, U * 4);
+  D2H(cluster_id, c->cid.p, U * 4);
+  D2H(is_max_leaf, c->ismax.p, U);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return HUMID_OK;
+}
+
+int humid_get_adjacency(humid_ctx *c, uint32_t *nbr_off, uint32_t *nbr_idx) {
+  NEED_RUN();
+  size_t U = (size_t)c->U;
+  if (U == 0) { if (nbr_off) nbr_off[0] = 0; return HUMID_OK; }
+  D2H(nbr_off, c->nbr_off.p, (U + 1) * 4);
+  D2H(nbr_idx, c->nbr_idx.p, (size_t)(2 * c->E) * 4);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return HUMID_OK;
+}
+
+static int export_clusters(humid_ctx *c, u32 U, u64 C, uint64_t *size, uint32_t *max_count, uint32_t *max_leaf) {
+  if (C == 0) return HUMID_OK;
+  ENSURE(c->scratch, (size_t)C * 16);
+  u64 *d_size = c->scratch.as<u64>();
+  u32 *d_mc = (u32 *)(d_size + C);
+  u32 *d_ml = d_mc + C;
+  hipLaunchKernelGGL(k_export_clusters, dim3(blocks_for(U)), dim3(256), 0, c->stream, c->flag.as<u32>(),
+                     c->pos.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>(), c->s_cnt.as<u32>(), U,
+                     d_size, d_mc, d_ml);
+  HIPCHK(hipGetLastError());
+  D2H(size, d_size, (size_t)C * 8);
+  D2H(max_count, d_mc, (size_t)C * 4);
+  D2H(max_leaf, d_ml, (size_t)C * 4);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return HUMID_OK;
+}
+
+int humid_get_clusters(humid_ctx *c, uint64_t *size, uint32_t *max_count, uint32_t *max_leaf) {
+  NEED_RUN();
+  return export_clusters(c, (u32)c->U, c->C, size, max_count, max_leaf);
+}
+
+int humid_get_histogram(humid_ctx *c, uint32_t which, uint64_t *keys, uint64_t *values, uint64_t cap,
+                        uint64_t *n_out) {
+  NEED_RUN();
+  if (which > 2 || !n_out) return fail(c, HUMID_E_INVALID, "bad histogram selector");
+  *n_out = 0;
+  const u32 U = (u32)c->U;
+  u64 n = (which == 2) ? c->C : U;
+  if (n == 0) return HUMID_OK;
+  hipStream_t st = c->stream;
+  // layout of scratch: vals[n] | sorted[n] | uniq[n] | counts u32[n] | runs u32
+  ENSURE(c->scratch, (size_t)n * 28 + 64);
+  u64 *vals = c->scratch.as<u64>();
+  u64 *sorted = vals + n;
+  u64 *uniq = sorted + n;
+  u32 *counts = (u32 *)(uniq + n);
+  u32 *runs = counts + n;
+  if (which == 0) hipLaunchKernelGGL(k_widen32, dim3(blocks_for(U)), dim3(256), 0, st, c->s_cnt.as<u32>(), U, vals);
+  else if (which == 1) hipLaunchKernelGGL(k_widen32, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(), U, vals);
+  else hipLaunchKernelGGL(k_creator_sizes, dim3(blocks_for(U)), dim3(256), 0, st, c->flag.as<u32>(),
+                          c->pos.as<u32>(), c->cl_size.as<u64>(), U, vals);
+  TRY(sort_keys<u64>(c, vals, sorted, n, 0, 64));
+  {
+    size_t bytes = 0;
+    HIPCHK(rocprim::run_length_encode(nullptr, bytes, sorted, (unsigned int)n, uniq, counts, runs, st));
+    ENSURE(c->tmp, bytes);
+    HIPCHK(rocprim::run_length_encode(c->tmp.p, bytes, sorted, (unsigned int)n, uniq, counts, runs, st));
+  }
+  u32 h_runs = 0;
+  HIPCHK(hipMemcpyAsync(&h_runs, runs, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  *n_out = h_runs;
+  u64 take = h_runs < cap ? h_runs : cap;
+  if (take && keys && values) {
+    std::vector<u32> hc(take);
+    HIPCHK(hipMemcpyAsync(keys, uniq, (size_t)take * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hc.data(), counts, (size_t)take * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (u64 i = 0; i < take; i++) values[i] = hc[i];
+  }
+  return HUMID_OK;
+}
+
+int humid_cluster_graph(humid_ctx *c, const uint32_t *count, const uint32_t *nbr_off,
+                        const uint32_t *nbr_idx, uint32_t n_leaves, uint32_t method,
+                        uint32_t *leaf_cluster, uint64_t *cl_size, uint32_t *cl_max_count,
+                        uint32_t *cl_max_leaf, uint32_t *n_clusters) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (method > 1) return fail(c, HUMID_E_INVALID, "method must be 0 or 1");
+  if (n_clusters) *n_clusters = 0;
+  const u32 U = n_leaves;
+  if (U == 0) return HUMID_OK;
+  if (!count || !nbr_off) return fail(c, HUMID_E_INVALID, "null buffer");
+  const u32 twoE = nbr_off[U];
+  if (twoE && !nbr_idx) return fail(c, HUMID_E_INVALID, "null nbr_idx");
+  for (u32 u = 0; u < U; u++)
+    if (nbr_off[u] > nbr_off[u + 1]) return fail(c, HUMID_E_INVALID, "nbr_off not monotone at %u", u);
+  for (u32 k = 0; k < twoE; k++)
+    if (nbr_idx[k] >= U) return fail(c, HUMID_E_INVALID, "nbr_idx[%u] = %u out of range", k, nbr_idx[k]);
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  c->have_run = false;
+  c->graph_mode = true;
+  ENSURE(c->s_cnt, (size_t)U * 4);
+  ENSURE(c->deg, (size_t)U * 4);
+  ENSURE(c->nbr_off, (size_t)(U + 1) * 4);
+  ENSURE(c->nbr_idx, (size_t)(twoE + 1) * 4);
+  ENSURE(c->parent, (size_t)U * 4);
+  std::vector<u32> hdeg(U);
+  u64 M = 0;
+  for (u32 u = 0; u < U; u++) { hdeg[u] = nbr_off[u + 1] - nbr_off[u]; M += hdeg[u] ? 1 : 0; }
+  HIPCHK(hipMemcpyAsync(c->s_cnt.p, count, (size_t)U * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(c->deg.p, hdeg.data(), (size_t)U * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(c->nbr_off.p, nbr_off, (size_t)(U + 1) * 4, hipMemcpyHostToDevice, st));
+  if (twoE) HIPCHK(hipMemcpyAsync(c->nbr_idx.p, nbr_idx, (size_t)twoE * 4, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_iota, dim3(blocks_for(U)), dim3(256), 0, st, c->parent.as<u32>(), U);
+  hipLaunchKernelGGL(k_union_csr, dim3(blocks_for(U)), dim3(256), 0, st, c->nbr_off.as<u32>(),
+                     c->nbr_idx.as<u32>(), U, c->parent.as<u32>());
+  HIPCHK(hipStreamSynchronize(st));   // hdeg is a host temporary
+  TRY(cluster_stage(c, U, M, method));
+  hipLaunchKernelGGL(k_finalize_nodes, dim3(blocks_for(U)), dim3(256), 0, st, c->cl_of.as<u32>(),
+                     c->pos.as<u32>(), c->maxleaf.as<u32>(), (const u32 *)nullptr, (const u32 *)nullptr, U,
+                     c->cid.as<u32>(), c->ismax.as<u8>(), (u64 *)nullptr);
+  HIPCHK(hipGetLastError());
+  u64 C = 0;
+  TRY(n_clusters_from_scan(c, U, &C));
+  D2H(leaf_cluster, c->cid.p, (size_t)U * 4);
+  HIPCHK(hipStreamSynchronize(st));
+  if (n_clusters) *n_clusters = (u32)C;
+  return export_clusters(c, U, C, cl_size, cl_max_count, cl_max_leaf);
+}
+
+int humid_at_least_double(humid_ctx *c, uint64_t a, uint64_t b, int *result) {
+  if (!c || !result) return fail(c, HUMID_E_INVALID, "null argument");
+  HIPCHK(hipSetDevice(c->device));
+  ENSURE(c->scratch, 64);
+  hipLaunchKernelGGL(k_at_least_double, dim3(1), dim3(1), 0, c->stream, a, b, c->scratch.as<int>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(result, c->scratch.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return HUMID_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+/*
+ * humid_hip.h -- C ABI of libhumid_hip.so: HUMID's neighbour-search-and-cluster hot
+ * path on one MI355X (gfx950), hand-written HIP.
+ *
+ * The reference (jfjlaros/HUMID, /root/reference) has no FFI/plugin seam; the seam
+ * this library fills is the C++ surface src/humid.cc uses between FastQ pass 1 and
+ * pass 2: lib/trie's Trie<4,NLeaf> (add / walk /
+ * asymmetricHamming / find) plus src/cluster.{h,cc} and src/leaf.h.  Each entry
+ * point below names the reference interface it replaces (paths relative to
+ * /root/reference).  Plain pointers and sizes only; nothing throws or aborts across
+ * the ABI; every function returns HUMID_OK (0) or a negative HUMID_E_* code and
+ * humid_last_error() gives the text.  There is NO CPU fallback in this library.
+ *
+ * Packed word: nucleotide i (A0 C1 G2 T3, src/fastq.cc:12) of an n-symbol word
+ * (n = -n word length, src/humid.cc:419) occupies bits [2(n-1-i), 2(n-1-i)+1] of a
+ * uint64, so unsigned integer order == lexicographic order == Trie::walk() order.
+ * This library handles n <= 32 (one uint64 per read); n > 32 returns
+ * HUMID_E_UNSUPPORTED (all BASELINE.json configs use n = 24).
+ */
+#ifndef HUMID_HIP_H
+#define HUMID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HUMID_OK             0
+#define HUMID_E_INVALID     -1   /* bad argument                                    */
+#define HUMID_E_UNSUPPORTED -2   /* word_nt > 32, edit distance (-e)                */
+#define HUMID_E_NOMEM       -3   /* device or host allocation failed                */
+#define HUMID_E_HIP         -4   /* HIP runtime error (text in humid_last_error)    */
+#define HUMID_E_OVERFLOW    -5   /* an index exceeded 32 bits (reads, 2*edges)      */
+#define HUMID_E_STATE       -6   /* accessor called before a successful run         */
+
+#define HUMID_METHOD_DIRECTIONAL 0u  /* default; src/cluster.cc:82-87               */
+#define HUMID_METHOD_MAXIMUM     1u  /* -x;      src/cluster.cc:72-80               */
+
+#define HUMID_ABI_VERSION 1u
+
+typedef struct humid_ctx humid_ctx;   /* device workspace + stream; not thread-safe */
+
+/* total/usable/unique/clusters are the four lines of stats.dat
+ * (src/humid.cc:351-355).  ms_* are device times (hipEvents on the ctx stream). */
+typedef struct humid_summary {
+  uint64_t total;       /* reads seen                    src/humid.cc:98          */
+  uint64_t usable;      /* reads without non-ACGT        src/humid.cc:96          */
+  uint64_t unique;      /* distinct words                src/humid.cc:125         */
+  uint64_t clusters;    /* clusters.size()               src/humid.cc:403         */
+  uint64_t edges;       /* undirected neighbour pairs                             */
+  uint64_t nonsingle;   /* unique words with >= 1 neighbour                       */
+  float ms_count;       /* hash insert + unique sort     (Trie::add, walk order)  */
+  float ms_neighbours;  /* bucket passes + CSR           (findHammingNeighbours)  */
+  float ms_cluster;     /* components + cluster kernel   (findClusters)           */
+  float ms_map;         /* per-read map                  (writeFiltered/Annotated)*/
+  float ms_total;       /* first kernel to last kernel on the stream              */
+  float ms_h2d, ms_d2h; /* host-buffer entry point only                           */
+  /* single kernels, HIP events directly around the launches on the ctx stream:      */
+  float ms_k_insert;    /* k_hash_insert (one launch)                               */
+  float ms_k_pairs;     /* sum over the d+1 k_pairs launches                        */
+  float ms_k_cluster;   /* k_cluster_components (one launch; 0 if no neighbours)    */
+  float ms_k_map;       /* k_read_map (one launch)                                  */
+} humid_summary;
+
+uint32_t humid_abi_version(void);
+int      humid_device_count(void);
+
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for
+ * a stream owned by the context.  device < 0: current device. */
+int  humid_ctx_create(humid_ctx **out, int device, void *stream);
+void humid_ctx_destroy(humid_ctx *ctx);
+const char *humid_last_error(const humid_ctx *ctx);   /* ctx may be NULL */
+
+/* ---- the whole hot path ----------------------------------------------------
+ * Replaces, between FastQ pass 1 and pass 2:
+ *   trie.add(word.data)                 src/humid.cc:94-97   (exact counts)
+ *   findHammingNeighbours(trie, d)      src/humid.cc:113-130 (lib/trie walk x asymmetricHamming)
+ *   findClusters(trie, maximum)         src/humid.cc:167-193 + src/cluster.cc:10-87
+ *   trie.find(word)->leaf->cluster ...  src/humid.cc:223-231 (keep), :276-277 (cluster id)
+ * words[N], filtered[N] in; cluster_id[N] (0 = filtered, ids 1.. in the order
+ * src/humid.cc:177-180 hands them out) and keep[N] (1 = the record writeFiltered
+ * emits: the first read, in input order, whose word is its cluster's maxLeaf) out.
+ * Host buffers, caller-owned; summary may be NULL. */
+int humid_dedup_run(humid_ctx *ctx, const uint64_t *words, const uint8_t *filtered,
+                    uint64_t n_reads, uint32_t word_nt, uint32_t distance, uint32_t method,
+                    uint32_t *cluster_id, uint8_t *keep, humid_summary *summary);
+
+/* Same contract with DEVICE pointers (inputs already resident in HBM, outputs left
+ * in HBM); work is queued on the context's stream and the call returns after the
+ * stream has drained.  summary (host) may be NULL. */
+int humid_dedup_run_device(humid_ctx *ctx, const uint64_t *d_words, const uint8_t *d_filtered,
+                           uint64_t n_reads, uint32_t word_nt, uint32_t distance,
+                           uint32_t method, uint32_t *d_cluster_id, uint8_t *d_keep,
+                           humid_summary *summary);
+
+/* ---- results of the last run, per unique word in Trie::walk() order ---------
+ * (what a caller would read through Result<NLeaf>{leaf,path}, src/humid.cc:117,178,307;
+ * NLeaf src/leaf.h:6-9; Cluster src/cluster.h:12-18).  Host output buffers sized by
+ * summary.unique / 2*summary.edges / summary.clusters; any pointer may be NULL. */
+int humid_get_leaves(humid_ctx *ctx, uint64_t *word, uint32_t *count, uint32_t *first_read,
+                     uint32_t *degree, uint32_t *cluster_id, uint8_t *is_max_leaf);
+int humid_get_adjacency(humid_ctx *ctx, uint32_t *nbr_off /* unique+1 */,
+                        uint32_t *nbr_idx /* 2*edges, each list ascending */);
+int humid_get_clusters(humid_ctx *ctx, uint64_t *size, uint32_t *max_count,
+                       uint32_t *max_leaf /* walk index of Cluster::maxLeaf */);
+
+/* Histograms of the last run: runStatistics src/humid.cc:301-315 and clusterStats
+ * src/cluster.cc:89-95 -> counts.dat / neigh.dat / clusters.dat.
+ * which: 0 = leaf->count, 1 = neighbours.size(), 2 = Cluster::size.
+ * Writes up to cap (key,value) pairs in ascending key order; *n_out = bins found
+ * (call with cap = 0 to size the buffers). */
+int humid_get_histogram(humid_ctx *ctx, uint32_t which, uint64_t *keys, uint64_t *values,
+                        uint64_t cap, uint64_t *n_out);
+
+/* ---- clustering over an explicit neighbour graph ----------------------------
+ * Replaces findClusters (src/humid.cc:167-193) + assignDirectionalCluster /
+ * assignMaxCluster (src/cluster.h:26-36) for a caller that built NLeaf::neighbours
+ * itself (as tests/test_cluster.cc:11-14 does with link()): leaves are walked in
+ * index order, neighbour lists are scanned in the order given.
+ * count[U]; nbr_off[U+1], nbr_idx[nbr_off[U]] (CSR, host).  Out: leaf_cluster[U]
+ * (ids 1..C), and per cluster id c at slot c-1: size, max_count, max_leaf.
+ * cl_* buffers must hold U entries; *n_clusters = C. */
+int humid_cluster_graph(humid_ctx *ctx, const uint32_t *count, const uint32_t *nbr_off,
+                        const uint32_t *nbr_idx, uint32_t n_leaves, uint32_t method,
+                        uint32_t *leaf_cluster, uint64_t *cl_size, uint32_t *cl_max_count,
+                        uint32_t *cl_max_leaf, uint32_t *n_clusters);
+
+/* src/cluster.cc:31-33 atLeastDouble_, evaluated on the device (parity probe). */
+int humid_at_least_double(humid_ctx *ctx, uint64_t a, uint64_t b, int *result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,286 @@
+"""-m gpu parity tests: the HIP path (through the C ABI) against the CPU oracle, bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import humid_amd
+from humid_amd.synth import synth_words
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dd():
+    d = humid_amd.Dedup()
+    yield d
+    d.close()
+
+
+def oracle_full(words, filt, n, d, maximum):
+    p = orc.Pipeline(n)
+    p.read_data(words, filt)
+    p.find_hamming_neighbours(d)
+    p.find_clusters(maximum)
+    cid, keep = p.map_reads()
+    return p, cid, keep
+
+
+def check_against_oracle(dd, words, filt, n, d, maximum, deep=True):
+    cid, keep, s = dd.run(words, filt, word_nt=n, distance=d, method=int(maximum))
+    p, ocid, okeep = oracle_full(words, filt, n, d, maximum)
+    os_ = p.summary()
+    for k in ("total", "usable", "unique", "clusters", "edges"):
+        assert s[k] == os_[k], (k, s[k], os_[k])
+    assert np.array_equal(cid, ocid)
+    assert np.array_equal(keep, okeep)
+    if deep and s["unique"]:
+        lv, olv = dd.leaves(), p.leaves()
+        assert np.array_equal(lv["word"], olv["word"])
+        assert np.array_equal(lv["count"].astype(np.uint64), olv["count"])
+        assert np.array_equal(lv["degree"], olv["degree"])
+        assert np.array_equal(lv["cluster_id"], olv["cluster_id"])
+        assert np.array_equal(lv["is_max_leaf"], olv["is_max_leaf"])
+        off, idx = dd.adjacency()
+        ooff, oidx = p.adjacency()
+        assert np.array_equal(off.astype(np.uint64), ooff)
+        assert np.array_equal(idx, oidx)
+        cl, ocl = dd.clusters(), p.clusters()
+        assert np.array_equal(cl["size"], ocl["size"])
+        assert np.array_equal(cl["max_count"].astype(np.uint64), ocl["max_count"])
+        assert np.array_equal(cl["max_leaf"], ocl["max_leaf"])
+        assert dd.histograms() == orc.histograms(p)
+    return s
+
+
+def dense_words(rng, n_reads, n, k):
+    base = rng.integers(0, 4 ** min(n, 31), dtype=np.uint64)
+    w = np.full(n_reads, base, dtype=np.uint64)
+    for _ in range(k):
+        pos = int(rng.integers(0, n))
+        sh = np.uint64(2 * pos)
+        v = rng.integers(0, 4, size=n_reads).astype(np.uint64)
+        w = (w & ~(np.uint64(3) << sh)) | (v << sh)
+    return w
+
+
+def test_at_least_double_device(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "ref_test_cluster.json")))
+    ctx = humid_amd.Context()
+    for c in g["at_least_double"]:
+        assert humid_amd.at_least_double(c["a"], c["b"], ctx) == c["expect"], c["ref"]
+    ctx.close()
+
+
+def test_reference_cluster_scenario_on_gpu(golden_dir):
+    """tests/test_cluster.cc:73-137 driven through humid_cluster_graph"""
+    g = json.load(open(os.path.join(golden_dir, "ref_test_cluster.json")))["assign_directional"]
+    cg = humid_amd.ClusterGraph(g["counts"])
+    for a, b in g["links"]:
+        cg.link(a, b)
+    r = cg.find_clusters(False)
+    assert r["n_clusters"] == 2
+    assert r["leaf_cluster"].tolist() == g["calls"][-1]["expect_leaf_cluster"]
+    assert r["size"].tolist() == g["expect_size"]
+    assert r["max_leaf"].tolist() == g["expect_max_leaf"]
+    assert r["max_count"].tolist() == g["expect_max_count"]
+    cg.close()
+
+
+def test_reference_max_neighbour_chains_on_gpu(golden_dir):
+    """tests/test_cluster.cc:45-71: the climb ends on the 4-count leaf, so cluster 1's maxLeaf
+    is that leaf when the findClusters loop starts from leaf 0"""
+    g = json.load(open(os.path.join(golden_dir, "ref_test_cluster.json")))
+    for case in g["max_neighbour"]:
+        if case["preassigned"] or case["counts"] == [0]:
+            continue
+        cg = humid_amd.ClusterGraph(case["counts"])
+        for a, b in case["links"]:
+            cg.link(a, b)
+        r = cg.find_clusters(False)
+        assert int(r["max_leaf"][0]) == case["queries"][0]["expect"], case["name"]
+        cg.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("maximum", [False, True])
+def test_random_graphs_arbitrary_list_order(seed, maximum):
+    """explicit graphs whose neighbour lists are in link() order, not ascending"""
+    rng = np.random.default_rng(100 + seed)
+    u = int(rng.integers(2, 300))
+    counts = rng.integers(1, 20, size=u)
+    cg = humid_amd.ClusterGraph(counts)
+    og = orc.Graph(counts)
+    seen = set()
+    for _ in range(int(rng.integers(1, 3 * u))):
+        a, b = int(rng.integers(0, u)), int(rng.integers(0, u))
+        if a == b or (a, b) in seen or (b, a) in seen:
+            continue
+        seen.add((a, b))
+        cg.link(a, b)
+        og.link(a, b)
+    r = cg.find_clusters(maximum)
+    nc = og.find_clusters(maximum)
+    lc, size, mc, ml = og.export(nc)
+    assert r["n_clusters"] == nc
+    assert np.array_equal(r["leaf_cluster"], lc)
+    assert np.array_equal(r["size"], size)
+    assert np.array_equal(r["max_count"].astype(np.uint64), mc)
+    assert np.array_equal(r["max_leaf"].astype(np.int64), ml)
+    cg.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("d", [1, 2, 3])
+@pytest.mark.parametrize("maximum", [False, True])
+def test_dense_small(dd, seed, d, maximum):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(4, 33))
+    n_reads = int(rng.integers(1, 3000))
+    words = dense_words(rng, n_reads, n, int(rng.integers(1, 6)))
+    filt = (rng.random(n_reads) < 0.05).astype(np.uint8)
+    check_against_oracle(dd, words, filt, n, d, maximum)
+
+
+@pytest.mark.parametrize("cfg", [
+    # (reads, word_nt, d, mode, p_sub) -- shapes of BASELINE.json configs at oracle-friendly size
+    (100_000, 24, 1, "umi", 1e-3),     # config 1: 100k SE UMI=8
+    (300_000, 24, 1, "umi", 1e-3),     # config 2/metric shape, reduced
+    (200_000, 24, 2, "genome", 1e-3),  # config 5 shape: no UMI, d=2
+    (50_000, 32, 1, "umi", 5e-3),      # widest single-word
+    (50_000, 12, 2, "umi", 1e-2),      # short words: heavy neighbourhoods
+    (20_000, 5, 1, "umi", 1e-2),       # saturated word space (every word has neighbours)
+    (5_000, 1, 1, "umi", 1e-2),        # d >= n: one zero-width segment
+])
+@pytest.mark.parametrize("maximum", [False, True])
+def test_synthetic_configs(dd, cfg, maximum):
+    n_reads, n, d, mode, p_sub = cfg
+    words, filt = synth_words(n_reads, 1000 + n + d, n, p_sub=p_sub, mode=mode,
+                              genome_bp=200_000 if mode == "genome" else 0)
+    check_against_oracle(dd, words, filt, n, d, maximum)
+
+
+def test_edge_cases(dd):
+    # empty
+    cid, keep, s = dd.run(np.zeros(0, np.uint64), np.zeros(0, np.uint8))
+    assert len(cid) == 0 and s["unique"] == 0
+    # everything filtered
+    cid, keep, s = dd.run(np.arange(7, dtype=np.uint64), np.ones(7, np.uint8))
+    assert cid.tolist() == [0] * 7 and keep.tolist() == [0] * 7 and s["usable"] == 0
+    # one read
+    check_against_oracle(dd, np.array([5], np.uint64), np.zeros(1, np.uint8), 24, 1, False)
+    # all identical
+    check_against_oracle(dd, np.full(1000, 12345, np.uint64), np.zeros(1000, np.uint8), 24, 1, False)
+    # n = 32 with the all-T word (equals the table's EMPTY sentinel)
+    w = np.array([2 ** 64 - 1, 2 ** 64 - 1, 2 ** 64 - 2, 2 ** 64 - 5, 7, 2 ** 64 - 1], dtype=np.uint64)
+    check_against_oracle(dd, w, np.zeros(6, np.uint8), 32, 1, False)
+    check_against_oracle(dd, w, np.zeros(6, np.uint8), 32, 1, True)
+    # distance 0: exact duplicates only
+    words, filt = synth_words(20000, 3, 24, p_sub=1e-2)
+    check_against_oracle(dd, words, filt, 24, 0, False)
+
+
+def test_unsupported_and_invalid(dd):
+    w = np.zeros(4, np.uint64)
+    f = np.zeros(4, np.uint8)
+    with pytest.raises(humid_amd.HumidError) as e:
+        dd.run(w, f, word_nt=33)
+    assert e.value.code == -2
+    with pytest.raises(humid_amd.HumidError) as e:
+        dd.run(w, f, word_nt=0)
+    assert e.value.code == -1
+    with pytest.raises(humid_amd.HumidError) as e:
+        dd.run(w, f, method=7)
+    assert e.value.code == -1
+
+
+def test_count_ties_and_steals(dd):
+    """shared low-count leaf between two maxima, equal counts (no edge), ratio exactly 2"""
+    A = orc.pack_word([0, 0, 0, 0, 0, 0])
+    B = orc.pack_word([0, 0, 0, 0, 0, 1])   # neighbour of A and C
+    Cw = orc.pack_word([0, 0, 0, 0, 1, 1])  # neighbour of B only
+    D = orc.pack_word([3, 3, 3, 3, 3, 3])
+    E = orc.pack_word([3, 3, 3, 3, 3, 2])
+    reads = [A] * 4 + [B] * 2 + [Cw] * 4 + [D] * 3 + [E] * 3
+    rng = np.random.default_rng(5)
+    for _ in range(5):
+        w = np.array(reads, dtype=np.uint64)
+        rng.shuffle(w)
+        for mx in (False, True):
+            check_against_oracle(dd, w, np.zeros(len(w), np.uint8), 6, 1, mx)
+
+
+def test_large_bucket(dd):
+    """amplicon-like: one read prefix shared by thousands of UMIs -> one big segment bucket"""
+    rng = np.random.default_rng(11)
+    n_reads = 60000
+    umi = rng.integers(0, 4 ** 6, size=n_reads, dtype=np.uint64)   # 4096 distinct UMIs
+    words = (umi << np.uint64(36)) | np.uint64(0x123456789)        # same 18-nt read part
+    check_against_oracle(dd, words, np.zeros(n_reads, np.uint8), 24, 1, False)
+    check_against_oracle(dd, words, np.zeros(n_reads, np.uint8), 24, 1, True)
+
+
+def test_long_chain_component(dd):
+    """a path-shaped component thousands of leaves deep (the reference recursion overflows here)"""
+    # words 0..L-1 in unary-like Gray walk: consecutive words differ in one nucleotide
+    L = 5000
+    words = []
+    w = 0
+    rng = np.random.default_rng(2)
+    seen = {0}
+    path = [0]
+    n = 24
+    while len(path) < L:
+        pos = int(rng.integers(0, n))
+        v = int(rng.integers(1, 4))
+        old = (w >> (2 * pos)) & 3
+        nw = (w & ~(3 << (2 * pos))) | (((old + v) & 3) << (2 * pos))
+        if nw in seen:
+            continue
+        seen.add(nw)
+        path.append(nw)
+        w = nw
+    reads = []
+    for i, x in enumerate(path):
+        reads += [x] * (1 + (i % 3))
+    words = np.array(reads, dtype=np.uint64)
+    check_against_oracle(dd, words, np.zeros(len(words), np.uint8), n, 1, False)
+    check_against_oracle(dd, words, np.zeros(len(words), np.uint8), n, 1, True)
+
+
+def test_full_size_properties(dd):
+    """BASELINE metric size (10 M reads): size-independent properties"""
+    n_reads = 10_000_000
+    words, filt = synth_words(n_reads, 1002, 24)
+    cid, keep, s = dd.run(words, filt)
+    assert s["total"] == n_reads and s["usable"] == int((filt == 0).sum())
+    # filtered <=> cluster 0, never kept
+    assert np.array_equal(cid == 0, filt == 1)
+    assert not keep[filt == 1].any()
+    # exactly one kept read per cluster, ids are 1..C
+    assert int(keep.sum()) == s["clusters"] == int(cid.max())
+    kept_ids = np.sort(cid[keep == 1])
+    assert np.array_equal(kept_ids, np.arange(1, s["clusters"] + 1, dtype=np.uint32))
+    # equal words share a cluster
+    order = np.argsort(words, kind="stable")
+    sw, sc, sf = words[order], cid[order], filt[order]
+    same = (sw[1:] == sw[:-1]) & (sf[1:] == 0) & (sf[:-1] == 0)
+    assert np.array_equal(sc[1:][same], sc[:-1][same])
+    # counts histogram sums to unique; sizes sum to usable
+    h = dd.histograms()
+    assert sum(v for _, v in h["counts"]) == s["unique"]
+    assert sum(k * v for k, v in h["counts"]) == s["usable"]
+    assert sum(k * v for k, v in h["clusters"]) == s["usable"]
+    assert sum(v for _, v in h["clusters"]) == s["clusters"]
+    assert sum(k * v for k, v in h["neigh"]) == 2 * s["edges"]
+    # idempotence: deduplicating the kept reads keeps all of them (no two kept words are
+    # directional duplicates of each other once counts are 1 -- a 1-count never absorbs a 1-count)
+    kw = words[keep == 1]
+    cid2, keep2, s2 = dd.run(kw, np.zeros(len(kw), np.uint8))
+    assert int(keep2.sum()) == len(kw) == s2["clusters"]
+    # cluster ids ascend with the smallest word... of the creating leaf: id 1 belongs to the
+    # cluster holding the smallest usable word
+    smallest = sw[sf == 0][0]
+    assert cid[(words == smallest) & (filt == 0)][0] >= 1
