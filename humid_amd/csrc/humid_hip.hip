@@ -64,65 +64,106 @@ __device__ __forceinline__ bool at_least_double(u64 a, u64 b) { return a >= 2 * 
 // --------------------------------------------------------------------------------
 // 1. exact counts: open-address hash of packed words
 // --------------------------------------------------------------------------------
-// keys[cap+1] (slot cap is reserved for the word that equals EMPTY_KEY, i.e. n=32 all-T),
-// cnt/first[cap+1].  One read per thread iteration; the claiming thread registers the slot
-// in uniq_slot (arbitrary order; sorted afterwards).
+// One 16-byte slot per word so that the key probe and both atomics touch ONE line.
+// The table is initialised by a plain 0xff memset: key = EMPTY, cnt = 0xffffffff (count-1,
+// wraps to 0 on the first add), first = 0xffffffff (atomicMin identity).
+// tab[cap+1]: slot `cap` is reserved for the word that equals EMPTY_KEY (n = 32, all T).
+struct __attribute__((aligned(16))) Slot {
+  u64 key;
+  u32 cntm1;   // occurrences - 1; 0xffffffff = never touched
+  u32 first;   // smallest read index with this word
+};
+
 __global__ void __launch_bounds__(256)
 k_hash_insert(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n_reads,
-              u64 *keys, u32 *cnt, u32 *first, u32 cap_log2, u32 *__restrict__ slot_of_read,
-              u32 *__restrict__ uniq_slot, ull *ctr) {
+              Slot *tab, u32 cap_log2, u32 *__restrict__ slot_of_read) {
   const u32 mask = (1u << cap_log2) - 1u;
   const u32 cap = 1u << cap_log2;
-  u32 usable = 0;
   for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
     if (filtered[r]) { slot_of_read[r] = NOSLOT; continue; }
-    usable++;
     const u64 w = words[r];
     u32 s;
     if (w == EMPTY_KEY) {
       s = cap;
-      if (atomicCAS((ull *)&ctr[CTR_SPECIAL], 0ull, 1ull) == 0ull) {
-        u32 uid = (u32)atomicAdd(&ctr[CTR_UNIQUE], 1ull);
-        uniq_slot[uid] = s;
-      }
     } else {
       s = (u32)(mix64(w) >> (64 - cap_log2)) & mask;
       while (true) {
-        u64 k = keys[s];
-        if (k == EMPTY_KEY) {
-          k = atomicCAS((ull *)&keys[s], EMPTY_KEY, (ull)w);
-          if (k == EMPTY_KEY) {
-            u32 uid = (u32)atomicAdd(&ctr[CTR_UNIQUE], 1ull);
-            uniq_slot[uid] = s;
-            break;
-          }
-        }
-        if (k == w) break;
+        u64 k = tab[s].key;
+        if (k == EMPTY_KEY) k = atomicCAS((ull *)&tab[s].key, EMPTY_KEY, (ull)w);
+        if (k == EMPTY_KEY || k == w) break;
         s = (s + 1) & mask;
       }
     }
-    atomicAdd(&cnt[s], 1u);
-    atomicMin(&first[s], r);
+    atomicAdd(&tab[s].cntm1, 1u);
+    atomicMin(&tab[s].first, r);
     slot_of_read[r] = s;
   }
-  if (usable) atomicAdd(&ctr[CTR_USABLE], (ull)usable);
 }
 
-__global__ void k_gather_words(const u64 *__restrict__ keys, const u32 *__restrict__ uniq_slot,
-                               u32 n, u64 *__restrict__ out) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = keys[uniq_slot[i]];
+// block-level stream compaction helper: every thread brings `n_mine` (0..4) items; returns the
+// global position of its first item.  One global atomic per block.
+__device__ __forceinline__ u32 block_reserve(u32 n_mine, ull *counter, u32 *lds /* >= 8 u32 */) {
+  const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // inclusive wave scan
+  u32 x = n_mine;
+#pragma unroll
+  for (u32 d = 1; d < 64; d <<= 1) {
+    u32 y = __shfl_up(x, d);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) lds[wv] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 tot = 0;
+    const u32 nw = (blockDim.x + 63) >> 6;
+    for (u32 k = 0; k < nw; k++) { u32 t = lds[k]; lds[k] = tot; tot += t; }
+    lds[4] = tot ? (u32)atomicAdd(counter, (ull)tot) : 0u;
+  }
+  __syncthreads();
+  const u32 pos = lds[4] + lds[wv] + (x - n_mine);
+  __syncthreads();
+  return pos;
 }
 
-// after the sort: per rank i gather count / first read, and record slot -> rank
-__global__ void k_post_sort(const u32 *__restrict__ s_slot, const u32 *__restrict__ cnt,
-                            const u32 *__restrict__ first, u32 n, u32 *__restrict__ s_cnt,
-                            u32 *__restrict__ s_first) {
+// occupied slots -> (word, slot) list in arbitrary order; also sums the usable reads
+__global__ void __launch_bounds__(256)
+k_compact_table(const Slot *__restrict__ tab, u32 n_slots, u64 *__restrict__ uniq_word,
+                u32 *__restrict__ uniq_slot, ull *ctr) {
+  __shared__ u32 lds[8];
+  const u32 base = blockIdx.x * 1024u;
+  Slot sl[4];
+  u32 mine = 0;
+  u32 reads = 0;
+#pragma unroll
+  for (u32 j = 0; j < 4; j++) {
+    const u32 sidx = base + j * 256u + threadIdx.x;
+    sl[j].cntm1 = NONE32;
+    if (sidx < n_slots) sl[j] = tab[sidx];
+    if (sl[j].cntm1 != NONE32) { mine++; reads += sl[j].cntm1 + 1u; }
+  }
+  u32 pos = block_reserve(mine, &ctr[CTR_UNIQUE], lds);
+#pragma unroll
+  for (u32 j = 0; j < 4; j++) {
+    if (sl[j].cntm1 != NONE32) {
+      uniq_word[pos] = sl[j].key;
+      uniq_slot[pos] = base + j * 256u + threadIdx.x;
+      pos++;
+    }
+  }
+  // usable reads: wave reduce, one atomic per wave
+#pragma unroll
+  for (u32 d = 32; d >= 1; d >>= 1) reads += __shfl_down(reads, d);
+  if ((threadIdx.x & 63) == 0 && reads) atomicAdd(&ctr[CTR_USABLE], (ull)reads);
+}
+
+// after the sort: per rank i gather count / first read from the table
+__global__ void k_post_sort(const u32 *__restrict__ s_slot, const Slot *__restrict__ tab, u32 n,
+                            u32 *__restrict__ s_cnt, u32 *__restrict__ s_first) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
-    u32 s = s_slot[i];
-    s_cnt[i] = cnt[s];
-    s_first[i] = first[s];
+    const Slot sl = tab[s_slot[i]];
+    s_cnt[i] = sl.cntm1 + 1u;
+    s_first[i] = sl.first;
   }
 }
 
@@ -147,10 +188,14 @@ __global__ void k_seg_keys(const u64 *__restrict__ s_word, u32 n, u32 shift, u64
 // One thread per position i of the bucket-sorted order; compares with the following
 // elements of its bucket.  Ranks ascend inside a bucket, so (ri < rj) always.  A pair is
 // emitted only from the FIRST segment it agrees on (earlier segments must all differ).
-template <bool PASS0>
+// Two phases with identical control flow, so there is no shared append counter:
+//   FILL = false: pc[i] = pairs found by thread i; deg[] += 1 per endpoint
+//   FILL = true : writes both directions of pair k of thread i at 2*(poff[i] + k)
+template <bool PASS0, bool FILL>
 __global__ void __launch_bounds__(256)
 k_pairs(const u64 *__restrict__ s_word, const u32 *__restrict__ K, const u32 *__restrict__ V,
-        u32 n, SegPlan plan, u32 seg, u32 distance, u32 *deg, u64 *ekeys, u64 ecap, ull *ctr) {
+        u32 n, SegPlan plan, u32 seg, u32 distance, u32 *deg, u32 *__restrict__ pc,
+        const u32 *__restrict__ poff, u64 *__restrict__ ekeys) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u32 shift = plan.shift[seg];
@@ -160,6 +205,8 @@ k_pairs(const u64 *__restrict__ s_word, const u32 *__restrict__ K, const u32 *__
   u64 ki;
   if (PASS0) { ri = i; wi = s_word[i]; ki = (wi >> shift) & mask; }
   else { ri = V[i]; wi = s_word[ri]; ki = K[i]; }
+  u32 found = 0;
+  u64 e = FILL ? (u64)poff[i] : 0;
   for (u32 j = i + 1; j < n; j++) {
     u32 rj;
     u64 wj;
@@ -176,14 +223,30 @@ k_pairs(const u64 *__restrict__ s_word, const u32 *__restrict__ K, const u32 *__
     for (u32 t = 0; t < seg; t++)
       if (((x >> plan.shift[t]) & plan.mask[t]) == 0) { firstseg = false; break; }
     if (!firstseg) continue;
-    ull e = atomicAdd(&ctr[CTR_EDGES], 1ull);
-    if (2 * e + 1 < ecap) {
+    if (FILL) {
       ekeys[2 * e] = ((u64)ri << 32) | rj;
       ekeys[2 * e + 1] = ((u64)rj << 32) | ri;
+      e++;
+    } else {
+      found++;
+      atomicAdd(&deg[rj], 1u);
     }
-    if (atomicAdd(&deg[ri], 1u) == 0) atomicAdd(&ctr[CTR_NONSINGLE], 1ull);
-    if (atomicAdd(&deg[rj], 1u) == 0) atomicAdd(&ctr[CTR_NONSINGLE], 1ull);
   }
+  if (!FILL) {
+    pc[i] = found;
+    if (found) atomicAdd(&deg[ri], found);
+  }
+}
+
+// number of leaves with at least one neighbour (block-reduced, one atomic per wave)
+__global__ void __launch_bounds__(256)
+k_count_nonzero(const u32 *__restrict__ deg, u32 n, ull *ctr) {
+  u32 c = 0;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    c += deg[i] ? 1u : 0u;
+#pragma unroll
+  for (u32 d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&ctr[CTR_NONSINGLE], (ull)c);
 }
 
 __global__ void k_low32(const u64 *__restrict__ in, u64 n, u32 *__restrict__ out) {
@@ -231,14 +294,16 @@ __global__ void k_union_csr(const u32 *__restrict__ off, const u32 *__restrict__
     if (idx[k] != u) uf_union(P, u, idx[k]);
 }
 
-// members = nodes with >= 1 neighbour, keyed (root << 32 | rank)
-__global__ void k_member_keys(const u32 *__restrict__ deg, u32 *P, u32 n, u64 *mkeys, ull *ctr) {
+// members = nodes with >= 1 neighbour, keyed (root << 32 | rank); unordered, sorted afterwards
+__global__ void __launch_bounds__(256)
+k_member_keys(const u32 *__restrict__ deg, u32 *P, u32 n, u64 *mkeys, ull *ctr) {
+  __shared__ u32 lds[8];
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= n) return;
-  if (deg[u] == 0) return;
-  u32 root = uf_find(P, u);
-  ull pos = atomicAdd(&ctr[CTR_MEMBERS], 1ull);
-  mkeys[pos] = ((u64)root << 32) | u;
+  const bool mem = (u < n) && deg[u] != 0;
+  u32 root = 0;
+  if (mem) root = uf_find(P, u);
+  const u32 pos = block_reserve(mem ? 1u : 0u, &ctr[CTR_MEMBERS], lds);
+  if (mem) mkeys[pos] = ((u64)root << 32) | u;
 }
 
 // --------------------------------------------------------------------------------
@@ -429,12 +494,12 @@ struct humid_ctx {
   ull *d_ctr = nullptr;
   ull *h_ctr = nullptr;   // pinned mirror
   DBuf in_words, in_filt, out_cid, out_keep;                 // host entry point staging
-  DBuf keys, cnt, first, slot_out, slot_of_read, uniq_slot;  // table (cap+1) and per-read
+  DBuf table, slot_out, slot_of_read, uniq_slot;             // table (cap+1) and per-read
   DBuf uniq_word, s_word, s_slot, s_cnt, s_first;            // unique words (walk order)
-  DBuf deg, nbr_off, nbr_idx, seg_k0, seg_k1, seg_v0, seg_v1, ek0, ek1;
+  DBuf deg, nbr_off, nbr_idx, seg_k0, seg_v0, seg_ks, seg_vs, pc, poff, ek0, ek1;
   DBuf parent, mk0, mk1, cl_of, maxleaf, cl_size, flag, pos, cid, ismax, stk, tmp, scratch;
   hipEvent_t ev[6] = {};
-  hipEvent_t kev[40] = {};   // per-kernel timing: [0,1] insert, [2,3] cluster, [4..] pairs per segment
+  hipEvent_t kev[40] = {};   // per-kernel timing: [0,1] insert, [2,3] cluster, [4..19] pairs fill, [20..35] pairs count
   bool have_run = false;
   bool graph_mode = false;
   u64 N = 0, U = 0, E = 0, M = 0, C = 0, usable = 0;
@@ -501,8 +566,12 @@ static int exscan_u32(humid_ctx *c, const u32 *in, u32 *out, u64 n) {
   return HUMID_OK;
 }
 
-static int read_counters(humid_ctx *c) {
+// device counters -> pinned mirror, one stream sync.  extra32 (device u32, may be null) lands
+// in h_ctr[CTR_N - 1].
+static int read_counters(humid_ctx *c, const u32 *extra32 = nullptr) {
   HIPCHK(hipMemcpyAsync(c->h_ctr, c->d_ctr, CTR_N * sizeof(ull), hipMemcpyDeviceToHost, c->stream));
+  if (extra32)
+    HIPCHK(hipMemcpyAsync(&c->h_ctr[CTR_N - 1], extra32, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return HUMID_OK;
 }
@@ -604,22 +673,21 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
   u32 cap_log2 = 10;
   while (((u64)1 << cap_log2) < (u64)N + N / 2) cap_log2++;
   const u64 cap = (u64)1 << cap_log2;
-  ENSURE(c->keys, (cap + 1) * 8);
-  ENSURE(c->cnt, (cap + 1) * 4);
-  ENSURE(c->first, (cap + 1) * 4);
+  ENSURE(c->table, (cap + 1) * sizeof(Slot));
   ENSURE(c->slot_out, (cap + 1) * 8);
   ENSURE(c->slot_of_read, (size_t)N * 4);
   ENSURE(c->uniq_slot, (size_t)N * 4);
+  ENSURE(c->uniq_word, (size_t)N * 8);
   HIPCHK(hipEventRecord(c->ev[0], st));
   HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_N * sizeof(ull), st));
-  HIPCHK(hipMemsetAsync(c->keys.p, 0xff, (cap + 1) * 8, st));
-  HIPCHK(hipMemsetAsync(c->cnt.p, 0, (cap + 1) * 4, st));
-  HIPCHK(hipMemsetAsync(c->first.p, 0xff, (cap + 1) * 4, st));
+  HIPCHK(hipMemsetAsync(c->table.p, 0xff, (cap + 1) * sizeof(Slot), st));
   HIPCHK(hipEventRecord(c->kev[0], st));
   hipLaunchKernelGGL(k_hash_insert, dim3(grid_stride_blocks(N)), dim3(256), 0, st, d_words, d_filt, N,
-                     c->keys.as<u64>(), c->cnt.as<u32>(), c->first.as<u32>(), cap_log2,
-                     c->slot_of_read.as<u32>(), c->uniq_slot.as<u32>(), c->d_ctr);
+                     c->table.as<Slot>(), cap_log2, c->slot_of_read.as<u32>());
   HIPCHK(hipEventRecord(c->kev[1], st));
+  hipLaunchKernelGGL(k_compact_table, dim3(blocks_for(cap + 1, 1024)), dim3(256), 0, st,
+                     c->table.as<Slot>(), (u32)(cap + 1), c->uniq_word.as<u64>(), c->uniq_slot.as<u32>(),
+                     c->d_ctr);
   HIPCHK(hipGetLastError());
   TRY(read_counters(c));
   const u32 U = (u32)c->h_ctr[CTR_UNIQUE];
@@ -636,83 +704,93 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
   }
 
   // ---------------- 2. walk order -----------------
-  ENSURE(c->uniq_word, (size_t)U * 8);
   ENSURE(c->s_word, (size_t)U * 8);
   ENSURE(c->s_slot, (size_t)U * 4);
   ENSURE(c->s_cnt, (size_t)U * 4);
   ENSURE(c->s_first, (size_t)U * 4);
-  hipLaunchKernelGGL(k_gather_words, dim3(blocks_for(U)), dim3(256), 0, st, c->keys.as<u64>(),
-                     c->uniq_slot.as<u32>(), U, c->uniq_word.as<u64>());
   TRY(sort_pairs<u64, u32>(c, c->uniq_word.as<u64>(), c->s_word.as<u64>(), c->uniq_slot.as<u32>(),
                            c->s_slot.as<u32>(), U, 0, 2 * word_nt));
   hipLaunchKernelGGL(k_post_sort, dim3(blocks_for(U)), dim3(256), 0, st, c->s_slot.as<u32>(),
-                     c->cnt.as<u32>(), c->first.as<u32>(), U, c->s_cnt.as<u32>(), c->s_first.as<u32>());
+                     c->table.as<Slot>(), U, c->s_cnt.as<u32>(), c->s_first.as<u32>());
   HIPCHK(hipEventRecord(c->ev[1], st));
 
   // ---------------- 3. neighbours -----------------
-  ENSURE(c->deg, (size_t)U * 4);
+  // deg has U+1 entries (last stays 0) so that one exclusive scan yields nbr_off[U] = 2E
+  ENSURE(c->deg, (size_t)(U + 1) * 4);
   ENSURE(c->nbr_off, (size_t)(U + 1) * 4);
+  HIPCHK(hipMemsetAsync(c->deg.p, 0, (size_t)(U + 1) * 4, st));
   u64 E = 0, M = 0;
   u32 n_pair_segs = 0;
-  if (distance > 0 && U > 1) {
-    SegPlan plan = make_plan(word_nt, distance);
-    if (plan.nseg > 1) {
-      ENSURE(c->seg_k0, (size_t)U * 4); ENSURE(c->seg_k1, (size_t)U * 4);
-      ENSURE(c->seg_v0, (size_t)U * 4); ENSURE(c->seg_v1, (size_t)U * 4);
+  SegPlan plan = make_plan(word_nt, distance);
+  const bool search = distance > 0 && U > 1;
+  if (search) {
+    const u32 nseg = plan.nseg;
+    n_pair_segs = nseg < 8 ? nseg : 8;
+    ENSURE(c->pc, ((size_t)nseg * U + 1) * 4);
+    ENSURE(c->poff, ((size_t)nseg * U + 1) * 4);
+    if (nseg > 1) {
+      ENSURE(c->seg_k0, (size_t)U * 4);
+      ENSURE(c->seg_v0, (size_t)U * 4);
+      ENSURE(c->seg_ks, (size_t)(nseg - 1) * U * 4);
+      ENSURE(c->seg_vs, (size_t)(nseg - 1) * U * 4);
     }
-    u64 ecap = c->ek0.cap / 8;
-    if (ecap < 2ull * 1024 * 1024) ecap = 2ull * 1024 * 1024;
-    if (ecap < (u64)U) ecap = U;
-    for (int attempt = 0; attempt < 2; attempt++) {
-      ENSURE(c->ek0, ecap * 8);
-      ecap = c->ek0.cap / 8;
-      HIPCHK(hipMemsetAsync(c->deg.p, 0, (size_t)U * 4, st));
-      HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_EDGES], 0, 2 * sizeof(ull), st));   // EDGES, NONSINGLE
-      for (u32 seg = 0; seg < plan.nseg; seg++) {
-        if (seg == 0) {
-          if (seg < 16) HIPCHK(hipEventRecord(c->kev[4 + 2 * seg], st));
-          hipLaunchKernelGGL(k_pairs<true>, dim3(blocks_for(U)), dim3(256), 0, st, c->s_word.as<u64>(),
-                             (const u32 *)nullptr, (const u32 *)nullptr, U, plan, seg, distance,
-                             c->deg.as<u32>(), c->ek0.as<u64>(), ecap, c->d_ctr);
-        } else {
-          u32 width = 0;
-          while (width < 64 && (plan.mask[seg] >> width)) width++;
-          hipLaunchKernelGGL(k_seg_keys, dim3(blocks_for(U)), dim3(256), 0, st, c->s_word.as<u64>(), U,
-                             plan.shift[seg], plan.mask[seg], c->seg_k0.as<u32>(), c->seg_v0.as<u32>());
-          TRY(sort_pairs<u32, u32>(c, c->seg_k0.as<u32>(), c->seg_k1.as<u32>(), c->seg_v0.as<u32>(),
-                                   c->seg_v1.as<u32>(), U, 0, width ? width : 1));
-          if (seg < 16) HIPCHK(hipEventRecord(c->kev[4 + 2 * seg], st));
-          hipLaunchKernelGGL(k_pairs<false>, dim3(blocks_for(U)), dim3(256), 0, st, c->s_word.as<u64>(),
-                             c->seg_k1.as<u32>(), c->seg_v1.as<u32>(), U, plan, seg, distance,
-                             c->deg.as<u32>(), c->ek0.as<u64>(), ecap, c->d_ctr);
-        }
-        if (seg < 16) HIPCHK(hipEventRecord(c->kev[5 + 2 * seg], st));
-        n_pair_segs = seg + 1 < 16 ? seg + 1 : 16;
+    HIPCHK(hipMemsetAsync(c->pc.as<u32>() + (size_t)nseg * U, 0, 4, st));
+    // phase A: bucket order per segment + pair counts
+    for (u32 seg = 0; seg < nseg; seg++) {
+      u32 *pcs = c->pc.as<u32>() + (size_t)seg * U;
+      if (seg == 0) HIPCHK(hipEventRecord(c->kev[20], st));
+      if (seg == 0) {
+        hipLaunchKernelGGL((k_pairs<true, false>), dim3(blocks_for(U)), dim3(256), 0, st, c->s_word.as<u64>(),
+                           (const u32 *)nullptr, (const u32 *)nullptr, U, plan, seg, distance,
+                           c->deg.as<u32>(), pcs, (const u32 *)nullptr, (u64 *)nullptr);
+      } else {
+        u32 width = 0;
+        while (width < 64 && (plan.mask[seg] >> width)) width++;
+        u32 *ks = c->seg_ks.as<u32>() + (size_t)(seg - 1) * U;
+        u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
+        hipLaunchKernelGGL(k_seg_keys, dim3(blocks_for(U)), dim3(256), 0, st, c->s_word.as<u64>(), U,
+                           plan.shift[seg], plan.mask[seg], c->seg_k0.as<u32>(), c->seg_v0.as<u32>());
+        TRY(sort_pairs<u32, u32>(c, c->seg_k0.as<u32>(), ks, c->seg_v0.as<u32>(), vs, U, 0, width ? width : 1));
+        if (seg < 8) HIPCHK(hipEventRecord(c->kev[20 + 2 * seg], st));
+        hipLaunchKernelGGL((k_pairs<false, false>), dim3(blocks_for(U)), dim3(256), 0, st, c->s_word.as<u64>(),
+                           ks, vs, U, plan, seg, distance, c->deg.as<u32>(), pcs, (const u32 *)nullptr,
+                           (u64 *)nullptr);
       }
-      HIPCHK(hipGetLastError());
-      TRY(read_counters(c));
-      E = c->h_ctr[CTR_EDGES];
-      M = c->h_ctr[CTR_NONSINGLE];
-      if (2 * E <= ecap) break;
-      if (attempt == 1) return fail(c, HUMID_E_HIP, "edge buffer overflow after regrow");
-      ecap = 2 * E;
+      if (seg < 8) HIPCHK(hipEventRecord(c->kev[21 + 2 * seg], st));
     }
+    TRY(exscan_u32(c, c->pc.as<u32>(), c->poff.as<u32>(), (u64)nseg * U + 1));
+    hipLaunchKernelGGL(k_count_nonzero, dim3(grid_stride_blocks(U)), dim3(256), 0, st, c->deg.as<u32>(), U, c->d_ctr);
+    HIPCHK(hipGetLastError());
+    TRY(read_counters(c, c->poff.as<u32>() + (size_t)nseg * U));   // d_ctr[CTR_N-1] is always 0
+    E = c->h_ctr[CTR_N - 1] & 0xffffffffull;
+    M = c->h_ctr[CTR_NONSINGLE];
     if (2 * E >= 0xffffffffull) return fail(c, HUMID_E_OVERFLOW, "2*edges = %llu exceeds 32 bits", (ull)(2 * E));
-  } else {
-    HIPCHK(hipMemsetAsync(c->deg.p, 0, (size_t)U * 4, st));
   }
   s.edges = c->E = E;
   s.nonsingle = c->M = M;
-  TRY(exscan_u32(c, c->deg.as<u32>(), c->nbr_off.as<u32>(), U));
-  {
-    u32 twoE = (u32)(2 * E);
-    HIPCHK(hipMemcpyAsync(c->nbr_off.as<u32>() + U, &twoE, 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));   // twoE is a stack variable
-  }
+  TRY(exscan_u32(c, c->deg.as<u32>(), c->nbr_off.as<u32>(), (u64)U + 1));
   ENSURE(c->nbr_idx, (size_t)(2 * E + 1) * 4);
   ENSURE(c->parent, (size_t)U * 4);
   if (E > 0) {
+    ENSURE(c->ek0, (size_t)2 * E * 8);
     ENSURE(c->ek1, (size_t)2 * E * 8);
+    // phase B: same loops, now writing the directed (src, dst) keys
+    for (u32 seg = 0; seg < plan.nseg; seg++) {
+      const u32 *pos = c->poff.as<u32>() + (size_t)seg * U;
+      if (seg < 8) HIPCHK(hipEventRecord(c->kev[4 + 2 * seg], st));
+      if (seg == 0) {
+        hipLaunchKernelGGL((k_pairs<true, true>), dim3(blocks_for(U)), dim3(256), 0, st, c->s_word.as<u64>(),
+                           (const u32 *)nullptr, (const u32 *)nullptr, U, plan, seg, distance,
+                           (u32 *)nullptr, (u32 *)nullptr, pos, c->ek0.as<u64>());
+      } else {
+        const u32 *ks = c->seg_ks.as<u32>() + (size_t)(seg - 1) * U;
+        const u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
+        hipLaunchKernelGGL((k_pairs<false, true>), dim3(blocks_for(U)), dim3(256), 0, st, c->s_word.as<u64>(),
+                           ks, vs, U, plan, seg, distance, (u32 *)nullptr, (u32 *)nullptr, pos,
+                           c->ek0.as<u64>());
+      }
+      if (seg < 8) HIPCHK(hipEventRecord(c->kev[5 + 2 * seg], st));
+    }
     // CSR lists ascending: sort the directed (src, dst) keys
     TRY(sort_keys<u64>(c, c->ek0.as<u64>(), c->ek1.as<u64>(), 2 * E, 0, 32 + bits_for(U)));
     hipLaunchKernelGGL(k_low32, dim3(blocks_for(2 * E)), dim3(256), 0, st, c->ek1.as<u64>(), 2 * E,
@@ -748,8 +826,12 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
   if (M > 0) HIPCHK(hipEventElapsedTime(&s.ms_k_cluster, c->kev[2], c->kev[3]));
   for (u32 g = 0; g < n_pair_segs; g++) {
     float t = 0;
-    HIPCHK(hipEventElapsedTime(&t, c->kev[4 + 2 * g], c->kev[5 + 2 * g]));
+    HIPCHK(hipEventElapsedTime(&t, c->kev[20 + 2 * g], c->kev[21 + 2 * g]));   // count phase
     s.ms_k_pairs += t;
+    if (E > 0) {
+      HIPCHK(hipEventElapsedTime(&t, c->kev[4 + 2 * g], c->kev[5 + 2 * g]));   // fill phase
+      s.ms_k_pairs += t;
+    }
   }
   if (sum) *sum = s;
   c->have_run = true;
@@ -810,10 +892,10 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->keys, &c->cnt, &c->first,
+  DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
-                  &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_k1,
-                  &c->seg_v0, &c->seg_v1, &c->ek0, &c->ek1, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
+                  &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
+                  &c->seg_v0, &c->seg_vs, &c->pc, &c->poff, &c->ek0, &c->ek1, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
                   &c->maxleaf, &c->cl_size, &c->flag, &c->pos, &c->cid, &c->ismax, &c->stk, &c->tmp,
                   &c->scratch};
   for (DBuf *b : bufs) b->release();

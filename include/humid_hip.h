@@ -59,7 +59,7 @@ typedef struct humid_summary {
   float ms_h2d, ms_d2h; /* host-buffer entry point only                           */
   /* single kernels, HIP events directly around the launches on the ctx stream:      */
   float ms_k_insert;    /* k_hash_insert (one launch)                               */
-  float ms_k_pairs;     /* sum over the d+1 k_pairs launches                        */
+  float ms_k_pairs;     /* sum over the 2(d+1) k_pairs launches (count + fill)      */
   float ms_k_cluster;   /* k_cluster_components (one launch; 0 if no neighbours)    */
   float ms_k_map;       /* k_read_map (one launch)                                  */
 } humid_summary;
