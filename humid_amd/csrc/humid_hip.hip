@@ -100,29 +100,34 @@ k_hash_insert(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u3
   }
 }
 
-// block-level stream compaction helper: every thread brings `n_mine` (0..4) items; returns the
-// global position of its first item.  One global atomic per block.
-__device__ __forceinline__ u32 block_reserve(u32 n_mine, ull *counter, u32 *lds /* >= 8 u32 */) {
-  const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  // inclusive wave scan
-  u32 x = n_mine;
+// A single-address global atomic costs ~12 ns and serialises (rocprof: 80 k of them = 1 ms), so
+// compaction kernels run a FIXED small grid; each block owns a contiguous chunk, counts its
+// items, reserves output space with ONE atomic, then writes in a second pass over the chunk
+// (L2-resident by then).
+#define COMPACT_BLOCKS 1024u
+
+// block-wide sum of a per-thread value (256 threads); result valid in all threads
+__device__ __forceinline__ u32 block_sum(u32 x, u32 *lds /* >= 4 u32 */) {
 #pragma unroll
-  for (u32 d = 1; d < 64; d <<= 1) {
-    u32 y = __shfl_up(x, d);
-    if (lane >= d) x += y;
-  }
-  if (lane == 63) lds[wv] = x;
+  for (u32 d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = x;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    u32 tot = 0;
-    const u32 nw = (blockDim.x + 63) >> 6;
-    for (u32 k = 0; k < nw; k++) { u32 t = lds[k]; lds[k] = tot; tot += t; }
-    lds[4] = tot ? (u32)atomicAdd(counter, (ull)tot) : 0u;
-  }
+  u32 t = lds[0] + lds[1] + lds[2] + lds[3];
   __syncthreads();
-  const u32 pos = lds[4] + lds[wv] + (x - n_mine);
+  return t;
+}
+
+// exclusive position of this thread's flag among the block's 256 flags; *total = block count
+__device__ __forceinline__ u32 block_rank(bool flag, u32 *lds /* >= 4 u32 */, u32 *total) {
+  const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const u64 m = __ballot(flag);
+  if (lane == 0) lds[wv] = (u32)__popcll(m);
   __syncthreads();
-  return pos;
+  u32 before = 0;
+  for (u32 k = 0; k < wv; k++) before += lds[k];
+  *total = lds[0] + lds[1] + lds[2] + lds[3];
+  __syncthreads();
+  return before + (u32)__popcll(m & ((1ull << lane) - 1ull));
 }
 
 // occupied slots -> (word, slot) list in arbitrary order; also sums the usable reads
@@ -130,30 +135,35 @@ __global__ void __launch_bounds__(256)
 k_compact_table(const Slot *__restrict__ tab, u32 n_slots, u64 *__restrict__ uniq_word,
                 u32 *__restrict__ uniq_slot, ull *ctr) {
   __shared__ u32 lds[8];
-  const u32 base = blockIdx.x * 1024u;
-  Slot sl[4];
-  u32 mine = 0;
-  u32 reads = 0;
-#pragma unroll
-  for (u32 j = 0; j < 4; j++) {
-    const u32 sidx = base + j * 256u + threadIdx.x;
-    sl[j].cntm1 = NONE32;
-    if (sidx < n_slots) sl[j] = tab[sidx];
-    if (sl[j].cntm1 != NONE32) { mine++; reads += sl[j].cntm1 + 1u; }
+  const u32 chunk = (n_slots + gridDim.x - 1) / gridDim.x;
+  const u32 lo = blockIdx.x * chunk;
+  const u32 hi = (lo + chunk < n_slots) ? lo + chunk : n_slots;
+  u32 mine = 0, reads = 0;
+  for (u32 sidx = lo + threadIdx.x; sidx < hi; sidx += 256) {
+    const u32 c = tab[sidx].cntm1;
+    if (c != NONE32) { mine++; reads += c + 1u; }
   }
-  u32 pos = block_reserve(mine, &ctr[CTR_UNIQUE], lds);
-#pragma unroll
-  for (u32 j = 0; j < 4; j++) {
-    if (sl[j].cntm1 != NONE32) {
-      uniq_word[pos] = sl[j].key;
-      uniq_slot[pos] = base + j * 256u + threadIdx.x;
-      pos++;
+  const u32 total = block_sum(mine, lds);
+  const u32 total_reads = block_sum(reads, lds);
+  if (threadIdx.x == 0) {
+    lds[4] = total ? (u32)atomicAdd(&ctr[CTR_UNIQUE], (ull)total) : 0u;
+    if (total_reads) atomicAdd(&ctr[CTR_USABLE], (ull)total_reads);
+  }
+  __syncthreads();
+  u32 base = lds[4];
+  for (u32 s0 = lo; s0 < hi; s0 += 256) {
+    const u32 sidx = s0 + threadIdx.x;
+    Slot sl;
+    sl.cntm1 = NONE32;
+    if (sidx < hi) sl = tab[sidx];
+    u32 tot;
+    const u32 r = block_rank(sl.cntm1 != NONE32, lds, &tot);
+    if (sl.cntm1 != NONE32) {
+      uniq_word[base + r] = sl.key;
+      uniq_slot[base + r] = sidx;
     }
+    base += tot;
   }
-  // usable reads: wave reduce, one atomic per wave
-#pragma unroll
-  for (u32 d = 32; d >= 1; d >>= 1) reads += __shfl_down(reads, d);
-  if ((threadIdx.x & 63) == 0 && reads) atomicAdd(&ctr[CTR_USABLE], (ull)reads);
 }
 
 // after the sort: per rank i gather count / first read from the table
@@ -238,15 +248,15 @@ k_pairs(const u64 *__restrict__ s_word, const u32 *__restrict__ K, const u32 *__
   }
 }
 
-// number of leaves with at least one neighbour (block-reduced, one atomic per wave)
+// number of leaves with at least one neighbour (fixed small grid, one atomic per block)
 __global__ void __launch_bounds__(256)
 k_count_nonzero(const u32 *__restrict__ deg, u32 n, ull *ctr) {
+  __shared__ u32 lds[4];
   u32 c = 0;
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     c += deg[i] ? 1u : 0u;
-#pragma unroll
-  for (u32 d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&ctr[CTR_NONSINGLE], (ull)c);
+  const u32 t = block_sum(c, lds);
+  if (threadIdx.x == 0 && t) atomicAdd(&ctr[CTR_NONSINGLE], (ull)t);
 }
 
 __global__ void k_low32(const u64 *__restrict__ in, u64 n, u32 *__restrict__ out) {
@@ -298,12 +308,24 @@ __global__ void k_union_csr(const u32 *__restrict__ off, const u32 *__restrict__
 __global__ void __launch_bounds__(256)
 k_member_keys(const u32 *__restrict__ deg, u32 *P, u32 n, u64 *mkeys, ull *ctr) {
   __shared__ u32 lds[8];
-  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool mem = (u < n) && deg[u] != 0;
-  u32 root = 0;
-  if (mem) root = uf_find(P, u);
-  const u32 pos = block_reserve(mem ? 1u : 0u, &ctr[CTR_MEMBERS], lds);
-  if (mem) mkeys[pos] = ((u64)root << 32) | u;
+  const u32 chunk = (n + gridDim.x - 1) / gridDim.x;
+  const u32 lo = blockIdx.x * chunk;
+  const u32 hi = (lo + chunk < n) ? lo + chunk : n;
+  u32 mine = 0;
+  for (u32 u = lo + threadIdx.x; u < hi; u += 256) mine += deg[u] ? 1u : 0u;
+  const u32 total = block_sum(mine, lds);
+  if (threadIdx.x == 0) lds[4] = total ? (u32)atomicAdd(&ctr[CTR_MEMBERS], (ull)total) : 0u;
+  __syncthreads();
+  u32 base = lds[4];
+  if (total == 0) return;
+  for (u32 u0 = lo; u0 < hi; u0 += 256) {
+    const u32 u = u0 + threadIdx.x;
+    const bool mem = (u < hi) && deg[u] != 0;
+    u32 tot;
+    const u32 r = block_rank(mem, lds, &tot);
+    if (mem) mkeys[base + r] = ((u64)uf_find(P, u) << 32) | u;
+    base += tot;
+  }
 }
 
 // --------------------------------------------------------------------------------
@@ -616,7 +638,7 @@ static int cluster_stage(humid_ctx *c, u32 U, u64 M, u32 method) {
     ENSURE(c->mk1, (size_t)M * 8);
     ENSURE(c->stk, (size_t)M * 8);
     HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_MEMBERS], 0, sizeof(ull), st));
-    hipLaunchKernelGGL(k_member_keys, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
+    hipLaunchKernelGGL(k_member_keys, dim3(COMPACT_BLOCKS), dim3(256), 0, st, c->deg.as<u32>(),
                        c->parent.as<u32>(), U, c->mk0.as<u64>(), c->d_ctr);
     TRY(sort_keys<u64>(c, c->mk0.as<u64>(), c->mk1.as<u64>(), M, 0, 32 + bits_for(U)));
     HIPCHK(hipEventRecord(c->kev[2], st));
@@ -685,7 +707,7 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
   hipLaunchKernelGGL(k_hash_insert, dim3(grid_stride_blocks(N)), dim3(256), 0, st, d_words, d_filt, N,
                      c->table.as<Slot>(), cap_log2, c->slot_of_read.as<u32>());
   HIPCHK(hipEventRecord(c->kev[1], st));
-  hipLaunchKernelGGL(k_compact_table, dim3(blocks_for(cap + 1, 1024)), dim3(256), 0, st,
+  hipLaunchKernelGGL(k_compact_table, dim3(COMPACT_BLOCKS), dim3(256), 0, st,
                      c->table.as<Slot>(), (u32)(cap + 1), c->uniq_word.as<u64>(), c->uniq_slot.as<u32>(),
                      c->d_ctr);
   HIPCHK(hipGetLastError());
@@ -759,7 +781,7 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
       if (seg < 8) HIPCHK(hipEventRecord(c->kev[21 + 2 * seg], st));
     }
     TRY(exscan_u32(c, c->pc.as<u32>(), c->poff.as<u32>(), (u64)nseg * U + 1));
-    hipLaunchKernelGGL(k_count_nonzero, dim3(grid_stride_blocks(U)), dim3(256), 0, st, c->deg.as<u32>(), U, c->d_ctr);
+    hipLaunchKernelGGL(k_count_nonzero, dim3(512), dim3(256), 0, st, c->deg.as<u32>(), U, c->d_ctr);
     HIPCHK(hipGetLastError());
     TRY(read_counters(c, c->poff.as<u32>() + (size_t)nseg * U));   // d_ctr[CTR_N-1] is always 0
     E = c->h_ctr[CTR_N - 1] & 0xffffffffull;
