@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--distance", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=4_000_000,
                     help="reads of the same workload the CPU oracle is timed on (0 = skip)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-GPU code path even with one rank (overhead measurement)")
     ap.add_argument("--traffic-json", default=None,
                     help="optional JSON with PMC-derived HBM bytes per launch of the dominant kernel")
     return ap.parse_args()
@@ -58,9 +60,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     n_local = a.reads
     seed = 1002                                   # metric config (1000 + config#)
@@ -73,7 +78,7 @@ def main():
     d_keep = torch.zeros(n_local, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
-    if world == 1:
+    if world == 1 and not a.force_sharded:
         dd = humid_amd.Dedup(device=local_rank)
 
         def step():

@@ -49,6 +49,17 @@ SYMBOLS = {
     "humid_cluster_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, u32p]),
+    "humid_stage_histogram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                        C.c_uint32, C.c_void_p]),
+    "humid_stage_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                    C.c_uint64, C.c_uint64, C.c_uint64, u64p, u64p]),
+    "humid_stage_unique": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_void_p)]),
+    "humid_stage_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                    C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_void_p), C.POINTER(HumidSummary)]),
+    "humid_stage_map": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                  C.c_void_p]),
     "humid_at_least_double": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_int)]),
 }
 

@@ -37,7 +37,7 @@ typedef unsigned long long ull;
 #define NONE32 0xffffffffu
 
 enum { CTR_UNIQUE = 0, CTR_USABLE, CTR_EDGES, CTR_NONSINGLE, CTR_MEMBERS, CTR_SPECIAL,
-       CTR_CLUSTERS, CTR_N = 16 };
+       CTR_CLUSTERS, CTR_OVERFULL, CTR_N = 16 };
 
 // --------------------------------------------------------------------------------
 // device helpers
@@ -76,23 +76,28 @@ struct __attribute__((aligned(16))) Slot {
 
 __global__ void __launch_bounds__(256)
 k_hash_insert(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n_reads,
-              Slot *tab, u32 cap_log2, u32 *__restrict__ slot_of_read) {
+              Slot *tab, u32 cap_log2, u32 *__restrict__ slot_of_read, u64 range_lo, u64 range_hi,
+              u32 max_probe, ull *ctr) {
   const u32 mask = (1u << cap_log2) - 1u;
   const u32 cap = 1u << cap_log2;
   for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
     if (filtered[r]) { slot_of_read[r] = NOSLOT; continue; }
     const u64 w = words[r];
+    if (w < range_lo || w > range_hi) { slot_of_read[r] = NOSLOT; continue; }   // another rank's word
     u32 s;
     if (w == EMPTY_KEY) {
       s = cap;
     } else {
       s = (u32)(mix64(w) >> (64 - cap_log2)) & mask;
+      u32 probes = 0;
       while (true) {
         u64 k = tab[s].key;
         if (k == EMPTY_KEY) k = atomicCAS((ull *)&tab[s].key, EMPTY_KEY, (ull)w);
         if (k == EMPTY_KEY || k == w) break;
         s = (s + 1) & mask;
+        if (++probes > max_probe) { s = NOSLOT; break; }   // table (nearly) full: never spin forever
       }
+      if (s == NOSLOT) { ctr[CTR_OVERFULL] = 1; slot_of_read[r] = NOSLOT; continue; }
     }
     atomicAdd(&tab[s].cntm1, 1u);
     atomicMin(&tab[s].first, r);
@@ -133,7 +138,7 @@ __device__ __forceinline__ u32 block_rank(bool flag, u32 *lds /* >= 4 u32 */, u3
 // occupied slots -> (word, slot) list in arbitrary order; also sums the usable reads
 __global__ void __launch_bounds__(256)
 k_compact_table(const Slot *__restrict__ tab, u32 n_slots, u64 *__restrict__ uniq_word,
-                u32 *__restrict__ uniq_slot, ull *ctr) {
+                u32 *__restrict__ uniq_slot, u32 uniq_cap, ull *ctr) {
   __shared__ u32 lds[8];
   const u32 chunk = (n_slots + gridDim.x - 1) / gridDim.x;
   const u32 lo = blockIdx.x * chunk;
@@ -159,8 +164,12 @@ k_compact_table(const Slot *__restrict__ tab, u32 n_slots, u64 *__restrict__ uni
     u32 tot;
     const u32 r = block_rank(sl.cntm1 != NONE32, lds, &tot);
     if (sl.cntm1 != NONE32) {
-      uniq_word[base + r] = sl.key;
-      uniq_slot[base + r] = sidx;
+      if (base + r < uniq_cap) {
+        uniq_word[base + r] = sl.key;
+        uniq_slot[base + r] = sidx;
+      } else {
+        ctr[CTR_OVERFULL] = 1;
+      }
     }
     base += tot;
   }
@@ -427,19 +436,24 @@ __global__ void k_creator_flags(const u32 *__restrict__ cl_of, u32 n, u32 *flag)
   if (u < n) flag[u] = (cl_of[u] == u + 1) ? 1u : 0u;
 }
 
-// per node: final cluster id, maxLeaf flag; per hash slot: (cluster id, read to keep)
+// per node: final cluster id (creators numbered in walk order) and maxLeaf flag
 __global__ void k_finalize_nodes(const u32 *__restrict__ cl_of, const u32 *__restrict__ pos,
-                                 const u32 *__restrict__ maxleaf, const u32 *__restrict__ s_first,
-                                 const u32 *__restrict__ s_slot, u32 n, u32 *__restrict__ cid,
-                                 u8 *__restrict__ ismax, u64 *__restrict__ slot_out) {
+                                 const u32 *__restrict__ maxleaf, u32 n, u32 *__restrict__ cid,
+                                 u8 *__restrict__ ismax) {
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n) return;
   const u32 creator = cl_of[u] - 1;
-  const u32 c = pos[creator] + 1;
-  const bool mx = maxleaf[creator] == u;
-  cid[u] = c;
-  ismax[u] = mx ? 1 : 0;
-  if (slot_out) slot_out[s_slot[u]] = ((u64)(mx ? s_first[u] : NONE32) << 32) | c;
+  cid[u] = pos[creator] + 1;
+  ismax[u] = (maxleaf[creator] == u) ? 1 : 0;
+}
+
+// per hash slot: (cluster id, read to keep) of the word it holds
+__global__ void k_slot_results(const u32 *__restrict__ l_cid, const u8 *__restrict__ l_ismax,
+                               const u32 *__restrict__ s_first, const u32 *__restrict__ s_slot, u32 n,
+                               u64 *__restrict__ slot_out) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  slot_out[s_slot[u]] = ((u64)(l_ismax[u] ? s_first[u] : NONE32) << 32) | l_cid[u];
 }
 
 __global__ void k_export_clusters(const u32 *__restrict__ flag, const u32 *__restrict__ pos,
@@ -487,6 +501,24 @@ __global__ void k_creator_sizes(const u32 *__restrict__ flag, const u32 *__restr
   if (u < n && flag[u]) out[pos[u]] = cl_size[u];
 }
 
+// reads per top-`bits` bin of the word (usable reads only): balanced range splitters for the
+// multi-GPU path.  LDS-privatised, fixed grid.
+__global__ void __launch_bounds__(256)
+k_top_hist(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n_reads, u32 shift,
+           u32 n_bins, u32 *hist) {
+  extern __shared__ u32 lh[];
+  for (u32 b = threadIdx.x; b < n_bins; b += blockDim.x) lh[b] = 0;
+  __syncthreads();
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x)
+    if (!filtered[r]) {
+      u32 b = (u32)(words[r] >> shift);
+      atomicAdd(&lh[b < n_bins ? b : n_bins - 1], 1u);   // malformed words cannot index out of LDS
+    }
+  __syncthreads();
+  for (u32 b = threadIdx.x; b < n_bins; b += blockDim.x)
+    if (lh[b]) atomicAdd(&hist[b], lh[b]);
+}
+
 __global__ void k_at_least_double(u64 a, u64 b, int *out) { *out = at_least_double(a, b) ? 1 : 0; }
 
 // --------------------------------------------------------------------------------
@@ -522,8 +554,13 @@ struct humid_ctx {
   DBuf parent, mk0, mk1, cl_of, maxleaf, cl_size, flag, pos, cid, ismax, stk, tmp, scratch;
   hipEvent_t ev[6] = {};
   hipEvent_t kev[40] = {};   // per-kernel timing: [0,1] insert, [2,3] cluster, [4..19] pairs fill, [20..35] pairs count
-  bool have_run = false;
-  bool graph_mode = false;
+  bool have_run = false;     // a full dedup run completed (all accessors valid)
+  bool have_graph = false;   // stage B completed (leaf/adjacency/cluster accessors valid)
+  bool graph_mode = false;   // last call was humid_cluster_graph
+  const u64 *g_word = nullptr;   // arrays stage B ran on
+  const u32 *g_cnt = nullptr;
+  u32 gU = 0;
+  u32 cap_log2 = 0;
   u64 N = 0, U = 0, E = 0, M = 0, C = 0, usable = 0;
   u32 word_nt = 0, distance = 0, method = 0;
 };
@@ -622,7 +659,7 @@ static SegPlan make_plan(u32 n, u32 d) {
 // ---- cluster stage shared by the full pipeline and the explicit-graph entry point ------
 // needs: s_cnt[U], deg[U], nbr_off[U+1], nbr_idx, parent[U] (components already unioned),
 // M = number of nodes with deg > 0.
-static int cluster_stage(humid_ctx *c, u32 U, u64 M, u32 method) {
+static int cluster_stage(humid_ctx *c, const u32 *g_cnt, u32 U, u64 M, u32 method) {
   hipStream_t st = c->stream;
   ENSURE(c->cl_of, (size_t)U * 4);
   ENSURE(c->maxleaf, (size_t)U * 4);
@@ -632,7 +669,7 @@ static int cluster_stage(humid_ctx *c, u32 U, u64 M, u32 method) {
   ENSURE(c->cid, (size_t)U * 4);
   ENSURE(c->ismax, (size_t)U);
   hipLaunchKernelGGL(k_cluster_singletons, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
-                     c->s_cnt.as<u32>(), U, c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
+                     g_cnt, U, c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
   if (M > 0) {
     ENSURE(c->mk0, (size_t)M * 8);
     ENSURE(c->mk1, (size_t)M * 8);
@@ -644,12 +681,12 @@ static int cluster_stage(humid_ctx *c, u32 U, u64 M, u32 method) {
     HIPCHK(hipEventRecord(c->kev[2], st));
     if (method == HUMID_METHOD_MAXIMUM)
       hipLaunchKernelGGL(k_cluster_components<true>, dim3(blocks_for(M, 64)), dim3(64), 0, st,
-                         c->mk1.as<u64>(), (u32)M, c->s_cnt.as<u32>(), c->nbr_off.as<u32>(),
+                         c->mk1.as<u64>(), (u32)M, g_cnt, c->nbr_off.as<u32>(),
                          c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(),
                          c->cl_size.as<u64>(), c->stk.as<u32>());
     else
       hipLaunchKernelGGL(k_cluster_components<false>, dim3(blocks_for(M, 64)), dim3(64), 0, st,
-                         c->mk1.as<u64>(), (u32)M, c->s_cnt.as<u32>(), c->nbr_off.as<u32>(),
+                         c->mk1.as<u64>(), (u32)M, g_cnt, c->nbr_off.as<u32>(),
                          c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(),
                          c->cl_size.as<u64>(), c->stk.as<u32>());
     HIPCHK(hipEventRecord(c->kev[3], st));
@@ -670,62 +707,42 @@ static int n_clusters_from_scan(humid_ctx *c, u32 U, u64 *out) {
   return HUMID_OK;
 }
 
-// ---- the full pipeline on device buffers ---------------------------------------------
-static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_reads, u32 word_nt,
-                      u32 distance, u32 method, u32 *d_cid, u8 *d_keep, humid_summary *sum) {
-  if (!c) return HUMID_E_INVALID;
-  c->have_run = false;
-  c->graph_mode = false;
-  if (word_nt == 0) return fail(c, HUMID_E_INVALID, "word_nt must be >= 1");
-  if (word_nt > 32) return fail(c, HUMID_E_UNSUPPORTED, "word_nt %u > 32 is not supported by the HIP path", word_nt);
-  if (method > 1) return fail(c, HUMID_E_INVALID, "method must be 0 (directional) or 1 (maximum)");
-  if (n_reads > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "n_reads %llu exceeds 2^31-1", (ull)n_reads);
-  if (n_reads && (!d_words || !d_filt || !d_cid || !d_keep)) return fail(c, HUMID_E_INVALID, "null buffer");
-  HIPCHK(hipSetDevice(c->device));
+// ---- stage A: exact counts + walk order ------------------------------------------------
+// Inserts the reads whose word lies in [range_lo, range_hi] (inclusive; the multi-GPU path
+// gives every rank one range, a single GPU takes everything), compacts the table and sorts
+// the unique words.  Leaves table/slot_of_read/s_word/s_slot/s_cnt/s_first in the context.
+static int stage_count(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N, u32 word_nt,
+                       u64 range_lo, u64 range_hi, u64 expected_reads, humid_summary &s) {
   hipStream_t st = c->stream;
-  const u32 N = (u32)n_reads;
-  humid_summary s;
-  memset(&s, 0, sizeof s);
-  s.total = n_reads;
-  c->N = n_reads; c->U = c->E = c->M = c->C = c->usable = 0;
-  c->word_nt = word_nt; c->distance = distance; c->method = method;
-  if (N == 0) { if (sum) *sum = s; c->have_run = true; return HUMID_OK; }
-
-  // ---------------- 1. exact counts -----------------
+  if (expected_reads == 0 || expected_reads > N) expected_reads = N;
   u32 cap_log2 = 10;
-  while (((u64)1 << cap_log2) < (u64)N + N / 2) cap_log2++;
+  while (((u64)1 << cap_log2) < expected_reads + expected_reads / 2) cap_log2++;
   const u64 cap = (u64)1 << cap_log2;
+  c->cap_log2 = cap_log2;
   ENSURE(c->table, (cap + 1) * sizeof(Slot));
   ENSURE(c->slot_out, (cap + 1) * 8);
   ENSURE(c->slot_of_read, (size_t)N * 4);
-  ENSURE(c->uniq_slot, (size_t)N * 4);
-  ENSURE(c->uniq_word, (size_t)N * 8);
+  ENSURE(c->uniq_slot, (size_t)expected_reads * 4 + 4);
+  ENSURE(c->uniq_word, (size_t)expected_reads * 8 + 8);
   HIPCHK(hipEventRecord(c->ev[0], st));
   HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_N * sizeof(ull), st));
   HIPCHK(hipMemsetAsync(c->table.p, 0xff, (cap + 1) * sizeof(Slot), st));
   HIPCHK(hipEventRecord(c->kev[0], st));
   hipLaunchKernelGGL(k_hash_insert, dim3(grid_stride_blocks(N)), dim3(256), 0, st, d_words, d_filt, N,
-                     c->table.as<Slot>(), cap_log2, c->slot_of_read.as<u32>());
+                     c->table.as<Slot>(), cap_log2, c->slot_of_read.as<u32>(), range_lo, range_hi,
+                     (u32)(cap - cap / 8), c->d_ctr);
   HIPCHK(hipEventRecord(c->kev[1], st));
   hipLaunchKernelGGL(k_compact_table, dim3(COMPACT_BLOCKS), dim3(256), 0, st,
                      c->table.as<Slot>(), (u32)(cap + 1), c->uniq_word.as<u64>(), c->uniq_slot.as<u32>(),
-                     c->d_ctr);
+                     (u32)expected_reads, c->d_ctr);
   HIPCHK(hipGetLastError());
   TRY(read_counters(c));
+  if (c->h_ctr[CTR_OVERFULL])
+    return fail(c, HUMID_E_INVALID, "hash table over-full: more reads fell into this range than expected_reads");
   const u32 U = (u32)c->h_ctr[CTR_UNIQUE];
   s.usable = c->usable = c->h_ctr[CTR_USABLE];
   s.unique = c->U = U;
-
-  if (U == 0) {   // everything filtered
-    HIPCHK(hipMemsetAsync(d_cid, 0, (size_t)N * 4, st));
-    HIPCHK(hipMemsetAsync(d_keep, 0, (size_t)N, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (sum) *sum = s;
-    c->have_run = true;
-    return HUMID_OK;
-  }
-
-  // ---------------- 2. walk order -----------------
+  if (U == 0) { HIPCHK(hipEventRecord(c->ev[1], st)); return HUMID_OK; }
   ENSURE(c->s_word, (size_t)U * 8);
   ENSURE(c->s_slot, (size_t)U * 4);
   ENSURE(c->s_cnt, (size_t)U * 4);
@@ -735,7 +752,20 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
   hipLaunchKernelGGL(k_post_sort, dim3(blocks_for(U)), dim3(256), 0, st, c->s_slot.as<u32>(),
                      c->table.as<Slot>(), U, c->s_cnt.as<u32>(), c->s_first.as<u32>());
   HIPCHK(hipEventRecord(c->ev[1], st));
+  HIPCHK(hipGetLastError());
+  return HUMID_OK;
+}
 
+// ---- stage B: neighbours + clusters over a sorted unique array ---------------------------
+// g_word[U] ascending, g_cnt[U] (device; the context's own arrays on one GPU, the gathered
+// arrays of all ranks on several).  Leaves deg/nbr_off/nbr_idx/cl_of/maxleaf/cl_size/flag/
+// pos/cid/ismax in the context.
+static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U, u32 word_nt,
+                       u32 distance, u32 method, humid_summary &s, u32 &n_pair_segs_out) {
+  hipStream_t st = c->stream;
+  c->g_word = g_word;
+  c->g_cnt = g_cnt;
+  c->gU = U;
   // ---------------- 3. neighbours -----------------
   // deg has U+1 entries (last stays 0) so that one exclusive scan yields nbr_off[U] = 2E
   ENSURE(c->deg, (size_t)(U + 1) * 4);
@@ -762,7 +792,7 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
       u32 *pcs = c->pc.as<u32>() + (size_t)seg * U;
       if (seg == 0) HIPCHK(hipEventRecord(c->kev[20], st));
       if (seg == 0) {
-        hipLaunchKernelGGL((k_pairs<true, false>), dim3(blocks_for(U)), dim3(256), 0, st, c->s_word.as<u64>(),
+        hipLaunchKernelGGL((k_pairs<true, false>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
                            (const u32 *)nullptr, (const u32 *)nullptr, U, plan, seg, distance,
                            c->deg.as<u32>(), pcs, (const u32 *)nullptr, (u64 *)nullptr);
       } else {
@@ -770,11 +800,11 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
         while (width < 64 && (plan.mask[seg] >> width)) width++;
         u32 *ks = c->seg_ks.as<u32>() + (size_t)(seg - 1) * U;
         u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
-        hipLaunchKernelGGL(k_seg_keys, dim3(blocks_for(U)), dim3(256), 0, st, c->s_word.as<u64>(), U,
+        hipLaunchKernelGGL(k_seg_keys, dim3(blocks_for(U)), dim3(256), 0, st, g_word, U,
                            plan.shift[seg], plan.mask[seg], c->seg_k0.as<u32>(), c->seg_v0.as<u32>());
         TRY(sort_pairs<u32, u32>(c, c->seg_k0.as<u32>(), ks, c->seg_v0.as<u32>(), vs, U, 0, width ? width : 1));
         if (seg < 8) HIPCHK(hipEventRecord(c->kev[20 + 2 * seg], st));
-        hipLaunchKernelGGL((k_pairs<false, false>), dim3(blocks_for(U)), dim3(256), 0, st, c->s_word.as<u64>(),
+        hipLaunchKernelGGL((k_pairs<false, false>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
                            ks, vs, U, plan, seg, distance, c->deg.as<u32>(), pcs, (const u32 *)nullptr,
                            (u64 *)nullptr);
       }
@@ -801,13 +831,13 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
       const u32 *pos = c->poff.as<u32>() + (size_t)seg * U;
       if (seg < 8) HIPCHK(hipEventRecord(c->kev[4 + 2 * seg], st));
       if (seg == 0) {
-        hipLaunchKernelGGL((k_pairs<true, true>), dim3(blocks_for(U)), dim3(256), 0, st, c->s_word.as<u64>(),
+        hipLaunchKernelGGL((k_pairs<true, true>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
                            (const u32 *)nullptr, (const u32 *)nullptr, U, plan, seg, distance,
                            (u32 *)nullptr, (u32 *)nullptr, pos, c->ek0.as<u64>());
       } else {
         const u32 *ks = c->seg_ks.as<u32>() + (size_t)(seg - 1) * U;
         const u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
-        hipLaunchKernelGGL((k_pairs<false, true>), dim3(blocks_for(U)), dim3(256), 0, st, c->s_word.as<u64>(),
+        hipLaunchKernelGGL((k_pairs<false, true>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
                            ks, vs, U, plan, seg, distance, (u32 *)nullptr, (u32 *)nullptr, pos,
                            c->ek0.as<u64>());
       }
@@ -820,24 +850,79 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
   }
   HIPCHK(hipEventRecord(c->ev[2], st));
 
-  // ---------------- 4+5. components and clusters -----------------
+  // components and clusters
   hipLaunchKernelGGL(k_iota, dim3(blocks_for(U)), dim3(256), 0, st, c->parent.as<u32>(), U);
   if (E > 0)
     hipLaunchKernelGGL(k_union_edges, dim3(blocks_for(E)), dim3(256), 0, st, c->ek0.as<u64>(), E,
                        c->parent.as<u32>());
-  TRY(cluster_stage(c, U, M, method));
+  TRY(cluster_stage(c, g_cnt, U, M, method));
   hipLaunchKernelGGL(k_finalize_nodes, dim3(blocks_for(U)), dim3(256), 0, st, c->cl_of.as<u32>(),
-                     c->pos.as<u32>(), c->maxleaf.as<u32>(), c->s_first.as<u32>(), c->s_slot.as<u32>(), U,
-                     c->cid.as<u32>(), c->ismax.as<u8>(), c->slot_out.as<u64>());
-  HIPCHK(hipEventRecord(c->ev[3], st));
+                     c->pos.as<u32>(), c->maxleaf.as<u32>(), U, c->cid.as<u32>(), c->ismax.as<u8>());
+  HIPCHK(hipGetLastError());
+  n_pair_segs_out = n_pair_segs;
+  return HUMID_OK;
+}
 
-  // ---------------- 6. per-read map -----------------
+// ---- stage C: per-read outputs -------------------------------------------------------------
+// l_cid/l_ismax: cluster id and maxLeaf flag of THIS context's unique words in local walk order
+// (on one GPU the arrays stage B left behind; on several, this rank's slice of them).
+static int stage_map(humid_ctx *c, const u32 *l_cid, const u8 *l_ismax, u32 N, u32 *d_cid, u8 *d_keep) {
+  hipStream_t st = c->stream;
+  const u32 U = (u32)c->U;
+  if (U > 0)
+    hipLaunchKernelGGL(k_slot_results, dim3(blocks_for(U)), dim3(256), 0, st, l_cid, l_ismax,
+                       c->s_first.as<u32>(), c->s_slot.as<u32>(), U, c->slot_out.as<u64>());
+  HIPCHK(hipEventRecord(c->ev[3], st));
   hipLaunchKernelGGL(k_read_map, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->slot_of_read.as<u32>(),
                      c->slot_out.as<u64>(), N, d_cid, d_keep);
   HIPCHK(hipEventRecord(c->ev[4], st));
   HIPCHK(hipGetLastError());
+  return HUMID_OK;
+}
+
+static int check_run_args(humid_ctx *c, u64 n_reads, u32 word_nt, u32 method) {
+  if (word_nt == 0) return fail(c, HUMID_E_INVALID, "word_nt must be >= 1");
+  if (word_nt > 32) return fail(c, HUMID_E_UNSUPPORTED, "word_nt %u > 32 is not supported by the HIP path", word_nt);
+  if (method > 1) return fail(c, HUMID_E_INVALID, "method must be 0 (directional) or 1 (maximum)");
+  if (n_reads > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "n_reads %llu exceeds 2^31-1", (ull)n_reads);
+  return HUMID_OK;
+}
+
+// ---- the full pipeline on device buffers (one GPU) -------------------------------------------
+static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_reads, u32 word_nt,
+                      u32 distance, u32 method, u32 *d_cid, u8 *d_keep, humid_summary *sum) {
+  if (!c) return HUMID_E_INVALID;
+  c->have_run = false;
+  c->graph_mode = false;
+  c->have_graph = false;
+  TRY(check_run_args(c, n_reads, word_nt, method));
+  if (n_reads && (!d_words || !d_filt || !d_cid || !d_keep)) return fail(c, HUMID_E_INVALID, "null buffer");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const u32 N = (u32)n_reads;
+  humid_summary s;
+  memset(&s, 0, sizeof s);
+  s.total = n_reads;
+  c->N = n_reads; c->U = c->E = c->M = c->C = c->usable = 0;
+  c->word_nt = word_nt; c->distance = distance; c->method = method;
+  c->gU = 0;
+  if (N == 0) { if (sum) *sum = s; c->have_run = c->have_graph = true; return HUMID_OK; }
+  TRY(stage_count(c, d_words, d_filt, N, word_nt, 0ull, ~0ull, 0, s));
+  const u32 U = (u32)c->U;
+  if (U == 0) {   // everything filtered
+    HIPCHK(hipMemsetAsync(d_cid, 0, (size_t)N * 4, st));
+    HIPCHK(hipMemsetAsync(d_keep, 0, (size_t)N, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (sum) *sum = s;
+    c->have_run = c->have_graph = true;
+    return HUMID_OK;
+  }
+  u32 n_pair_segs = 0;
+  TRY(stage_graph(c, c->s_word.as<u64>(), c->s_cnt.as<u32>(), U, word_nt, distance, method, s, n_pair_segs));
+  TRY(stage_map(c, c->cid.as<u32>(), c->ismax.as<u8>(), N, d_cid, d_keep));
   TRY(n_clusters_from_scan(c, U, &c->C));
   s.clusters = c->C;
+  const u64 E = c->E, M = c->M;
   HIPCHK(hipEventElapsedTime(&s.ms_count, c->ev[0], c->ev[1]));
   HIPCHK(hipEventElapsedTime(&s.ms_neighbours, c->ev[1], c->ev[2]));
   HIPCHK(hipEventElapsedTime(&s.ms_cluster, c->ev[2], c->ev[3]));
@@ -857,6 +942,7 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
   }
   if (sum) *sum = s;
   c->have_run = true;
+  c->have_graph = true;
   return HUMID_OK;
 }
 
@@ -980,7 +1066,7 @@ int humid_dedup_run(humid_ctx *c, const uint64_t *words, const uint8_t *filtered
 #define NEED_RUN()                                                                            \
   do {                                                                                        \
     if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");                             \
-    if (!c->have_run || c->graph_mode) return fail(c, HUMID_E_STATE, "no completed dedup run in this context"); \
+    if (!c->have_graph || c->graph_mode) return fail(c, HUMID_E_STATE, "no completed dedup run / graph stage in this context"); \
     HIPCHK(hipSetDevice(c->device));                                                          \
   } while (0)
 
@@ -990,10 +1076,12 @@ int humid_dedup_run(humid_ctx *c, const uint64_t *words, const uint8_t *filtered
 int humid_get_leaves(humid_ctx *c, uint64_t *word, uint32_t *count, uint32_t *first_read,
                      uint32_t *degree, uint32_t *cluster_id, uint8_t *is_max_leaf) {
   NEED_RUN();
-  size_t U = (size_t)c->U;
+  size_t U = (size_t)c->gU;
   if (U == 0) return HUMID_OK;
-  D2H(word, c->s_word.p, U * 8);
-  D2H(count, c->s_cnt.p, U * 4);
+  if (first_read && !c->have_run)
+    return fail(c, HUMID_E_STATE, "first_read is only available after a single-GPU humid_dedup_run*");
+  D2H(word, c->g_word, U * 8);
+  D2H(count, c->g_cnt, U * 4);
   D2H(first_read, c->s_first.p, U * 4);
   D2H(degree, c->deg.p, U * 4);
   D2H(cluster_id, c->cid.p, U * 4);
@@ -1004,7 +1092,7 @@ int humid_get_leaves(humid_ctx *c, uint64_t *word, uint32_t *count, uint32_t *fi
 
 int humid_get_adjacency(humid_ctx *c, uint32_t *nbr_off, uint32_t *nbr_idx) {
   NEED_RUN();
-  size_t U = (size_t)c->U;
+  size_t U = (size_t)c->gU;
   if (U == 0) { if (nbr_off) nbr_off[0] = 0; return HUMID_OK; }
   D2H(nbr_off, c->nbr_off.p, (U + 1) * 4);
   D2H(nbr_idx, c->nbr_idx.p, (size_t)(2 * c->E) * 4);
@@ -1019,7 +1107,7 @@ static int export_clusters(humid_ctx *c, u32 U, u64 C, uint64_t *size, uint32_t 
   u32 *d_mc = (u32 *)(d_size + C);
   u32 *d_ml = d_mc + C;
   hipLaunchKernelGGL(k_export_clusters, dim3(blocks_for(U)), dim3(256), 0, c->stream, c->flag.as<u32>(),
-                     c->pos.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>(), c->s_cnt.as<u32>(), U,
+                     c->pos.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>(), c->g_cnt, U,
                      d_size, d_mc, d_ml);
   HIPCHK(hipGetLastError());
   D2H(size, d_size, (size_t)C * 8);
@@ -1031,7 +1119,7 @@ static int export_clusters(humid_ctx *c, u32 U, u64 C, uint64_t *size, uint32_t 
 
 int humid_get_clusters(humid_ctx *c, uint64_t *size, uint32_t *max_count, uint32_t *max_leaf) {
   NEED_RUN();
-  return export_clusters(c, (u32)c->U, c->C, size, max_count, max_leaf);
+  return export_clusters(c, c->gU, c->C, size, max_count, max_leaf);
 }
 
 int humid_get_histogram(humid_ctx *c, uint32_t which, uint64_t *keys, uint64_t *values, uint64_t cap,
@@ -1039,7 +1127,7 @@ int humid_get_histogram(humid_ctx *c, uint32_t which, uint64_t *keys, uint64_t *
   NEED_RUN();
   if (which > 2 || !n_out) return fail(c, HUMID_E_INVALID, "bad histogram selector");
   *n_out = 0;
-  const u32 U = (u32)c->U;
+  const u32 U = c->gU;
   u64 n = (which == 2) ? c->C : U;
   if (n == 0) return HUMID_OK;
   hipStream_t st = c->stream;
@@ -1050,7 +1138,7 @@ int humid_get_histogram(humid_ctx *c, uint32_t which, uint64_t *keys, uint64_t *
   u64 *uniq = sorted + n;
   u32 *counts = (u32 *)(uniq + n);
   u32 *runs = counts + n;
-  if (which == 0) hipLaunchKernelGGL(k_widen32, dim3(blocks_for(U)), dim3(256), 0, st, c->s_cnt.as<u32>(), U, vals);
+  if (which == 0) hipLaunchKernelGGL(k_widen32, dim3(blocks_for(U)), dim3(256), 0, st, c->g_cnt, U, vals);
   else if (which == 1) hipLaunchKernelGGL(k_widen32, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(), U, vals);
   else hipLaunchKernelGGL(k_creator_sizes, dim3(blocks_for(U)), dim3(256), 0, st, c->flag.as<u32>(),
                           c->pos.as<u32>(), c->cl_size.as<u64>(), U, vals);
@@ -1095,8 +1183,11 @@ int humid_cluster_graph(humid_ctx *c, const uint32_t *count, const uint32_t *nbr
   HIPCHK(hipSetDevice(c->device));
   hipStream_t st = c->stream;
   c->have_run = false;
+  c->have_graph = false;
   c->graph_mode = true;
   ENSURE(c->s_cnt, (size_t)U * 4);
+  c->g_cnt = c->s_cnt.as<u32>();
+  c->gU = U;
   ENSURE(c->deg, (size_t)U * 4);
   ENSURE(c->nbr_off, (size_t)(U + 1) * 4);
   ENSURE(c->nbr_idx, (size_t)(twoE + 1) * 4);
@@ -1112,10 +1203,9 @@ int humid_cluster_graph(humid_ctx *c, const uint32_t *count, const uint32_t *nbr
   hipLaunchKernelGGL(k_union_csr, dim3(blocks_for(U)), dim3(256), 0, st, c->nbr_off.as<u32>(),
                      c->nbr_idx.as<u32>(), U, c->parent.as<u32>());
   HIPCHK(hipStreamSynchronize(st));   // hdeg is a host temporary
-  TRY(cluster_stage(c, U, M, method));
+  TRY(cluster_stage(c, c->s_cnt.as<u32>(), U, M, method));
   hipLaunchKernelGGL(k_finalize_nodes, dim3(blocks_for(U)), dim3(256), 0, st, c->cl_of.as<u32>(),
-                     c->pos.as<u32>(), c->maxleaf.as<u32>(), (const u32 *)nullptr, (const u32 *)nullptr, U,
-                     c->cid.as<u32>(), c->ismax.as<u8>(), (u64 *)nullptr);
+                     c->pos.as<u32>(), c->maxleaf.as<u32>(), U, c->cid.as<u32>(), c->ismax.as<u8>());
   HIPCHK(hipGetLastError());
   u64 C = 0;
   TRY(n_clusters_from_scan(c, U, &C));
@@ -1132,6 +1222,94 @@ int humid_at_least_double(humid_ctx *c, uint64_t a, uint64_t b, int *result) {
   hipLaunchKernelGGL(k_at_least_double, dim3(1), dim3(1), 0, c->stream, a, b, c->scratch.as<int>());
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(result, c->scratch.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return HUMID_OK;
+}
+
+// ---- multi-GPU stages (device pointers; see humid_amd/sharded.py) ----------------------------
+int humid_stage_histogram(humid_ctx *c, const uint64_t *d_words, const uint8_t *d_filtered,
+                          uint64_t n_reads, uint32_t word_nt, uint32_t bits, uint32_t *d_hist) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  TRY(check_run_args(c, n_reads, word_nt, 0));
+  if (bits == 0 || bits > 12 || bits > 2 * word_nt || !d_hist) return fail(c, HUMID_E_INVALID, "bits must be 1..min(12, 2*word_nt)");
+  HIPCHK(hipSetDevice(c->device));
+  const u32 n_bins = 1u << bits;
+  HIPCHK(hipMemsetAsync(d_hist, 0, n_bins * 4, c->stream));
+  if (n_reads)
+    hipLaunchKernelGGL(k_top_hist, dim3(512), dim3(256), n_bins * 4, c->stream, d_words, d_filtered,
+                       (u32)n_reads, 2 * word_nt - bits, n_bins, d_hist);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return HUMID_OK;
+}
+
+int humid_stage_count(humid_ctx *c, const uint64_t *d_words, const uint8_t *d_filtered, uint64_t n_reads,
+                      uint32_t word_nt, uint64_t range_lo, uint64_t range_hi, uint64_t expected_reads,
+                      uint64_t *n_unique, uint64_t *n_usable) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  c->have_run = c->have_graph = false;
+  c->graph_mode = false;
+  TRY(check_run_args(c, n_reads, word_nt, 0));
+  if (n_reads && (!d_words || !d_filtered)) return fail(c, HUMID_E_INVALID, "null buffer");
+  HIPCHK(hipSetDevice(c->device));
+  humid_summary s;
+  memset(&s, 0, sizeof s);
+  c->N = n_reads; c->U = c->E = c->M = c->C = c->usable = 0;
+  c->word_nt = word_nt;
+  if (n_reads) TRY(stage_count(c, d_words, d_filtered, (u32)n_reads, word_nt, range_lo, range_hi, expected_reads, s));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (n_unique) *n_unique = c->U;
+  if (n_usable) *n_usable = c->usable;
+  return HUMID_OK;
+}
+
+int humid_stage_unique(humid_ctx *c, const uint64_t **d_word, const uint32_t **d_count,
+                       const uint32_t **d_first) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (d_word) *d_word = c->U ? c->s_word.as<u64>() : nullptr;
+  if (d_count) *d_count = c->U ? c->s_cnt.as<u32>() : nullptr;
+  if (d_first) *d_first = c->U ? c->s_first.as<u32>() : nullptr;
+  return HUMID_OK;
+}
+
+int humid_stage_graph(humid_ctx *c, const uint64_t *d_g_word, const uint32_t *d_g_count,
+                      uint64_t n_unique, uint32_t word_nt, uint32_t distance, uint32_t method,
+                      const uint32_t **d_cluster_id, const uint8_t **d_is_max, humid_summary *summary) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  c->have_graph = false;
+  c->graph_mode = false;
+  TRY(check_run_args(c, n_unique, word_nt, method));
+  HIPCHK(hipSetDevice(c->device));
+  humid_summary s;
+  memset(&s, 0, sizeof s);
+  s.unique = n_unique;
+  c->distance = distance; c->method = method;
+  c->gU = 0; c->E = c->M = c->C = 0;
+  if (d_cluster_id) *d_cluster_id = nullptr;
+  if (d_is_max) *d_is_max = nullptr;
+  if (n_unique) {
+    if (!d_g_word || !d_g_count) return fail(c, HUMID_E_INVALID, "null buffer");
+    u32 nps = 0;
+    TRY(stage_graph(c, d_g_word, d_g_count, (u32)n_unique, word_nt, distance, method, s, nps));
+    TRY(n_clusters_from_scan(c, (u32)n_unique, &c->C));
+    s.clusters = c->C;
+    if (d_cluster_id) *d_cluster_id = c->cid.as<u32>();
+    if (d_is_max) *d_is_max = c->ismax.as<u8>();
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (summary) *summary = s;
+  c->have_graph = true;
+  return HUMID_OK;
+}
+
+int humid_stage_map(humid_ctx *c, const uint32_t *d_local_cluster_id, const uint8_t *d_local_is_max,
+                    uint64_t n_reads, uint32_t *d_cluster_id, uint8_t *d_keep) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (n_reads != c->N) return fail(c, HUMID_E_STATE, "n_reads differs from the preceding humid_stage_count");
+  if (n_reads && (!d_cluster_id || !d_keep)) return fail(c, HUMID_E_INVALID, "null buffer");
+  if (c->U && (!d_local_cluster_id || !d_local_is_max)) return fail(c, HUMID_E_INVALID, "null buffer");
+  HIPCHK(hipSetDevice(c->device));
+  if (n_reads) TRY(stage_map(c, d_local_cluster_id, d_local_is_max, (u32)n_reads, d_cluster_id, d_keep));
   HIPCHK(hipStreamSynchronize(c->stream));
   return HUMID_OK;
 }

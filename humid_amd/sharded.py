@@ -1,0 +1,242 @@
+"""Multi-GPU driver of the hot path: one process per GPU, torch.distributed over RCCL/xGMI.
+
+The read set is sharded over the ranks in input order.  Per pass:
+
+  1. RCCL all-gather of the packed words (+ filtered flags): every rank sees every candidate
+     neighbour (BASELINE.json north_star).  This is the path's one real exchange step.
+  2. every rank histograms the gathered words (same input -> same result on all ranks, no
+     collective) and derives P disjoint, ordered value ranges with balanced read counts;
+  3. humid_stage_count: rank r counts only the words of range r (the random-access work, the
+     bulk of the single-GPU time, is divided by P); ranges are ordered, so the concatenation of
+     the per-rank sorted unique arrays IS Trie::walk() order;
+  4. all-gather of the unique (word, count) arrays (U is ~N/4, far smaller than step 1);
+  5. humid_stage_graph over the global unique array (neighbours + clusters; replicated);
+  6. humid_stage_map: every rank emits (cluster_id, keep) for the reads whose word it owns,
+     0 elsewhere; a reduce-scatter (sum) hands every rank the results of its own shard.
+
+The compute is behind an `ops` object: HipStageOps (libhumid_hip.so through the C ABI) in
+production; the CPU tests drive the same orchestration over gloo with an oracle-backed ops
+object that lives under tests/ (this package never imports the oracle).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .api import Context, HumidError
+
+HIST_BITS = 12
+
+
+class _DevArray:
+    """zero-copy view of ctx-owned device memory for torch (CUDA array interface)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2}
+
+
+def _wrap(ptr, n, typestr, dtype, device):
+    if n == 0 or not ptr:
+        return torch.empty(0, dtype=dtype, device=device)
+    return torch.as_tensor(_DevArray(ptr, n, typestr), device=device).view(dtype)
+
+
+class HipStageOps(Context):
+    """The stage entry points of include/humid_hip.h on this rank's GPU."""
+
+    def __init__(self, device: int):
+        self.device = torch.device("cuda", device)
+        super().__init__(device=device)
+
+    def histogram(self, g_w, g_f, word_nt, bits):
+        hist = torch.zeros(1 << bits, dtype=torch.int32, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check(self._lib.humid_stage_histogram(self._h, C.c_void_p(g_w.data_ptr()),
+                                                    C.c_void_p(g_f.data_ptr()), g_w.numel(), word_nt,
+                                                    bits, C.c_void_p(hist.data_ptr())))
+        return hist
+
+    def count(self, g_w, g_f, word_nt, lo, hi, expected):
+        nu, ns = C.c_uint64(), C.c_uint64()
+        self._n_reads = g_w.numel()
+        self._check(self._lib.humid_stage_count(self._h, C.c_void_p(g_w.data_ptr()),
+                                                C.c_void_p(g_f.data_ptr()), g_w.numel(), word_nt,
+                                                C.c_uint64(lo), C.c_uint64(hi), expected,
+                                                C.byref(nu), C.byref(ns)))
+        self._u = nu.value
+        return nu.value, ns.value
+
+    def unique(self):
+        pw, pc, pf = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._check(self._lib.humid_stage_unique(self._h, C.byref(pw), C.byref(pc), C.byref(pf)))
+        w = _wrap(pw.value, self._u, "<i8", torch.int64, self.device)
+        c = _wrap(pc.value, self._u, "<i4", torch.int32, self.device)
+        return w, c
+
+    def graph(self, g_word, g_cnt, word_nt, distance, method):
+        pc, pm = C.c_void_p(), C.c_void_p()
+        s = _lib.HumidSummary()
+        n = g_word.numel()
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check(self._lib.humid_stage_graph(self._h, C.c_void_p(g_word.data_ptr()),
+                                                C.c_void_p(g_cnt.data_ptr()), n, word_nt, distance,
+                                                method, C.byref(pc), C.byref(pm), C.byref(s)))
+        cid = _wrap(pc.value, n, "<i4", torch.int32, self.device)
+        ismax = _wrap(pm.value, n, "|u1", torch.uint8, self.device)
+        return cid, ismax, s.asdict()
+
+    def map(self, l_cid, l_ismax, out_cid, out_keep):
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check(self._lib.humid_stage_map(self._h, C.c_void_p(l_cid.data_ptr()),
+                                              C.c_void_p(l_ismax.data_ptr()), out_cid.numel(),
+                                              C.c_void_p(out_cid.data_ptr()),
+                                              C.c_void_p(out_keep.data_ptr())))
+
+
+# ------------------------------------------------------------------------------------------
+# collectives with a fallback for backends (gloo, CPU tests) that lack the tensor forms
+# ------------------------------------------------------------------------------------------
+def _all_gather_flat(dist, out, inp, world):
+    try:
+        dist.all_gather_into_tensor(out, inp)
+    except (RuntimeError, NotImplementedError):
+        parts = [torch.empty_like(inp) for _ in range(world)]
+        dist.all_gather(parts, inp)
+        out.copy_(torch.cat(parts))
+
+
+def _reduce_scatter_sum(dist, out, inp, world, rank):
+    try:
+        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM)
+    except (RuntimeError, NotImplementedError):
+        tmp = inp.clone()
+        if tmp.dtype == torch.uint8:        # gloo has no uint8 sum
+            tmp = tmp.to(torch.int32)
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+        n = out.numel()
+        out.copy_(tmp[rank * n:(rank + 1) * n].to(out.dtype))
+
+
+def splitters_from_hist(hist: np.ndarray, world: int, word_nt: int, bits: int):
+    """P ordered, disjoint, covering value ranges with balanced usable-read counts.
+    Returns [(lo, hi_inclusive, expected_reads)] -- identical on every rank."""
+    shift = 2 * word_nt - bits
+    cum = np.cumsum(hist.astype(np.int64))
+    total = int(cum[-1]) if len(cum) else 0
+    n_bins = len(hist)
+    bounds = [0]
+    for k in range(1, world):
+        b = int(np.searchsorted(cum, (total * k + world - 1) // world, side="left")) + 1
+        bounds.append(min(max(b, bounds[-1]), n_bins))
+    bounds.append(n_bins)
+    out = []
+    top = (1 << 64) - 1
+    for r in range(world):
+        b0, b1 = bounds[r], bounds[r + 1]
+        if b1 <= b0:
+            out.append((1, 0, 0))              # empty range
+            continue
+        lo = b0 << shift
+        hi = top if r == world - 1 else (b1 << shift) - 1
+        exp = int(cum[b1 - 1] - (cum[b0 - 1] if b0 > 0 else 0))
+        out.append((lo, min(hi, top), exp))
+    return out
+
+
+class ShardedDedup:
+    """Global deduplication of a read set sharded over the ranks of the default process group."""
+
+    def __init__(self, device: int = 0, word_nt: int = 24, distance: int = 1, method: int = 0,
+                 ops=None, dist=None):
+        import torch.distributed as tdist
+        self.dist = dist or tdist
+        self.world = self.dist.get_world_size()
+        self.rank = self.dist.get_rank()
+        self.word_nt, self.distance, self.method = word_nt, distance, method
+        self.ops = ops if ops is not None else HipStageOps(device)
+        self.bits = min(HIST_BITS, 2 * word_nt)
+        self._n_max = None
+
+    def run(self, d_w, d_f, d_cid, d_keep):
+        """d_w int64[n_local] packed words, d_f uint8[n_local]; writes d_cid int32[n_local] and
+        d_keep uint8[n_local] (torch tensors on this rank's device).  Returns a summary dict."""
+        dist, P, r = self.dist, self.world, self.rank
+        dev = d_w.device
+        n_local = d_w.numel()
+        if self._n_max is None:                      # shard sizes are fixed per instance
+            t = torch.tensor([n_local], dtype=torch.int64, device=dev)
+            sizes = torch.empty(P, dtype=torch.int64, device=dev)
+            _all_gather_flat(dist, sizes, t, P)
+            self._sizes = sizes.cpu().tolist()
+            self._n_max = max(self._sizes)
+        n_max = self._n_max
+        # ---- 1. all-gather of the packed words (padding reads are flagged filtered) ----
+        if n_local == n_max:
+            pw, pf = d_w, d_f
+        else:
+            pw = torch.zeros(n_max, dtype=torch.int64, device=dev)
+            pf = torch.ones(n_max, dtype=torch.uint8, device=dev)
+            pw[:n_local] = d_w
+            pf[:n_local] = d_f
+        g_w = torch.empty(P * n_max, dtype=torch.int64, device=dev)
+        g_f = torch.empty(P * n_max, dtype=torch.uint8, device=dev)
+        _all_gather_flat(dist, g_w, pw, P)
+        _all_gather_flat(dist, g_f, pf, P)
+        # ---- 2. balanced ordered ranges (replicated, deterministic) ----
+        hist = self.ops.histogram(g_w, g_f, self.word_nt, self.bits)
+        ranges = splitters_from_hist(hist.cpu().numpy(), P, self.word_nt, self.bits)
+        lo, hi, exp = ranges[r]
+        # ---- 3. exact counts of this rank's range ----
+        u_local, usable_local = self.ops.count(g_w, g_f, self.word_nt, lo, hi, max(exp, 1))
+        meta = torch.tensor([u_local, usable_local], dtype=torch.int64, device=dev)
+        metas = torch.empty(2 * P, dtype=torch.int64, device=dev)
+        _all_gather_flat(dist, metas, meta, P)
+        metas = metas.cpu().view(P, 2)
+        u_all = metas[:, 0].tolist()
+        usable = int(metas[:, 1].sum())
+        u_max, u_total = max(u_all), sum(u_all)
+        goff = sum(u_all[:r])
+        total_reads = sum(self._sizes)
+        g_cid = torch.zeros(P * n_max, dtype=torch.int32, device=dev)
+        g_keep = torch.zeros(P * n_max, dtype=torch.uint8, device=dev)
+        summ = dict(total=total_reads, usable=usable, unique=u_total, clusters=0, edges=0, nonsingle=0)
+        if u_total > 0:
+            # ---- 4. all-gather of the per-range unique arrays -> global walk order ----
+            lw, lc = self.ops.unique()
+            sw = torch.zeros(u_max, dtype=torch.int64, device=dev)
+            sc = torch.zeros(u_max, dtype=torch.int32, device=dev)
+            sw[:u_local] = lw
+            sc[:u_local] = lc
+            aw = torch.empty(P * u_max, dtype=torch.int64, device=dev)
+            ac = torch.empty(P * u_max, dtype=torch.int32, device=dev)
+            _all_gather_flat(dist, aw, sw, P)
+            _all_gather_flat(dist, ac, sc, P)
+            if all(u == u_max for u in u_all):
+                gw, gc = aw, ac
+            else:
+                gw = torch.cat([aw[q * u_max:q * u_max + u_all[q]] for q in range(P)])
+                gc = torch.cat([ac[q * u_max:q * u_max + u_all[q]] for q in range(P)])
+            # ---- 5. neighbours + clusters over the global unique array ----
+            cid_g, ismax_g, gs = self.ops.graph(gw, gc, self.word_nt, self.distance, self.method)
+            for k in ("clusters", "edges", "nonsingle"):
+                summ[k] = int(gs[k])
+            for k, v in gs.items():
+                if k.startswith("ms_"):
+                    summ[k] = v
+            # ---- 6. results of the words this rank owns, then reduce-scatter to the shards ----
+            self.ops.map(cid_g[goff:goff + u_local], ismax_g[goff:goff + u_local], g_cid, g_keep)
+        o_cid = torch.empty(n_max, dtype=torch.int32, device=dev)
+        o_keep = torch.empty(n_max, dtype=torch.uint8, device=dev)
+        _reduce_scatter_sum(dist, o_cid, g_cid, P, r)
+        _reduce_scatter_sum(dist, o_keep, g_keep, P, r)
+        d_cid.copy_(o_cid[:n_local])
+        d_keep.copy_(o_keep[:n_local])
+        self.summary = summ
+        return summ
+
+
+__all__ = ["ShardedDedup", "HipStageOps", "splitters_from_hist", "HumidError"]

@@ -127,6 +127,41 @@ int humid_cluster_graph(humid_ctx *ctx, const uint32_t *count, const uint32_t *n
                         uint32_t *leaf_cluster, uint64_t *cl_size, uint32_t *cl_max_count,
                         uint32_t *cl_max_leaf, uint32_t *n_clusters);
 
+/* ---- stages of the same path, for the multi-GPU driver --------------------------
+ * One process per GPU (humid_amd/sharded.py, torch.distributed over RCCL): the packed words of
+ * all ranks are all-gathered, every rank counts the words of ONE value range
+ * (humid_stage_count), the per-range unique arrays are all-gathered (ranges are disjoint and
+ * ordered, so their concatenation is Trie::walk() order), neighbours + clusters run over that
+ * array (humid_stage_graph) and every rank emits the per-read results of the words it owns
+ * (humid_stage_map; 0 elsewhere, so a sum over ranks is the answer).  All pointers are DEVICE
+ * pointers unless noted; every call returns after the context's stream has drained.  The
+ * reference has no counterpart (it is single-process); semantics per read are those of
+ * humid_dedup_run. */
+
+/* usable reads per top-`bits` bin of the word -> d_hist[1 << bits] (u32), for range splitters */
+int humid_stage_histogram(humid_ctx *ctx, const uint64_t *d_words, const uint8_t *d_filtered,
+                          uint64_t n_reads, uint32_t word_nt, uint32_t bits, uint32_t *d_hist);
+/* Trie::add for the reads whose word is in [range_lo, range_hi] (inclusive); expected_reads =
+ * upper bound of such reads (0 = n_reads) sizes the table.  n_unique/n_usable: host outputs. */
+int humid_stage_count(humid_ctx *ctx, const uint64_t *d_words, const uint8_t *d_filtered,
+                      uint64_t n_reads, uint32_t word_nt, uint64_t range_lo, uint64_t range_hi,
+                      uint64_t expected_reads, uint64_t *n_unique, uint64_t *n_usable);
+/* device pointers (owned by ctx, valid until the next stage_count) of this range's unique words
+ * in ascending order, their counts and first read indices */
+int humid_stage_unique(humid_ctx *ctx, const uint64_t **d_word, const uint32_t **d_count,
+                       const uint32_t **d_first);
+/* findHammingNeighbours + findClusters over an ascending unique array; *d_cluster_id /
+ * *d_is_max: device arrays (owned by ctx) in the same order.  summary: host. */
+int humid_stage_graph(humid_ctx *ctx, const uint64_t *d_g_word, const uint32_t *d_g_count,
+                      uint64_t n_unique, uint32_t word_nt, uint32_t distance, uint32_t method,
+                      const uint32_t **d_cluster_id, const uint8_t **d_is_max,
+                      humid_summary *summary);
+/* per-read (cluster_id, keep) for the reads counted by the preceding humid_stage_count, given
+ * the cluster ids / maxLeaf flags of ITS unique words (local order); other reads get 0 */
+int humid_stage_map(humid_ctx *ctx, const uint32_t *d_local_cluster_id,
+                    const uint8_t *d_local_is_max, uint64_t n_reads, uint32_t *d_cluster_id,
+                    uint8_t *d_keep);
+
 /* src/cluster.cc:31-33 atLeastDouble_, evaluated on the device (parity probe). */
 int humid_at_least_double(humid_ctx *ctx, uint64_t a, uint64_t b, int *result);
 

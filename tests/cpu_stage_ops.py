@@ -1,0 +1,59 @@
+"""CPU stand-in for humid_amd.sharded.HipStageOps, built on numpy and the oracle.
+
+TEST INFRASTRUCTURE: lets the multi-rank orchestration (humid_amd/sharded.py) run under gloo
+on a CPU-only box.  Same method signatures as HipStageOps; tensors are CPU torch tensors."""
+import numpy as np
+import torch
+
+from oracle import pyoracle as orc
+
+
+class CpuStageOps:
+    def histogram(self, g_w, g_f, word_nt, bits):
+        w = g_w.numpy().view(np.uint64)
+        f = g_f.numpy()
+        shift = np.uint64(2 * word_nt - bits)
+        b = (w[f == 0] >> shift).astype(np.int64)
+        return torch.from_numpy(np.bincount(b, minlength=1 << bits).astype(np.int32))
+
+    def count(self, g_w, g_f, word_nt, lo, hi, expected):
+        w = g_w.numpy().view(np.uint64)
+        f = g_f.numpy()
+        if lo > hi:
+            own = np.zeros(len(w), dtype=bool)
+        else:
+            own = (f == 0) & (w >= np.uint64(lo)) & (w <= np.uint64(hi))
+        assert int(own.sum()) <= expected
+        self.read_idx = np.nonzero(own)[0]
+        uw, first, inv, cnt = np.unique(w[own], return_index=True, return_inverse=True, return_counts=True)
+        self.uw, self.cnt = uw, cnt.astype(np.int32)
+        self.first = self.read_idx[first] if len(first) else np.zeros(0, np.int64)
+        self.inv = inv
+        return len(uw), int(own.sum())
+
+    def unique(self):
+        return (torch.from_numpy(self.uw.view(np.int64).copy()), torch.from_numpy(self.cnt.copy()))
+
+    def graph(self, g_word, g_cnt, word_nt, distance, method):
+        uw = g_word.numpy().view(np.uint64)
+        cnt = g_cnt.numpy().astype(np.int64)
+        assert np.all(uw[1:] > uw[:-1]), "global unique array must be strictly ascending"
+        reads = np.repeat(uw, cnt)
+        p = orc.Pipeline(word_nt)
+        p.read_data(reads, np.zeros(len(reads), np.uint8))
+        p.find_hamming_neighbours(distance)
+        p.find_clusters(bool(method))
+        lv = p.leaves()
+        s = dict(clusters=p.n_clusters, edges=p.n_edges, nonsingle=int((lv["degree"] > 0).sum()))
+        return (torch.from_numpy(lv["cluster_id"].astype(np.int32)),
+                torch.from_numpy(lv["is_max_leaf"].copy()), s)
+
+    def map(self, l_cid, l_ismax, out_cid, out_keep):
+        out_cid.zero_()
+        out_keep.zero_()
+        if len(self.read_idx) == 0:
+            return
+        cid = l_cid.numpy()[self.inv]
+        keep = (l_ismax.numpy()[self.inv] != 0) & (self.first[self.inv] == self.read_idx)
+        out_cid.numpy()[self.read_idx] = cid
+        out_keep.numpy()[self.read_idx] = keep.astype(np.uint8)

@@ -284,3 +284,88 @@ def test_full_size_properties(dd):
     # cluster holding the smallest usable word
     smallest = sw[sf == 0][0]
     assert cid[(words == smallest) & (filt == 0)][0] >= 1
+
+
+# ------------------------------------------------------------------------------------------
+# multi-GPU stage entry points, exercised on ONE GPU: P virtual ranks, one context each
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("P", [1, 2, 4, 8])
+@pytest.mark.parametrize("cfg", [(200_000, 24, 1, "umi", 0), (60_000, 12, 2, "umi", 1),
+                                 (50_000, 32, 1, "umi", 0), (3000, 4, 1, "umi", 0)])
+def test_stage_functions_with_virtual_ranks(P, cfg):
+    import torch
+    from humid_amd.sharded import HipStageOps, splitters_from_hist
+    n_reads, n, d, mode, method = cfg
+    words, filt = synth_words(n_reads, 77 + P, n, p_sub=5e-3, p_n=1e-3, mode=mode)
+    ocid, okeep, osum, _ = orc.dedup_run(words, filt, n, d, method)
+    dev = torch.device("cuda:0")
+    g_w = torch.from_numpy(words.view(np.int64)).to(dev)
+    g_f = torch.from_numpy(filt).to(dev)
+    ops = [HipStageOps(0) for _ in range(P)]
+    bits = min(12, 2 * n)
+    hist = ops[0].histogram(g_w, g_f, n, bits).cpu().numpy()
+    assert int(hist.sum()) == osum["usable"]
+    ranges = splitters_from_hist(hist, P, n, bits)
+    u_all, uw, uc = [], [], []
+    usable = 0
+    for r in range(P):
+        lo, hi, exp = ranges[r]
+        u, us = ops[r].count(g_w, g_f, n, lo, hi, max(exp, 1))
+        usable += us
+        u_all.append(u)
+        w, c = ops[r].unique()
+        uw.append(w.clone())
+        uc.append(c.clone())
+    assert usable == osum["usable"] and sum(u_all) == osum["unique"]
+    gw, gc = torch.cat(uw), torch.cat(uc)
+    assert bool((gw.cpu().numpy().view(np.uint64)[1:] > gw.cpu().numpy().view(np.uint64)[:-1]).all())
+    cid_g, ismax_g, gs = ops[0].graph(gw, gc, n, d, method)
+    assert gs["clusters"] == osum["clusters"]
+    tot_cid = torch.zeros(n_reads, dtype=torch.int32, device=dev)
+    tot_keep = torch.zeros(n_reads, dtype=torch.int32, device=dev)
+    off = 0
+    for r in range(P):
+        o_c = torch.empty(n_reads, dtype=torch.int32, device=dev)
+        o_k = torch.empty(n_reads, dtype=torch.uint8, device=dev)
+        l_c = cid_g[off:off + u_all[r]].clone()
+        l_m = ismax_g[off:off + u_all[r]].clone()
+        ops[r].map(l_c, l_m, o_c, o_k)
+        tot_cid += o_c
+        tot_keep += o_k.to(torch.int32)
+        off += u_all[r]
+    assert np.array_equal(tot_cid.cpu().numpy().view(np.uint32), ocid)
+    assert np.array_equal(tot_keep.cpu().numpy().astype(np.uint8), okeep)
+    for o in ops:
+        o.close()
+
+
+def test_sharded_world1_nccl():
+    """ShardedDedup end to end over RCCL with a single rank (all collectives degenerate)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from humid_amd.sharded import ShardedDedup
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=dev)
+    try:
+        words, filt = synth_words(300_000, 31, 24, p_sub=2e-3)
+        ocid, okeep, osum, _ = orc.dedup_run(words, filt, 24, 1, 0)
+        d_w = torch.from_numpy(words.view(np.int64)).to(dev)
+        d_f = torch.from_numpy(filt).to(dev)
+        d_c = torch.zeros(len(words), dtype=torch.int32, device=dev)
+        d_k = torch.zeros(len(words), dtype=torch.uint8, device=dev)
+        sd = ShardedDedup(device=0, word_nt=24, distance=1)
+        for _ in range(2):
+            s = sd.run(d_w, d_f, d_c, d_k)
+        assert np.array_equal(d_c.cpu().numpy().view(np.uint32), ocid)
+        assert np.array_equal(d_k.cpu().numpy(), okeep)
+        for k in ("total", "usable", "unique", "clusters"):
+            assert s[k] == osum[k]
+    finally:
+        dist.destroy_process_group()

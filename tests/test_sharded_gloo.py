@@ -1,0 +1,120 @@
+"""The N>1 path on CPU: world_size 2 and 3 over gloo, orchestration from humid_amd/sharded.py,
+stage compute from tests/cpu_stage_ops.py (numpy + oracle).  Every rank's shard results must be
+bit-identical to a single-process oracle run over the whole read set."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cpu_stage_ops import CpuStageOps
+        from humid_amd.sharded import ShardedDedup
+        from humid_amd.synth import synth_words
+        from oracle import pyoracle as orc
+        n_reads, n, d, method, sizes, mode, p_sub = case
+        words, filt = synth_words(n_reads, 4242, n, p_sub=p_sub, p_n=2e-3, mode=mode, genome_bp=3000)
+        ocid, okeep, osum, _ = orc.dedup_run(words, filt, n, d, method)
+        if sizes is None:
+            base = n_reads // world
+            sizes = [base] * (world - 1) + [n_reads - base * (world - 1)]
+        off = sum(sizes[:rank])
+        w = torch.from_numpy(words[off:off + sizes[rank]].view(np.int64).copy())
+        f = torch.from_numpy(filt[off:off + sizes[rank]].copy())
+        cid = torch.zeros(sizes[rank], dtype=torch.int32)
+        keep = torch.zeros(sizes[rank], dtype=torch.uint8)
+        sd = ShardedDedup(word_nt=n, distance=d, method=method, ops=CpuStageOps())
+        for _ in range(2):          # second pass re-uses the instance (cached shard sizes)
+            s = sd.run(w, f, cid, keep)
+        ok = (np.array_equal(cid.numpy().view(np.uint32), ocid[off:off + sizes[rank]]) and
+              np.array_equal(keep.numpy(), okeep[off:off + sizes[rank]]))
+        ok = ok and all(s[k] == osum[k] for k in ("total", "usable", "unique", "clusters"))
+        q.put((rank, bool(ok), {k: s[k] for k in ("total", "usable", "unique", "clusters")}, osum))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc(), str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+CASES = [
+    # reads, word_nt, d, method, shard sizes, mode, p_sub
+    (6000, 24, 1, 0, None, "umi", 5e-3),
+    (5000, 12, 2, 0, None, "umi", 1e-2),
+    (4000, 24, 2, 1, None, "genome", 5e-3),
+    (3001, 8, 1, 0, "uneven", "umi", 1e-2),
+    (300, 32, 1, 0, None, "umi", 1e-2),
+    (40, 3, 1, 0, None, "umi", 0.0),       # tiny word space: most ranges empty
+]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", CASES)
+def test_sharded_matches_single_process(world, case):
+    case = list(case)
+    if case[4] == "uneven":
+        n = case[0]
+        case[4] = [n // 5] + [n - n // 5 - 7 * (world - 2)] + [7] * (world - 2)
+        assert sum(case[4]) == n
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tuple(case), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, got, want in sorted(res):
+        assert ok, (rank, got, want)
+
+
+def test_splitters_cover_and_balance():
+    from humid_amd.sharded import splitters_from_hist
+    rng = np.random.default_rng(0)
+    for world in (1, 2, 3, 8):
+        for bits, n in ((12, 24), (12, 32), (6, 3), (2, 1)):
+            hist = rng.integers(0, 100, size=1 << bits)
+            hist[rng.random(1 << bits) < 0.5] = 0
+            rs = splitters_from_hist(hist, world, n, bits)
+            assert len(rs) == world
+            assert sum(e for _, _, e in rs) == int(hist.sum())
+            nxt = 0
+            for lo, hi, e in rs:
+                if lo > hi:
+                    assert e == 0
+                    continue
+                assert lo == nxt or e == 0 or lo >= nxt
+                assert hi >= lo
+                nxt = hi + 1
+            live = [x for x in rs if x[0] <= x[1]]
+            assert live[0][0] == 0 and live[-1][1] >= 4 ** n - 1   # every valid word is covered
+            for a, b in zip(live[:-1], live[1:]):
+                assert a[1] + 1 == b[0]
+    # skew: everything in one bin -> one rank owns it all, still a cover
+    hist = np.zeros(4096, dtype=np.int64)
+    hist[77] = 1000
+    rs = splitters_from_hist(hist, 8, 24, 12)
+    assert sum(e for _, _, e in rs) == 1000 and max(e for _, _, e in rs) == 1000
