@@ -42,5 +42,26 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     return SO
 
 
+HOST_DIR = os.path.join(HERE, "csrc", "host")
+HOST_EXE = os.path.join(HERE, "humid")
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """The `humid` command-line host (C++17, g++): FastQ streaming + the C ABI."""
+    srcs = [os.path.join(HOST_DIR, f) for f in ("main.cpp", "fastq_io.cpp", "words.cpp")]
+    deps = srcs + [os.path.join(HOST_DIR, f) for f in ("fastq_io.hpp", "words.hpp")] + [HDR]
+    build_hip(force=False, verbose=verbose)
+    if not force and os.path.exists(HOST_EXE) and \
+            all(os.path.getmtime(p) <= os.path.getmtime(HOST_EXE) for p in deps + [SO]):
+        return HOST_EXE
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", HOST_EXE] + srcs + \
+          ["-L" + HERE, "-lhumid_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=ROOT)
+    return HOST_EXE
+
+
 if __name__ == "__main__":
     print(build_hip(force=True, verbose=True))
+    print(build_host(force=True, verbose=True))

@@ -1,0 +1,103 @@
+#include "fastq_io.hpp"
+
+#include <cstdio>
+#include <cstring>
+
+static const size_t kBuf = 1u << 20;
+
+FastqReader::FastqReader(const std::string &path) : buf_(kBuf) {
+  gz_ = gzopen(path.c_str(), "rb");
+  if (gz_) gzbuffer(gz_, 1u << 18);
+}
+
+FastqReader::~FastqReader() {
+  if (gz_) gzclose(gz_);
+}
+
+bool FastqReader::getline(std::string &line) {
+  line.clear();
+  if (!gz_) return false;
+  while (true) {
+    if (pos_ == len_) {
+      if (eof_) return !line.empty();
+      int n = gzread(gz_, buf_.data(), (unsigned)buf_.size());
+      if (n <= 0) { eof_ = true; return !line.empty(); }
+      len_ = (size_t)n;
+      pos_ = 0;
+    }
+    const char *start = buf_.data() + pos_;
+    const char *nl = (const char *)memchr(start, '\n', len_ - pos_);
+    if (nl) {
+      line.append(start, (size_t)(nl - start));
+      pos_ += (size_t)(nl - start) + 1;
+      if (!line.empty() && line.back() == '\r') line.pop_back();
+      return true;
+    }
+    line.append(start, len_ - pos_);
+    pos_ = len_;
+  }
+}
+
+bool FastqReader::read(FastqRecord &rec) {
+  // skip blank lines between records
+  do {
+    if (!getline(rec.name)) return false;
+  } while (rec.name.empty());
+  if (!getline(rec.seq)) return false;
+  if (!getline(rec.strand)) return false;
+  if (!getline(rec.quality)) rec.quality.clear();
+  return true;
+}
+
+MultiReader::MultiReader(const std::vector<std::string> &files) {
+  for (const std::string &f : files) {
+    FastqReader *r = new FastqReader(f);
+    if (!r->ok()) { ok_ = false; if (bad_.empty()) bad_ = f; }
+    readers_.push_back(r);
+  }
+}
+
+MultiReader::~MultiReader() {
+  for (FastqReader *r : readers_) delete r;
+}
+
+bool MultiReader::next(std::vector<FastqRecord> &recs) {
+  recs.resize(readers_.size());
+  bool all = true;
+  for (size_t i = 0; i < readers_.size(); i++)
+    if (!readers_[i]->read(recs[i])) all = false;   // src/fastq.cc:39-45: every reader advances
+  return all;
+}
+
+static bool ends_with(const std::string &s, const char *suf) {
+  size_t n = strlen(suf);
+  return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+FastqWriter::FastqWriter(const std::string &path) {
+  if (ends_with(path, ".gz")) {
+    gz_ = gzopen(path.c_str(), "wb4");   // fastp Options default compression level 4
+    if (gz_) gzbuffer(gz_, 1u << 18);
+  } else {
+    plain_ = fopen(path.c_str(), "wb");
+  }
+  pending_.reserve(kBuf + 4096);
+}
+
+void FastqWriter::flush() {
+  if (pending_.empty()) return;
+  if (gz_) gzwrite(gz_, pending_.data(), (unsigned)pending_.size());
+  else if (plain_) fwrite(pending_.data(), 1, pending_.size(), plain_);
+  pending_.clear();
+}
+
+void FastqWriter::write(const char *data, size_t n) {
+  pending_.append(data, n);
+  if (pending_.size() >= kBuf) flush();
+}
+
+FastqWriter::~FastqWriter() {
+  flush();
+  if (gz_) gzclose(gz_);
+  if (plain_) fclose(plain_);
+}

@@ -1,0 +1,69 @@
+// fastq_io.hpp -- minimal FastQ reader/writer for the `humid` host (plain + gzip via zlib).
+//
+// The reference streams FastQ through OpenGene/fastp (FastqReader::read() -> Read*, Writer;
+// used at /root/reference/src/fastq.cc:37-47,96-114 and src/humid.cc:214-238,262-289).  fastp
+// is an un-vendored submodule, so this host carries its own record reader with the same
+// observable behaviour for this path: four-line records, name line kept verbatim including
+// '@', '\r' stripped, reading stops at the first file that runs out (src/fastq.cc:41-43).
+#pragma once
+#include <zlib.h>
+
+#include <string>
+#include <vector>
+
+struct FastqRecord {
+  std::string name;     // header line including the leading '@' (fastp Read::mName)
+  std::string seq;      // fastp Read::mSeq
+  std::string strand;   // the '+' line
+  std::string quality;
+  // fastp Read::toString(): the four lines, '\n' terminated
+  void append_to(std::string &out) const {
+    out.append(name).push_back('\n');
+    out.append(seq).push_back('\n');
+    out.append(strand).push_back('\n');
+    out.append(quality).push_back('\n');
+  }
+};
+
+class FastqReader {
+ public:
+  explicit FastqReader(const std::string &path);
+  ~FastqReader();
+  bool ok() const { return gz_ != nullptr; }
+  bool read(FastqRecord &rec);   // false at end of file / truncated record
+ private:
+  bool getline(std::string &line);
+  gzFile gz_ = nullptr;          // gzopen reads plain files transparently
+  std::vector<char> buf_;
+  size_t pos_ = 0, len_ = 0;
+  bool eof_ = false;
+};
+
+// Lock-step over several files (src/fastq.cc:96-114 readFiles): one record from each file per
+// step; stops when ANY file is exhausted.
+class MultiReader {
+ public:
+  explicit MultiReader(const std::vector<std::string> &files);
+  ~MultiReader();
+  bool ok() const { return ok_; }
+  const std::string &bad_file() const { return bad_; }
+  bool next(std::vector<FastqRecord> &recs);
+ private:
+  std::vector<FastqReader *> readers_;
+  bool ok_ = true;
+  std::string bad_;
+};
+
+// Output file; gzip-compressed when the name ends in ".gz" (as fastp's Writer decides).
+class FastqWriter {
+ public:
+  explicit FastqWriter(const std::string &path);
+  ~FastqWriter();
+  bool ok() const { return plain_ != nullptr || gz_ != nullptr; }
+  void write(const char *data, size_t n);
+  void flush();
+ private:
+  FILE *plain_ = nullptr;
+  gzFile gz_ = nullptr;
+  std::string pending_;
+};

@@ -1,0 +1,251 @@
+// humid -- command-line host of the MI355X-native HUMID hot path.
+//
+// Keeps the reference's CLI and FastQ-in / FastQ-out contract
+// (/root/reference/src/humid.cc:369-429): same flags, same log lines, same output names
+// (<name>_dedup.<ext>, <name>_annotated.<ext>), same .dat statistics.  FastQ is streamed twice:
+// pass 1 builds the packed words, libhumid_hip.so (include/humid_hip.h) does counts ->
+// neighbours -> clusters on the GPU, pass 2 writes with the per-read (cluster_id, keep) arrays
+// instead of trie.find() (src/humid.cc:223-231,276-277).
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../../include/humid_hip.h"
+#include "fastq_io.hpp"
+#include "words.hpp"
+
+using namespace humid_host;
+
+namespace {
+
+struct Args {
+  size_t word_length = 24;     // -n
+  size_t distance = 1;         // -m
+  std::string log_name = "/dev/stderr";   // -l
+  std::string dir_name = ".";  // -d
+  bool stats = false;          // -s
+  bool filter = true;          // -q flips
+  bool annotate = false;       // -a
+  bool edit = false;           // -e
+  bool maximum = false;        // -x
+  std::vector<std::string> files;
+  std::string dump_words;      // --dump-words (development: stop after pass 1, no GPU)
+};
+
+void usage(const char *argv0) {
+  std::fprintf(stderr,
+               "usage: %s [-n 24] [-m 1] [-l /dev/stderr] [-d .] [-s] [-q] [-a] [-e] [-x] files...\n"
+               "Deduplicate a dataset.\n"
+               "  -n  word length\n  -m  allowed mismatches\n  -l  log file name\n  -d  output directory\n"
+               "  -s  calculate statistics\n  -q  write deduplicated FastQ files (flag turns it OFF)\n"
+               "  -a  write annotated FastQ files\n  -e  use edit distance (not supported on the GPU path)\n"
+               "  -x  use maximum clustering method\n",
+               argv0);
+}
+
+bool parse(int argc, char **argv, Args &a) {
+  for (int i = 1; i < argc; i++) {
+    std::string t = argv[i];
+    auto need = [&](const char *what) -> const char * {
+      if (i + 1 >= argc) { std::fprintf(stderr, "humid: %s needs a value\n", what); return nullptr; }
+      return argv[++i];
+    };
+    if (t == "-h" || t == "--help") { usage(argv[0]); std::exit(0); }
+    else if (t == "-n") { const char *v = need("-n"); if (!v) return false; a.word_length = std::strtoull(v, nullptr, 10); }
+    else if (t == "-m") { const char *v = need("-m"); if (!v) return false; a.distance = std::strtoull(v, nullptr, 10); }
+    else if (t == "-l") { const char *v = need("-l"); if (!v) return false; a.log_name = v; }
+    else if (t == "-d") { const char *v = need("-d"); if (!v) return false; a.dir_name = v; }
+    else if (t == "--dump-words") { const char *v = need("--dump-words"); if (!v) return false; a.dump_words = v; }
+    else if (t == "-s") a.stats = !a.stats;
+    else if (t == "-q") a.filter = !a.filter;
+    else if (t == "-a") a.annotate = !a.annotate;
+    else if (t == "-e") a.edit = !a.edit;
+    else if (t == "-x") a.maximum = !a.maximum;
+    else if (t.size() > 1 && t[0] == '-') { std::fprintf(stderr, "humid: unknown option %s\n", t.c_str()); return false; }
+    else a.files.push_back(t);
+  }
+  if (a.files.empty()) { std::fprintf(stderr, "humid: no input files\n"); return false; }
+  return true;
+}
+
+// src/log.cc:4-15
+time_t start_message(std::ofstream &log, const char *msg) {
+  log << msg << "... ";
+  log.flush();
+  return time(nullptr);
+}
+void end_message(std::ofstream &log, time_t start) {
+  time_t seconds = (time_t)difftime(time(nullptr), start);
+  log << "done. (" << seconds / 60 << 'm' << seconds % 60 << "s)\n";
+  log.flush();
+}
+
+void make_dirs(const std::string &path) {   // std::filesystem::create_directories
+  std::string cur;
+  for (size_t i = 0; i <= path.size(); i++) {
+    if (i == path.size() || path[i] == '/') {
+      if (!cur.empty()) mkdir(cur.c_str(), 0777);
+    }
+    if (i < path.size()) cur.push_back(path[i]);
+  }
+}
+
+bool write_hist(humid_ctx *ctx, uint32_t which, const std::string &path) {
+  uint64_t n = 0;
+  if (humid_get_histogram(ctx, which, nullptr, nullptr, 0, &n) != HUMID_OK) return false;
+  std::vector<uint64_t> k(n ? n : 1), v(n ? n : 1);
+  if (n && humid_get_histogram(ctx, which, k.data(), v.data(), n, &n) != HUMID_OK) return false;
+  std::ofstream out(path, std::ios::out | std::ios::binary);
+  for (uint64_t i = 0; i < n; i++) out << k[i] << ' ' << v[i] << '\n';   // src/humid.cc:333-349
+  return true;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  Args a;
+  if (!parse(argc, argv, a)) { usage(argv[0]); return 2; }
+  if (a.edit) {
+    std::fprintf(stderr, "humid: edit distance (-e) is not supported by the HIP path (Hamming only)\n");
+    return 2;
+  }
+  if (a.word_length == 0 || a.word_length > 32) {
+    std::fprintf(stderr, "humid: word length %zu is not supported by the HIP path (1..32)\n", a.word_length);
+    return 2;
+  }
+  std::ofstream log(a.log_name.c_str(), std::ios::out | std::ios::binary);
+
+  // ---- preCompute (src/humid.cc:38-59): UMI size from the first header of the first file ----
+  size_t first_umi = 0;
+  {
+    FastqReader peek(a.files.front());
+    if (!peek.ok()) { std::fprintf(stderr, "humid: cannot open %s\n", a.files.front().c_str()); return 1; }
+    FastqRecord r;
+    if (peek.read(r)) first_umi = header_umi(r.name).size();   // empty file: no UMI (the reference crashes)
+  }
+  WordPlan plan = make_plan(first_umi, a.files.size(), a.word_length);
+  time_t t = start_message(log, "Determing nucleotides to take");
+  end_message(log, t);
+  log << "  header: " << plan.header_umi;
+  for (size_t i = 0; i < a.files.size(); i++) log << "\n  " << a.files[i] << ": " << plan.take[i];
+  log << "\n";
+
+  // ---- pass 1: readData (src/humid.cc:89-100) ----
+  t = start_message(log, "Reading data");
+  std::vector<uint64_t> words;
+  std::vector<uint8_t> filtered;
+  {
+    MultiReader in(a.files);
+    if (!in.ok()) { std::fprintf(stderr, "humid: cannot open %s\n", in.bad_file().c_str()); return 1; }
+    std::vector<FastqRecord> recs;
+    while (in.next(recs)) {
+      uint64_t w;
+      bool f = make_word(recs, plan, w);
+      words.push_back(w);
+      filtered.push_back(f ? 1 : 0);
+    }
+  }
+  end_message(log, t);
+  const uint64_t N = words.size();
+
+  if (!a.dump_words.empty()) {   // development aid: host-side parsing can be checked without a GPU
+    std::ofstream out(a.dump_words, std::ios::out | std::ios::binary);
+    out.write((const char *)&N, 8);
+    out.write((const char *)words.data(), (std::streamsize)(N * 8));
+    out.write((const char *)filtered.data(), (std::streamsize)N);
+    return 0;
+  }
+
+  // ---- the hot path on the GPU ----
+  humid_ctx *ctx = nullptr;
+  if (humid_ctx_create(&ctx, -1, nullptr) != HUMID_OK) {
+    std::fprintf(stderr, "humid: %s\n", humid_last_error(nullptr));
+    return 1;
+  }
+  std::vector<uint32_t> cluster_id(N ? N : 1);
+  std::vector<uint8_t> keep(N ? N : 1);
+  humid_summary sum;
+  std::memset(&sum, 0, sizeof sum);
+  t = start_message(log, "Calculating neighbours using Hamming distance");
+  int rc = humid_dedup_run(ctx, words.data(), filtered.data(), N, (uint32_t)a.word_length,
+                           (uint32_t)a.distance, a.maximum ? HUMID_METHOD_MAXIMUM : HUMID_METHOD_DIRECTIONAL,
+                           cluster_id.data(), keep.data(), &sum);
+  if (rc != HUMID_OK) {
+    log << "failed.\n";
+    std::fprintf(stderr, "humid: %s\n", humid_last_error(ctx));
+    humid_ctx_destroy(ctx);
+    return 1;
+  }
+  end_message(log, t);
+  t = start_message(log, a.maximum ? "Calculating maximum clusters" : "Calculating directional clusters");
+  end_message(log, t);
+  std::vector<uint64_t>().swap(words);
+
+  make_dirs(a.dir_name);
+
+  // ---- pass 2: writeFiltered (src/humid.cc:203-241) / writeAnnotated (:251-292) ----
+  if (a.filter || a.annotate) {
+    time_t tf = 0, ta = 0;
+    if (a.filter) tf = start_message(log, "Writing filtered results");
+    std::vector<FastqWriter *> dedup, annot;
+    for (const std::string &f : a.files) {
+      if (a.filter) dedup.push_back(new FastqWriter(make_file_name(f, a.dir_name, "dedup")));
+      if (a.annotate) annot.push_back(new FastqWriter(make_file_name(f, a.dir_name, "annotated")));
+    }
+    bool ok = true;
+    for (FastqWriter *w : dedup) ok = ok && w->ok();
+    for (FastqWriter *w : annot) ok = ok && w->ok();
+    if (!ok) { std::fprintf(stderr, "humid: cannot create output files in %s\n", a.dir_name.c_str()); return 1; }
+    MultiReader in(a.files);
+    std::vector<FastqRecord> recs;
+    std::string s;
+    uint64_t i = 0;
+    while (i < N && in.next(recs)) {
+      if (a.filter && keep[i]) {
+        for (size_t f = 0; f < recs.size(); f++) {
+          s.clear();
+          recs[f].append_to(s);
+          dedup[f]->write(s.data(), s.size());
+        }
+      }
+      if (a.annotate) {
+        const std::string tag = ":" + std::to_string(cluster_id[i]);   // src/humid.cc:281
+        for (size_t f = 0; f < recs.size(); f++) {
+          recs[f].name += tag;
+          s.clear();
+          recs[f].append_to(s);
+          annot[f]->write(s.data(), s.size());
+        }
+      }
+      i++;
+    }
+    for (FastqWriter *w : dedup) delete w;
+    for (FastqWriter *w : annot) delete w;
+    if (a.filter) end_message(log, tf);
+    if (a.annotate) { ta = start_message(log, "Writing annotated results"); end_message(log, ta); }
+  }
+
+  // ---- statistics (src/humid.cc:301-357, src/cluster.cc:89-95) ----
+  if (a.stats) {
+    t = start_message(log, "Calculating count and neighbour stats");
+    bool ok = write_hist(ctx, 0, a.dir_name + "/counts.dat") && write_hist(ctx, 1, a.dir_name + "/neigh.dat") &&
+              write_hist(ctx, 2, a.dir_name + "/clusters.dat");
+    end_message(log, t);
+    if (!ok) { std::fprintf(stderr, "humid: %s\n", humid_last_error(ctx)); humid_ctx_destroy(ctx); return 1; }
+    std::ofstream out(a.dir_name + "/stats.dat", std::ios::out | std::ios::binary);
+    out << "total: " << sum.total << '\n';
+    out << "usable: " << sum.usable << '\n';
+    out << "unique: " << sum.unique << '\n';
+    out << "clusters: " << sum.clusters << '\n';
+  }
+  log.close();
+  humid_ctx_destroy(ctx);
+  return 0;
+}

@@ -1,0 +1,81 @@
+"""-m gpu: the `humid` CLI end to end (FastQ in -> _dedup/_annotated FastQ + .dat out) against
+outputs constructed from the oracle."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cli_util import HUMID, expected_words, read_fastq
+from humid_amd.synth import synth_fastq
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def run_oracle(words, filt, n, d, maximum):
+    p = orc.Pipeline(n)
+    p.read_data(words, filt)
+    p.find_hamming_neighbours(d)
+    p.find_clusters(maximum)
+    cid, keep = p.map_reads()
+    return p, cid, keep
+
+
+def dat(path):
+    return [tuple(int(x) for x in l.split()) for l in open(path).read().strip().split("\n") if l]
+
+
+@pytest.mark.parametrize("case", [
+    dict(n_files=1, umi_len=8, umi_in_header=True, word_nt=24, d=1, x=False, n=3000),
+    dict(n_files=2, umi_len=8, umi_in_header=True, word_nt=24, d=1, x=False, n=3000),
+    dict(n_files=2, umi_len=12, umi_in_header=False, umi_file=True, word_nt=24, d=1, x=True, n=2000),
+    dict(n_files=2, umi_len=0, umi_in_header=False, word_nt=12, d=2, x=False, n=2000),
+])
+def test_cli_end_to_end(case, tmp_path):
+    case = dict(case)
+    word_nt, d, x, n = case.pop("word_nt"), case.pop("d"), case.pop("x"), case.pop("n")
+    files = synth_fastq(str(tmp_path / "in"), n, 123, p_sub=4e-3, p_n=2e-3, read_len=36,
+                        short_frac=0.01, **case)
+    out = str(tmp_path / "out" / "nested")
+    cmd = [HUMID, "-n", str(word_nt), "-m", str(d), "-d", out, "-l", str(tmp_path / "log.txt"), "-s", "-a"]
+    if x:
+        cmd.append("-x")
+    subprocess.check_call(cmd + files)
+    words, filt, recs, _ = expected_words(files, word_nt)
+    p, cid, keep = run_oracle(words, filt, word_nt, d, x)
+    for fi, f in enumerate(files):
+        base = os.path.basename(f)
+        dedup = read_fastq(os.path.join(out, base.replace(".fastq", "_dedup.fastq")))
+        annot = read_fastq(os.path.join(out, base.replace(".fastq", "_annotated.fastq")))
+        assert dedup == [recs[fi][i] for i in range(n) if keep[i]]
+        exp_annot = [(recs[fi][i][0] + ":%d" % cid[i],) + recs[fi][i][1:] for i in range(n)]
+        assert annot == exp_annot
+    h = orc.histograms(p)
+    assert dat(os.path.join(out, "counts.dat")) == h["counts"]
+    assert dat(os.path.join(out, "neigh.dat")) == h["neigh"]
+    assert dat(os.path.join(out, "clusters.dat")) == h["clusters"]
+    stats = dict(l.split(": ") for l in open(os.path.join(out, "stats.dat")).read().strip().split("\n"))
+    assert {k: int(v) for k, v in stats.items()} == h["stats"]
+    log = open(tmp_path / "log.txt").read()
+    assert "Calculating neighbours using Hamming distance... done." in log
+    assert ("Calculating maximum clusters" if x else "Calculating directional clusters") in log
+    assert "Writing filtered results... done." in log and "Writing annotated results... done." in log
+
+
+def test_cli_gz_roundtrip_and_q_flag(tmp_path):
+    files = synth_fastq(str(tmp_path), 500, 9, n_files=1, read_len=30)
+    gz = str(tmp_path / "reads.fastq.gz")
+    with gzip.open(gz, "wb") as fh:
+        fh.write(open(files[0], "rb").read())
+    out = str(tmp_path / "o")
+    subprocess.check_call([HUMID, "-d", out, "-l", "/dev/null", gz])
+    d1 = read_fastq(os.path.join(out, "reads_dedup.fastq.gz"))
+    words, filt, recs, _ = expected_words([gz], 24)
+    _, cid, keep = run_oracle(words, filt, 24, 1, False)
+    assert d1 == [recs[0][i] for i in range(len(words)) if keep[i]]
+    # -q flips the default: no dedup output
+    out2 = str(tmp_path / "o2")
+    subprocess.check_call([HUMID, "-q", "-d", out2, "-l", "/dev/null", gz])
+    assert not os.path.exists(os.path.join(out2, "reads_dedup.fastq.gz"))

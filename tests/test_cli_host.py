@@ -1,0 +1,79 @@
+"""Host side of the `humid` CLI without a GPU: FastQ parsing + word extraction
+(--dump-words stops after pass 1) against the oracle's restatement of src/fastq.cc."""
+import gzip
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from cli_util import HUMID, dump_words, expected_words
+from humid_amd import build
+from humid_amd.synth import synth_fastq
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    build.build_host()
+
+
+CASES = [
+    dict(n_files=1, umi_len=8, umi_in_header=True, word_nt=24),                      # config 1/2 shape
+    dict(n_files=2, umi_len=8, umi_in_header=True, word_nt=24),                      # metric shape PE
+    dict(n_files=2, umi_len=12, umi_in_header=False, umi_file=True, word_nt=24),     # config 3 shape
+    dict(n_files=2, umi_len=0, umi_in_header=False, word_nt=24),                     # config 5 shape
+    dict(n_files=2, umi_len=8, umi_in_header=True, word_nt=23),                      # uneven split
+    dict(n_files=1, umi_len=8, umi_in_header=True, word_nt=6),                       # UMI longer than word
+    dict(n_files=1, umi_len=8, umi_in_header=True, word_nt=32, header_style=":"),    # BCL style
+    dict(n_files=2, umi_len=8, umi_in_header=True, word_nt=24, short_frac=0.2),      # N padding
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_words_match_oracle(case, tmp_path):
+    case = dict(case)
+    word_nt = case.pop("word_nt")
+    files = synth_fastq(str(tmp_path), 400, 99, p_sub=5e-3, p_n=3e-3, read_len=40, **case)
+    w, f = dump_words(files, word_nt, str(tmp_path))
+    ew, ef, _, _ = expected_words(files, word_nt)
+    assert len(w) == 400
+    assert np.array_equal(f, ef)
+    assert np.array_equal(w, ew)
+
+
+def test_gz_input_and_crlf(tmp_path):
+    files = synth_fastq(str(tmp_path), 100, 5, n_files=1, read_len=30)
+    plain = open(files[0], "rb").read()
+    gz = str(tmp_path / "in.fastq.gz")
+    with gzip.open(gz, "wb") as fh:
+        fh.write(plain.replace(b"\n", b"\r\n"))
+    w1, f1 = dump_words(files, 24, str(tmp_path))
+    w2, f2 = dump_words([gz], 24, str(tmp_path))
+    assert np.array_equal(w1, w2) and np.array_equal(f1, f2)
+
+
+def test_unequal_files_stop_at_shortest(tmp_path):
+    files = synth_fastq(str(tmp_path), 50, 6, n_files=2, read_len=30)
+    lines = open(files[1]).read().split("\n")
+    open(files[1], "w").write("\n".join(lines[:4 * 20]) + "\n")
+    w, _ = dump_words(files, 24, str(tmp_path))
+    assert len(w) == 20                       # src/fastq.cc:41-43,104
+
+
+def test_log_reports_plan(tmp_path):
+    files = synth_fastq(str(tmp_path), 10, 7, n_files=2, read_len=30)
+    dump_words(files, 23, str(tmp_path))
+    log = open(tmp_path / "log.txt").read()
+    assert "Determing nucleotides to take... done." in log       # src/humid.cc:80 (sic)
+    assert "  header: 8" in log
+    assert "%s: 7" % files[0] in log and "%s: 8" % files[1] in log
+    assert "Reading data... done." in log
+
+
+def test_cli_errors(tmp_path):
+    files = synth_fastq(str(tmp_path), 4, 8, n_files=1, read_len=30)
+    assert subprocess.call([HUMID, "-e"] + files, stderr=subprocess.DEVNULL) == 2
+    assert subprocess.call([HUMID, "-n", "40"] + files, stderr=subprocess.DEVNULL) == 2
+    assert subprocess.call([HUMID], stderr=subprocess.DEVNULL) == 2
+    assert subprocess.call([HUMID, str(tmp_path / "missing.fastq")], stderr=subprocess.DEVNULL) == 1
