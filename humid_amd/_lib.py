@@ -22,7 +22,7 @@ class HumidSummary(C.Structure):
                 ("ms_count", C.c_float), ("ms_neighbours", C.c_float), ("ms_cluster", C.c_float),
                 ("ms_map", C.c_float), ("ms_total", C.c_float), ("ms_h2d", C.c_float),
                 ("ms_d2h", C.c_float), ("ms_k_insert", C.c_float), ("ms_k_pairs", C.c_float),
-                ("ms_k_cluster", C.c_float), ("ms_k_map", C.c_float)]
+                ("ms_k_cluster", C.c_float), ("ms_k_map", C.c_float), ("count_mode_used", C.c_uint32)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -35,6 +35,7 @@ SYMBOLS = {
     "humid_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "humid_ctx_destroy": (None, [C.c_void_p]),
     "humid_last_error": (C.c_char_p, [C.c_void_p]),
+    "humid_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "humid_dedup_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                   C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                   C.POINTER(HumidSummary)]),

@@ -43,6 +43,10 @@ class Context:
             raise HumidError(rc, self._lib.humid_last_error(None).decode())
         self._h = h
 
+    def set_option(self, key: str, value: int):
+        """tuning knobs of include/humid_hip.h (humid_ctx_set_option); never change results"""
+        self._check(self._lib.humid_ctx_set_option(self._h, key.encode(), int(value)))
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.humid_ctx_destroy(self._h)

@@ -15,6 +15,7 @@
 // No CPU fallback lives here: every entry point either runs on the GPU or fails.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -24,6 +25,8 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_run_length_encode.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "../../include/humid_hip.h"
 
@@ -46,6 +49,14 @@ __device__ __forceinline__ u64 mix64(u64 x) {
   x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
   x ^= x >> 27; x *= 0x94d049bb133111ebull;
   x ^= x >> 31;
+  return x;
+}
+
+// inverse of mix64 (mix64 is a bijection on 64-bit words)
+__host__ __device__ __forceinline__ u64 unmix64(u64 x) {
+  x = (x ^ (x >> 31) ^ (x >> 62)) * 0x319642b2d24d8ec3ull;
+  x = (x ^ (x >> 27) ^ (x >> 54)) * 0x96de1b173f119089ull;
+  x = x ^ (x >> 30) ^ (x >> 60);
   return x;
 }
 
@@ -172,6 +183,173 @@ k_compact_table(const Slot *__restrict__ tab, u32 n_slots, u64 *__restrict__ uni
       }
     }
     base += tot;
+  }
+}
+
+// --------------------------------------------------------------------------------
+// 1b. exact counts, partitioned: the reads are first bucketed by the top PB bits of mix64(word)
+// (radix partition; mix64 is a bijection, so equal keys <=> equal words), then every bucket is
+// counted by one workgroup in an LDS-resident open-address table.  No random HBM line traffic:
+// the only scattered access left is the 4-byte slot_of_read[r] store.
+// --------------------------------------------------------------------------------
+#define LDS_SLOTS 2048u          // 16-byte entries: 32 KiB of LDS per workgroup, 5 workgroups per CU
+#define LDS_FILL_LIMIT 1536u     // unique words a bucket may hold (75 % load)
+#define PART_TARGET 700u         // mean reads per bucket
+
+struct MixKeyOp {                // keys_input transform: word -> partition-ordered key
+  __host__ __device__ u64 operator()(u64 w) const { return mix64(w); }
+};
+struct ReadTagOp {               // values_input transform: read index | excluded << 31
+  const u64 *words;
+  const u8 *filtered;
+  u64 lo, hi;
+  __device__ u32 operator()(u32 r) const {
+    const u64 w = words[r];
+    const bool excl = filtered[r] != 0 || w < lo || w > hi;
+    return r | (excl ? 0x80000000u : 0u);
+  }
+};
+
+// first position of every bucket in the partitioned key array (binary search)
+__global__ void k_part_bounds(const u64 *__restrict__ keys, u32 n, u32 pb, u32 n_parts, u32 *__restrict__ pbeg) {
+  u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > n_parts) return;
+  if (p == n_parts) { pbeg[p] = n; return; }
+  const u64 target = (u64)p << (64 - pb);
+  u32 lo = 0, hi = n;
+  while (lo < hi) {
+    u32 mid = lo + ((hi - lo) >> 1);
+    if (keys[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  pbeg[p] = lo;
+}
+
+// One workgroup per bucket.  Entry s of the LDS table: lkey (mixed word), lcnt (occurrences, 0 =
+// empty), lfirst (smallest read index).  Entry LDS_SLOTS is reserved for the key that equals the
+// EMPTY sentinel.  Outputs, in a PADDED layout (bucket b owns positions [pbeg[b], pbeg[b+1]) of
+// N-sized arrays, its u unique words take the first u of them):
+//   pad_word/pad_cnt/pad_first, ucount[b], pusable[b]; slot_of_read[r] = padded position.
+__global__ void __launch_bounds__(256)
+k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u32 *__restrict__ pbeg,
+            u32 n_reads, u32 pb, u64 *__restrict__ pad_word, u32 *__restrict__ pad_cnt, u32 *__restrict__ pad_first,
+            u32 *__restrict__ ucount, u32 *__restrict__ pusable, u32 *__restrict__ slot_of_read, ull *ctr) {
+  __shared__ u64 lkey[LDS_SLOTS + 1];
+  __shared__ u32 lcnt[LDS_SLOTS + 1];
+  __shared__ u32 lfirst[LDS_SLOTS + 1];
+  __shared__ u32 lds[8];
+  const u32 b = blockIdx.x;
+  const u32 beg = pbeg[b], end = pbeg[b + 1];
+  if (beg >= end || end > n_reads) {
+    if (beg > end || end > n_reads) ctr[CTR_OVERFULL] = 1;   // malformed partition: never index with it
+    if (threadIdx.x == 0) { ucount[b] = 0; pusable[b] = 0; }
+    return;
+  }
+  for (u32 s = threadIdx.x; s <= LDS_SLOTS; s += 256) { lkey[s] = EMPTY_KEY; lcnt[s] = 0; lfirst[s] = NONE32; }
+  __syncthreads();
+  const u32 hshift = 64 - pb - 11;      // table index = the 11 key bits below the bucket bits
+  u32 usable = 0;
+  bool overflow = false;
+  for (u32 i = beg + threadIdx.x; i < end; i += 256) {
+    const u32 v = vals[i];
+    if ((v & 0x7fffffffu) >= n_reads) { overflow = true; break; }   // never store through a bad index
+    if (v & 0x80000000u) { slot_of_read[v & 0x7fffffffu] = NOSLOT; continue; }
+    usable++;
+    const u64 k = keys[i];
+    u32 s;
+    if (k == EMPTY_KEY) {
+      s = LDS_SLOTS;
+    } else {
+      s = (u32)(k >> hshift) & (LDS_SLOTS - 1);
+      u32 probes = 0;
+      while (true) {
+        u64 cur = lkey[s];
+        if (cur == EMPTY_KEY) cur = atomicCAS((ull *)&lkey[s], EMPTY_KEY, (ull)k);
+        if (cur == EMPTY_KEY || cur == k) break;
+        s = (s + 1) & (LDS_SLOTS - 1);
+        if (++probes >= LDS_SLOTS) { overflow = true; break; }
+      }
+      if (overflow) break;
+    }
+    atomicAdd(&lcnt[s], 1u);
+    atomicMin(&lfirst[s], v);
+  }
+  if (overflow) ctr[CTR_OVERFULL] = 1;
+  __syncthreads();
+  // compaction of the occupied entries -> padded arrays; lfirst[s] is then reused as slot -> index
+  u32 base = 0;
+  for (u32 s0 = 0; s0 <= LDS_SLOTS; s0 += 256) {
+    const u32 s = s0 + threadIdx.x;
+    const bool occ = (s <= LDS_SLOTS) && lcnt[s] != 0;
+    u32 tot;
+    const u32 r = block_rank(occ, lds, &tot);
+    if (occ) {
+      const u32 li = base + r;           // li < unique words <= reads of the bucket = padded room
+      pad_word[beg + li] = unmix64(lkey[s]);
+      pad_cnt[beg + li] = lcnt[s];
+      pad_first[beg + li] = lfirst[s];
+      lfirst[s] = li;
+    }
+    base += tot;
+  }
+  if (threadIdx.x == 0) ucount[b] = base;
+  const u32 tu = block_sum(usable, lds);
+  if (threadIdx.x == 0) pusable[b] = tu;
+  __syncthreads();
+  // second pass: every read learns the padded position of its word
+  for (u32 i = beg + threadIdx.x; i < end; i += 256) {
+    const u32 v = vals[i];
+    if (v >= n_reads) continue;          // excluded read (bit 31) or malformed index
+    const u64 k = keys[i];
+    u32 s;
+    if (k == EMPTY_KEY) {
+      s = LDS_SLOTS;
+    } else {
+      s = (u32)(k >> hshift) & (LDS_SLOTS - 1);
+      u32 probes = 0;
+      while (lkey[s] != k && probes++ < LDS_SLOTS) s = (s + 1) & (LDS_SLOTS - 1);
+    }
+    const u32 li = lfirst[s];
+    slot_of_read[v] = (li < end - beg) ? beg + li : NOSLOT;
+  }
+}
+
+// totals over the buckets: U = sum ucount, usable = sum pusable (one block)
+__global__ void __launch_bounds__(256)
+k_part_totals(const u32 *__restrict__ ucount, const u32 *__restrict__ pusable, u32 n_parts, ull *ctr) {
+  __shared__ u32 lds[4];
+  ull u = 0, us = 0;
+  for (u32 p = threadIdx.x; p < n_parts; p += 256) { u += ucount[p]; us += pusable[p]; }
+  // 64-bit block sums via two 32-bit halves are unnecessary: both totals are < 2^32
+  const u32 tu = block_sum((u32)u, lds);
+  const u32 ts = block_sum((u32)us, lds);
+  if (threadIdx.x == 0) { ctr[CTR_UNIQUE] = tu; ctr[CTR_USABLE] = ts; }
+}
+
+// padded -> dense unique list (word, padded position); order = bucket order (sorted afterwards)
+__global__ void __launch_bounds__(256)
+k_compact_padded(const u64 *__restrict__ pad_word, const u32 *__restrict__ pbeg, const u32 *__restrict__ ucount,
+                 const u32 *__restrict__ ubase, u32 n_parts, u64 *__restrict__ uniq_word,
+                 u32 *__restrict__ uniq_slot) {
+  // one wave per bucket
+  const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const u32 lane = threadIdx.x & 63;
+  if (wave >= n_parts) return;
+  const u32 beg = pbeg[wave], uc = ucount[wave], ub = ubase[wave];
+  for (u32 j = lane; j < uc; j += 64) {
+    uniq_word[ub + j] = pad_word[beg + j];
+    uniq_slot[ub + j] = beg + j;
+  }
+}
+
+// after the sort, padded variant: gather count / first read of rank i
+__global__ void k_post_sort_padded(const u32 *__restrict__ s_slot, const u32 *__restrict__ pad_cnt,
+                                   const u32 *__restrict__ pad_first, u32 n, u32 *__restrict__ s_cnt,
+                                   u32 *__restrict__ s_first) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const u32 p = s_slot[i];
+    s_cnt[i] = pad_cnt[p];
+    s_first[i] = pad_first[p];
   }
 }
 
@@ -549,6 +727,9 @@ struct humid_ctx {
   ull *h_ctr = nullptr;   // pinned mirror
   DBuf in_words, in_filt, out_cid, out_keep;                 // host entry point staging
   DBuf table, slot_out, slot_of_read, uniq_slot;             // table (cap+1) and per-read
+  DBuf pk_keys, pk_vals, pbeg, ucount, pusable, ubase, pad_word, pad_cnt, pad_first;   // partitioned counts
+  int count_mode = 0;        // 0: hash-partitioned LDS tables (default), 1: one global HBM table
+  bool last_count_lds = false;
   DBuf uniq_word, s_word, s_slot, s_cnt, s_first;            // unique words (walk order)
   DBuf deg, nbr_off, nbr_idx, seg_k0, seg_v0, seg_ks, seg_vs, pc, poff, ek0, ek1;
   DBuf parent, mk0, mk1, cl_of, maxleaf, cl_size, flag, pos, cid, ismax, stk, tmp, scratch;
@@ -711,9 +892,10 @@ static int n_clusters_from_scan(humid_ctx *c, u32 U, u64 *out) {
 // Inserts the reads whose word lies in [range_lo, range_hi] (inclusive; the multi-GPU path
 // gives every rank one range, a single GPU takes everything), compacts the table and sorts
 // the unique words.  Leaves table/slot_of_read/s_word/s_slot/s_cnt/s_first in the context.
-static int stage_count(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N, u32 word_nt,
-                       u64 range_lo, u64 range_hi, u64 expected_reads, humid_summary &s) {
+static int stage_count_global(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N, u32 word_nt,
+                              u64 range_lo, u64 range_hi, u64 expected_reads, humid_summary &s) {
   hipStream_t st = c->stream;
+  c->last_count_lds = false;
   if (expected_reads == 0 || expected_reads > N) expected_reads = N;
   u32 cap_log2 = 10;
   while (((u64)1 << cap_log2) < expected_reads + expected_reads / 2) cap_log2++;
@@ -754,6 +936,93 @@ static int stage_count(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N
   HIPCHK(hipEventRecord(c->ev[1], st));
   HIPCHK(hipGetLastError());
   return HUMID_OK;
+}
+
+// Partitioned variant of stage A (see section 1b of the kernels).  Returns HUMID_OK with
+// *overflowed = true when a bucket held more unique words than its LDS table (the caller then
+// runs the global-table variant; results are never taken from an overflowed run).
+static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N, u32 word_nt,
+                           u64 range_lo, u64 range_hi, humid_summary &s, bool *overflowed) {
+  hipStream_t st = c->stream;
+  *overflowed = false;
+  c->last_count_lds = true;
+  u32 pb = 1;
+  while (pb < 26 && ((u64)PART_TARGET << pb) < (u64)N) pb++;
+  const u32 n_parts = 1u << pb;
+  ENSURE(c->pk_keys, (size_t)N * 8);
+  ENSURE(c->pk_vals, (size_t)N * 4);
+  ENSURE(c->pbeg, (size_t)(n_parts + 1) * 4);
+  ENSURE(c->ucount, (size_t)(n_parts + 1) * 4);
+  ENSURE(c->pusable, (size_t)(n_parts + 1) * 4);
+  ENSURE(c->ubase, (size_t)(n_parts + 1) * 4);
+  ENSURE(c->pad_word, (size_t)N * 8);
+  ENSURE(c->pad_cnt, (size_t)N * 4);
+  ENSURE(c->pad_first, (size_t)N * 4);
+  ENSURE(c->slot_out, ((size_t)N + 1) * 8);
+  ENSURE(c->slot_of_read, (size_t)N * 4);
+  ENSURE(c->uniq_slot, (size_t)N * 4 + 4);
+  ENSURE(c->uniq_word, (size_t)N * 8 + 8);
+  HIPCHK(hipEventRecord(c->ev[0], st));
+  HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_N * sizeof(ull), st));
+  HIPCHK(hipMemsetAsync(c->ucount.as<u32>() + n_parts, 0, 4, st));
+  {
+    auto kin = rocprim::make_transform_iterator(d_words, MixKeyOp{});
+    auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<u32>(0),
+                                                ReadTagOp{d_words, d_filt, range_lo, range_hi});
+    // MergeSortLimit = 0: block sort up to 1024 items, Onesweep above (never the merge path)
+    using part_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                rocprim::default_config, 0>;
+    size_t bytes = 0;
+    HIPCHK(rocprim::radix_sort_pairs<part_cfg>(nullptr, bytes, kin, c->pk_keys.as<u64>(), vin,
+                                               c->pk_vals.as<u32>(), (size_t)N, 64 - pb, 64, st));
+    ENSURE(c->tmp, bytes);
+    HIPCHK(rocprim::radix_sort_pairs<part_cfg>(c->tmp.p, bytes, kin, c->pk_keys.as<u64>(), vin,
+                                               c->pk_vals.as<u32>(), (size_t)N, 64 - pb, 64, st));
+  }
+  hipLaunchKernelGGL(k_part_bounds, dim3(blocks_for(n_parts + 1)), dim3(256), 0, st, c->pk_keys.as<u64>(), N,
+                     pb, n_parts, c->pbeg.as<u32>());
+  HIPCHK(hipEventRecord(c->kev[0], st));
+  hipLaunchKernelGGL(k_dedup_lds, dim3(n_parts), dim3(256), 0, st, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(),
+                     c->pbeg.as<u32>(), N, pb, c->pad_word.as<u64>(), c->pad_cnt.as<u32>(), c->pad_first.as<u32>(),
+                     c->ucount.as<u32>(), c->pusable.as<u32>(), c->slot_of_read.as<u32>(), c->d_ctr);
+  HIPCHK(hipEventRecord(c->kev[1], st));
+  hipLaunchKernelGGL(k_part_totals, dim3(1), dim3(256), 0, st, c->ucount.as<u32>(), c->pusable.as<u32>(),
+                     n_parts, c->d_ctr);
+  TRY(exscan_u32(c, c->ucount.as<u32>(), c->ubase.as<u32>(), (u64)n_parts + 1));
+  HIPCHK(hipGetLastError());
+  TRY(read_counters(c));
+  if (c->h_ctr[CTR_OVERFULL]) { *overflowed = true; return HUMID_OK; }
+  const u32 U = (u32)c->h_ctr[CTR_UNIQUE];
+  s.usable = c->usable = c->h_ctr[CTR_USABLE];
+  s.unique = c->U = U;
+  if (U == 0) { HIPCHK(hipEventRecord(c->ev[1], st)); return HUMID_OK; }
+  ENSURE(c->s_word, (size_t)U * 8);
+  ENSURE(c->s_slot, (size_t)U * 4);
+  ENSURE(c->s_cnt, (size_t)U * 4);
+  ENSURE(c->s_first, (size_t)U * 4);
+  hipLaunchKernelGGL(k_compact_padded, dim3(blocks_for((u64)n_parts * 64)), dim3(256), 0, st,
+                     c->pad_word.as<u64>(), c->pbeg.as<u32>(), c->ucount.as<u32>(), c->ubase.as<u32>(), n_parts,
+                     c->uniq_word.as<u64>(), c->uniq_slot.as<u32>());
+  TRY(sort_pairs<u64, u32>(c, c->uniq_word.as<u64>(), c->s_word.as<u64>(), c->uniq_slot.as<u32>(),
+                           c->s_slot.as<u32>(), U, 0, 2 * word_nt));
+  hipLaunchKernelGGL(k_post_sort_padded, dim3(blocks_for(U)), dim3(256), 0, st, c->s_slot.as<u32>(),
+                     c->pad_cnt.as<u32>(), c->pad_first.as<u32>(), U, c->s_cnt.as<u32>(), c->s_first.as<u32>());
+  HIPCHK(hipEventRecord(c->ev[1], st));
+  HIPCHK(hipGetLastError());
+  return HUMID_OK;
+}
+
+// stage A dispatcher: partitioned LDS tables when the whole value range is counted here, the
+// global table for a partial range (multi-GPU ranks) or after a bucket overflow.
+static int stage_count(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N, u32 word_nt,
+                       u64 range_lo, u64 range_hi, u64 expected_reads, humid_summary &s) {
+  const bool full_range = (range_lo == 0 && range_hi == ~0ull);
+  if (c->count_mode == 0 && full_range) {
+    bool overflowed = false;
+    TRY(stage_count_lds(c, d_words, d_filt, N, word_nt, range_lo, range_hi, s, &overflowed));
+    if (!overflowed) return HUMID_OK;
+  }
+  return stage_count_global(c, d_words, d_filt, N, word_nt, range_lo, range_hi, expected_reads, s);
 }
 
 // ---- stage B: neighbours + clusters over a sorted unique array ---------------------------
@@ -930,6 +1199,7 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
   HIPCHK(hipEventElapsedTime(&s.ms_total, c->ev[0], c->ev[4]));
   HIPCHK(hipEventElapsedTime(&s.ms_k_insert, c->kev[0], c->kev[1]));
   s.ms_k_map = s.ms_map;   // ev[3]..ev[4] bracket exactly the k_read_map launch
+  s.count_mode_used = c->last_count_lds ? 0u : 1u;
   if (M > 0) HIPCHK(hipEventElapsedTime(&s.ms_k_cluster, c->kev[2], c->kev[3]));
   for (u32 g = 0; g < n_pair_segs; g++) {
     float t = 0;
@@ -992,6 +1262,7 @@ int humid_ctx_create(humid_ctx **out, int device, void *stream) {
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
   for (auto &ev : c->kev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
+  if (const char *m = getenv("HUMID_COUNT_MODE")) c->count_mode = (atoi(m) == 1) ? 1 : 0;
   *out = c;
   return HUMID_OK;
 }
@@ -1000,7 +1271,8 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table,
+  DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
+                  &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cnt, &c->pad_first,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->pc, &c->poff, &c->ek0, &c->ek1, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -1013,6 +1285,16 @@ void humid_ctx_destroy(humid_ctx *c) {
   for (auto &ev : c->kev) if (ev) (void)hipEventDestroy(ev);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+}
+
+int humid_ctx_set_option(humid_ctx *c, const char *key, int64_t value) {
+  if (!c || !key) return fail(c, HUMID_E_INVALID, "null argument");
+  if (strcmp(key, "count_mode") == 0) {
+    if (value != 0 && value != 1) return fail(c, HUMID_E_INVALID, "count_mode must be 0 (LDS-partitioned) or 1 (global table)");
+    c->count_mode = (int)value;
+    return HUMID_OK;
+  }
+  return fail(c, HUMID_E_INVALID, "unknown option '%s'", key);
 }
 
 int humid_dedup_run_device(humid_ctx *c, const uint64_t *d_words, const uint8_t *d_filtered,

@@ -58,10 +58,11 @@ typedef struct humid_summary {
   float ms_total;       /* first kernel to last kernel on the stream              */
   float ms_h2d, ms_d2h; /* host-buffer entry point only                           */
   /* single kernels, HIP events directly around the launches on the ctx stream:      */
-  float ms_k_insert;    /* k_hash_insert (one launch)                               */
+  float ms_k_insert;    /* k_dedup_lds or k_hash_insert (one launch)                */
   float ms_k_pairs;     /* sum over the 2(d+1) k_pairs launches (count + fill)      */
   float ms_k_cluster;   /* k_cluster_components (one launch; 0 if no neighbours)    */
   float ms_k_map;       /* k_read_map (one launch)                                  */
+  uint32_t count_mode_used;  /* 0 = LDS-partitioned tables, 1 = global HBM table (option or fallback) */
 } humid_summary;
 
 uint32_t humid_abi_version(void);
@@ -72,6 +73,10 @@ int      humid_device_count(void);
 int  humid_ctx_create(humid_ctx **out, int device, void *stream);
 void humid_ctx_destroy(humid_ctx *ctx);
 const char *humid_last_error(const humid_ctx *ctx);   /* ctx may be NULL */
+/* Tuning knobs (never change results).  "count_mode": 0 = exact counts in hash-partitioned
+ * LDS-resident tables (default; falls back to 1 by itself when a bucket overflows), 1 = one
+ * open-address table in HBM.  Environment HUMID_COUNT_MODE presets it. */
+int  humid_ctx_set_option(humid_ctx *ctx, const char *key, int64_t value);
 
 /* ---- the whole hot path ----------------------------------------------------
  * Replaces, between FastQ pass 1 and pass 2:

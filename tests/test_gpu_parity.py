@@ -12,9 +12,12 @@ from oracle import pyoracle as orc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def dd():
+@pytest.fixture(scope="module", params=[0, 1], ids=["lds_partitioned", "global_table"])
+def dd(request):
+    """every parity test runs with both exact-count variants (humid_ctx_set_option count_mode)"""
     d = humid_amd.Dedup()
+    d.set_option("count_mode", request.param)
+    d.count_mode = request.param
     yield d
     d.close()
 
@@ -180,6 +183,31 @@ def test_edge_cases(dd):
     # distance 0: exact duplicates only
     words, filt = synth_words(20000, 3, 24, p_sub=1e-2)
     check_against_oracle(dd, words, filt, 24, 0, False)
+
+
+def np_mix64(x):
+    x = x.astype(np.uint64)
+    x ^= x >> np.uint64(30); x *= np.uint64(0xbf58476d1ce4e5b9)
+    x ^= x >> np.uint64(27); x *= np.uint64(0x94d049bb133111eb)
+    x ^= x >> np.uint64(31)
+    return x
+
+
+def test_bucket_overflow_falls_back_to_global_table(dd):
+    """> 2048 distinct words in ONE hash bucket: the LDS table overflows, the run is redone with
+    the global table, results stay exact"""
+    rng = np.random.default_rng(3)
+    cand = rng.integers(0, 4 ** 24, size=1_500_000, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        top = np_mix64(cand) >> np.uint64(59)          # N = 20000 -> 2^5 buckets
+    words = np.unique(cand[top == 7])[:20000]
+    assert len(words) == 20000
+    s = check_against_oracle(dd, words, np.zeros(len(words), np.uint8), 24, 1, False)
+    assert s["count_mode_used"] == 1                   # fallback (or the forced global mode)
+    # the same amount of reads, but duplicates of few words: no overflow, LDS path is used
+    few = np.repeat(words[:100], 200)
+    s = check_against_oracle(dd, few, np.zeros(len(few), np.uint8), 24, 1, False)
+    assert s["count_mode_used"] == dd.count_mode
 
 
 def test_unsupported_and_invalid(dd):
