@@ -13,6 +13,7 @@
 //                         (replaces trie.find()->leaf->cluster, src/humid.cc:223-231,276-277)
 //
 // No CPU fallback lives here: every entry point either runs on the GPU or fails.
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -382,75 +383,6 @@ __global__ void k_seg_keys(const u64 *__restrict__ s_word, u32 n, u32 shift, u64
   }
 }
 
-// One thread per position i of the bucket-sorted order; compares with the following
-// elements of its bucket.  Ranks ascend inside a bucket, so (ri < rj) always.  A pair is
-// emitted only from the FIRST segment it agrees on (earlier segments must all differ).
-// Two phases with identical control flow, so there is no shared append counter:
-//   FILL = false: pc[i] = pairs found by thread i; deg[] += 1 per endpoint
-//   FILL = true : writes both directions of pair k of thread i at 2*(poff[i] + k)
-template <bool PASS0, bool FILL>
-__global__ void __launch_bounds__(256)
-k_pairs(const u64 *__restrict__ s_word, const u32 *__restrict__ K, const u32 *__restrict__ V,
-        u32 n, SegPlan plan, u32 seg, u32 distance, u32 *deg, u32 *__restrict__ pc,
-        const u32 *__restrict__ poff, u64 *__restrict__ ekeys) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const u32 shift = plan.shift[seg];
-  const u64 mask = plan.mask[seg];
-  u32 ri;
-  u64 wi;
-  u64 ki;
-  if (PASS0) { ri = i; wi = s_word[i]; ki = (wi >> shift) & mask; }
-  else { ri = V[i]; wi = s_word[ri]; ki = K[i]; }
-  u32 found = 0;
-  u64 e = FILL ? (u64)poff[i] : 0;
-  for (u32 j = i + 1; j < n; j++) {
-    u32 rj;
-    u64 wj;
-    if (PASS0) {
-      rj = j; wj = s_word[j];
-      if (((wj >> shift) & mask) != ki) break;
-    } else {
-      if ((u64)K[j] != ki) break;
-      rj = V[j]; wj = s_word[rj];
-    }
-    const u64 x = wi ^ wj;
-    if (nt_mismatch(x) > distance) continue;
-    bool firstseg = true;
-    for (u32 t = 0; t < seg; t++)
-      if (((x >> plan.shift[t]) & plan.mask[t]) == 0) { firstseg = false; break; }
-    if (!firstseg) continue;
-    if (FILL) {
-      ekeys[2 * e] = ((u64)ri << 32) | rj;
-      ekeys[2 * e + 1] = ((u64)rj << 32) | ri;
-      e++;
-    } else {
-      found++;
-      atomicAdd(&deg[rj], 1u);
-    }
-  }
-  if (!FILL) {
-    pc[i] = found;
-    if (found) atomicAdd(&deg[ri], found);
-  }
-}
-
-// number of leaves with at least one neighbour (fixed small grid, one atomic per block)
-__global__ void __launch_bounds__(256)
-k_count_nonzero(const u32 *__restrict__ deg, u32 n, ull *ctr) {
-  __shared__ u32 lds[4];
-  u32 c = 0;
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    c += deg[i] ? 1u : 0u;
-  const u32 t = block_sum(c, lds);
-  if (threadIdx.x == 0 && t) atomicAdd(&ctr[CTR_NONSINGLE], (ull)t);
-}
-
-__global__ void k_low32(const u64 *__restrict__ in, u64 n, u32 *__restrict__ out) {
-  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (u32)in[i];
-}
-
 // --------------------------------------------------------------------------------
 // 4. connected components (lock-free union-find, smaller index wins => root = min rank)
 // --------------------------------------------------------------------------------
@@ -470,17 +402,138 @@ __device__ __forceinline__ void uf_union(u32 *P, u32 a, u32 b) {
   }
 }
 
+// One thread per position i of the bucket-sorted order; compares with the following
+// elements of its bucket.  Ranks ascend inside a bucket, so (ri < rj) always.  A pair is
+// emitted only from the FIRST segment it agrees on (earlier segments must all differ).
+// Two phases with identical control flow and no shared append counter:
+//   FILL = false: deg[] += 1 per endpoint, union(ri, rj) in the component forest
+//   FILL = true : writes rj into ri's CSR row and ri into rj's (per-row cursors; the rows are
+//                 put in ascending order afterwards by k_sort_lists)
+template <bool PASS0, bool FILL>
+__global__ void __launch_bounds__(256)
+k_pairs(const u64 *__restrict__ s_word, const u32 *__restrict__ K, const u32 *__restrict__ V,
+        u32 n, SegPlan plan, u32 seg, u32 distance, u32 *deg, u32 *parent,
+        const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 shift = plan.shift[seg];
+  const u64 mask = plan.mask[seg];
+  u32 ri;
+  u64 wi;
+  u64 ki;
+  if (PASS0) { ri = i; wi = s_word[i]; ki = (wi >> shift) & mask; }
+  else { ri = V[i]; wi = s_word[ri]; ki = K[i]; }
+  u32 found = 0;
+  for (u32 j = i + 1; j < n; j++) {
+    u32 rj;
+    u64 wj;
+    if (PASS0) {
+      rj = j; wj = s_word[j];
+      if (((wj >> shift) & mask) != ki) break;
+    } else {
+      if ((u64)K[j] != ki) break;
+      rj = V[j]; wj = s_word[rj];
+    }
+    const u64 x = wi ^ wj;
+    if (nt_mismatch(x) > distance) continue;
+    bool firstseg = true;
+    for (u32 t = 0; t < seg; t++)
+      if (((x >> plan.shift[t]) & plan.mask[t]) == 0) { firstseg = false; break; }
+    if (!firstseg) continue;
+    if (FILL) {
+      nbr_idx[nbr_off[ri] + atomicAdd(&cur[ri], 1u)] = rj;
+      nbr_idx[nbr_off[rj] + atomicAdd(&cur[rj], 1u)] = ri;
+    } else {
+      found++;
+      atomicAdd(&deg[rj], 1u);
+      uf_union(parent, ri, rj);
+    }
+  }
+  if (!FILL && found) atomicAdd(&deg[ri], found);
+}
+
+// every CSR row ascending (the order NLeaf::neighbours has under the trie hypotheses H1+H2)
+__global__ void __launch_bounds__(256)
+k_sort_lists(const u32 *__restrict__ off, u32 n, u32 *idx) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  const u32 b = off[u], d = off[u + 1] - b;
+  if (d < 2) return;
+  u32 *a = idx + b;
+  if (d <= 32) {
+    u32 v[32];
+    for (u32 k = 0; k < d; k++) v[k] = a[k];
+    for (u32 k = 1; k < d; k++) {          // insertion sort
+      u32 x = v[k];
+      u32 m = k;
+      while (m > 0 && v[m - 1] > x) { v[m] = v[m - 1]; m--; }
+      v[m] = x;
+    }
+    for (u32 k = 0; k < d; k++) a[k] = v[k];
+  } else {                                 // heap sort in place
+    for (u32 start = d / 2; start-- > 0;) {
+      u32 r = start;
+      while (true) {
+        u32 ch = 2 * r + 1;
+        if (ch >= d) break;
+        if (ch + 1 < d && a[ch + 1] > a[ch]) ch++;
+        if (a[r] >= a[ch]) break;
+        u32 t = a[r]; a[r] = a[ch]; a[ch] = t;
+        r = ch;
+      }
+    }
+    for (u32 end = d - 1; end > 0; end--) {
+      u32 t = a[0]; a[0] = a[end]; a[end] = t;
+      u32 r = 0;
+      while (true) {
+        u32 ch = 2 * r + 1;
+        if (ch >= end) break;
+        if (ch + 1 < end && a[ch + 1] > a[ch]) ch++;
+        if (a[r] >= a[ch]) break;
+        u32 t2 = a[r]; a[r] = a[ch]; a[ch] = t2;
+        r = ch;
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------
+// 4. connected components: sizes, and the split small / big
+// --------------------------------------------------------------------------------
+#define SMALL_COMP 32u      // components up to this many leaves are clustered by one lane, in registers
+
+// flatten the forest and count the leaves of every component at its root
+__global__ void k_comp_stats(const u32 *__restrict__ deg, u32 *P, u32 n, u32 *csize) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n || deg[u] == 0) return;
+  const u32 root = uf_find(P, u);
+  P[u] = root;
+  atomicAdd(&csize[root], 1u);
+}
+
+// M = leaves with >= 1 neighbour, Mbig = those in components larger than SMALL_COMP
+__global__ void __launch_bounds__(256)
+k_comp_count(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *__restrict__ csize, u32 n,
+             ull *ctr) {
+  __shared__ u32 lds[4];
+  u32 m = 0, mb = 0;
+  for (u32 u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
+    if (deg[u]) {
+      m++;
+      if (csize[uf_find(P, u)] > SMALL_COMP) mb++;
+    }
+  }
+  const u32 tm = block_sum(m, lds);
+  const u32 tb = block_sum(mb, lds);
+  if (threadIdx.x == 0) {
+    if (tm) atomicAdd(&ctr[CTR_NONSINGLE], (ull)tm);
+    if (tb) atomicAdd(&ctr[CTR_MEMBERS], (ull)tb);
+  }
+}
+
 __global__ void k_iota(u32 *p, u32 n) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
-}
-
-// undirected edges are the even entries of the (unsorted) directed key buffer
-__global__ void k_union_edges(const u64 *__restrict__ ekeys, u64 n_edges, u32 *P) {
-  u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_edges) return;
-  u64 k = ekeys[2 * e];
-  uf_union(P, (u32)(k >> 32), (u32)k);
 }
 
 // explicit-graph entry point: union every CSR entry (u, nbr)
@@ -491,26 +544,30 @@ __global__ void k_union_csr(const u32 *__restrict__ off, const u32 *__restrict__
     if (idx[k] != u) uf_union(P, u, idx[k]);
 }
 
-// members = nodes with >= 1 neighbour, keyed (root << 32 | rank); unordered, sorted afterwards
+// members of the BIG components, keyed (root << 32 | rank); unordered, sorted afterwards
 __global__ void __launch_bounds__(256)
-k_member_keys(const u32 *__restrict__ deg, u32 *P, u32 n, u64 *mkeys, ull *ctr) {
+k_member_keys(const u32 *__restrict__ deg, u32 *P, const u32 *__restrict__ csize, u32 n, u64 *mkeys,
+              ull *ctr) {
   __shared__ u32 lds[8];
   const u32 chunk = (n + gridDim.x - 1) / gridDim.x;
   const u32 lo = blockIdx.x * chunk;
   const u32 hi = (lo + chunk < n) ? lo + chunk : n;
   u32 mine = 0;
-  for (u32 u = lo + threadIdx.x; u < hi; u += 256) mine += deg[u] ? 1u : 0u;
+  for (u32 u = lo + threadIdx.x; u < hi; u += 256)
+    mine += (deg[u] && csize[uf_find(P, u)] > SMALL_COMP) ? 1u : 0u;
   const u32 total = block_sum(mine, lds);
-  if (threadIdx.x == 0) lds[4] = total ? (u32)atomicAdd(&ctr[CTR_MEMBERS], (ull)total) : 0u;
+  if (threadIdx.x == 0) lds[4] = total ? (u32)atomicAdd(&ctr[CTR_SPECIAL], (ull)total) : 0u;
   __syncthreads();
   u32 base = lds[4];
   if (total == 0) return;
   for (u32 u0 = lo; u0 < hi; u0 += 256) {
     const u32 u = u0 + threadIdx.x;
-    const bool mem = (u < hi) && deg[u] != 0;
+    u32 root = 0;
+    bool mem = (u < hi) && deg[u] != 0;
+    if (mem) { root = uf_find(P, u); mem = csize[root] > SMALL_COMP; }
     u32 tot;
     const u32 r = block_rank(mem, lds, &tot);
-    if (mem) mkeys[base + r] = ((u64)uf_find(P, u) << 32) | u;
+    if (mem) mkeys[base + r] = ((u64)root << 32) | u;
     base += tot;
   }
 }
@@ -533,28 +590,22 @@ __global__ void k_cluster_singletons(const u32 *__restrict__ deg, const u32 *__r
   }
 }
 
-// One thread per connected component (the head of its run in the sorted member keys).
-// Literal restatement, per component, of
+// The findClusters loop over the leaves of ONE connected component, ascending.  Literal
+// restatement of
 //   findClusters loop            /root/reference/src/humid.cc:176-189  (members ascending)
 //   maxNeighbour_                src/cluster.cc:39-51  (first qualifying neighbour, restart)
 //   assignDirectionalCluster_    src/cluster.cc:58-69  (pre-order flood, explicit stack)
 //   assignMaxCluster             src/cluster.cc:72-80
 // A cluster is named by its creating leaf (cl_of = creator rank + 1); ids come later from a
-// prefix sum over creators, which reproduces `id++` in walk order.
-template <bool MAXIMUM>
-__global__ void __launch_bounds__(64)
-k_cluster_components(const u64 *__restrict__ mkeys, u32 n_members, const u32 *__restrict__ cnt,
-                     const u32 *__restrict__ off, const u32 *__restrict__ idx, u32 *cl_of,
-                     u32 *maxleaf, u64 *cl_size, u32 *stk) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_members) return;
-  const u32 root = (u32)(mkeys[i] >> 32);
-  if (i > 0 && (u32)(mkeys[i - 1] >> 32) == root) return;   // not a component head
-  u32 *st = stk + 2 * (u64)i;
-  for (u32 m = i; m < n_members; m++) {
-    const u64 mk = mkeys[m];
-    if ((u32)(mk >> 32) != root) break;
-    const u32 u = (u32)mk;
+// prefix sum over creators, which reproduces `id++` in walk order.  `st` holds 2 words per member.
+template <bool MAXIMUM, class MemberAt>
+__device__ __forceinline__ void cluster_one_component(MemberAt member_at, u32 n_members,
+                                                      const u32 *__restrict__ cnt,
+                                                      const u32 *__restrict__ off,
+                                                      const u32 *__restrict__ idx, u32 *cl_of,
+                                                      u32 *maxleaf, u64 *cl_size, u32 *st) {
+  for (u32 m = 0; m < n_members; m++) {
+    const u32 u = member_at(m);
     if (cl_of[u] != 0) continue;                  // src/humid.cc:179
     const u32 label = u + 1;                      // new Cluster, creator u
     u32 start = u;
@@ -607,6 +658,57 @@ k_cluster_components(const u64 *__restrict__ mkeys, u32 n_members, const u32 *__
     maxleaf[u] = best;
     cl_size[u] = size;
   }
+}
+
+// BIG components: one lane per component = the head of its run in the sorted member keys;
+// stack in HBM scratch (2 words per member of the run).
+template <bool MAXIMUM>
+__global__ void __launch_bounds__(64)
+k_cluster_components(const u64 *__restrict__ mkeys, u32 n_members, const u32 *__restrict__ cnt,
+                     const u32 *__restrict__ off, const u32 *__restrict__ idx, u32 *cl_of,
+                     u32 *maxleaf, u64 *cl_size, u32 *stk) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_members) return;
+  const u32 root = (u32)(mkeys[i] >> 32);
+  if (i > 0 && (u32)(mkeys[i - 1] >> 32) == root) return;   // not a component head
+  u32 len = 1;
+  while (i + len < n_members && (u32)(mkeys[i + len] >> 32) == root) len++;
+  cluster_one_component<MAXIMUM>([&](u32 m) { return (u32)mkeys[i + m]; }, len, cnt, off, idx, cl_of,
+                                 maxleaf, cl_size, stk + 2 * (u64)i);
+}
+
+// SMALL components (<= SMALL_COMP leaves): one lane per component root collects the members by
+// a breadth-first walk, orders them, and runs the same loop with member list and stack in
+// private memory.  No sort, no scratch.
+template <bool MAXIMUM>
+__global__ void __launch_bounds__(128)
+k_cluster_small(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *__restrict__ csize,
+                u32 n, const u32 *__restrict__ cnt, const u32 *__restrict__ off,
+                const u32 *__restrict__ idx, u32 *cl_of, u32 *maxleaf, u64 *cl_size) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n || deg[u] == 0 || P[u] != u) return;
+  const u32 target = csize[u];
+  if (target > SMALL_COMP) return;
+  u32 mem[SMALL_COMP];
+  u32 st[2 * SMALL_COMP];
+  u32 nm = 1;
+  mem[0] = u;
+  for (u32 q = 0; q < nm && nm < target; q++) {
+    const u32 v = mem[q];
+    for (u32 k = off[v]; k < off[v + 1] && nm < target; k++) {
+      const u32 nb = idx[k];
+      bool seen = false;
+      for (u32 t = 0; t < nm; t++) seen |= (mem[t] == nb);
+      if (!seen) mem[nm++] = nb;
+    }
+  }
+  for (u32 k = 1; k < nm; k++) {              // ascending = walk order inside the component
+    u32 x = mem[k];
+    u32 m = k;
+    while (m > 0 && mem[m - 1] > x) { mem[m] = mem[m - 1]; m--; }
+    mem[m] = x;
+  }
+  cluster_one_component<MAXIMUM>([&](u32 m) { return mem[m]; }, nm, cnt, off, idx, cl_of, maxleaf, cl_size, st);
 }
 
 __global__ void k_creator_flags(const u32 *__restrict__ cl_of, u32 n, u32 *flag) {
@@ -731,7 +833,7 @@ struct humid_ctx {
   int count_mode = 0;        // 0: hash-partitioned LDS tables (default), 1: one global HBM table
   bool last_count_lds = false;
   DBuf uniq_word, s_word, s_slot, s_cnt, s_first;            // unique words (walk order)
-  DBuf deg, nbr_off, nbr_idx, seg_k0, seg_v0, seg_ks, seg_vs, pc, poff, ek0, ek1;
+  DBuf deg, nbr_off, nbr_idx, seg_k0, seg_v0, seg_ks, seg_vs, csize, cur;
   DBuf parent, mk0, mk1, cl_of, maxleaf, cl_size, flag, pos, cid, ismax, stk, tmp, scratch;
   hipEvent_t ev[6] = {};
   hipEvent_t kev[40] = {};   // per-kernel timing: [0,1] insert, [2,3] cluster, [4..19] pairs fill, [20..35] pairs count
@@ -838,9 +940,9 @@ static SegPlan make_plan(u32 n, u32 d) {
 }
 
 // ---- cluster stage shared by the full pipeline and the explicit-graph entry point ------
-// needs: s_cnt[U], deg[U], nbr_off[U+1], nbr_idx, parent[U] (components already unioned),
-// M = number of nodes with deg > 0.
-static int cluster_stage(humid_ctx *c, const u32 *g_cnt, u32 U, u64 M, u32 method) {
+// needs: g_cnt[U], deg[U], nbr_off[U+1], nbr_idx, parent[U] + csize[U] (k_comp_stats done),
+// M = leaves with deg > 0, Mbig = those in components larger than SMALL_COMP.
+static int cluster_stage(humid_ctx *c, const u32 *g_cnt, u32 U, u64 M, u64 Mbig, u32 method) {
   hipStream_t st = c->stream;
   ENSURE(c->cl_of, (size_t)U * 4);
   ENSURE(c->maxleaf, (size_t)U * 4);
@@ -852,24 +954,34 @@ static int cluster_stage(humid_ctx *c, const u32 *g_cnt, u32 U, u64 M, u32 metho
   hipLaunchKernelGGL(k_cluster_singletons, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
                      g_cnt, U, c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
   if (M > 0) {
-    ENSURE(c->mk0, (size_t)M * 8);
-    ENSURE(c->mk1, (size_t)M * 8);
-    ENSURE(c->stk, (size_t)M * 8);
-    HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_MEMBERS], 0, sizeof(ull), st));
-    hipLaunchKernelGGL(k_member_keys, dim3(COMPACT_BLOCKS), dim3(256), 0, st, c->deg.as<u32>(),
-                       c->parent.as<u32>(), U, c->mk0.as<u64>(), c->d_ctr);
-    TRY(sort_keys<u64>(c, c->mk0.as<u64>(), c->mk1.as<u64>(), M, 0, 32 + bits_for(U)));
     HIPCHK(hipEventRecord(c->kev[2], st));
     if (method == HUMID_METHOD_MAXIMUM)
-      hipLaunchKernelGGL(k_cluster_components<true>, dim3(blocks_for(M, 64)), dim3(64), 0, st,
-                         c->mk1.as<u64>(), (u32)M, g_cnt, c->nbr_off.as<u32>(),
-                         c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(),
-                         c->cl_size.as<u64>(), c->stk.as<u32>());
+      hipLaunchKernelGGL(k_cluster_small<true>, dim3(blocks_for(U, 128)), dim3(128), 0, st, c->deg.as<u32>(),
+                         c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
+                         c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
     else
-      hipLaunchKernelGGL(k_cluster_components<false>, dim3(blocks_for(M, 64)), dim3(64), 0, st,
-                         c->mk1.as<u64>(), (u32)M, g_cnt, c->nbr_off.as<u32>(),
-                         c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(),
-                         c->cl_size.as<u64>(), c->stk.as<u32>());
+      hipLaunchKernelGGL(k_cluster_small<false>, dim3(blocks_for(U, 128)), dim3(128), 0, st, c->deg.as<u32>(),
+                         c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
+                         c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
+    if (Mbig > 0) {
+      ENSURE(c->mk0, (size_t)Mbig * 8);
+      ENSURE(c->mk1, (size_t)Mbig * 8);
+      ENSURE(c->stk, (size_t)Mbig * 8);
+      HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_SPECIAL], 0, sizeof(ull), st));
+      hipLaunchKernelGGL(k_member_keys, dim3(COMPACT_BLOCKS), dim3(256), 0, st, c->deg.as<u32>(),
+                         c->parent.as<u32>(), c->csize.as<u32>(), U, c->mk0.as<u64>(), c->d_ctr);
+      TRY(sort_keys<u64>(c, c->mk0.as<u64>(), c->mk1.as<u64>(), Mbig, 0, 32 + bits_for(U)));
+      if (method == HUMID_METHOD_MAXIMUM)
+        hipLaunchKernelGGL(k_cluster_components<true>, dim3(blocks_for(Mbig, 64)), dim3(64), 0, st,
+                           c->mk1.as<u64>(), (u32)Mbig, g_cnt, c->nbr_off.as<u32>(),
+                           c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(),
+                           c->cl_size.as<u64>(), c->stk.as<u32>());
+      else
+        hipLaunchKernelGGL(k_cluster_components<false>, dim3(blocks_for(Mbig, 64)), dim3(64), 0, st,
+                           c->mk1.as<u64>(), (u32)Mbig, g_cnt, c->nbr_off.as<u32>(),
+                           c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(),
+                           c->cl_size.as<u64>(), c->stk.as<u32>());
+    }
     HIPCHK(hipEventRecord(c->kev[3], st));
   }
   hipLaunchKernelGGL(k_creator_flags, dim3(blocks_for(U)), dim3(256), 0, st, c->cl_of.as<u32>(), U,
@@ -1039,31 +1151,33 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
   // deg has U+1 entries (last stays 0) so that one exclusive scan yields nbr_off[U] = 2E
   ENSURE(c->deg, (size_t)(U + 1) * 4);
   ENSURE(c->nbr_off, (size_t)(U + 1) * 4);
+  ENSURE(c->parent, (size_t)U * 4);
+  ENSURE(c->csize, (size_t)U * 4);
   HIPCHK(hipMemsetAsync(c->deg.p, 0, (size_t)(U + 1) * 4, st));
-  u64 E = 0, M = 0;
+  HIPCHK(hipMemsetAsync(c->csize.p, 0, (size_t)U * 4, st));
+  HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_NONSINGLE], 0, 2 * sizeof(ull), st));   // NONSINGLE, MEMBERS
+  hipLaunchKernelGGL(k_iota, dim3(blocks_for(U)), dim3(256), 0, st, c->parent.as<u32>(), U);
+  u64 E = 0, M = 0, Mbig = 0;
   u32 n_pair_segs = 0;
   SegPlan plan = make_plan(word_nt, distance);
   const bool search = distance > 0 && U > 1;
   if (search) {
     const u32 nseg = plan.nseg;
     n_pair_segs = nseg < 8 ? nseg : 8;
-    ENSURE(c->pc, ((size_t)nseg * U + 1) * 4);
-    ENSURE(c->poff, ((size_t)nseg * U + 1) * 4);
     if (nseg > 1) {
       ENSURE(c->seg_k0, (size_t)U * 4);
       ENSURE(c->seg_v0, (size_t)U * 4);
       ENSURE(c->seg_ks, (size_t)(nseg - 1) * U * 4);
       ENSURE(c->seg_vs, (size_t)(nseg - 1) * U * 4);
     }
-    HIPCHK(hipMemsetAsync(c->pc.as<u32>() + (size_t)nseg * U, 0, 4, st));
-    // phase A: bucket order per segment + pair counts
+    // phase A: bucket order per segment; degrees and component forest
     for (u32 seg = 0; seg < nseg; seg++) {
-      u32 *pcs = c->pc.as<u32>() + (size_t)seg * U;
-      if (seg == 0) HIPCHK(hipEventRecord(c->kev[20], st));
       if (seg == 0) {
+        HIPCHK(hipEventRecord(c->kev[20], st));
         hipLaunchKernelGGL((k_pairs<true, false>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
                            (const u32 *)nullptr, (const u32 *)nullptr, U, plan, seg, distance,
-                           c->deg.as<u32>(), pcs, (const u32 *)nullptr, (u64 *)nullptr);
+                           c->deg.as<u32>(), c->parent.as<u32>(), (const u32 *)nullptr, (u32 *)nullptr,
+                           (u32 *)nullptr);
       } else {
         u32 width = 0;
         while (width < 64 && (plan.mask[seg] >> width)) width++;
@@ -1074,57 +1188,55 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
         TRY(sort_pairs<u32, u32>(c, c->seg_k0.as<u32>(), ks, c->seg_v0.as<u32>(), vs, U, 0, width ? width : 1));
         if (seg < 8) HIPCHK(hipEventRecord(c->kev[20 + 2 * seg], st));
         hipLaunchKernelGGL((k_pairs<false, false>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
-                           ks, vs, U, plan, seg, distance, c->deg.as<u32>(), pcs, (const u32 *)nullptr,
-                           (u64 *)nullptr);
+                           ks, vs, U, plan, seg, distance, c->deg.as<u32>(), c->parent.as<u32>(),
+                           (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr);
       }
       if (seg < 8) HIPCHK(hipEventRecord(c->kev[21 + 2 * seg], st));
     }
-    TRY(exscan_u32(c, c->pc.as<u32>(), c->poff.as<u32>(), (u64)nseg * U + 1));
-    hipLaunchKernelGGL(k_count_nonzero, dim3(512), dim3(256), 0, st, c->deg.as<u32>(), U, c->d_ctr);
+    hipLaunchKernelGGL(k_comp_stats, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
+                       c->parent.as<u32>(), U, c->csize.as<u32>());
+    hipLaunchKernelGGL(k_comp_count, dim3(512), dim3(256), 0, st, c->deg.as<u32>(), c->parent.as<u32>(),
+                       c->csize.as<u32>(), U, c->d_ctr);
+  }
+  TRY(exscan_u32(c, c->deg.as<u32>(), c->nbr_off.as<u32>(), (u64)U + 1));
+  if (search) {
     HIPCHK(hipGetLastError());
-    TRY(read_counters(c, c->poff.as<u32>() + (size_t)nseg * U));   // d_ctr[CTR_N-1] is always 0
-    E = c->h_ctr[CTR_N - 1] & 0xffffffffull;
+    TRY(read_counters(c, c->nbr_off.as<u32>() + U));   // h_ctr[CTR_N-1] = 2E
+    const u64 twoE = c->h_ctr[CTR_N - 1] & 0xffffffffull;
+    E = twoE / 2;
     M = c->h_ctr[CTR_NONSINGLE];
-    if (2 * E >= 0xffffffffull) return fail(c, HUMID_E_OVERFLOW, "2*edges = %llu exceeds 32 bits", (ull)(2 * E));
+    Mbig = c->h_ctr[CTR_MEMBERS];
   }
   s.edges = c->E = E;
   s.nonsingle = c->M = M;
-  TRY(exscan_u32(c, c->deg.as<u32>(), c->nbr_off.as<u32>(), (u64)U + 1));
   ENSURE(c->nbr_idx, (size_t)(2 * E + 1) * 4);
-  ENSURE(c->parent, (size_t)U * 4);
   if (E > 0) {
-    ENSURE(c->ek0, (size_t)2 * E * 8);
-    ENSURE(c->ek1, (size_t)2 * E * 8);
-    // phase B: same loops, now writing the directed (src, dst) keys
+    ENSURE(c->cur, (size_t)U * 4);
+    HIPCHK(hipMemsetAsync(c->cur.p, 0, (size_t)U * 4, st));
+    // phase B: same loops, now writing the CSR rows
     for (u32 seg = 0; seg < plan.nseg; seg++) {
-      const u32 *pos = c->poff.as<u32>() + (size_t)seg * U;
       if (seg < 8) HIPCHK(hipEventRecord(c->kev[4 + 2 * seg], st));
       if (seg == 0) {
         hipLaunchKernelGGL((k_pairs<true, true>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
                            (const u32 *)nullptr, (const u32 *)nullptr, U, plan, seg, distance,
-                           (u32 *)nullptr, (u32 *)nullptr, pos, c->ek0.as<u64>());
+                           (u32 *)nullptr, (u32 *)nullptr, c->nbr_off.as<u32>(), c->cur.as<u32>(),
+                           c->nbr_idx.as<u32>());
       } else {
         const u32 *ks = c->seg_ks.as<u32>() + (size_t)(seg - 1) * U;
         const u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
         hipLaunchKernelGGL((k_pairs<false, true>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
-                           ks, vs, U, plan, seg, distance, (u32 *)nullptr, (u32 *)nullptr, pos,
-                           c->ek0.as<u64>());
+                           ks, vs, U, plan, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
+                           c->nbr_off.as<u32>(), c->cur.as<u32>(), c->nbr_idx.as<u32>());
       }
       if (seg < 8) HIPCHK(hipEventRecord(c->kev[5 + 2 * seg], st));
     }
-    // CSR lists ascending: sort the directed (src, dst) keys
-    TRY(sort_keys<u64>(c, c->ek0.as<u64>(), c->ek1.as<u64>(), 2 * E, 0, 32 + bits_for(U)));
-    hipLaunchKernelGGL(k_low32, dim3(blocks_for(2 * E)), dim3(256), 0, st, c->ek1.as<u64>(), 2 * E,
+    hipLaunchKernelGGL(k_sort_lists, dim3(blocks_for(U)), dim3(256), 0, st, c->nbr_off.as<u32>(), U,
                        c->nbr_idx.as<u32>());
   }
   HIPCHK(hipEventRecord(c->ev[2], st));
 
-  // components and clusters
-  hipLaunchKernelGGL(k_iota, dim3(blocks_for(U)), dim3(256), 0, st, c->parent.as<u32>(), U);
-  if (E > 0)
-    hipLaunchKernelGGL(k_union_edges, dim3(blocks_for(E)), dim3(256), 0, st, c->ek0.as<u64>(), E,
-                       c->parent.as<u32>());
-  TRY(cluster_stage(c, g_cnt, U, M, method));
+  // clusters
+  TRY(cluster_stage(c, g_cnt, U, M, Mbig, method));
   hipLaunchKernelGGL(k_finalize_nodes, dim3(blocks_for(U)), dim3(256), 0, st, c->cl_of.as<u32>(),
                      c->pos.as<u32>(), c->maxleaf.as<u32>(), U, c->cid.as<u32>(), c->ismax.as<u8>());
   HIPCHK(hipGetLastError());
@@ -1275,7 +1387,7 @@ void humid_ctx_destroy(humid_ctx *c) {
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cnt, &c->pad_first,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
-                  &c->seg_v0, &c->seg_vs, &c->pc, &c->poff, &c->ek0, &c->ek1, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
+                  &c->seg_v0, &c->seg_vs, &c->csize, &c->cur, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
                   &c->maxleaf, &c->cl_size, &c->flag, &c->pos, &c->cid, &c->ismax, &c->stk, &c->tmp,
                   &c->scratch};
   for (DBuf *b : bufs) b->release();
@@ -1475,17 +1587,42 @@ int humid_cluster_graph(humid_ctx *c, const uint32_t *count, const uint32_t *nbr
   ENSURE(c->nbr_idx, (size_t)(twoE + 1) * 4);
   ENSURE(c->parent, (size_t)U * 4);
   std::vector<u32> hdeg(U);
-  u64 M = 0;
-  for (u32 u = 0; u < U; u++) { hdeg[u] = nbr_off[u + 1] - nbr_off[u]; M += hdeg[u] ? 1 : 0; }
+  for (u32 u = 0; u < U; u++) hdeg[u] = nbr_off[u + 1] - nbr_off[u];
+  {
+    // NLeaf::neighbours is always symmetric (src/humid.cc:121-122, tests' link()); the component
+    // walk relies on it.  Two linked leaves of count 0 make maxNeighbour_ (cluster.cc:39-51)
+    // ping-pong forever in the reference: refuse instead of hanging the GPU.
+    std::vector<u64> fwd, rev;
+    fwd.reserve(twoE); rev.reserve(twoE);
+    for (u32 u = 0; u < U; u++)
+      for (u32 k = nbr_off[u]; k < nbr_off[u + 1]; k++) {
+        const u32 v = nbr_idx[k];
+        if (count[u] == 0 && count[v] == 0)
+          return fail(c, HUMID_E_INVALID, "leaves %u and %u are linked and both have count 0", u, v);
+        fwd.push_back(((u64)u << 32) | v);
+        rev.push_back(((u64)v << 32) | u);
+      }
+    std::sort(fwd.begin(), fwd.end());
+    std::sort(rev.begin(), rev.end());
+    if (fwd != rev) return fail(c, HUMID_E_INVALID, "neighbour lists are not symmetric");
+  }
   HIPCHK(hipMemcpyAsync(c->s_cnt.p, count, (size_t)U * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(c->deg.p, hdeg.data(), (size_t)U * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(c->nbr_off.p, nbr_off, (size_t)(U + 1) * 4, hipMemcpyHostToDevice, st));
   if (twoE) HIPCHK(hipMemcpyAsync(c->nbr_idx.p, nbr_idx, (size_t)twoE * 4, hipMemcpyHostToDevice, st));
+  ENSURE(c->csize, (size_t)U * 4);
+  HIPCHK(hipMemsetAsync(c->csize.p, 0, (size_t)U * 4, st));
+  HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_NONSINGLE], 0, 2 * sizeof(ull), st));
   hipLaunchKernelGGL(k_iota, dim3(blocks_for(U)), dim3(256), 0, st, c->parent.as<u32>(), U);
   hipLaunchKernelGGL(k_union_csr, dim3(blocks_for(U)), dim3(256), 0, st, c->nbr_off.as<u32>(),
                      c->nbr_idx.as<u32>(), U, c->parent.as<u32>());
-  HIPCHK(hipStreamSynchronize(st));   // hdeg is a host temporary
-  TRY(cluster_stage(c, c->s_cnt.as<u32>(), U, M, method));
+  hipLaunchKernelGGL(k_comp_stats, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
+                     c->parent.as<u32>(), U, c->csize.as<u32>());
+  hipLaunchKernelGGL(k_comp_count, dim3(512), dim3(256), 0, st, c->deg.as<u32>(), c->parent.as<u32>(),
+                     c->csize.as<u32>(), U, c->d_ctr);
+  HIPCHK(hipGetLastError());
+  TRY(read_counters(c));   // also drains the stream: hdeg is a host temporary
+  TRY(cluster_stage(c, c->s_cnt.as<u32>(), U, c->h_ctr[CTR_NONSINGLE], c->h_ctr[CTR_MEMBERS], method));
   hipLaunchKernelGGL(k_finalize_nodes, dim3(blocks_for(U)), dim3(256), 0, st, c->cl_of.as<u32>(),
                      c->pos.as<u32>(), c->maxleaf.as<u32>(), U, c->cid.as<u32>(), c->ismax.as<u8>());
   HIPCHK(hipGetLastError());

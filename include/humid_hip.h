@@ -126,7 +126,10 @@ int humid_get_histogram(humid_ctx *ctx, uint32_t which, uint64_t *keys, uint64_t
  * index order, neighbour lists are scanned in the order given.
  * count[U]; nbr_off[U+1], nbr_idx[nbr_off[U]] (CSR, host).  Out: leaf_cluster[U]
  * (ids 1..C), and per cluster id c at slot c-1: size, max_count, max_leaf.
- * cl_* buffers must hold U entries; *n_clusters = C. */
+ * cl_* buffers must hold U entries; *n_clusters = C.  Neighbour lists must be symmetric (b in
+ * a's list <=> a in b's, as link() and src/humid.cc:121-122 produce) and two linked leaves may
+ * not both have count 0 (the reference's maxNeighbour_ never terminates on that input):
+ * HUMID_E_INVALID otherwise. */
 int humid_cluster_graph(humid_ctx *ctx, const uint32_t *count, const uint32_t *nbr_off,
                         const uint32_t *nbr_idx, uint32_t n_leaves, uint32_t method,
                         uint32_t *leaf_cluster, uint64_t *cl_size, uint32_t *cl_max_count,
