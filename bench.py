@@ -125,19 +125,24 @@ def main():
     ms_per_step = 1e3 * dt / a.steps
     value = total_reads * a.steps / dt
 
-    # ---- roofline of the dominant kernel (HIP events around its launch, live) ----
-    kern = {"k_hash_insert": ks["ms_k_insert"], "k_read_map": ks["ms_k_map"],
-            "k_pairs": ks["ms_k_pairs"], "k_cluster_components": ks["ms_k_cluster"]}
+    # ---- roofline of the dominant kernel (HIP events around its single launch, live) ----
+    # candidates: the two N-proportional single-launch kernels (13 B/read x N is their unit)
+    lds = int(last.get("count_mode_used", 0)) == 0 and world == 1 and not a.force_sharded
+    kern = {("k_dedup_lds" if lds else "k_hash_insert"): ks["ms_k_insert"],
+            ("k_read_map_part" if lds else "k_read_map"): ks["ms_k_map"]}
     dom = max(kern, key=lambda k: kern[k])
     dom_ms = kern[dom]
     achieved = (BYTES_PER_READ * n_local / (dom_ms * 1e-3)) / 1e9 if dom_ms > 0 else 0.0
     traffic = None
-    if a.traffic_json and os.path.exists(a.traffic_json):
-        traffic = json.load(open(a.traffic_json)).get(dom)
+    tj = a.traffic_json or os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tj):
+        traffic = json.load(open(tj)).get(dom)
     roofline = {"bound": "hbm", "kernel": dom, "kernel_ms": round(dom_ms, 4),
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                "alg_bytes_per_read": BYTES_PER_READ, "reads_per_launch": n_local}
+                "traffic_source": "profiles/traffic.json (separate rocprofv3 --pmc passes of this command; 2*FETCH_SIZE+WRITE_SIZE)" if traffic else None,
+                "alg_bytes_per_read": BYTES_PER_READ, "reads_per_launch": n_local,
+                "other_kernels_ms": {k: round(v, 4) for k, v in kern.items() if k != dom}}
 
     # ---- CPU baseline: the oracle, 1 thread, bounded sample of the same workload ----
     cpu = None

@@ -212,10 +212,11 @@ struct ReadTagOp {               // values_input transform: read index | exclude
 };
 
 // first position of every bucket in the partitioned key array (binary search)
-__global__ void k_part_bounds(const u64 *__restrict__ keys, u32 n, u32 pb, u32 n_parts, u32 *__restrict__ pbeg) {
+__global__ void k_part_bounds(const u64 *__restrict__ keys, u32 n, u32 pb, u32 n_parts, u32 *__restrict__ pbeg,
+                              u32 *__restrict__ ucount) {
   u32 p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > n_parts) return;
-  if (p == n_parts) { pbeg[p] = n; return; }
+  if (p == n_parts) { pbeg[p] = n; ucount[p] = 0; return; }   // ucount tail: scan sentinel
   const u64 target = (u64)p << (64 - pb);
   u32 lo = 0, hi = n;
   while (lo < hi) {
@@ -232,8 +233,8 @@ __global__ void k_part_bounds(const u64 *__restrict__ keys, u32 n, u32 pb, u32 n
 //   pad_word/pad_cnt/pad_first, ucount[b], pusable[b]; slot_of_read[r] = padded position.
 __global__ void __launch_bounds__(256)
 k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u32 *__restrict__ pbeg,
-            u32 n_reads, u32 pb, u64 *__restrict__ pad_word, u32 *__restrict__ pad_cnt, u32 *__restrict__ pad_first,
-            u32 *__restrict__ ucount, u32 *__restrict__ pusable, u32 *__restrict__ slot_of_read, ull *ctr) {
+            u32 n_reads, u32 pb, u64 *__restrict__ pad_word, uint2 *__restrict__ pad_cf,
+            u32 *__restrict__ ucount, u32 *__restrict__ pusable, u32 *__restrict__ pslot, ull *ctr) {
   __shared__ u64 lkey[LDS_SLOTS + 1];
   __shared__ u32 lcnt[LDS_SLOTS + 1];
   __shared__ u32 lfirst[LDS_SLOTS + 1];
@@ -252,8 +253,8 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
   bool overflow = false;
   for (u32 i = beg + threadIdx.x; i < end; i += 256) {
     const u32 v = vals[i];
-    if ((v & 0x7fffffffu) >= n_reads) { overflow = true; break; }   // never store through a bad index
-    if (v & 0x80000000u) { slot_of_read[v & 0x7fffffffu] = NOSLOT; continue; }
+    if ((v & 0x7fffffffu) >= n_reads) { overflow = true; break; }   // a malformed index is never used
+    if (v & 0x80000000u) { pslot[i] = NOSLOT; continue; }
     usable++;
     const u64 k = keys[i];
     u32 s;
@@ -286,8 +287,7 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
     if (occ) {
       const u32 li = base + r;           // li < unique words <= reads of the bucket = padded room
       pad_word[beg + li] = unmix64(lkey[s]);
-      pad_cnt[beg + li] = lcnt[s];
-      pad_first[beg + li] = lfirst[s];
+      pad_cf[beg + li] = make_uint2(lcnt[s], lfirst[s]);
       lfirst[s] = li;
     }
     base += tot;
@@ -296,7 +296,8 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
   const u32 tu = block_sum(usable, lds);
   if (threadIdx.x == 0) pusable[b] = tu;
   __syncthreads();
-  // second pass: every read learns the padded position of its word
+  // second pass: every position learns the padded slot of its word (coalesced store; the
+  // per-read outputs are produced later in this same partition order, see k_read_map_part)
   for (u32 i = beg + threadIdx.x; i < end; i += 256) {
     const u32 v = vals[i];
     if (v >= n_reads) continue;          // excluded read (bit 31) or malformed index
@@ -310,7 +311,7 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
       while (lkey[s] != k && probes++ < LDS_SLOTS) s = (s + 1) & (LDS_SLOTS - 1);
     }
     const u32 li = lfirst[s];
-    slot_of_read[v] = (li < end - beg) ? beg + li : NOSLOT;
+    pslot[i] = (li < end - beg) ? beg + li : NOSLOT;
   }
 }
 
@@ -342,15 +343,14 @@ k_compact_padded(const u64 *__restrict__ pad_word, const u32 *__restrict__ pbeg,
   }
 }
 
-// after the sort, padded variant: gather count / first read of rank i
-__global__ void k_post_sort_padded(const u32 *__restrict__ s_slot, const u32 *__restrict__ pad_cnt,
-                                   const u32 *__restrict__ pad_first, u32 n, u32 *__restrict__ s_cnt,
-                                   u32 *__restrict__ s_first) {
+// after the sort, padded variant: gather count / first read of rank i (one 8-byte gather)
+__global__ void k_post_sort_padded(const u32 *__restrict__ s_slot, const uint2 *__restrict__ pad_cf, u32 n,
+                                   u32 *__restrict__ s_cnt, u32 *__restrict__ s_first) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
-    const u32 p = s_slot[i];
-    s_cnt[i] = pad_cnt[p];
-    s_first[i] = pad_first[p];
+    const uint2 cf = pad_cf[s_slot[i]];
+    s_cnt[i] = cf.x;
+    s_first[i] = cf.y;
   }
 }
 
@@ -520,7 +520,7 @@ k_comp_count(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *
   for (u32 u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
     if (deg[u]) {
       m++;
-      if (csize[uf_find(P, u)] > SMALL_COMP) mb++;
+      if (csize[P[u]] > SMALL_COMP) mb++;              // P was flattened by k_comp_stats
     }
   }
   const u32 tm = block_sum(m, lds);
@@ -677,6 +677,37 @@ k_cluster_components(const u64 *__restrict__ mkeys, u32 n_members, const u32 *__
                                  maxleaf, cl_size, stk + 2 * (u64)i);
 }
 
+// Components of exactly two leaves a < b (one centre + one satellite: the bulk of the non-trivial
+// components on UMI data) have a closed form of the same loop; no private arrays, no scratch.
+template <bool MAXIMUM>
+__global__ void __launch_bounds__(256)
+k_cluster_pairs(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *__restrict__ csize, u32 n,
+                const u32 *__restrict__ cnt, const u32 *__restrict__ off, const u32 *__restrict__ idx,
+                u32 *cl_of, u32 *maxleaf, u64 *cl_size) {
+  u32 a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n || deg[a] == 0 || P[a] != a || csize[a] != 2) return;
+  const u32 b = idx[off[a]];
+  const u64 ca = cnt[a], cb = cnt[b];
+  if (MAXIMUM) {                                   // whole component, maxLeaf = first strict maximum
+    cl_of[a] = a + 1; cl_of[b] = a + 1;
+    maxleaf[a] = (cb > ca) ? b : a;
+    cl_size[a] = ca + cb;
+    return;
+  }
+  if (at_least_double(cb, ca)) {                   // a climbs to b, b floods back to a
+    cl_of[a] = a + 1; cl_of[b] = a + 1;
+    maxleaf[a] = b;
+    cl_size[a] = ca + cb;
+  } else if (at_least_double(ca, cb)) {            // a stays, absorbs b
+    cl_of[a] = a + 1; cl_of[b] = a + 1;
+    maxleaf[a] = a;
+    cl_size[a] = ca + cb;
+  } else {                                         // two clusters; b finds a already assigned
+    cl_of[a] = a + 1; maxleaf[a] = a; cl_size[a] = ca;
+    cl_of[b] = b + 1; maxleaf[b] = b; cl_size[b] = cb;
+  }
+}
+
 // SMALL components (<= SMALL_COMP leaves): one lane per component root collects the members by
 // a breadth-first walk, orders them, and runs the same loop with member list and stack in
 // private memory.  No sort, no scratch.
@@ -688,7 +719,7 @@ k_cluster_small(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u3
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n || deg[u] == 0 || P[u] != u) return;
   const u32 target = csize[u];
-  if (target > SMALL_COMP) return;
+  if (target > SMALL_COMP || target == 2) return;   // pairs: k_cluster_pairs; big: k_cluster_components
   u32 mem[SMALL_COMP];
   u32 st[2 * SMALL_COMP];
   u32 nm = 1;
@@ -770,6 +801,35 @@ k_read_map(const u32 *__restrict__ slot_of_read, const u64 *__restrict__ slot_ou
   }
 }
 
+// The same in PARTITION order (LDS-partitioned counts): position i of the partitioned arrays
+// holds read vals[i] and the slot of its word; the slot lookups are partition-local (cached).
+// The un-permute is ONE scattered 4-byte store per read (cluster id | keep << 31; ids < 2^31
+// because n_reads < 2^31); k_split_out then writes both output arrays coalesced.
+__global__ void __launch_bounds__(256)
+k_read_map_part(const u32 *__restrict__ vals, const u32 *__restrict__ pslot, const u64 *__restrict__ slot_out,
+                u32 n_reads, u32 *__restrict__ packed) {
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_reads; i += gridDim.x * blockDim.x) {
+    const u32 r = vals[i] & 0x7fffffffu;
+    if (r >= n_reads) continue;
+    const u32 s = pslot[i];
+    u32 c = 0;
+    if (s != NOSLOT) {
+      const u64 o = slot_out[s];
+      c = (u32)o | (((u32)(o >> 32) == r) ? 0x80000000u : 0u);
+    }
+    packed[r] = c;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_split_out(const u32 *__restrict__ packed, u32 n_reads, u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
+    const u32 t = packed[r];
+    cluster_id[r] = t & 0x7fffffffu;
+    keep[r] = (u8)(t >> 31);
+  }
+}
+
 __global__ void k_widen32(const u32 *__restrict__ in, u32 n, u64 *__restrict__ out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i];
@@ -829,7 +889,7 @@ struct humid_ctx {
   ull *h_ctr = nullptr;   // pinned mirror
   DBuf in_words, in_filt, out_cid, out_keep;                 // host entry point staging
   DBuf table, slot_out, slot_of_read, uniq_slot;             // table (cap+1) and per-read
-  DBuf pk_keys, pk_vals, pbeg, ucount, pusable, ubase, pad_word, pad_cnt, pad_first;   // partitioned counts
+  DBuf pk_keys, pk_vals, pbeg, ucount, pusable, ubase, pad_word, pad_cf, pslot;   // partitioned counts
   int count_mode = 0;        // 0: hash-partitioned LDS tables (default), 1: one global HBM table
   bool last_count_lds = false;
   DBuf uniq_word, s_word, s_slot, s_cnt, s_first;            // unique words (walk order)
@@ -956,6 +1016,14 @@ static int cluster_stage(humid_ctx *c, const u32 *g_cnt, u32 U, u64 M, u64 Mbig,
   if (M > 0) {
     HIPCHK(hipEventRecord(c->kev[2], st));
     if (method == HUMID_METHOD_MAXIMUM)
+      hipLaunchKernelGGL(k_cluster_pairs<true>, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
+                         c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
+                         c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
+    else
+      hipLaunchKernelGGL(k_cluster_pairs<false>, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
+                         c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
+                         c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
+    if (method == HUMID_METHOD_MAXIMUM)
       hipLaunchKernelGGL(k_cluster_small<true>, dim3(blocks_for(U, 128)), dim3(128), 0, st, c->deg.as<u32>(),
                          c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
                          c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
@@ -1068,15 +1136,13 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   ENSURE(c->pusable, (size_t)(n_parts + 1) * 4);
   ENSURE(c->ubase, (size_t)(n_parts + 1) * 4);
   ENSURE(c->pad_word, (size_t)N * 8);
-  ENSURE(c->pad_cnt, (size_t)N * 4);
-  ENSURE(c->pad_first, (size_t)N * 4);
+  ENSURE(c->pad_cf, (size_t)N * 8);
+  ENSURE(c->pslot, (size_t)N * 4);
   ENSURE(c->slot_out, ((size_t)N + 1) * 8);
-  ENSURE(c->slot_of_read, (size_t)N * 4);
   ENSURE(c->uniq_slot, (size_t)N * 4 + 4);
   ENSURE(c->uniq_word, (size_t)N * 8 + 8);
   HIPCHK(hipEventRecord(c->ev[0], st));
   HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_N * sizeof(ull), st));
-  HIPCHK(hipMemsetAsync(c->ucount.as<u32>() + n_parts, 0, 4, st));
   {
     auto kin = rocprim::make_transform_iterator(d_words, MixKeyOp{});
     auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<u32>(0),
@@ -1092,11 +1158,11 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
                                                c->pk_vals.as<u32>(), (size_t)N, 64 - pb, 64, st));
   }
   hipLaunchKernelGGL(k_part_bounds, dim3(blocks_for(n_parts + 1)), dim3(256), 0, st, c->pk_keys.as<u64>(), N,
-                     pb, n_parts, c->pbeg.as<u32>());
+                     pb, n_parts, c->pbeg.as<u32>(), c->ucount.as<u32>());
   HIPCHK(hipEventRecord(c->kev[0], st));
   hipLaunchKernelGGL(k_dedup_lds, dim3(n_parts), dim3(256), 0, st, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(),
-                     c->pbeg.as<u32>(), N, pb, c->pad_word.as<u64>(), c->pad_cnt.as<u32>(), c->pad_first.as<u32>(),
-                     c->ucount.as<u32>(), c->pusable.as<u32>(), c->slot_of_read.as<u32>(), c->d_ctr);
+                     c->pbeg.as<u32>(), N, pb, c->pad_word.as<u64>(), c->pad_cf.as<uint2>(),
+                     c->ucount.as<u32>(), c->pusable.as<u32>(), c->pslot.as<u32>(), c->d_ctr);
   HIPCHK(hipEventRecord(c->kev[1], st));
   hipLaunchKernelGGL(k_part_totals, dim3(1), dim3(256), 0, st, c->ucount.as<u32>(), c->pusable.as<u32>(),
                      n_parts, c->d_ctr);
@@ -1118,7 +1184,7 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   TRY(sort_pairs<u64, u32>(c, c->uniq_word.as<u64>(), c->s_word.as<u64>(), c->uniq_slot.as<u32>(),
                            c->s_slot.as<u32>(), U, 0, 2 * word_nt));
   hipLaunchKernelGGL(k_post_sort_padded, dim3(blocks_for(U)), dim3(256), 0, st, c->s_slot.as<u32>(),
-                     c->pad_cnt.as<u32>(), c->pad_first.as<u32>(), U, c->s_cnt.as<u32>(), c->s_first.as<u32>());
+                     c->pad_cf.as<uint2>(), U, c->s_cnt.as<u32>(), c->s_first.as<u32>());
   HIPCHK(hipEventRecord(c->ev[1], st));
   HIPCHK(hipGetLastError());
   return HUMID_OK;
@@ -1254,8 +1320,16 @@ static int stage_map(humid_ctx *c, const u32 *l_cid, const u8 *l_ismax, u32 N, u
     hipLaunchKernelGGL(k_slot_results, dim3(blocks_for(U)), dim3(256), 0, st, l_cid, l_ismax,
                        c->s_first.as<u32>(), c->s_slot.as<u32>(), U, c->slot_out.as<u64>());
   HIPCHK(hipEventRecord(c->ev[3], st));
-  hipLaunchKernelGGL(k_read_map, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->slot_of_read.as<u32>(),
-                     c->slot_out.as<u64>(), N, d_cid, d_keep);
+  if (c->last_count_lds) {
+    // pk_keys (the partitioned keys) is dead by now: reuse it for the packed per-read results
+    u32 *packed = c->pk_keys.as<u32>();
+    hipLaunchKernelGGL(k_read_map_part, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->pk_vals.as<u32>(),
+                       c->pslot.as<u32>(), c->slot_out.as<u64>(), N, packed);
+    HIPCHK(hipEventRecord(c->kev[36], st));
+    hipLaunchKernelGGL(k_split_out, dim3(grid_stride_blocks(N)), dim3(256), 0, st, packed, N, d_cid, d_keep);
+  } else
+    hipLaunchKernelGGL(k_read_map, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->slot_of_read.as<u32>(),
+                       c->slot_out.as<u64>(), N, d_cid, d_keep);
   HIPCHK(hipEventRecord(c->ev[4], st));
   HIPCHK(hipGetLastError());
   return HUMID_OK;
@@ -1310,7 +1384,8 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
   HIPCHK(hipEventElapsedTime(&s.ms_map, c->ev[3], c->ev[4]));
   HIPCHK(hipEventElapsedTime(&s.ms_total, c->ev[0], c->ev[4]));
   HIPCHK(hipEventElapsedTime(&s.ms_k_insert, c->kev[0], c->kev[1]));
-  s.ms_k_map = s.ms_map;   // ev[3]..ev[4] bracket exactly the k_read_map launch
+  if (c->last_count_lds) HIPCHK(hipEventElapsedTime(&s.ms_k_map, c->ev[3], c->kev[36]));   // k_read_map_part alone
+  else s.ms_k_map = s.ms_map;   // ev[3]..ev[4] bracket exactly the k_read_map launch
   s.count_mode_used = c->last_count_lds ? 0u : 1u;
   if (M > 0) HIPCHK(hipEventElapsedTime(&s.ms_k_cluster, c->kev[2], c->kev[3]));
   for (u32 g = 0; g < n_pair_segs; g++) {
@@ -1384,7 +1459,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
-                  &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cnt, &c->pad_first,
+                  &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->csize, &c->cur, &c->parent, &c->mk0, &c->mk1, &c->cl_of,

@@ -60,8 +60,8 @@ typedef struct humid_summary {
   /* single kernels, HIP events directly around the launches on the ctx stream:      */
   float ms_k_insert;    /* k_dedup_lds or k_hash_insert (one launch)                */
   float ms_k_pairs;     /* sum over the 2(d+1) k_pairs launches (count + fill)      */
-  float ms_k_cluster;   /* k_cluster_components (one launch; 0 if no neighbours)    */
-  float ms_k_map;       /* k_read_map (one launch)                                  */
+  float ms_k_cluster;   /* k_cluster_pairs + _small (+ _components): 2-3 launches   */
+  float ms_k_map;       /* k_read_map_part or k_read_map (one launch)               */
   uint32_t count_mode_used;  /* 0 = LDS-partitioned tables, 1 = global HBM table (option or fallback) */
 } humid_summary;
 
