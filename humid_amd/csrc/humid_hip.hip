@@ -368,19 +368,57 @@ __global__ void k_post_sort(const u32 *__restrict__ s_slot, const Slot *__restri
 // --------------------------------------------------------------------------------
 // 3. neighbour search: pigeonhole segments
 // --------------------------------------------------------------------------------
-struct SegPlan {
-  u32 nseg;
-  u32 shift[33];
-  u64 mask[33];
+// Generalised pigeonhole: the n nucleotides are cut into s segments; two words within
+// Hamming distance d agree exactly on at least s-d of them, so every pair is found in the bucket
+// of some COMBINATION of s-d segments.  d=1: s=2, 2 combos of 12 nt (n=24).  d=2: s=4, 6 combos
+// of 12 nt -- not 3 segments of 8 nt, whose 65 536 buckets hold hundreds of words each.
+// Combo 0 is always the top s-d segments, i.e. a prefix: its buckets are runs of the sorted
+// unique array and need no sort.  mask[c] = bits of combo c; a pair is emitted from the FIRST
+// combo it agrees on.
+#define MAX_COMBOS 20
+#define MAX_FIELDS 8
+struct ComboPlan {
+  u32 ncombo;
+  u32 key_bits;                       // bits of a combo key (sum of its field widths)
+  u64 mask[MAX_COMBOS];
+  u8 nfield[MAX_COMBOS];
+  u8 shift[MAX_COMBOS][MAX_FIELDS];   // fields from most to least significant
+  u8 width[MAX_COMBOS][MAX_FIELDS];
 };
 
-__global__ void k_seg_keys(const u64 *__restrict__ s_word, u32 n, u32 shift, u64 mask,
-                           u32 *__restrict__ key, u32 *__restrict__ val) {
+// bucket key of combo `cb` for every unique word (fields concatenated, most significant first)
+// Kernel arguments derived from the plan are passed BY VALUE in small structs and indexed
+// STATICALLY (unrolled loops with a predicate).  A 1 KB plan struct indexed dynamically in the
+// kernarg segment -- and equally a plan freshly uploaded to device memory and read through
+// wave-uniform (scalar) loads -- returned stale fields for single waves on gfx950 / ROCm 7.2
+// (5-25 of 219 k edges lost at 10 M reads, tools/det_check.py), so neither form is used.
+struct EarlierMasks {
+  u64 m[MAX_COMBOS];
+};
+
+// fields of ONE combo
+struct ComboFields {
+  u32 nf;
+  u8 shift[MAX_FIELDS];
+  u8 width[MAX_FIELDS];
+};
+
+template <class KeyT>
+__global__ void k_combo_keys(const u64 *__restrict__ s_word, u32 n, ComboFields cf,
+                             KeyT *__restrict__ key, u32 *__restrict__ val) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    key[i] = (u32)((s_word[i] >> shift) & mask);
-    val[i] = i;
+  if (i >= n) return;
+  const u64 w = s_word[i];
+  u64 k = 0;
+#pragma unroll
+  for (u32 f = 0; f < MAX_FIELDS; f++) {
+    if (f < cf.nf) {
+      const u32 wd = cf.width[f];
+      k = (k << wd) | ((w >> cf.shift[f]) & ((wd >= 64) ? ~0ull : ((1ull << wd) - 1ull)));
+    }
   }
+  key[i] = (KeyT)k;
+  val[i] = i;
 }
 
 // --------------------------------------------------------------------------------
@@ -402,44 +440,34 @@ __device__ __forceinline__ void uf_union(u32 *P, u32 a, u32 b) {
   }
 }
 
-// One thread per position i of the bucket-sorted order; compares with the following
-// elements of its bucket.  Ranks ascend inside a bucket, so (ri < rj) always.  A pair is
-// emitted only from the FIRST segment it agrees on (earlier segments must all differ).
+// One thread per position i of the bucket-sorted order (V = ranks in that order; combo 0 uses
+// the sorted unique array itself); compares with the following elements of its bucket: the
+// bucket ends at the first j whose word differs inside the combo mask.  Ranks ascend inside a
+// bucket, so (ri < rj) always.  A pair is emitted only from the FIRST combo it agrees on.
 // Two phases with identical control flow and no shared append counter:
 //   FILL = false: deg[] += 1 per endpoint, union(ri, rj) in the component forest
 //   FILL = true : writes rj into ri's CSR row and ri into rj's (per-row cursors; the rows are
 //                 put in ascending order afterwards by k_sort_lists)
 template <bool PASS0, bool FILL>
 __global__ void __launch_bounds__(256)
-k_pairs(const u64 *__restrict__ s_word, const u32 *__restrict__ K, const u32 *__restrict__ V,
-        u32 n, SegPlan plan, u32 seg, u32 distance, u32 *deg, u32 *parent,
+k_pairs(const u64 *__restrict__ s_word, const u32 *__restrict__ V, u32 n, u64 mask,
+        EarlierMasks em, u32 cb, u32 distance, u32 *deg, u32 *parent,
         const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const u32 shift = plan.shift[seg];
-  const u64 mask = plan.mask[seg];
-  u32 ri;
-  u64 wi;
-  u64 ki;
-  if (PASS0) { ri = i; wi = s_word[i]; ki = (wi >> shift) & mask; }
-  else { ri = V[i]; wi = s_word[ri]; ki = K[i]; }
+  const u32 ri = PASS0 ? i : V[i];
+  const u64 wi = s_word[ri];
   u32 found = 0;
   for (u32 j = i + 1; j < n; j++) {
-    u32 rj;
-    u64 wj;
-    if (PASS0) {
-      rj = j; wj = s_word[j];
-      if (((wj >> shift) & mask) != ki) break;
-    } else {
-      if ((u64)K[j] != ki) break;
-      rj = V[j]; wj = s_word[rj];
-    }
-    const u64 x = wi ^ wj;
+    const u32 rj = PASS0 ? j : V[j];
+    const u64 x = wi ^ s_word[rj];
+    if (x & mask) break;                           // left the bucket
     if (nt_mismatch(x) > distance) continue;
-    bool firstseg = true;
-    for (u32 t = 0; t < seg; t++)
-      if (((x >> plan.shift[t]) & plan.mask[t]) == 0) { firstseg = false; break; }
-    if (!firstseg) continue;
+    bool first = true;
+#pragma unroll
+    for (u32 t = 0; t < MAX_COMBOS; t++)
+      first = first && !(t < cb && (x & em.m[t]) == 0);
+    if (!first) continue;
     if (FILL) {
       nbr_idx[nbr_off[ri] + atomicAdd(&cur[ri], 1u)] = rj;
       nbr_idx[nbr_off[rj] + atomicAdd(&cur[rj], 1u)] = ri;
@@ -891,9 +919,11 @@ struct humid_ctx {
   DBuf table, slot_out, slot_of_read, uniq_slot;             // table (cap+1) and per-read
   DBuf pk_keys, pk_vals, pbeg, ucount, pusable, ubase, pad_word, pad_cf, pslot;   // partitioned counts
   int count_mode = 0;        // 0: hash-partitioned LDS tables (default), 1: one global HBM table
+  u32 force_segments = 0;    // 0: automatic pigeonhole plan; else the number of segments s
   bool last_count_lds = false;
   DBuf uniq_word, s_word, s_slot, s_cnt, s_first;            // unique words (walk order)
-  DBuf deg, nbr_off, nbr_idx, seg_k0, seg_v0, seg_ks, seg_vs, csize, cur;
+  DBuf deg, nbr_off, nbr_idx, seg_k0, seg_v0, seg_ks, seg_vs, csize, cur, plan_dev;
+  ComboPlan h_plan;          // host copy of the plan in flight (source of the async upload)
   DBuf parent, mk0, mk1, cl_of, maxleaf, cl_size, flag, pos, cid, ismax, stk, tmp, scratch;
   hipEvent_t ev[6] = {};
   hipEvent_t kev[40] = {};   // per-kernel timing: [0,1] insert, [2,3] cluster, [4..19] pairs fill, [20..35] pairs count
@@ -980,22 +1010,73 @@ static int read_counters(humid_ctx *c, const u32 *extra32 = nullptr) {
 
 #define TRY(...) do { int _rc = (__VA_ARGS__); if (_rc != HUMID_OK) return _rc; } while (0)
 
-// segments for the pigeonhole search: d+1 segments over n nucleotides (first segment = most
-// significant nucleotides, so its buckets are runs of the sorted unique array).  d >= n: one
-// zero-width segment (every pair is compared).
-static SegPlan make_plan(u32 n, u32 d) {
-  SegPlan p;
+// Plan of the generalised pigeonhole search (see ComboPlan).  s is chosen so that combo keys are
+// long enough for buckets to be small at this U (>= ~log4(U) nucleotides) without exceeding
+// MAX_COMBOS combinations; d >= n degenerates to one empty-mask combo (every pair compared).
+static u64 n_choose_k(u32 n, u32 k) {
+  if (k > n) return 0;
+  u64 r = 1;
+  for (u32 i = 1; i <= k; i++) r = r * (n - k + i) / i;
+  return r;
+}
+
+static ComboPlan make_plan(u32 n, u32 d, u64 U, u32 force_segments) {
+  ComboPlan p;
   memset(&p, 0, sizeof p);
-  if (d + 1 > n) { p.nseg = 1; p.shift[0] = 0; p.mask[0] = 0; return p; }
-  p.nseg = d + 1;
-  u32 base = n / p.nseg, rem = n % p.nseg, pos = 0;
-  for (u32 s = 0; s < p.nseg; s++) {
-    u32 len = base + (s < rem ? 1 : 0);
-    u32 end = pos + len;               // nucleotides [pos, end) from the most significant
-    p.shift[s] = 2 * (n - end);
-    p.mask[s] = (len >= 32) ? ~0ull : (((u64)1 << (2 * len)) - 1);
-    pos = end;
+  if (d >= n) { p.ncombo = 1; p.key_bits = 0; p.mask[0] = 0; p.nfield[0] = 0; return p; }
+  u32 want = 1;                                  // nucleotides of key wanted: 4^want >= U
+  while (want < n && ((u64)1 << (2 * want)) < U) want++;
+  u32 best_s = d + 1, best_len = 0;
+  u64 best_c = ~0ull;
+  for (u32 sgm = d + 1; sgm <= n && sgm <= d + MAX_FIELDS; sgm++) {
+    const u64 combos = n_choose_k(sgm, sgm - d);
+    if (combos > MAX_COMBOS) break;
+    if (force_segments) {                         // test hook: take exactly this s if it is legal
+      if (sgm == force_segments) { best_s = sgm; best_len = (sgm - d) * (n / sgm); best_c = combos; break; }
+      continue;
+    }
+    const u32 len = (sgm - d) * (n / sgm);       // guaranteed key length (short segments)
+    const bool better = (best_len < want) ? (len > best_len) : (len >= want && combos < best_c);
+    if (best_len == 0 || better) { best_s = sgm; best_len = len; best_c = combos; }
+    if (best_len >= want) break;                 // smallest s that reaches the wanted length
   }
+  const u32 sgm = best_s, k = sgm - d;
+  u32 seg_shift[64], seg_width[64];
+  {
+    u32 base = n / sgm, rem = n % sgm, pos = 0;
+    for (u32 t = 0; t < sgm; t++) {
+      u32 len = base + (t < rem ? 1 : 0);
+      seg_shift[t] = 2 * (n - pos - len);
+      seg_width[t] = 2 * len;
+      pos += len;
+    }
+  }
+  // combinations of k segments in lexicographic order: the first is {0..k-1}, a prefix
+  u32 idx[64];
+  for (u32 t = 0; t < k; t++) idx[t] = t;
+  u32 c = 0, maxbits = 0;
+  while (true) {
+    u64 m = 0;
+    u32 bits = 0;
+    for (u32 t = 0; t < k; t++) {
+      const u32 sg = idx[t];
+      p.shift[c][t] = (u8)seg_shift[sg];
+      p.width[c][t] = (u8)seg_width[sg];
+      m |= ((seg_width[sg] >= 64) ? ~0ull : (((u64)1 << seg_width[sg]) - 1)) << seg_shift[sg];
+      bits += seg_width[sg];
+    }
+    p.mask[c] = m;
+    p.nfield[c] = (u8)k;
+    if (bits > maxbits) maxbits = bits;
+    c++;
+    int t = (int)k - 1;
+    while (t >= 0 && idx[t] == sgm - k + (u32)t) t--;
+    if (t < 0) break;
+    idx[t]++;
+    for (u32 q = (u32)t + 1; q < k; q++) idx[q] = idx[q - 1] + 1;
+  }
+  p.ncombo = c;
+  p.key_bits = maxbits;
   return p;
 }
 
@@ -1225,36 +1306,48 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
   hipLaunchKernelGGL(k_iota, dim3(blocks_for(U)), dim3(256), 0, st, c->parent.as<u32>(), U);
   u64 E = 0, M = 0, Mbig = 0;
   u32 n_pair_segs = 0;
-  SegPlan plan = make_plan(word_nt, distance);
+  c->h_plan = make_plan(word_nt, distance, U, c->force_segments);
+  const ComboPlan &plan = c->h_plan;
+  EarlierMasks d_masks;                              // masks of all combos, for the first-combo rule
+  for (u32 t = 0; t < MAX_COMBOS; t++) d_masks.m[t] = plan.mask[t];
+  auto fields_of = [&](u32 cb) {
+    ComboFields cf;
+    cf.nf = plan.nfield[cb];
+    for (u32 f = 0; f < MAX_FIELDS; f++) { cf.shift[f] = plan.shift[cb][f]; cf.width[f] = plan.width[cb][f]; }
+    return cf;
+  };
   const bool search = distance > 0 && U > 1;
   if (search) {
-    const u32 nseg = plan.nseg;
+    const u32 nseg = plan.ncombo;
     n_pair_segs = nseg < 8 ? nseg : 8;
     if (nseg > 1) {
-      ENSURE(c->seg_k0, (size_t)U * 4);
+      ENSURE(c->seg_k0, (size_t)U * 8);
       ENSURE(c->seg_v0, (size_t)U * 4);
-      ENSURE(c->seg_ks, (size_t)(nseg - 1) * U * 4);
-      ENSURE(c->seg_vs, (size_t)(nseg - 1) * U * 4);
+      ENSURE(c->seg_ks, (size_t)U * 8);                     // sorted keys: scratch, not kept
+      ENSURE(c->seg_vs, (size_t)(nseg - 1) * U * 4);        // ranks in bucket order, per combo
     }
-    // phase A: bucket order per segment; degrees and component forest
+    // phase A: bucket order per combo; degrees and component forest
     for (u32 seg = 0; seg < nseg; seg++) {
       if (seg == 0) {
         HIPCHK(hipEventRecord(c->kev[20], st));
         hipLaunchKernelGGL((k_pairs<true, false>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
-                           (const u32 *)nullptr, (const u32 *)nullptr, U, plan, seg, distance,
-                           c->deg.as<u32>(), c->parent.as<u32>(), (const u32 *)nullptr, (u32 *)nullptr,
-                           (u32 *)nullptr);
+                           (const u32 *)nullptr, U, plan.mask[seg], d_masks, seg, distance, c->deg.as<u32>(),
+                           c->parent.as<u32>(), (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr);
       } else {
-        u32 width = 0;
-        while (width < 64 && (plan.mask[seg] >> width)) width++;
-        u32 *ks = c->seg_ks.as<u32>() + (size_t)(seg - 1) * U;
         u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
-        hipLaunchKernelGGL(k_seg_keys, dim3(blocks_for(U)), dim3(256), 0, st, g_word, U,
-                           plan.shift[seg], plan.mask[seg], c->seg_k0.as<u32>(), c->seg_v0.as<u32>());
-        TRY(sort_pairs<u32, u32>(c, c->seg_k0.as<u32>(), ks, c->seg_v0.as<u32>(), vs, U, 0, width ? width : 1));
+        const u32 kb = plan.key_bits ? plan.key_bits : 1;
+        if (kb <= 32) {
+          hipLaunchKernelGGL(k_combo_keys<u32>, dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, fields_of(seg),
+                             c->seg_k0.as<u32>(), c->seg_v0.as<u32>());
+          TRY(sort_pairs<u32, u32>(c, c->seg_k0.as<u32>(), c->seg_ks.as<u32>(), c->seg_v0.as<u32>(), vs, U, 0, kb));
+        } else {
+          hipLaunchKernelGGL(k_combo_keys<u64>, dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, fields_of(seg),
+                             c->seg_k0.as<u64>(), c->seg_v0.as<u32>());
+          TRY(sort_pairs<u64, u32>(c, c->seg_k0.as<u64>(), c->seg_ks.as<u64>(), c->seg_v0.as<u32>(), vs, U, 0, kb));
+        }
         if (seg < 8) HIPCHK(hipEventRecord(c->kev[20 + 2 * seg], st));
         hipLaunchKernelGGL((k_pairs<false, false>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
-                           ks, vs, U, plan, seg, distance, c->deg.as<u32>(), c->parent.as<u32>(),
+                           vs, U, plan.mask[seg], d_masks, seg, distance, c->deg.as<u32>(), c->parent.as<u32>(),
                            (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr);
       }
       if (seg < 8) HIPCHK(hipEventRecord(c->kev[21 + 2 * seg], st));
@@ -1280,18 +1373,16 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
     ENSURE(c->cur, (size_t)U * 4);
     HIPCHK(hipMemsetAsync(c->cur.p, 0, (size_t)U * 4, st));
     // phase B: same loops, now writing the CSR rows
-    for (u32 seg = 0; seg < plan.nseg; seg++) {
+    for (u32 seg = 0; seg < plan.ncombo; seg++) {
       if (seg < 8) HIPCHK(hipEventRecord(c->kev[4 + 2 * seg], st));
       if (seg == 0) {
         hipLaunchKernelGGL((k_pairs<true, true>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
-                           (const u32 *)nullptr, (const u32 *)nullptr, U, plan, seg, distance,
-                           (u32 *)nullptr, (u32 *)nullptr, c->nbr_off.as<u32>(), c->cur.as<u32>(),
-                           c->nbr_idx.as<u32>());
+                           (const u32 *)nullptr, U, plan.mask[seg], d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
+                           c->nbr_off.as<u32>(), c->cur.as<u32>(), c->nbr_idx.as<u32>());
       } else {
-        const u32 *ks = c->seg_ks.as<u32>() + (size_t)(seg - 1) * U;
         const u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
         hipLaunchKernelGGL((k_pairs<false, true>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
-                           ks, vs, U, plan, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
+                           vs, U, plan.mask[seg], d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
                            c->nbr_off.as<u32>(), c->cur.as<u32>(), c->nbr_idx.as<u32>());
       }
       if (seg < 8) HIPCHK(hipEventRecord(c->kev[5 + 2 * seg], st));
@@ -1462,7 +1553,7 @@ void humid_ctx_destroy(humid_ctx *c) {
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
-                  &c->seg_v0, &c->seg_vs, &c->csize, &c->cur, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
+                  &c->seg_v0, &c->seg_vs, &c->csize, &c->cur, &c->plan_dev, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
                   &c->maxleaf, &c->cl_size, &c->flag, &c->pos, &c->cid, &c->ismax, &c->stk, &c->tmp,
                   &c->scratch};
   for (DBuf *b : bufs) b->release();
@@ -1479,6 +1570,11 @@ int humid_ctx_set_option(humid_ctx *c, const char *key, int64_t value) {
   if (strcmp(key, "count_mode") == 0) {
     if (value != 0 && value != 1) return fail(c, HUMID_E_INVALID, "count_mode must be 0 (LDS-partitioned) or 1 (global table)");
     c->count_mode = (int)value;
+    return HUMID_OK;
+  }
+  if (strcmp(key, "plan_segments") == 0) {
+    if (value < 0 || value > 32) return fail(c, HUMID_E_INVALID, "plan_segments must be 0 (auto) .. 32");
+    c->force_segments = (u32)value;
     return HUMID_OK;
   }
   return fail(c, HUMID_E_INVALID, "unknown option '%s'", key);

@@ -75,7 +75,9 @@ void humid_ctx_destroy(humid_ctx *ctx);
 const char *humid_last_error(const humid_ctx *ctx);   /* ctx may be NULL */
 /* Tuning knobs (never change results).  "count_mode": 0 = exact counts in hash-partitioned
  * LDS-resident tables (default; falls back to 1 by itself when a bucket overflows), 1 = one
- * open-address table in HBM.  Environment HUMID_COUNT_MODE presets it. */
+ * open-address table in HBM.  Environment HUMID_COUNT_MODE presets it.
+ * "plan_segments": 0 = automatic choice of the pigeonhole plan (s segments, buckets on every
+ * combination of s-d of them), else force s (ignored when illegal for the given n, d). */
 int  humid_ctx_set_option(humid_ctx *ctx, const char *key, int64_t value);
 
 /* ---- the whole hot path ----------------------------------------------------

@@ -210,6 +210,31 @@ def test_bucket_overflow_falls_back_to_global_table(dd):
     assert s["count_mode_used"] == dd.count_mode
 
 
+@pytest.mark.parametrize("d,s", [(1, 2), (1, 3), (1, 4), (2, 3), (2, 4), (2, 5), (3, 4), (3, 6)])
+def test_forced_pigeonhole_plans(dd, d, s):
+    """every plan (s segments, combos of s-d) finds the same neighbour graph: the automatic choice
+    only picks the larger s at millions of unique words, so the test forces it"""
+    dd.set_option("plan_segments", s)
+    try:
+        for n, mode in ((24, "umi"), (24, "genome"), (13, "umi")):
+            words, filt = synth_words(60_000, 500 + d + s, n, p_sub=8e-3, mode=mode, genome_bp=30_000)
+            check_against_oracle(dd, words, filt, n, d, False)
+    finally:
+        dd.set_option("plan_segments", 0)
+
+
+def test_repeatable_at_scale(dd):
+    """same input, same answer, run after run (guards the stale-kernel-argument bug recorded in
+    humid_hip.hip: single waves lost their edges 5-25 times per 219 k)"""
+    words, filt = synth_words(3_000_000, 1002, 24)
+    ref = None
+    for _ in range(4):
+        cid, keep, s = dd.run(words, filt)
+        cur = (s["edges"], s["clusters"], s["unique"], int(cid.astype(np.uint64).sum()), int(keep.sum()))
+        ref = ref or cur
+        assert cur == ref
+
+
 def test_unsupported_and_invalid(dd):
     w = np.zeros(4, np.uint64)
     f = np.zeros(4, np.uint8)
