@@ -858,6 +858,73 @@ k_split_out(const u32 *__restrict__ packed, u32 n_reads, u32 *__restrict__ clust
   }
 }
 
+// --------------------------------------------------------------------------------
+// 7. multi-GPU result return: dense per-shard streams instead of N-sized arrays
+// --------------------------------------------------------------------------------
+#define MAX_RANKS 16
+struct OwnerRanges {            // value ranges of the ranks, by value, statically indexed
+  u64 lo[MAX_RANKS];
+  u64 hi[MAX_RANKS];
+};
+
+struct OwnedFlagOp {            // 1 for the reads this rank counted (global-table variant)
+  const u32 *slot_of_read;
+  u32 n;
+  __device__ u32 operator()(u32 i) const { return (i < n && slot_of_read[i] != NOSLOT) ? 1u : 0u; }
+};
+
+// packed result (cluster id | keep << 31) of every owned read, dense, in read order
+__global__ void __launch_bounds__(256)
+k_owned_results(const u32 *__restrict__ slot_of_read, const u32 *__restrict__ opos,
+                const u64 *__restrict__ slot_out, u32 n_reads, u32 *__restrict__ packed) {
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
+    const u32 s = slot_of_read[r];
+    if (s == NOSLOT) continue;
+    const u64 o = slot_out[s];
+    packed[opos[r]] = (u32)o | (((u32)(o >> 32) == r) ? 0x80000000u : 0u);
+  }
+}
+
+// owner rank of every local read (n_ranks = nobody: filtered reads)
+__global__ void __launch_bounds__(256)
+k_owner_of(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n, OwnerRanges rg,
+           u32 n_ranks, u8 *__restrict__ owner) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 o = n_ranks;
+  if (!filtered[i]) {
+    const u64 w = words[i];
+#pragma unroll
+    for (u32 q = 0; q < MAX_RANKS; q++)
+      if (q < n_ranks && rg.lo[q] <= rg.hi[q] && w >= rg.lo[q] && w <= rg.hi[q]) o = q;
+  }
+  owner[i] = (u8)o;
+}
+
+// first position of every owner in the owner-sorted order (n_ranks + 2 boundaries)
+__global__ void k_owner_bounds(const u8 *__restrict__ sorted_owner, u32 n, u32 n_ranks, u32 *__restrict__ bounds) {
+  u32 q = threadIdx.x;
+  if (q > n_ranks + 1) return;
+  u32 lo = 0, hi = n;
+  while (lo < hi) {
+    u32 mid = lo + ((hi - lo) >> 1);
+    if (sorted_owner[mid] < q) lo = mid + 1; else hi = mid;
+  }
+  bounds[q] = lo;
+}
+
+// received dense stream (owner-major, read order inside) -> this shard's outputs
+__global__ void __launch_bounds__(256)
+k_scatter_results(const u32 *__restrict__ perm, const u32 *__restrict__ packed, u32 n_recv,
+                  u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
+  for (u32 k = blockIdx.x * blockDim.x + threadIdx.x; k < n_recv; k += gridDim.x * blockDim.x) {
+    const u32 r = perm[k];
+    const u32 t = packed[k];
+    cluster_id[r] = t & 0x7fffffffu;
+    keep[r] = (u8)(t >> 31);
+  }
+}
+
 __global__ void k_widen32(const u32 *__restrict__ in, u32 n, u64 *__restrict__ out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i];
@@ -918,6 +985,7 @@ struct humid_ctx {
   DBuf in_words, in_filt, out_cid, out_keep;                 // host entry point staging
   DBuf table, slot_out, slot_of_read, uniq_slot;             // table (cap+1) and per-read
   DBuf pk_keys, pk_vals, pbeg, ucount, pusable, ubase, pad_word, pad_cf, pslot;   // partitioned counts
+  DBuf opos, own_packed, owner, owner_sorted, perm, small;                        // multi-GPU result return
   int count_mode = 0;        // 0: hash-partitioned LDS tables (default), 1: one global HBM table
   u32 force_segments = 0;    // 0: automatic pigeonhole plan; else the number of segments s
   bool last_count_lds = false;
@@ -1551,6 +1619,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->csize, &c->cur, &c->plan_dev, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -1901,6 +1970,119 @@ int humid_stage_map(humid_ctx *c, const uint32_t *d_local_cluster_id, const uint
   HIPCHK(hipSetDevice(c->device));
   if (n_reads) TRY(stage_map(c, d_local_cluster_id, d_local_is_max, (u32)n_reads, d_cluster_id, d_keep));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return HUMID_OK;
+}
+
+// ---- multi-GPU result return ------------------------------------------------------------------
+int humid_stage_owned_results(humid_ctx *c, const uint32_t *d_local_cluster_id, const uint8_t *d_local_is_max,
+                              const uint64_t *shard_begin, uint32_t n_shards, const uint32_t **d_packed,
+                              uint64_t *counts) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (c->last_count_lds) return fail(c, HUMID_E_STATE, "owned results need the global-table count variant (count_mode 1)");
+  if (!shard_begin || !counts || !d_packed || n_shards == 0 || n_shards > 4096) return fail(c, HUMID_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const u32 N = (u32)c->N, U = (u32)c->U;
+  *d_packed = nullptr;
+  for (u32 q = 0; q < n_shards; q++) counts[q] = 0;
+  if (N == 0) return HUMID_OK;
+  for (u32 q = 0; q <= n_shards; q++)
+    if (shard_begin[q] > N || (q && shard_begin[q] < shard_begin[q - 1])) return fail(c, HUMID_E_INVALID, "shard_begin must ascend within [0, n_reads]");
+  if (U && (!d_local_cluster_id || !d_local_is_max)) return fail(c, HUMID_E_INVALID, "null buffer");
+  if (U > 0)
+    hipLaunchKernelGGL(k_slot_results, dim3(blocks_for(U)), dim3(256), 0, st, d_local_cluster_id, d_local_is_max,
+                       c->s_first.as<u32>(), c->s_slot.as<u32>(), U, c->slot_out.as<u64>());
+  ENSURE(c->opos, ((size_t)N + 1) * 4);
+  {
+    auto fin = rocprim::make_transform_iterator(rocprim::counting_iterator<u32>(0),
+                                                OwnedFlagOp{c->slot_of_read.as<u32>(), N});
+    size_t bytes = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, bytes, fin, c->opos.as<u32>(), 0u, (size_t)N + 1, rocprim::plus<u32>(), st));
+    ENSURE(c->tmp, bytes);
+    HIPCHK(rocprim::exclusive_scan(c->tmp.p, bytes, fin, c->opos.as<u32>(), 0u, (size_t)N + 1, rocprim::plus<u32>(), st));
+  }
+  // per-shard counts: opos at the shard boundaries (a handful of 4-byte copies, one sync)
+  std::vector<u32> got(n_shards + 1);
+  for (u32 q = 0; q <= n_shards; q++)
+    HIPCHK(hipMemcpyAsync(&got[q], c->opos.as<u32>() + shard_begin[q], 4, hipMemcpyDeviceToHost, st));
+  u32 total = 0;
+  HIPCHK(hipMemcpyAsync(&total, c->opos.as<u32>() + N, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  // reads outside [shard_begin[0], shard_begin[n_shards]) must not be owned
+  if (got[0] != 0 || got[n_shards] != total) return fail(c, HUMID_E_INVALID, "owned reads outside the shard table");
+  for (u32 q = 0; q < n_shards; q++) counts[q] = got[q + 1] - got[q];
+  ENSURE(c->own_packed, ((size_t)total + 1) * 4);
+  if (total)
+    hipLaunchKernelGGL(k_owned_results, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->slot_of_read.as<u32>(),
+                       c->opos.as<u32>(), c->slot_out.as<u64>(), N, c->own_packed.as<u32>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  *d_packed = c->own_packed.as<u32>();
+  return HUMID_OK;
+}
+
+int humid_stage_owner_perm(humid_ctx *c, const uint64_t *d_words, const uint8_t *d_filtered, uint64_t n_reads,
+                           const uint64_t *range_lo, const uint64_t *range_hi, uint32_t n_ranks,
+                           const uint32_t **d_perm, uint64_t *counts) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (!range_lo || !range_hi || !counts || !d_perm || n_ranks == 0) return fail(c, HUMID_E_INVALID, "bad argument");
+  if (n_ranks > MAX_RANKS) return fail(c, HUMID_E_UNSUPPORTED, "more than %d ranks", MAX_RANKS);
+  if (n_reads > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "n_reads exceeds 2^31-1");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const u32 n = (u32)n_reads;
+  *d_perm = nullptr;
+  for (u32 q = 0; q < n_ranks; q++) counts[q] = 0;
+  if (n == 0) return HUMID_OK;
+  if (!d_words || !d_filtered) return fail(c, HUMID_E_INVALID, "null buffer");
+  OwnerRanges rg;
+  for (u32 q = 0; q < MAX_RANKS; q++) { rg.lo[q] = q < n_ranks ? range_lo[q] : 1; rg.hi[q] = q < n_ranks ? range_hi[q] : 0; }
+  ENSURE(c->owner, (size_t)n);
+  ENSURE(c->owner_sorted, (size_t)n);
+  ENSURE(c->perm, (size_t)n * 4);
+  hipLaunchKernelGGL(k_owner_of, dim3(blocks_for(n)), dim3(256), 0, st, d_words, d_filtered, n, rg, n_ranks,
+                     c->owner.as<u8>());
+  {
+    using part_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                rocprim::default_config, 0>;   // never the merge path
+    rocprim::counting_iterator<u32> vin(0);
+    size_t bytes = 0;
+    HIPCHK(rocprim::radix_sort_pairs<part_cfg>(nullptr, bytes, c->owner.as<u8>(), c->owner_sorted.as<u8>(), vin,
+                                               c->perm.as<u32>(), (size_t)n, 0, 8, st));
+    ENSURE(c->tmp, bytes);
+    HIPCHK(rocprim::radix_sort_pairs<part_cfg>(c->tmp.p, bytes, c->owner.as<u8>(), c->owner_sorted.as<u8>(), vin,
+                                               c->perm.as<u32>(), (size_t)n, 0, 8, st));
+  }
+  ENSURE(c->small, (size_t)(n_ranks + 2) * 4);
+  hipLaunchKernelGGL(k_owner_bounds, dim3(1), dim3(64), 0, st, c->owner_sorted.as<u8>(), n, n_ranks,
+                     c->small.as<u32>());
+  std::vector<u32> b(n_ranks + 2);
+  HIPCHK(hipMemcpyAsync(b.data(), c->small.p, (n_ranks + 2) * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  for (u32 q = 0; q < n_ranks; q++) counts[q] = b[q + 1] - b[q];
+  *d_perm = c->perm.as<u32>();
+  return HUMID_OK;
+}
+
+int humid_stage_scatter(humid_ctx *c, const uint32_t *d_perm, const uint32_t *d_packed, uint64_t n_recv,
+                        uint64_t n_reads, uint32_t *d_cluster_id, uint8_t *d_keep) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (n_recv > n_reads) return fail(c, HUMID_E_INVALID, "n_recv > n_reads");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  if (n_reads) {
+    if (!d_cluster_id || !d_keep) return fail(c, HUMID_E_INVALID, "null buffer");
+    HIPCHK(hipMemsetAsync(d_cluster_id, 0, (size_t)n_reads * 4, st));
+    HIPCHK(hipMemsetAsync(d_keep, 0, (size_t)n_reads, st));
+  }
+  if (n_recv) {
+    if (!d_perm || !d_packed) return fail(c, HUMID_E_INVALID, "null buffer");
+    hipLaunchKernelGGL(k_scatter_results, dim3(grid_stride_blocks(n_recv)), dim3(256), 0, st, d_perm, d_packed,
+                       (u32)n_recv, d_cluster_id, d_keep);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
   return HUMID_OK;
 }
 

@@ -11,8 +11,11 @@ The read set is sharded over the ranks in input order.  Per pass:
      the per-rank sorted unique arrays IS Trie::walk() order;
   4. all-gather of the unique (word, count) arrays (U is ~N/4, far smaller than step 1);
   5. humid_stage_graph over the global unique array (neighbours + clusters; replicated);
-  6. humid_stage_map: every rank emits (cluster_id, keep) for the reads whose word it owns,
-     0 elsewhere; a reduce-scatter (sum) hands every rank the results of its own shard.
+  6. result return: the owner of a word emits the packed results of its reads as dense
+     per-shard streams (humid_stage_owned_results), one all-to-all moves 4 B per read, the home
+     rank scatters them (humid_stage_owner_perm / humid_stage_scatter).  Both sides derive the
+     split sizes from the value ranges, so the streams carry no indices.  (Fallback for > 16
+     ranks: humid_stage_map + reduce-scatter of N-sized arrays.)
 
 The compute is behind an `ops` object: HipStageOps (libhumid_hip.so through the C ABI) in
 production; the CPU tests drive the same orchestration over gloo with an oracle-backed ops
@@ -51,6 +54,7 @@ class HipStageOps(Context):
     def __init__(self, device: int):
         self.device = torch.device("cuda", device)
         super().__init__(device=device)
+        self.set_option("count_mode", 1)      # a rank counts a value range: global-table variant
 
     def histogram(self, g_w, g_f, word_nt, bits):
         hist = torch.zeros(1 << bits, dtype=torch.int32, device=self.device)
@@ -89,6 +93,41 @@ class HipStageOps(Context):
         ismax = _wrap(pm.value, n, "|u1", torch.uint8, self.device)
         return cid, ismax, s.asdict()
 
+    def owned_results(self, l_cid, l_ismax, shard_begin):
+        """dense packed results of the reads this rank counted + send split sizes per shard"""
+        n = len(shard_begin) - 1
+        sb = (C.c_uint64 * (n + 1))(*shard_begin)
+        counts = (C.c_uint64 * n)()
+        pp = C.c_void_p()
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check(self._lib.humid_stage_owned_results(
+            self._h, C.c_void_p(l_cid.data_ptr()), C.c_void_p(l_ismax.data_ptr()), sb, n,
+            C.byref(pp), counts))
+        counts = [int(x) for x in counts]
+        return _wrap(pp.value, sum(counts), "<i4", torch.int32, self.device), counts
+
+    def owner_perm(self, d_w, d_f, ranges):
+        """owner-major stable order of this rank's own reads + receive split sizes per owner"""
+        P = len(ranges)
+        lo = (C.c_uint64 * P)(*[r[0] for r in ranges])
+        hi = (C.c_uint64 * P)(*[r[1] for r in ranges])
+        counts = (C.c_uint64 * P)()
+        pp = C.c_void_p()
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check(self._lib.humid_stage_owner_perm(
+            self._h, C.c_void_p(d_w.data_ptr()), C.c_void_p(d_f.data_ptr()), d_w.numel(), lo, hi, P,
+            C.byref(pp), counts))
+        counts = [int(x) for x in counts]
+        return _wrap(pp.value, d_w.numel(), "<i4", torch.int32, self.device), counts
+
+    def scatter(self, perm, recv, out_cid, out_keep):
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check(self._lib.humid_stage_scatter(
+            self._h, C.c_void_p(perm.data_ptr()), C.c_void_p(recv.data_ptr()), recv.numel(),
+            out_cid.numel(), C.c_void_p(out_cid.data_ptr()), C.c_void_p(out_keep.data_ptr())))
+
+    max_ranks_dense = 16
+
     def map(self, l_cid, l_ismax, out_cid, out_keep):
         torch.cuda.current_stream(self.device).synchronize()
         self._check(self._lib.humid_stage_map(self._h, C.c_void_p(l_cid.data_ptr()),
@@ -121,6 +160,33 @@ def _reduce_scatter_sum(dist, out, inp, world, rank):
         out.copy_(tmp[rank * n:(rank + 1) * n].to(out.dtype))
 
 
+def _all_to_all_v(dist, out, inp, out_splits, in_splits, world, rank):
+    """variable all-to-all of 1-D tensors; emulated with an all-gather where the backend (gloo)
+    has no all_to_all"""
+    try:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits)
+        return
+    except (RuntimeError, NotImplementedError, ValueError):
+        pass
+    dev = inp.device
+    meta = torch.tensor(in_splits, dtype=torch.int64, device=dev)
+    metas = torch.empty(world * world, dtype=torch.int64, device=dev)
+    _all_gather_flat(dist, metas, meta, world)
+    metas = metas.cpu().view(world, world)            # metas[src][dst]
+    totals = metas.sum(dim=1).tolist()
+    m = max(max(totals), 1)
+    pad = torch.zeros(m, dtype=inp.dtype, device=dev)
+    pad[:inp.numel()] = inp
+    allb = torch.empty(world * m, dtype=inp.dtype, device=dev)
+    _all_gather_flat(dist, allb, pad, world)
+    o = 0
+    for src in range(world):
+        off = int(metas[src, :rank].sum())
+        cnt = int(metas[src, rank])
+        out[o:o + cnt] = allb[src * m + off: src * m + off + cnt]
+        o += cnt
+
+
 def splitters_from_hist(hist: np.ndarray, world: int, word_nt: int, bits: int):
     """P ordered, disjoint, covering value ranges with balanced usable-read counts.
     Returns [(lo, hi_inclusive, expected_reads)] -- identical on every rank."""
@@ -151,7 +217,7 @@ class ShardedDedup:
     """Global deduplication of a read set sharded over the ranks of the default process group."""
 
     def __init__(self, device: int = 0, word_nt: int = 24, distance: int = 1, method: int = 0,
-                 ops=None, dist=None):
+                 ops=None, dist=None, dense_return: bool = True):
         import torch.distributed as tdist
         self.dist = dist or tdist
         self.world = self.dist.get_world_size()
@@ -159,6 +225,7 @@ class ShardedDedup:
         self.word_nt, self.distance, self.method = word_nt, distance, method
         self.ops = ops if ops is not None else HipStageOps(device)
         self.bits = min(HIST_BITS, 2 * word_nt)
+        self.dense_return = dense_return
         self._n_max = None
 
     def run(self, d_w, d_f, d_cid, d_keep):
@@ -201,8 +268,6 @@ class ShardedDedup:
         u_max, u_total = max(u_all), sum(u_all)
         goff = sum(u_all[:r])
         total_reads = sum(self._sizes)
-        g_cid = torch.zeros(P * n_max, dtype=torch.int32, device=dev)
-        g_keep = torch.zeros(P * n_max, dtype=torch.uint8, device=dev)
         summ = dict(total=total_reads, usable=usable, unique=u_total, clusters=0, edges=0, nonsingle=0)
         if u_total > 0:
             # ---- 4. all-gather of the per-range unique arrays -> global walk order ----
@@ -227,8 +292,26 @@ class ShardedDedup:
             for k, v in gs.items():
                 if k.startswith("ms_"):
                     summ[k] = v
-            # ---- 6. results of the words this rank owns, then reduce-scatter to the shards ----
+            dense = self.dense_return and P <= getattr(self.ops, "max_ranks_dense", 0)
+            if dense:
+                # ---- 6. owners emit dense per-shard result streams; one all-to-all; home ranks
+                #         scatter them (both sides derive the split sizes from the value ranges)
+                shard_begin = [q * n_max for q in range(P + 1)]
+                packed, send_counts = self.ops.owned_results(cid_g[goff:goff + u_local],
+                                                             ismax_g[goff:goff + u_local], shard_begin)
+                perm, recv_counts = self.ops.owner_perm(d_w, d_f, ranges)
+                recv = torch.empty(sum(recv_counts), dtype=torch.int32, device=dev)
+                _all_to_all_v(dist, recv, packed, recv_counts, send_counts, P, r)
+                self.ops.scatter(perm, recv, d_cid, d_keep)
+                self.summary = summ
+                return summ
+            # ---- 6'. fallback: N-sized result arrays + reduce-scatter (sum) to the shards ----
+            g_cid = torch.zeros(P * n_max, dtype=torch.int32, device=dev)
+            g_keep = torch.zeros(P * n_max, dtype=torch.uint8, device=dev)
             self.ops.map(cid_g[goff:goff + u_local], ismax_g[goff:goff + u_local], g_cid, g_keep)
+        else:
+            g_cid = torch.zeros(P * n_max, dtype=torch.int32, device=dev)
+            g_keep = torch.zeros(P * n_max, dtype=torch.uint8, device=dev)
         o_cid = torch.empty(n_max, dtype=torch.int32, device=dev)
         o_keep = torch.empty(n_max, dtype=torch.uint8, device=dev)
         _reduce_scatter_sum(dist, o_cid, g_cid, P, r)

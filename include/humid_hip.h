@@ -172,6 +172,28 @@ int humid_stage_map(humid_ctx *ctx, const uint32_t *d_local_cluster_id,
                     const uint8_t *d_local_is_max, uint64_t n_reads, uint32_t *d_cluster_id,
                     uint8_t *d_keep);
 
+/* Result return without N-sized collectives.  The owner of a word computes the results of its
+ * reads; the reads' home ranks need them.  Both sides know the same predicate (value ranges), so
+ * the streams carry no indices:
+ *   humid_stage_owned_results (owner):  packed results (cluster_id | keep << 31) of all reads this
+ *     context counted, dense, in read order; counts[q] = how many fall into
+ *     [shard_begin[q], shard_begin[q+1]) -- the split sizes of an all-to-all send.
+ *   humid_stage_owner_perm (home rank): for its own reads, the owner of each (by range) and the
+ *     stable owner-major order: *d_perm[k] = local read of the k-th received result,
+ *     counts[o] = reads owned by rank o -- the split sizes of the all-to-all receive.
+ *   humid_stage_scatter (home rank):    writes cluster_id/keep of the received stream (0 for
+ *     filtered reads).
+ * shard_begin, range_lo/hi, counts: host arrays; the rest device pointers (owned by ctx where
+ * returned through **).  Requires the global-table count variant on the owner side. */
+int humid_stage_owned_results(humid_ctx *ctx, const uint32_t *d_local_cluster_id,
+                              const uint8_t *d_local_is_max, const uint64_t *shard_begin,
+                              uint32_t n_shards, const uint32_t **d_packed, uint64_t *counts);
+int humid_stage_owner_perm(humid_ctx *ctx, const uint64_t *d_words, const uint8_t *d_filtered,
+                           uint64_t n_reads, const uint64_t *range_lo, const uint64_t *range_hi,
+                           uint32_t n_ranks, const uint32_t **d_perm, uint64_t *counts);
+int humid_stage_scatter(humid_ctx *ctx, const uint32_t *d_perm, const uint32_t *d_packed,
+                        uint64_t n_recv, uint64_t n_reads, uint32_t *d_cluster_id, uint8_t *d_keep);
+
 /* src/cluster.cc:31-33 atLeastDouble_, evaluated on the device (parity probe). */
 int humid_at_least_double(humid_ctx *ctx, uint64_t a, uint64_t b, int *result);
 

@@ -57,3 +57,40 @@ class CpuStageOps:
         keep = (l_ismax.numpy()[self.inv] != 0) & (self.first[self.inv] == self.read_idx)
         out_cid.numpy()[self.read_idx] = cid
         out_keep.numpy()[self.read_idx] = keep.astype(np.uint8)
+
+    # ---- dense result return ----
+    max_ranks_dense = 16
+
+    def owned_results(self, l_cid, l_ismax, shard_begin):
+        idx = self.read_idx
+        if len(idx) == 0:
+            return torch.zeros(0, dtype=torch.int32), [0] * (len(shard_begin) - 1)
+        cid = l_cid.numpy()[self.inv].astype(np.uint32)
+        keep = (l_ismax.numpy()[self.inv] != 0) & (self.first[self.inv] == idx)
+        packed = (cid | (keep.astype(np.uint32) << np.uint32(31))).view(np.int32)
+        counts = [int(((idx >= shard_begin[q]) & (idx < shard_begin[q + 1])).sum())
+                  for q in range(len(shard_begin) - 1)]
+        assert sum(counts) == len(idx)
+        return torch.from_numpy(packed.copy()), counts
+
+    def owner_perm(self, d_w, d_f, ranges):
+        w = d_w.numpy().view(np.uint64)
+        f = d_f.numpy()
+        P = len(ranges)
+        owner = np.full(len(w), P, dtype=np.int64)
+        for q, (lo, hi, _) in enumerate(ranges):
+            if lo <= hi:
+                owner[(f == 0) & (w >= np.uint64(lo)) & (w <= np.uint64(hi))] = q
+        perm = np.argsort(owner, kind="stable").astype(np.int32)
+        counts = [int((owner == q).sum()) for q in range(P)]
+        return torch.from_numpy(perm), counts
+
+    def scatter(self, perm, recv, out_cid, out_keep):
+        out_cid.zero_()
+        out_keep.zero_()
+        n = recv.numel()
+        if n:
+            p = perm.numpy()[:n]
+            t = recv.numpy().view(np.uint32)
+            out_cid.numpy()[p] = (t & np.uint32(0x7fffffff)).astype(np.int32)
+            out_keep.numpy()[p] = (t >> np.uint32(31)).astype(np.uint8)

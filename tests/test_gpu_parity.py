@@ -388,6 +388,26 @@ def test_stage_functions_with_virtual_ranks(P, cfg):
         off += u_all[r]
     assert np.array_equal(tot_cid.cpu().numpy().view(np.uint32), ocid)
     assert np.array_equal(tot_keep.cpu().numpy().astype(np.uint8), okeep)
+    # dense result return: owners emit packed per-shard streams, home shards scatter them
+    bounds = [n_reads * q // P for q in range(P + 1)]
+    packed, send = [], []
+    off = 0
+    for r in range(P):
+        pk, cnts = ops[r].owned_results(cid_g[off:off + u_all[r]].clone(), ismax_g[off:off + u_all[r]].clone(), bounds)
+        packed.append(pk.clone())
+        send.append(cnts)
+        off += u_all[r]
+    for q in range(P):
+        lw, lf = g_w[bounds[q]:bounds[q + 1]].clone(), g_f[bounds[q]:bounds[q + 1]].clone()
+        perm, recv_counts = ops[q].owner_perm(lw, lf, ranges)
+        assert recv_counts == [send[o][q] for o in range(P)]
+        parts = [packed[o][sum(send[o][:q]):sum(send[o][:q + 1])] for o in range(P)]
+        recv = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int32, device=dev)
+        oc = torch.empty(bounds[q + 1] - bounds[q], dtype=torch.int32, device=dev)
+        ok = torch.empty(bounds[q + 1] - bounds[q], dtype=torch.uint8, device=dev)
+        ops[q].scatter(perm, recv, oc, ok)
+        assert np.array_equal(oc.cpu().numpy().view(np.uint32), ocid[bounds[q]:bounds[q + 1]])
+        assert np.array_equal(ok.cpu().numpy(), okeep[bounds[q]:bounds[q + 1]])
     for o in ops:
         o.close()
 

@@ -34,7 +34,7 @@ def _worker(rank, world, port, case, q):
         from humid_amd.sharded import ShardedDedup
         from humid_amd.synth import synth_words
         from oracle import pyoracle as orc
-        n_reads, n, d, method, sizes, mode, p_sub = case
+        n_reads, n, d, method, sizes, mode, p_sub, dense = case
         words, filt = synth_words(n_reads, 4242, n, p_sub=p_sub, p_n=2e-3, mode=mode, genome_bp=3000)
         ocid, okeep, osum, _ = orc.dedup_run(words, filt, n, d, method)
         if sizes is None:
@@ -45,7 +45,7 @@ def _worker(rank, world, port, case, q):
         f = torch.from_numpy(filt[off:off + sizes[rank]].copy())
         cid = torch.zeros(sizes[rank], dtype=torch.int32)
         keep = torch.zeros(sizes[rank], dtype=torch.uint8)
-        sd = ShardedDedup(word_nt=n, distance=d, method=method, ops=CpuStageOps())
+        sd = ShardedDedup(word_nt=n, distance=d, method=method, ops=CpuStageOps(), dense_return=dense)
         for _ in range(2):          # second pass re-uses the instance (cached shard sizes)
             s = sd.run(w, f, cid, keep)
         ok = (np.array_equal(cid.numpy().view(np.uint32), ocid[off:off + sizes[rank]]) and
@@ -71,9 +71,10 @@ CASES = [
 
 
 @pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("dense", [True, False], ids=["dense_all_to_all", "reduce_scatter"])
 @pytest.mark.parametrize("case", CASES)
-def test_sharded_matches_single_process(world, case):
-    case = list(case)
+def test_sharded_matches_single_process(world, case, dense):
+    case = list(case) + [dense]
     if case[4] == "uneven":
         n = case[0]
         case[4] = [n // 5] + [n - n // 5 - 7 * (world - 2)] + [7] * (world - 2)
