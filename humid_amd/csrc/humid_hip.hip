@@ -448,16 +448,28 @@ __device__ __forceinline__ void uf_union(u32 *P, u32 a, u32 b) {
 //   FILL = false: deg[] += 1 per endpoint, union(ri, rj) in the component forest
 //   FILL = true : writes rj into ri's CSR row and ri into rj's (per-row cursors; the rows are
 //                 put in ascending order afterwards by k_sort_lists)
-template <bool PASS0, bool FILL>
+// MODE: what happens to a found pair
+//   PM_COUNT      deg[] += 1 per endpoint, union(ri, rj)            (single-GPU phase A)
+//   PM_FILL       both directions into the CSR rows via cursors      (single-GPU phase B)
+//   PM_EMIT_COUNT pc[t] = pairs found by this thread                 (multi-GPU share, phase A)
+//   PM_EMIT_FILL  edge (min << 32 | max) at poff[t] + k              (multi-GPU share, phase B)
+// i0/n_i: the thread block covers positions [i0, i0 + n_i) as the first element of a pair; the
+// second runs on to the end of the bucket anywhere in [0, n).
+enum { PM_COUNT = 0, PM_FILL = 1, PM_EMIT_COUNT = 2, PM_EMIT_FILL = 3 };
+
+template <bool PASS0, int MODE>
 __global__ void __launch_bounds__(256)
-k_pairs(const u64 *__restrict__ s_word, const u32 *__restrict__ V, u32 n, u64 mask,
+k_pairs(const u64 *__restrict__ s_word, const u32 *__restrict__ V, u32 n, u32 i0, u32 n_i, u64 mask,
         EarlierMasks em, u32 cb, u32 distance, u32 *deg, u32 *parent,
-        const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+        const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, u32 *__restrict__ pc,
+        const u32 *__restrict__ poff, u64 *__restrict__ edges) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_i) return;
+  const u32 i = i0 + t;
   const u32 ri = PASS0 ? i : V[i];
   const u64 wi = s_word[ri];
   u32 found = 0;
+  u64 e = (MODE == PM_EMIT_FILL) ? (u64)poff[t] : 0;
   for (u32 j = i + 1; j < n; j++) {
     const u32 rj = PASS0 ? j : V[j];
     const u64 x = wi ^ s_word[rj];
@@ -465,19 +477,88 @@ k_pairs(const u64 *__restrict__ s_word, const u32 *__restrict__ V, u32 n, u64 ma
     if (nt_mismatch(x) > distance) continue;
     bool first = true;
 #pragma unroll
-    for (u32 t = 0; t < MAX_COMBOS; t++)
-      first = first && !(t < cb && (x & em.m[t]) == 0);
+    for (u32 q = 0; q < MAX_COMBOS; q++)
+      first = first && !(q < cb && (x & em.m[q]) == 0);
     if (!first) continue;
-    if (FILL) {
+    if (MODE == PM_FILL) {
       nbr_idx[nbr_off[ri] + atomicAdd(&cur[ri], 1u)] = rj;
       nbr_idx[nbr_off[rj] + atomicAdd(&cur[rj], 1u)] = ri;
-    } else {
+    } else if (MODE == PM_COUNT) {
       found++;
       atomicAdd(&deg[rj], 1u);
       uf_union(parent, ri, rj);
+    } else if (MODE == PM_EMIT_COUNT) {
+      found++;
+    } else {
+      edges[e++] = ri < rj ? (((u64)ri << 32) | rj) : (((u64)rj << 32) | ri);
     }
   }
-  if (!FILL && found) atomicAdd(&deg[ri], found);
+  if (MODE == PM_COUNT && found) atomicAdd(&deg[ri], found);
+  if (MODE == PM_EMIT_COUNT) pc[t] = found;
+}
+
+// the same two phases driven by an explicit edge list (multi-GPU: the ranks' shares, all-gathered)
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+k_edges_apply(const u64 *__restrict__ edges, u64 n_edges, u32 n_nodes, u32 *deg, u32 *parent,
+              const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, ull *ctr) {
+  for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n_edges; k += (u64)gridDim.x * blockDim.x) {
+    const u64 ed = edges[k];
+    const u32 a = (u32)(ed >> 32), b = (u32)ed;
+    if (a >= n_nodes || b >= n_nodes || a == b) { ctr[CTR_OVERFULL] = 1; continue; }   // malformed edge
+    if (FILL) {
+      nbr_idx[nbr_off[a] + atomicAdd(&cur[a], 1u)] = b;
+      nbr_idx[nbr_off[b] + atomicAdd(&cur[b], 1u)] = a;
+    } else {
+      atomicAdd(&deg[a], 1u);
+      atomicAdd(&deg[b], 1u);
+      uf_union(parent, a, b);
+    }
+  }
+}
+
+// multi-GPU share of a sorted combo: the unique words whose combo key lies in [klo, khi]
+// (key, rank) appended in arbitrary order; fixed grid, one global atomic per block
+template <class KeyT>
+__global__ void __launch_bounds__(256)
+k_select_keyrange(const u64 *__restrict__ s_word, u32 n, ComboFields cf, u64 klo, u64 khi,
+                  KeyT *__restrict__ key_out, u32 *__restrict__ val_out, ull *ctr) {
+  __shared__ u32 lds[8];
+  const u32 chunk = (n + gridDim.x - 1) / gridDim.x;
+  const u32 lo = blockIdx.x * chunk;
+  const u32 hi = (lo + chunk < n) ? lo + chunk : n;
+  auto key_of = [&](u32 i) {
+    const u64 w = s_word[i];
+    u64 k = 0;
+#pragma unroll
+    for (u32 f = 0; f < MAX_FIELDS; f++) {
+      if (f < cf.nf) {
+        const u32 wd = cf.width[f];
+        k = (k << wd) | ((w >> cf.shift[f]) & ((wd >= 64) ? ~0ull : ((1ull << wd) - 1ull)));
+      }
+    }
+    return k;
+  };
+  u32 mine = 0;
+  for (u32 i = lo + threadIdx.x; i < hi; i += 256) {
+    const u64 k = key_of(i);
+    mine += (k >= klo && k <= khi) ? 1u : 0u;
+  }
+  const u32 total = block_sum(mine, lds);
+  if (threadIdx.x == 0) lds[4] = total ? (u32)atomicAdd(&ctr[CTR_SPECIAL], (ull)total) : 0u;
+  __syncthreads();
+  u32 base = lds[4];
+  if (total == 0) return;
+  for (u32 i0 = lo; i0 < hi; i0 += 256) {
+    const u32 i = i0 + threadIdx.x;
+    u64 k = 0;
+    bool sel = false;
+    if (i < hi) { k = key_of(i); sel = (k >= klo && k <= khi); }
+    u32 tot;
+    const u32 r = block_rank(sel, lds, &tot);
+    if (sel) { key_out[base + r] = (KeyT)k; val_out[base + r] = i; }
+    base += tot;
+  }
 }
 
 // every CSR row ascending (the order NLeaf::neighbours has under the trie hypotheses H1+H2)
@@ -986,6 +1067,7 @@ struct humid_ctx {
   DBuf table, slot_out, slot_of_read, uniq_slot;             // table (cap+1) and per-read
   DBuf pk_keys, pk_vals, pbeg, ucount, pusable, ubase, pad_word, pad_cf, pslot;   // partitioned counts
   DBuf opos, own_packed, owner, owner_sorted, perm, small;                        // multi-GPU result return
+  DBuf pc, poff, share_edges;                                                     // multi-GPU pair-search share
   int count_mode = 0;        // 0: hash-partitioned LDS tables (default), 1: one global HBM table
   u32 force_segments = 0;    // 0: automatic pigeonhole plan; else the number of segments s
   bool last_count_lds = false;
@@ -1356,8 +1438,11 @@ static int stage_count(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N
 // g_word[U] ascending, g_cnt[U] (device; the context's own arrays on one GPU, the gathered
 // arrays of all ranks on several).  Leaves deg/nbr_off/nbr_idx/cl_of/maxleaf/cl_size/flag/
 // pos/cid/ismax in the context.
+// ext_edges != nullptr: the neighbour pairs are GIVEN (multi-GPU: every rank searched its share,
+// humid_stage_pairs, and the shares were all-gathered); otherwise they are searched here.
 static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U, u32 word_nt,
-                       u32 distance, u32 method, humid_summary &s, u32 &n_pair_segs_out) {
+                       u32 distance, u32 method, humid_summary &s, u32 &n_pair_segs_out,
+                       const u64 *ext_edges = nullptr, u64 n_ext_edges = 0) {
   hipStream_t st = c->stream;
   c->g_word = g_word;
   c->g_cnt = g_cnt;
@@ -1371,6 +1456,7 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
   HIPCHK(hipMemsetAsync(c->deg.p, 0, (size_t)(U + 1) * 4, st));
   HIPCHK(hipMemsetAsync(c->csize.p, 0, (size_t)U * 4, st));
   HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_NONSINGLE], 0, 2 * sizeof(ull), st));   // NONSINGLE, MEMBERS
+  HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_OVERFULL], 0, sizeof(ull), st));
   hipLaunchKernelGGL(k_iota, dim3(blocks_for(U)), dim3(256), 0, st, c->parent.as<u32>(), U);
   u64 E = 0, M = 0, Mbig = 0;
   u32 n_pair_segs = 0;
@@ -1384,7 +1470,17 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
     for (u32 f = 0; f < MAX_FIELDS; f++) { cf.shift[f] = plan.shift[cb][f]; cf.width[f] = plan.width[cb][f]; }
     return cf;
   };
-  const bool search = distance > 0 && U > 1;
+  const bool given = ext_edges != nullptr;
+  const bool search = !given && distance > 0 && U > 1;
+  if (given && n_ext_edges) {
+    hipLaunchKernelGGL(k_edges_apply<false>, dim3(grid_stride_blocks(n_ext_edges)), dim3(256), 0, st, ext_edges,
+                       n_ext_edges, U, c->deg.as<u32>(), c->parent.as<u32>(), (const u32 *)nullptr,
+                       (u32 *)nullptr, (u32 *)nullptr, c->d_ctr);
+    hipLaunchKernelGGL(k_comp_stats, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
+                       c->parent.as<u32>(), U, c->csize.as<u32>());
+    hipLaunchKernelGGL(k_comp_count, dim3(512), dim3(256), 0, st, c->deg.as<u32>(), c->parent.as<u32>(),
+                       c->csize.as<u32>(), U, c->d_ctr);
+  }
   if (search) {
     const u32 nseg = plan.ncombo;
     n_pair_segs = nseg < 8 ? nseg : 8;
@@ -1398,9 +1494,10 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
     for (u32 seg = 0; seg < nseg; seg++) {
       if (seg == 0) {
         HIPCHK(hipEventRecord(c->kev[20], st));
-        hipLaunchKernelGGL((k_pairs<true, false>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
-                           (const u32 *)nullptr, U, plan.mask[seg], d_masks, seg, distance, c->deg.as<u32>(),
-                           c->parent.as<u32>(), (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr);
+        hipLaunchKernelGGL((k_pairs<true, PM_COUNT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
+                           (const u32 *)nullptr, U, 0u, U, plan.mask[seg], d_masks, seg, distance, c->deg.as<u32>(),
+                           c->parent.as<u32>(), (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
+                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr);
       } else {
         u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
         const u32 kb = plan.key_bits ? plan.key_bits : 1;
@@ -1414,9 +1511,10 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
           TRY(sort_pairs<u64, u32>(c, c->seg_k0.as<u64>(), c->seg_ks.as<u64>(), c->seg_v0.as<u32>(), vs, U, 0, kb));
         }
         if (seg < 8) HIPCHK(hipEventRecord(c->kev[20 + 2 * seg], st));
-        hipLaunchKernelGGL((k_pairs<false, false>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
-                           vs, U, plan.mask[seg], d_masks, seg, distance, c->deg.as<u32>(), c->parent.as<u32>(),
-                           (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr);
+        hipLaunchKernelGGL((k_pairs<false, PM_COUNT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
+                           vs, U, 0u, U, plan.mask[seg], d_masks, seg, distance, c->deg.as<u32>(), c->parent.as<u32>(),
+                           (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
+                           (const u32 *)nullptr, (u64 *)nullptr);
       }
       if (seg < 8) HIPCHK(hipEventRecord(c->kev[21 + 2 * seg], st));
     }
@@ -1426,9 +1524,10 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
                        c->csize.as<u32>(), U, c->d_ctr);
   }
   TRY(exscan_u32(c, c->deg.as<u32>(), c->nbr_off.as<u32>(), (u64)U + 1));
-  if (search) {
+  if (search || (given && n_ext_edges)) {
     HIPCHK(hipGetLastError());
     TRY(read_counters(c, c->nbr_off.as<u32>() + U));   // h_ctr[CTR_N-1] = 2E
+    if (c->h_ctr[CTR_OVERFULL]) return fail(c, HUMID_E_INVALID, "malformed edge list (node index out of range)");
     const u64 twoE = c->h_ctr[CTR_N - 1] & 0xffffffffull;
     E = twoE / 2;
     M = c->h_ctr[CTR_NONSINGLE];
@@ -1440,18 +1539,24 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
   if (E > 0) {
     ENSURE(c->cur, (size_t)U * 4);
     HIPCHK(hipMemsetAsync(c->cur.p, 0, (size_t)U * 4, st));
+    if (given)
+      hipLaunchKernelGGL(k_edges_apply<true>, dim3(grid_stride_blocks(n_ext_edges)), dim3(256), 0, st, ext_edges,
+                         n_ext_edges, U, (u32 *)nullptr, (u32 *)nullptr, c->nbr_off.as<u32>(),
+                         c->cur.as<u32>(), c->nbr_idx.as<u32>(), c->d_ctr);
     // phase B: same loops, now writing the CSR rows
-    for (u32 seg = 0; seg < plan.ncombo; seg++) {
+    for (u32 seg = 0; !given && seg < plan.ncombo; seg++) {
       if (seg < 8) HIPCHK(hipEventRecord(c->kev[4 + 2 * seg], st));
       if (seg == 0) {
-        hipLaunchKernelGGL((k_pairs<true, true>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
-                           (const u32 *)nullptr, U, plan.mask[seg], d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
-                           c->nbr_off.as<u32>(), c->cur.as<u32>(), c->nbr_idx.as<u32>());
+        hipLaunchKernelGGL((k_pairs<true, PM_FILL>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
+                           (const u32 *)nullptr, U, 0u, U, plan.mask[seg], d_masks, seg, distance, (u32 *)nullptr,
+                           (u32 *)nullptr, c->nbr_off.as<u32>(), c->cur.as<u32>(), c->nbr_idx.as<u32>(),
+                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr);
       } else {
         const u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
-        hipLaunchKernelGGL((k_pairs<false, true>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
-                           vs, U, plan.mask[seg], d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
-                           c->nbr_off.as<u32>(), c->cur.as<u32>(), c->nbr_idx.as<u32>());
+        hipLaunchKernelGGL((k_pairs<false, PM_FILL>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
+                           vs, U, 0u, U, plan.mask[seg], d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
+                           c->nbr_off.as<u32>(), c->cur.as<u32>(), c->nbr_idx.as<u32>(),
+                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr);
       }
       if (seg < 8) HIPCHK(hipEventRecord(c->kev[5 + 2 * seg], st));
     }
@@ -1466,6 +1571,107 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
                      c->pos.as<u32>(), c->maxleaf.as<u32>(), U, c->cid.as<u32>(), c->ismax.as<u8>());
   HIPCHK(hipGetLastError());
   n_pair_segs_out = n_pair_segs;
+  return HUMID_OK;
+}
+
+// ---- multi-GPU: this rank's share of the neighbour search ----------------------------------
+// Every rank holds the whole ascending unique array.  Rank r of P looks for the pairs whose
+// first element lies in its slice: for the prefix combo the r-th P-th of the positions, for a
+// sorted combo the words whose combo key falls into the r-th P-th of the key space (a bucket is
+// never split).  The union over ranks is every pair exactly once; pairs come out as
+// (smaller rank << 32 | larger rank), unordered.
+static int stage_pairs_share(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt, u32 distance,
+                             u32 part_rank, u32 part_world, u64 *n_edges_out) {
+  hipStream_t st = c->stream;
+  *n_edges_out = 0;
+  if (distance == 0 || U < 2) return HUMID_OK;
+  c->h_plan = make_plan(word_nt, distance, U, c->force_segments);
+  const ComboPlan &plan = c->h_plan;
+  EarlierMasks d_masks;
+  for (u32 t = 0; t < MAX_COMBOS; t++) d_masks.m[t] = plan.mask[t];
+  auto fields_of = [&](u32 cb) {
+    ComboFields cf;
+    cf.nf = plan.nfield[cb];
+    for (u32 f = 0; f < MAX_FIELDS; f++) { cf.shift[f] = plan.shift[cb][f]; cf.width[f] = plan.width[cb][f]; }
+    return cf;
+  };
+  const u32 nseg = plan.ncombo;
+  const u32 kb = plan.key_bits ? plan.key_bits : 1;
+  // share of the prefix combo: an equal slice of the positions
+  const u32 p_lo = (u32)((u64)U * part_rank / part_world), p_hi = (u32)((u64)U * (part_rank + 1) / part_world);
+  std::vector<u32> n_sel(nseg, 0);
+  n_sel[0] = p_hi - p_lo;
+  if (nseg > 1) {
+    ENSURE(c->seg_k0, (size_t)U * 8);
+    ENSURE(c->seg_v0, (size_t)U * 4);
+    ENSURE(c->seg_ks, (size_t)U * 8);
+    ENSURE(c->seg_vs, (size_t)(nseg - 1) * U * 4);
+  }
+  // key range of this rank: [floor(r 2^kb / P), floor((r+1) 2^kb / P) - 1]
+  const unsigned __int128 span = (unsigned __int128)1 << kb;
+  const u64 klo = (u64)(span * part_rank / part_world);
+  const u64 khi = (u64)(span * (part_rank + 1) / part_world - 1);
+  for (u32 seg = 1; seg < nseg; seg++) {
+    u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
+    HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_SPECIAL], 0, sizeof(ull), st));
+    if (kb <= 32)
+      hipLaunchKernelGGL(k_select_keyrange<u32>, dim3(COMPACT_BLOCKS), dim3(256), 0, st, g_word, U, fields_of(seg),
+                         klo, khi, c->seg_k0.as<u32>(), c->seg_v0.as<u32>(), c->d_ctr);
+    else
+      hipLaunchKernelGGL(k_select_keyrange<u64>, dim3(COMPACT_BLOCKS), dim3(256), 0, st, g_word, U, fields_of(seg),
+                         klo, khi, c->seg_k0.as<u64>(), c->seg_v0.as<u32>(), c->d_ctr);
+    HIPCHK(hipGetLastError());
+    TRY(read_counters(c));
+    n_sel[seg] = (u32)c->h_ctr[CTR_SPECIAL];
+    if (n_sel[seg] > 1) {
+      if (kb <= 32) TRY(sort_pairs<u32, u32>(c, c->seg_k0.as<u32>(), c->seg_ks.as<u32>(), c->seg_v0.as<u32>(), vs, n_sel[seg], 0, kb));
+      else TRY(sort_pairs<u64, u32>(c, c->seg_k0.as<u64>(), c->seg_ks.as<u64>(), c->seg_v0.as<u32>(), vs, n_sel[seg], 0, kb));
+    }
+  }
+  u64 T = 0;
+  std::vector<u64> base(nseg, 0);
+  for (u32 seg = 0; seg < nseg; seg++) { base[seg] = T; T += n_sel[seg]; }
+  if (T == 0) return HUMID_OK;
+  if (T + 1 >= 0xffffffffull) return fail(c, HUMID_E_OVERFLOW, "too many positions in one share");
+  ENSURE(c->pc, (size_t)(T + 1) * 4);
+  ENSURE(c->poff, (size_t)(T + 1) * 4);
+  HIPCHK(hipMemsetAsync(c->pc.as<u32>() + T, 0, 4, st));
+  for (int phase = 0; phase < 2; phase++) {
+    for (u32 seg = 0; seg < nseg; seg++) {
+      if (n_sel[seg] == 0) continue;
+      u32 *pcs = c->pc.as<u32>() + base[seg];
+      const u32 *pos = c->poff.as<u32>() + base[seg];
+      const u32 *vs = seg ? c->seg_vs.as<u32>() + (size_t)(seg - 1) * U : nullptr;
+      u64 *ed = c->share_edges.as<u64>();
+      const dim3 grid(blocks_for(n_sel[seg])), blk(256);
+      if (seg == 0 && phase == 0)
+        hipLaunchKernelGGL((k_pairs<true, PM_EMIT_COUNT>), grid, blk, 0, st, g_word, vs, U, p_lo, n_sel[0], plan.mask[0],
+                           d_masks, 0u, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr,
+                           (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed);
+      else if (seg == 0)
+        hipLaunchKernelGGL((k_pairs<true, PM_EMIT_FILL>), grid, blk, 0, st, g_word, vs, U, p_lo, n_sel[0], plan.mask[0],
+                           d_masks, 0u, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr,
+                           (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed);
+      else if (phase == 0)
+        hipLaunchKernelGGL((k_pairs<false, PM_EMIT_COUNT>), grid, blk, 0, st, g_word, vs, n_sel[seg], 0u, n_sel[seg],
+                           plan.mask[seg], d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
+                           (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed);
+      else
+        hipLaunchKernelGGL((k_pairs<false, PM_EMIT_FILL>), grid, blk, 0, st, g_word, vs, n_sel[seg], 0u, n_sel[seg],
+                           plan.mask[seg], d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
+                           (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed);
+    }
+    if (phase == 0) {
+      TRY(exscan_u32(c, c->pc.as<u32>(), c->poff.as<u32>(), T + 1));
+      HIPCHK(hipGetLastError());
+      TRY(read_counters(c, c->poff.as<u32>() + T));
+      const u64 E = c->h_ctr[CTR_N - 1] & 0xffffffffull;
+      *n_edges_out = E;
+      if (E == 0) return HUMID_OK;
+      ENSURE(c->share_edges, (size_t)E * 8);
+    }
+  }
+  HIPCHK(hipGetLastError());
   return HUMID_OK;
 }
 
@@ -1619,7 +1825,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
-                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->csize, &c->cur, &c->plan_dev, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -1970,6 +2176,58 @@ int humid_stage_map(humid_ctx *c, const uint32_t *d_local_cluster_id, const uint
   HIPCHK(hipSetDevice(c->device));
   if (n_reads) TRY(stage_map(c, d_local_cluster_id, d_local_is_max, (u32)n_reads, d_cluster_id, d_keep));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return HUMID_OK;
+}
+
+int humid_stage_pairs(humid_ctx *c, const uint64_t *d_g_word, uint64_t n_unique, uint32_t word_nt,
+                      uint32_t distance, uint32_t part_rank, uint32_t part_world, const uint64_t **d_edges,
+                      uint64_t *n_edges) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (!d_edges || !n_edges || part_world == 0 || part_rank >= part_world) return fail(c, HUMID_E_INVALID, "bad argument");
+  TRY(check_run_args(c, n_unique, word_nt, 0));
+  HIPCHK(hipSetDevice(c->device));
+  *d_edges = nullptr;
+  *n_edges = 0;
+  if (n_unique && !d_g_word) return fail(c, HUMID_E_INVALID, "null buffer");
+  u64 E = 0;
+  if (n_unique) TRY(stage_pairs_share(c, d_g_word, (u32)n_unique, word_nt, distance, part_rank, part_world, &E));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *n_edges = E;
+  *d_edges = E ? c->share_edges.as<u64>() : nullptr;
+  return HUMID_OK;
+}
+
+int humid_stage_graph_edges(humid_ctx *c, const uint64_t *d_g_word, const uint32_t *d_g_count, uint64_t n_unique,
+                            const uint64_t *d_edges, uint64_t n_edges, uint32_t word_nt, uint32_t distance,
+                            uint32_t method, const uint32_t **d_cluster_id, const uint8_t **d_is_max,
+                            humid_summary *summary) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  c->have_graph = false;
+  c->graph_mode = false;
+  TRY(check_run_args(c, n_unique, word_nt, method));
+  if (n_edges >= 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "2*edges exceeds 32 bits");
+  HIPCHK(hipSetDevice(c->device));
+  humid_summary s;
+  memset(&s, 0, sizeof s);
+  s.unique = n_unique;
+  c->distance = distance; c->method = method;
+  c->gU = 0; c->E = c->M = c->C = 0;
+  if (d_cluster_id) *d_cluster_id = nullptr;
+  if (d_is_max) *d_is_max = nullptr;
+  if (n_unique) {
+    if (!d_g_word || !d_g_count || (n_edges && !d_edges)) return fail(c, HUMID_E_INVALID, "null buffer");
+    u32 nps = 0;
+    static const u64 no_edges = 0;
+    TRY(stage_graph(c, d_g_word, d_g_count, (u32)n_unique, word_nt, distance, method, s, nps,
+                    n_edges ? d_edges : &no_edges, n_edges));
+    TRY(n_clusters_from_scan(c, (u32)n_unique, &c->C));
+    s.clusters = c->C;
+    if (d_cluster_id) *d_cluster_id = c->cid.as<u32>();
+    if (d_is_max) *d_is_max = c->ismax.as<u8>();
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (summary) *summary = s;
+  c->have_graph = true;
   return HUMID_OK;
 }
 

@@ -10,7 +10,9 @@ The read set is sharded over the ranks in input order.  Per pass:
      bulk of the single-GPU time, is divided by P); ranges are ordered, so the concatenation of
      the per-rank sorted unique arrays IS Trie::walk() order;
   4. all-gather of the unique (word, count) arrays (U is ~N/4, far smaller than step 1);
-  5. humid_stage_graph over the global unique array (neighbours + clusters; replicated);
+  5. neighbours + clusters over the global unique array: every rank searches its SHARE of the
+     pairs (humid_stage_pairs), the shares are all-gathered (few: ~2 % of N) and every rank
+     builds components and clusters from the same complete list (humid_stage_graph_edges);
   6. result return: the owner of a word emits the packed results of its reads as dense
      per-shard streams (humid_stage_owned_results), one all-to-all moves 4 B per read, the home
      rank scatters them (humid_stage_owner_perm / humid_stage_scatter).  Both sides derive the
@@ -89,6 +91,29 @@ class HipStageOps(Context):
         self._check(self._lib.humid_stage_graph(self._h, C.c_void_p(g_word.data_ptr()),
                                                 C.c_void_p(g_cnt.data_ptr()), n, word_nt, distance,
                                                 method, C.byref(pc), C.byref(pm), C.byref(s)))
+        cid = _wrap(pc.value, n, "<i4", torch.int32, self.device)
+        ismax = _wrap(pm.value, n, "|u1", torch.uint8, self.device)
+        return cid, ismax, s.asdict()
+
+    def pairs(self, g_word, word_nt, distance, part_rank, part_world):
+        """this rank's share of the neighbour pairs: int64 tensor of (smaller << 32 | larger)"""
+        pe = C.c_void_p()
+        ne = C.c_uint64()
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check(self._lib.humid_stage_pairs(self._h, C.c_void_p(g_word.data_ptr()), g_word.numel(),
+                                                word_nt, distance, part_rank, part_world,
+                                                C.byref(pe), C.byref(ne)))
+        return _wrap(pe.value, ne.value, "<i8", torch.int64, self.device)
+
+    def graph_edges(self, g_word, g_cnt, edges, word_nt, distance, method):
+        pc, pm = C.c_void_p(), C.c_void_p()
+        s = _lib.HumidSummary()
+        n = g_word.numel()
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check(self._lib.humid_stage_graph_edges(
+            self._h, C.c_void_p(g_word.data_ptr()), C.c_void_p(g_cnt.data_ptr()), n,
+            C.c_void_p(edges.data_ptr()) if edges.numel() else None, edges.numel(), word_nt, distance,
+            method, C.byref(pc), C.byref(pm), C.byref(s)))
         cid = _wrap(pc.value, n, "<i4", torch.int32, self.device)
         ismax = _wrap(pm.value, n, "|u1", torch.uint8, self.device)
         return cid, ismax, s.asdict()
@@ -217,7 +242,7 @@ class ShardedDedup:
     """Global deduplication of a read set sharded over the ranks of the default process group."""
 
     def __init__(self, device: int = 0, word_nt: int = 24, distance: int = 1, method: int = 0,
-                 ops=None, dist=None, dense_return: bool = True):
+                 ops=None, dist=None, dense_return: bool = True, partition_search: bool = True):
         import torch.distributed as tdist
         self.dist = dist or tdist
         self.world = self.dist.get_world_size()
@@ -226,6 +251,7 @@ class ShardedDedup:
         self.ops = ops if ops is not None else HipStageOps(device)
         self.bits = min(HIST_BITS, 2 * word_nt)
         self.dense_return = dense_return
+        self.partition_search = partition_search
         self._n_max = None
 
     def run(self, d_w, d_f, d_cid, d_keep):
@@ -286,7 +312,24 @@ class ShardedDedup:
                 gw = torch.cat([aw[q * u_max:q * u_max + u_all[q]] for q in range(P)])
                 gc = torch.cat([ac[q * u_max:q * u_max + u_all[q]] for q in range(P)])
             # ---- 5. neighbours + clusters over the global unique array ----
-            cid_g, ismax_g, gs = self.ops.graph(gw, gc, self.word_nt, self.distance, self.method)
+            if self.partition_search and hasattr(self.ops, "pairs"):
+                # every rank searches its share of the pairs; the shares are all-gathered (tiny:
+                # ~2 % of N pairs) and every rank builds the graph from the same complete list
+                e_loc = self.ops.pairs(gw, self.word_nt, self.distance, r, P)
+                ne = torch.tensor([e_loc.numel()], dtype=torch.int64, device=dev)
+                nes = torch.empty(P, dtype=torch.int64, device=dev)
+                _all_gather_flat(dist, nes, ne, P)
+                nes = nes.cpu().tolist()
+                e_max = max(max(nes), 1)
+                pe = torch.zeros(e_max, dtype=torch.int64, device=dev)
+                pe[:e_loc.numel()] = e_loc
+                ae = torch.empty(P * e_max, dtype=torch.int64, device=dev)
+                _all_gather_flat(dist, ae, pe, P)
+                e_all = torch.cat([ae[q * e_max:q * e_max + nes[q]] for q in range(P)])
+                cid_g, ismax_g, gs = self.ops.graph_edges(gw, gc, e_all, self.word_nt, self.distance,
+                                                          self.method)
+            else:
+                cid_g, ismax_g, gs = self.ops.graph(gw, gc, self.word_nt, self.distance, self.method)
             for k in ("clusters", "edges", "nonsingle"):
                 summ[k] = int(gs[k])
             for k, v in gs.items():

@@ -172,6 +172,22 @@ int humid_stage_map(humid_ctx *ctx, const uint32_t *d_local_cluster_id,
                     const uint8_t *d_local_is_max, uint64_t n_reads, uint32_t *d_cluster_id,
                     uint8_t *d_keep);
 
+/* Partitioned neighbour search.  Every rank holds the whole ascending unique array (after the
+ * all-gather of the per-range arrays); rank part_rank of part_world finds the pairs whose first
+ * element lies in its slice -- an equal slice of the positions for the prefix combination, the
+ * words whose combination key falls into its part of the key space for the sorted combinations.
+ * The union over the ranks is every neighbour pair exactly once.  *d_edges: device array (owned by
+ * ctx) of (smaller index << 32 | larger index).  The shares are all-gathered and handed to
+ * humid_stage_graph_edges, which is humid_stage_graph with the pairs given instead of searched. */
+int humid_stage_pairs(humid_ctx *ctx, const uint64_t *d_g_word, uint64_t n_unique, uint32_t word_nt,
+                      uint32_t distance, uint32_t part_rank, uint32_t part_world,
+                      const uint64_t **d_edges, uint64_t *n_edges);
+int humid_stage_graph_edges(humid_ctx *ctx, const uint64_t *d_g_word, const uint32_t *d_g_count,
+                            uint64_t n_unique, const uint64_t *d_edges, uint64_t n_edges,
+                            uint32_t word_nt, uint32_t distance, uint32_t method,
+                            const uint32_t **d_cluster_id, const uint8_t **d_is_max,
+                            humid_summary *summary);
+
 /* Result return without N-sized collectives.  The owner of a word computes the results of its
  * reads; the reads' home ranks need them.  Both sides know the same predicate (value ranges), so
  * the streams carry no indices:

@@ -58,6 +58,34 @@ class CpuStageOps:
         out_cid.numpy()[self.read_idx] = cid
         out_keep.numpy()[self.read_idx] = keep.astype(np.uint8)
 
+    # ---- partitioned pair search ----
+    def pairs(self, g_word, word_nt, distance, part_rank, part_world):
+        uw = g_word.numpy().view(np.uint64)
+        p = orc.Pipeline(word_nt)
+        p.read_data(uw, np.zeros(len(uw), np.uint8))
+        p.find_hamming_neighbours(distance)
+        off, idx = p.adjacency()
+        src = np.repeat(np.arange(len(uw), dtype=np.int64), np.diff(off.astype(np.int64)))
+        dst = idx.astype(np.int64)
+        m = src < dst
+        a, b = src[m], dst[m]
+        mine = (a * 7 + b) % part_world == part_rank        # any disjoint cover of the pairs will do
+        return torch.from_numpy(((a[mine] << 32) | b[mine]).astype(np.int64))
+
+    def graph_edges(self, g_word, g_cnt, edges, word_nt, distance, method):
+        cnt = g_cnt.numpy().astype(np.int64)
+        e = np.sort(edges.numpy().astype(np.int64))             # (a, b) ascending: lists come out ascending
+        g = orc.Graph(cnt)
+        for x in e.tolist():
+            g.link(x >> 32, x & 0xffffffff)
+        nc = g.find_clusters(bool(method))
+        lc, size, mc, ml = g.export(nc)
+        ismax = np.zeros(len(cnt), dtype=np.uint8)
+        ismax[ml[ml >= 0]] = 1
+        nonsingle = len(np.unique(np.concatenate([e >> 32, e & 0xffffffff]))) if len(e) else 0
+        return (torch.from_numpy(lc.astype(np.int32)), torch.from_numpy(ismax),
+                dict(clusters=nc, edges=len(e), nonsingle=nonsingle))
+
     # ---- dense result return ----
     max_ranks_dense = 16
 

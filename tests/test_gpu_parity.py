@@ -344,7 +344,8 @@ def test_full_size_properties(dd):
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("P", [1, 2, 4, 8])
 @pytest.mark.parametrize("cfg", [(200_000, 24, 1, "umi", 0), (60_000, 12, 2, "umi", 1),
-                                 (50_000, 32, 1, "umi", 0), (3000, 4, 1, "umi", 0)])
+                                 (50_000, 32, 1, "umi", 0), (3000, 4, 1, "umi", 0),
+                                 (80_000, 24, 2, "genome", 0), (2000, 2, 3, "umi", 0)])
 def test_stage_functions_with_virtual_ranks(P, cfg):
     import torch
     from humid_amd.sharded import HipStageOps, splitters_from_hist
@@ -374,6 +375,16 @@ def test_stage_functions_with_virtual_ranks(P, cfg):
     assert bool((gw.cpu().numpy().view(np.uint64)[1:] > gw.cpu().numpy().view(np.uint64)[:-1]).all())
     cid_g, ismax_g, gs = ops[0].graph(gw, gc, n, d, method)
     assert gs["clusters"] == osum["clusters"]
+    # partitioned search: the shares are disjoint and cover every pair; the graph built from the
+    # gathered edge list equals the searched one
+    shares = [ops[r].pairs(gw, n, d, r, P).clone() for r in range(P)]
+    e_all = torch.cat(shares) if shares else torch.zeros(0, dtype=torch.int64, device=dev)
+    assert e_all.numel() == gs["edges"]
+    assert torch.unique(e_all).numel() == e_all.numel()
+    cid_e, ismax_e, ges = ops[P - 1].graph_edges(gw, gc, e_all, n, d, method)
+    assert ges["clusters"] == gs["clusters"] and ges["edges"] == gs["edges"]
+    assert torch.equal(cid_e, cid_g) and torch.equal(ismax_e, ismax_g)
+    cid_g, ismax_g = cid_e.clone(), ismax_e.clone()
     tot_cid = torch.zeros(n_reads, dtype=torch.int32, device=dev)
     tot_keep = torch.zeros(n_reads, dtype=torch.int32, device=dev)
     off = 0

@@ -45,7 +45,8 @@ def _worker(rank, world, port, case, q):
         f = torch.from_numpy(filt[off:off + sizes[rank]].copy())
         cid = torch.zeros(sizes[rank], dtype=torch.int32)
         keep = torch.zeros(sizes[rank], dtype=torch.uint8)
-        sd = ShardedDedup(word_nt=n, distance=d, method=method, ops=CpuStageOps(), dense_return=dense)
+        sd = ShardedDedup(word_nt=n, distance=d, method=method, ops=CpuStageOps(), dense_return=dense,
+                          partition_search=dense)   # old pair: replicated search + reduce-scatter
         for _ in range(2):          # second pass re-uses the instance (cached shard sizes)
             s = sd.run(w, f, cid, keep)
         ok = (np.array_equal(cid.numpy().view(np.uint32), ocid[off:off + sizes[rank]]) and
