@@ -1,0 +1,68 @@
+// common.hip.h -- types, counters and device helpers shared by all kernels
+// Part of libhumid_hip.so (see humid_hip.hip for the pipeline and the C ABI).  Device code for
+// gfx950 only; included once, in this order, by humid_hip.hip.
+#ifndef HUMID_COMMON_HIP_H
+#define HUMID_COMMON_HIP_H
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+#include "../../include/humid_hip.h"
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+typedef unsigned long long ull;
+
+#define EMPTY_KEY 0xffffffffffffffffull
+#define NOSLOT 0xffffffffu
+#define NONE32 0xffffffffu
+
+enum { CTR_UNIQUE = 0, CTR_USABLE, CTR_EDGES, CTR_NONSINGLE, CTR_MEMBERS, CTR_SPECIAL,
+       CTR_CLUSTERS, CTR_OVERFULL, CTR_N = 16 };
+
+// --------------------------------------------------------------------------------
+// device helpers
+// --------------------------------------------------------------------------------
+__device__ __forceinline__ u64 mix64(u64 x) {
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+  x ^= x >> 27; x *= 0x94d049bb133111ebull;
+  x ^= x >> 31;
+  return x;
+}
+
+// inverse of mix64 (mix64 is a bijection on 64-bit words)
+__host__ __device__ __forceinline__ u64 unmix64(u64 x) {
+  x = (x ^ (x >> 31) ^ (x >> 62)) * 0x319642b2d24d8ec3ull;
+  x = (x ^ (x >> 27) ^ (x >> 54)) * 0x96de1b173f119089ull;
+  x = x ^ (x >> 30) ^ (x >> 60);
+  return x;
+}
+
+// nucleotide (not bit) mismatches between two packed words
+__device__ __forceinline__ u32 nt_mismatch(u64 x) {
+  return (u32)__popcll((x | (x >> 1)) & 0x5555555555555555ull);
+}
+
+__device__ __forceinline__ u32 ld_agent(const u32 *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// /root/reference/src/cluster.cc:31-33 atLeastDouble_
+__device__ __forceinline__ bool at_least_double(u64 a, u64 b) { return a >= 2 * b; }
+
+
+#endif  // HUMID_COMMON_HIP_H

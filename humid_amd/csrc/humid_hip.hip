@@ -1,1041 +1,28 @@
-// humid_hip.hip -- HUMID's neighbour-search-and-cluster hot path for MI355X (gfx950).
+// humid_hip.hip -- HUMID's neighbour-search-and-cluster hot path for MI355X (gfx950): the host
+// side of libhumid_hip.so (context, stages, C ABI of include/humid_hip.h).  Kernels live in the
+// headers included below.
 //
 // Pipeline (all device-side; integer/bit work, HBM/latency bound, no MFMA):
-//   1. k_hash_insert      exact counts: open-address table of 2-bit-packed words in HBM
-//                         (replaces Trie::add, call site /root/reference/src/humid.cc:95)
-//   2. unique sort        radix sort of the U unique words -> Trie::walk() order
-//   3. k_pairs            pigeonhole radix buckets (d+1 segments), nucleotide Hamming by
-//                         popcount, both directions appended -> CSR with ascending lists
-//                         (replaces walk x asymmetricHamming, src/humid.cc:113-130)
-//   4. union-find CC      components of the neighbour graph (independent clustering units)
-//   5. k_cluster          per component: the findClusters loop + src/cluster.cc, order-exact
-//   6. ids + k_read_map   cluster ids in creator order; per read (cluster_id, keep)
-//                         (replaces trie.find()->leaf->cluster, src/humid.cc:223-231,276-277)
-//
-// No CPU fallback lives here: every entry point either runs on the GPU or fails.
-#include <algorithm>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <new>
-#include <string>
-#include <vector>
-
-#include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_run_length_encode.hpp>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
-
-#include "../../include/humid_hip.h"
-
-typedef uint64_t u64;
-typedef uint32_t u32;
-typedef uint8_t u8;
-typedef unsigned long long ull;
-
-#define EMPTY_KEY 0xffffffffffffffffull
-#define NOSLOT 0xffffffffu
-#define NONE32 0xffffffffu
-
-enum { CTR_UNIQUE = 0, CTR_USABLE, CTR_EDGES, CTR_NONSINGLE, CTR_MEMBERS, CTR_SPECIAL,
-       CTR_CLUSTERS, CTR_OVERFULL, CTR_N = 16 };
-
-// --------------------------------------------------------------------------------
-// device helpers
-// --------------------------------------------------------------------------------
-__device__ __forceinline__ u64 mix64(u64 x) {
-  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
-  x ^= x >> 27; x *= 0x94d049bb133111ebull;
-  x ^= x >> 31;
-  return x;
-}
-
-// inverse of mix64 (mix64 is a bijection on 64-bit words)
-__host__ __device__ __forceinline__ u64 unmix64(u64 x) {
-  x = (x ^ (x >> 31) ^ (x >> 62)) * 0x319642b2d24d8ec3ull;
-  x = (x ^ (x >> 27) ^ (x >> 54)) * 0x96de1b173f119089ull;
-  x = x ^ (x >> 30) ^ (x >> 60);
-  return x;
-}
-
-// nucleotide (not bit) mismatches between two packed words
-__device__ __forceinline__ u32 nt_mismatch(u64 x) {
-  return (u32)__popcll((x | (x >> 1)) & 0x5555555555555555ull);
-}
-
-__device__ __forceinline__ u32 ld_agent(const u32 *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// /root/reference/src/cluster.cc:31-33 atLeastDouble_
-__device__ __forceinline__ bool at_least_double(u64 a, u64 b) { return a >= 2 * b; }
-
-// --------------------------------------------------------------------------------
-// 1. exact counts: open-address hash of packed words
-// --------------------------------------------------------------------------------
-// One 16-byte slot per word so that the key probe and both atomics touch ONE line.
-// The table is initialised by a plain 0xff memset: key = EMPTY, cnt = 0xffffffff (count-1,
-// wraps to 0 on the first add), first = 0xffffffff (atomicMin identity).
-// tab[cap+1]: slot `cap` is reserved for the word that equals EMPTY_KEY (n = 32, all T).
-struct __attribute__((aligned(16))) Slot {
-  u64 key;
-  u32 cntm1;   // occurrences - 1; 0xffffffff = never touched
-  u32 first;   // smallest read index with this word
-};
-
-__global__ void __launch_bounds__(256)
-k_hash_insert(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n_reads,
-              Slot *tab, u32 cap_log2, u32 *__restrict__ slot_of_read, u64 range_lo, u64 range_hi,
-              u32 max_probe, ull *ctr) {
-  const u32 mask = (1u << cap_log2) - 1u;
-  const u32 cap = 1u << cap_log2;
-  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
-    if (filtered[r]) { slot_of_read[r] = NOSLOT; continue; }
-    const u64 w = words[r];
-    if (w < range_lo || w > range_hi) { slot_of_read[r] = NOSLOT; continue; }   // another rank's word
-    u32 s;
-    if (w == EMPTY_KEY) {
-      s = cap;
-    } else {
-      s = (u32)(mix64(w) >> (64 - cap_log2)) & mask;
-      u32 probes = 0;
-      while (true) {
-        u64 k = tab[s].key;
-        if (k == EMPTY_KEY) k = atomicCAS((ull *)&tab[s].key, EMPTY_KEY, (ull)w);
-        if (k == EMPTY_KEY || k == w) break;
-        s = (s + 1) & mask;
-        if (++probes > max_probe) { s = NOSLOT; break; }   // table (nearly) full: never spin forever
-      }
-      if (s == NOSLOT) { ctr[CTR_OVERFULL] = 1; slot_of_read[r] = NOSLOT; continue; }
-    }
-    atomicAdd(&tab[s].cntm1, 1u);
-    atomicMin(&tab[s].first, r);
-    slot_of_read[r] = s;
-  }
-}
-
-// A single-address global atomic costs ~12 ns and serialises (rocprof: 80 k of them = 1 ms), so
-// compaction kernels run a FIXED small grid; each block owns a contiguous chunk, counts its
-// items, reserves output space with ONE atomic, then writes in a second pass over the chunk
-// (L2-resident by then).
-#define COMPACT_BLOCKS 1024u
-
-// block-wide sum of a per-thread value (256 threads); result valid in all threads
-__device__ __forceinline__ u32 block_sum(u32 x, u32 *lds /* >= 4 u32 */) {
-#pragma unroll
-  for (u32 d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
-  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = x;
-  __syncthreads();
-  u32 t = lds[0] + lds[1] + lds[2] + lds[3];
-  __syncthreads();
-  return t;
-}
-
-// exclusive position of this thread's flag among the block's 256 flags; *total = block count
-__device__ __forceinline__ u32 block_rank(bool flag, u32 *lds /* >= 4 u32 */, u32 *total) {
-  const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const u64 m = __ballot(flag);
-  if (lane == 0) lds[wv] = (u32)__popcll(m);
-  __syncthreads();
-  u32 before = 0;
-  for (u32 k = 0; k < wv; k++) before += lds[k];
-  *total = lds[0] + lds[1] + lds[2] + lds[3];
-  __syncthreads();
-  return before + (u32)__popcll(m & ((1ull << lane) - 1ull));
-}
-
-// occupied slots -> (word, slot) list in arbitrary order; also sums the usable reads
-__global__ void __launch_bounds__(256)
-k_compact_table(const Slot *__restrict__ tab, u32 n_slots, u64 *__restrict__ uniq_word,
-                u32 *__restrict__ uniq_slot, u32 uniq_cap, ull *ctr) {
-  __shared__ u32 lds[8];
-  const u32 chunk = (n_slots + gridDim.x - 1) / gridDim.x;
-  const u32 lo = blockIdx.x * chunk;
-  const u32 hi = (lo + chunk < n_slots) ? lo + chunk : n_slots;
-  u32 mine = 0, reads = 0;
-  for (u32 sidx = lo + threadIdx.x; sidx < hi; sidx += 256) {
-    const u32 c = tab[sidx].cntm1;
-    if (c != NONE32) { mine++; reads += c + 1u; }
-  }
-  const u32 total = block_sum(mine, lds);
-  const u32 total_reads = block_sum(reads, lds);
-  if (threadIdx.x == 0) {
-    lds[4] = total ? (u32)atomicAdd(&ctr[CTR_UNIQUE], (ull)total) : 0u;
-    if (total_reads) atomicAdd(&ctr[CTR_USABLE], (ull)total_reads);
-  }
-  __syncthreads();
-  u32 base = lds[4];
-  for (u32 s0 = lo; s0 < hi; s0 += 256) {
-    const u32 sidx = s0 + threadIdx.x;
-    Slot sl;
-    sl.cntm1 = NONE32;
-    if (sidx < hi) sl = tab[sidx];
-    u32 tot;
-    const u32 r = block_rank(sl.cntm1 != NONE32, lds, &tot);
-    if (sl.cntm1 != NONE32) {
-      if (base + r < uniq_cap) {
-        uniq_word[base + r] = sl.key;
-        uniq_slot[base + r] = sidx;
-      } else {
-        ctr[CTR_OVERFULL] = 1;
-      }
-    }
-    base += tot;
-  }
-}
-
-// --------------------------------------------------------------------------------
-// 1b. exact counts, partitioned: the reads are first bucketed by the top PB bits of mix64(word)
-// (radix partition; mix64 is a bijection, so equal keys <=> equal words), then every bucket is
-// counted by one workgroup in an LDS-resident open-address table.  No random HBM line traffic:
-// the only scattered access left is the 4-byte slot_of_read[r] store.
-// --------------------------------------------------------------------------------
-#define LDS_SLOTS 2048u          // 16-byte entries: 32 KiB of LDS per workgroup, 5 workgroups per CU
-#define LDS_FILL_LIMIT 1536u     // unique words a bucket may hold (75 % load)
-#define PART_TARGET 700u         // mean reads per bucket
-
-struct MixKeyOp {                // keys_input transform: word -> partition-ordered key
-  __host__ __device__ u64 operator()(u64 w) const { return mix64(w); }
-};
-struct ReadTagOp {               // values_input transform: read index | excluded << 31
-  const u64 *words;
-  const u8 *filtered;
-  u64 lo, hi;
-  __device__ u32 operator()(u32 r) const {
-    const u64 w = words[r];
-    const bool excl = filtered[r] != 0 || w < lo || w > hi;
-    return r | (excl ? 0x80000000u : 0u);
-  }
-};
-
-// first position of every bucket in the partitioned key array (binary search)
-__global__ void k_part_bounds(const u64 *__restrict__ keys, u32 n, u32 pb, u32 n_parts, u32 *__restrict__ pbeg,
-                              u32 *__restrict__ ucount) {
-  u32 p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p > n_parts) return;
-  if (p == n_parts) { pbeg[p] = n; ucount[p] = 0; return; }   // ucount tail: scan sentinel
-  const u64 target = (u64)p << (64 - pb);
-  u32 lo = 0, hi = n;
-  while (lo < hi) {
-    u32 mid = lo + ((hi - lo) >> 1);
-    if (keys[mid] < target) lo = mid + 1; else hi = mid;
-  }
-  pbeg[p] = lo;
-}
-
-// One workgroup per bucket.  Entry s of the LDS table: lkey (mixed word), lcnt (occurrences, 0 =
-// empty), lfirst (smallest read index).  Entry LDS_SLOTS is reserved for the key that equals the
-// EMPTY sentinel.  Outputs, in a PADDED layout (bucket b owns positions [pbeg[b], pbeg[b+1]) of
-// N-sized arrays, its u unique words take the first u of them):
-//   pad_word/pad_cnt/pad_first, ucount[b], pusable[b]; slot_of_read[r] = padded position.
-__global__ void __launch_bounds__(256)
-k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u32 *__restrict__ pbeg,
-            u32 n_reads, u32 pb, u64 *__restrict__ pad_word, uint2 *__restrict__ pad_cf,
-            u32 *__restrict__ ucount, u32 *__restrict__ pusable, u32 *__restrict__ pslot, ull *ctr) {
-  __shared__ u64 lkey[LDS_SLOTS + 1];
-  __shared__ u32 lcnt[LDS_SLOTS + 1];
-  __shared__ u32 lfirst[LDS_SLOTS + 1];
-  __shared__ u32 lds[8];
-  const u32 b = blockIdx.x;
-  const u32 beg = pbeg[b], end = pbeg[b + 1];
-  if (beg >= end || end > n_reads) {
-    if (beg > end || end > n_reads) ctr[CTR_OVERFULL] = 1;   // malformed partition: never index with it
-    if (threadIdx.x == 0) { ucount[b] = 0; pusable[b] = 0; }
-    return;
-  }
-  for (u32 s = threadIdx.x; s <= LDS_SLOTS; s += 256) { lkey[s] = EMPTY_KEY; lcnt[s] = 0; lfirst[s] = NONE32; }
-  __syncthreads();
-  const u32 hshift = 64 - pb - 11;      // table index = the 11 key bits below the bucket bits
-  u32 usable = 0;
-  bool overflow = false;
-  for (u32 i = beg + threadIdx.x; i < end; i += 256) {
-    const u32 v = vals[i];
-    if ((v & 0x7fffffffu) >= n_reads) { overflow = true; break; }   // a malformed index is never used
-    if (v & 0x80000000u) { pslot[i] = NOSLOT; continue; }
-    usable++;
-    const u64 k = keys[i];
-    u32 s;
-    if (k == EMPTY_KEY) {
-      s = LDS_SLOTS;
-    } else {
-      s = (u32)(k >> hshift) & (LDS_SLOTS - 1);
-      u32 probes = 0;
-      while (true) {
-        u64 cur = lkey[s];
-        if (cur == EMPTY_KEY) cur = atomicCAS((ull *)&lkey[s], EMPTY_KEY, (ull)k);
-        if (cur == EMPTY_KEY || cur == k) break;
-        s = (s + 1) & (LDS_SLOTS - 1);
-        if (++probes >= LDS_SLOTS) { overflow = true; break; }
-      }
-      if (overflow) break;
-    }
-    atomicAdd(&lcnt[s], 1u);
-    atomicMin(&lfirst[s], v);
-  }
-  if (overflow) ctr[CTR_OVERFULL] = 1;
-  __syncthreads();
-  // compaction of the occupied entries -> padded arrays; lfirst[s] is then reused as slot -> index
-  u32 base = 0;
-  for (u32 s0 = 0; s0 <= LDS_SLOTS; s0 += 256) {
-    const u32 s = s0 + threadIdx.x;
-    const bool occ = (s <= LDS_SLOTS) && lcnt[s] != 0;
-    u32 tot;
-    const u32 r = block_rank(occ, lds, &tot);
-    if (occ) {
-      const u32 li = base + r;           // li < unique words <= reads of the bucket = padded room
-      pad_word[beg + li] = unmix64(lkey[s]);
-      pad_cf[beg + li] = make_uint2(lcnt[s], lfirst[s]);
-      lfirst[s] = li;
-    }
-    base += tot;
-  }
-  if (threadIdx.x == 0) ucount[b] = base;
-  const u32 tu = block_sum(usable, lds);
-  if (threadIdx.x == 0) pusable[b] = tu;
-  __syncthreads();
-  // second pass: every position learns the padded slot of its word (coalesced store; the
-  // per-read outputs are produced later in this same partition order, see k_read_map_part)
-  for (u32 i = beg + threadIdx.x; i < end; i += 256) {
-    const u32 v = vals[i];
-    if (v >= n_reads) continue;          // excluded read (bit 31) or malformed index
-    const u64 k = keys[i];
-    u32 s;
-    if (k == EMPTY_KEY) {
-      s = LDS_SLOTS;
-    } else {
-      s = (u32)(k >> hshift) & (LDS_SLOTS - 1);
-      u32 probes = 0;
-      while (lkey[s] != k && probes++ < LDS_SLOTS) s = (s + 1) & (LDS_SLOTS - 1);
-    }
-    const u32 li = lfirst[s];
-    pslot[i] = (li < end - beg) ? beg + li : NOSLOT;
-  }
-}
-
-// totals over the buckets: U = sum ucount, usable = sum pusable (one block)
-__global__ void __launch_bounds__(256)
-k_part_totals(const u32 *__restrict__ ucount, const u32 *__restrict__ pusable, u32 n_parts, ull *ctr) {
-  __shared__ u32 lds[4];
-  ull u = 0, us = 0;
-  for (u32 p = threadIdx.x; p < n_parts; p += 256) { u += ucount[p]; us += pusable[p]; }
-  // 64-bit block sums via two 32-bit halves are unnecessary: both totals are < 2^32
-  const u32 tu = block_sum((u32)u, lds);
-  const u32 ts = block_sum((u32)us, lds);
-  if (threadIdx.x == 0) { ctr[CTR_UNIQUE] = tu; ctr[CTR_USABLE] = ts; }
-}
-
-// padded -> dense unique list (word, padded position); order = bucket order (sorted afterwards)
-__global__ void __launch_bounds__(256)
-k_compact_padded(const u64 *__restrict__ pad_word, const u32 *__restrict__ pbeg, const u32 *__restrict__ ucount,
-                 const u32 *__restrict__ ubase, u32 n_parts, u64 *__restrict__ uniq_word,
-                 u32 *__restrict__ uniq_slot) {
-  // one wave per bucket
-  const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const u32 lane = threadIdx.x & 63;
-  if (wave >= n_parts) return;
-  const u32 beg = pbeg[wave], uc = ucount[wave], ub = ubase[wave];
-  for (u32 j = lane; j < uc; j += 64) {
-    uniq_word[ub + j] = pad_word[beg + j];
-    uniq_slot[ub + j] = beg + j;
-  }
-}
-
-// after the sort, padded variant: gather count / first read of rank i (one 8-byte gather)
-__global__ void k_post_sort_padded(const u32 *__restrict__ s_slot, const uint2 *__restrict__ pad_cf, u32 n,
-                                   u32 *__restrict__ s_cnt, u32 *__restrict__ s_first) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const uint2 cf = pad_cf[s_slot[i]];
-    s_cnt[i] = cf.x;
-    s_first[i] = cf.y;
-  }
-}
-
-// after the sort: per rank i gather count / first read from the table
-__global__ void k_post_sort(const u32 *__restrict__ s_slot, const Slot *__restrict__ tab, u32 n,
-                            u32 *__restrict__ s_cnt, u32 *__restrict__ s_first) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const Slot sl = tab[s_slot[i]];
-    s_cnt[i] = sl.cntm1 + 1u;
-    s_first[i] = sl.first;
-  }
-}
-
-// --------------------------------------------------------------------------------
-// 3. neighbour search: pigeonhole segments
-// --------------------------------------------------------------------------------
-// Generalised pigeonhole: the n nucleotides are cut into s segments; two words within
-// Hamming distance d agree exactly on at least s-d of them, so every pair is found in the bucket
-// of some COMBINATION of s-d segments.  d=1: s=2, 2 combos of 12 nt (n=24).  d=2: s=4, 6 combos
-// of 12 nt -- not 3 segments of 8 nt, whose 65 536 buckets hold hundreds of words each.
-// Combo 0 is always the top s-d segments, i.e. a prefix: its buckets are runs of the sorted
-// unique array and need no sort.  mask[c] = bits of combo c; a pair is emitted from the FIRST
-// combo it agrees on.
-#define MAX_COMBOS 20
-#define MAX_FIELDS 8
-struct ComboPlan {
-  u32 ncombo;
-  u32 key_bits;                       // bits of a combo key (sum of its field widths)
-  u64 mask[MAX_COMBOS];
-  u8 nfield[MAX_COMBOS];
-  u8 shift[MAX_COMBOS][MAX_FIELDS];   // fields from most to least significant
-  u8 width[MAX_COMBOS][MAX_FIELDS];
-};
-
-// bucket key of combo `cb` for every unique word (fields concatenated, most significant first)
-// Kernel arguments derived from the plan are passed BY VALUE in small structs and indexed
-// STATICALLY (unrolled loops with a predicate).  A 1 KB plan struct indexed dynamically in the
-// kernarg segment -- and equally a plan freshly uploaded to device memory and read through
-// wave-uniform (scalar) loads -- returned stale fields for single waves on gfx950 / ROCm 7.2
-// (5-25 of 219 k edges lost at 10 M reads, tools/det_check.py), so neither form is used.
-struct EarlierMasks {
-  u64 m[MAX_COMBOS];
-};
-
-// fields of ONE combo
-struct ComboFields {
-  u32 nf;
-  u8 shift[MAX_FIELDS];
-  u8 width[MAX_FIELDS];
-};
-
-template <class KeyT>
-__global__ void k_combo_keys(const u64 *__restrict__ s_word, u32 n, ComboFields cf,
-                             KeyT *__restrict__ key, u32 *__restrict__ val) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const u64 w = s_word[i];
-  u64 k = 0;
-#pragma unroll
-  for (u32 f = 0; f < MAX_FIELDS; f++) {
-    if (f < cf.nf) {
-      const u32 wd = cf.width[f];
-      k = (k << wd) | ((w >> cf.shift[f]) & ((wd >= 64) ? ~0ull : ((1ull << wd) - 1ull)));
-    }
-  }
-  key[i] = (KeyT)k;
-  val[i] = i;
-}
-
-// --------------------------------------------------------------------------------
-// 4. connected components (lock-free union-find, smaller index wins => root = min rank)
-// --------------------------------------------------------------------------------
-__device__ __forceinline__ u32 uf_find(const u32 *P, u32 x) {
-  u32 p = ld_agent(&P[x]);
-  while (p != x) { x = p; p = ld_agent(&P[x]); }
-  return x;
-}
-
-__device__ __forceinline__ void uf_union(u32 *P, u32 a, u32 b) {
-  while (true) {
-    a = uf_find(P, a);
-    b = uf_find(P, b);
-    if (a == b) return;
-    if (a > b) { u32 t = a; a = b; b = t; }
-    if (atomicCAS(&P[b], b, a) == b) return;
-  }
-}
-
-// One thread per position i of the bucket-sorted order (V = ranks in that order; combo 0 uses
-// the sorted unique array itself); compares with the following elements of its bucket: the
-// bucket ends at the first j whose word differs inside the combo mask.  Ranks ascend inside a
-// bucket, so (ri < rj) always.  A pair is emitted only from the FIRST combo it agrees on.
-// Two phases with identical control flow and no shared append counter:
-//   FILL = false: deg[] += 1 per endpoint, union(ri, rj) in the component forest
-//   FILL = true : writes rj into ri's CSR row and ri into rj's (per-row cursors; the rows are
-//                 put in ascending order afterwards by k_sort_lists)
-// MODE: what happens to a found pair
-//   PM_COUNT      deg[] += 1 per endpoint, union(ri, rj)            (single-GPU phase A)
-//   PM_FILL       both directions into the CSR rows via cursors      (single-GPU phase B)
-//   PM_EMIT_COUNT pc[t] = pairs found by this thread                 (multi-GPU share, phase A)
-//   PM_EMIT_FILL  edge (min << 32 | max) at poff[t] + k              (multi-GPU share, phase B)
-// i0/n_i: the thread block covers positions [i0, i0 + n_i) as the first element of a pair; the
-// second runs on to the end of the bucket anywhere in [0, n).
-enum { PM_COUNT = 0, PM_FILL = 1, PM_EMIT_COUNT = 2, PM_EMIT_FILL = 3 };
-
-template <bool PASS0, int MODE>
-__global__ void __launch_bounds__(256)
-k_pairs(const u64 *__restrict__ s_word, const u32 *__restrict__ V, u32 n, u32 i0, u32 n_i, u64 mask,
-        EarlierMasks em, u32 cb, u32 distance, u32 *deg, u32 *parent,
-        const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, u32 *__restrict__ pc,
-        const u32 *__restrict__ poff, u64 *__restrict__ edges) {
-  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_i) return;
-  const u32 i = i0 + t;
-  const u32 ri = PASS0 ? i : V[i];
-  const u64 wi = s_word[ri];
-  u32 found = 0;
-  u64 e = (MODE == PM_EMIT_FILL) ? (u64)poff[t] : 0;
-  for (u32 j = i + 1; j < n; j++) {
-    const u32 rj = PASS0 ? j : V[j];
-    const u64 x = wi ^ s_word[rj];
-    if (x & mask) break;                           // left the bucket
-    if (nt_mismatch(x) > distance) continue;
-    bool first = true;
-#pragma unroll
-    for (u32 q = 0; q < MAX_COMBOS; q++)
-      first = first && !(q < cb && (x & em.m[q]) == 0);
-    if (!first) continue;
-    if (MODE == PM_FILL) {
-      nbr_idx[nbr_off[ri] + atomicAdd(&cur[ri], 1u)] = rj;
-      nbr_idx[nbr_off[rj] + atomicAdd(&cur[rj], 1u)] = ri;
-    } else if (MODE == PM_COUNT) {
-      found++;
-      atomicAdd(&deg[rj], 1u);
-      uf_union(parent, ri, rj);
-    } else if (MODE == PM_EMIT_COUNT) {
-      found++;
-    } else {
-      edges[e++] = ri < rj ? (((u64)ri << 32) | rj) : (((u64)rj << 32) | ri);
-    }
-  }
-  if (MODE == PM_COUNT && found) atomicAdd(&deg[ri], found);
-  if (MODE == PM_EMIT_COUNT) pc[t] = found;
-}
-
-// the same two phases driven by an explicit edge list (multi-GPU: the ranks' shares, all-gathered)
-template <bool FILL>
-__global__ void __launch_bounds__(256)
-k_edges_apply(const u64 *__restrict__ edges, u64 n_edges, u32 n_nodes, u32 *deg, u32 *parent,
-              const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, ull *ctr) {
-  for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n_edges; k += (u64)gridDim.x * blockDim.x) {
-    const u64 ed = edges[k];
-    const u32 a = (u32)(ed >> 32), b = (u32)ed;
-    if (a >= n_nodes || b >= n_nodes || a == b) { ctr[CTR_OVERFULL] = 1; continue; }   // malformed edge
-    if (FILL) {
-      nbr_idx[nbr_off[a] + atomicAdd(&cur[a], 1u)] = b;
-      nbr_idx[nbr_off[b] + atomicAdd(&cur[b], 1u)] = a;
-    } else {
-      atomicAdd(&deg[a], 1u);
-      atomicAdd(&deg[b], 1u);
-      uf_union(parent, a, b);
-    }
-  }
-}
-
-// multi-GPU share of a sorted combo: the unique words whose combo key lies in [klo, khi]
-// (key, rank) appended in arbitrary order; fixed grid, one global atomic per block
-template <class KeyT>
-__global__ void __launch_bounds__(256)
-k_select_keyrange(const u64 *__restrict__ s_word, u32 n, ComboFields cf, u64 klo, u64 khi,
-                  KeyT *__restrict__ key_out, u32 *__restrict__ val_out, ull *ctr) {
-  __shared__ u32 lds[8];
-  const u32 chunk = (n + gridDim.x - 1) / gridDim.x;
-  const u32 lo = blockIdx.x * chunk;
-  const u32 hi = (lo + chunk < n) ? lo + chunk : n;
-  auto key_of = [&](u32 i) {
-    const u64 w = s_word[i];
-    u64 k = 0;
-#pragma unroll
-    for (u32 f = 0; f < MAX_FIELDS; f++) {
-      if (f < cf.nf) {
-        const u32 wd = cf.width[f];
-        k = (k << wd) | ((w >> cf.shift[f]) & ((wd >= 64) ? ~0ull : ((1ull << wd) - 1ull)));
-      }
-    }
-    return k;
-  };
-  u32 mine = 0;
-  for (u32 i = lo + threadIdx.x; i < hi; i += 256) {
-    const u64 k = key_of(i);
-    mine += (k >= klo && k <= khi) ? 1u : 0u;
-  }
-  const u32 total = block_sum(mine, lds);
-  if (threadIdx.x == 0) lds[4] = total ? (u32)atomicAdd(&ctr[CTR_SPECIAL], (ull)total) : 0u;
-  __syncthreads();
-  u32 base = lds[4];
-  if (total == 0) return;
-  for (u32 i0 = lo; i0 < hi; i0 += 256) {
-    const u32 i = i0 + threadIdx.x;
-    u64 k = 0;
-    bool sel = false;
-    if (i < hi) { k = key_of(i); sel = (k >= klo && k <= khi); }
-    u32 tot;
-    const u32 r = block_rank(sel, lds, &tot);
-    if (sel) { key_out[base + r] = (KeyT)k; val_out[base + r] = i; }
-    base += tot;
-  }
-}
-
-// every CSR row ascending (the order NLeaf::neighbours has under the trie hypotheses H1+H2)
-__global__ void __launch_bounds__(256)
-k_sort_lists(const u32 *__restrict__ off, u32 n, u32 *idx) {
-  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= n) return;
-  const u32 b = off[u], d = off[u + 1] - b;
-  if (d < 2) return;
-  u32 *a = idx + b;
-  if (d <= 32) {
-    u32 v[32];
-    for (u32 k = 0; k < d; k++) v[k] = a[k];
-    for (u32 k = 1; k < d; k++) {          // insertion sort
-      u32 x = v[k];
-      u32 m = k;
-      while (m > 0 && v[m - 1] > x) { v[m] = v[m - 1]; m--; }
-      v[m] = x;
-    }
-    for (u32 k = 0; k < d; k++) a[k] = v[k];
-  } else {                                 // heap sort in place
-    for (u32 start = d / 2; start-- > 0;) {
-      u32 r = start;
-      while (true) {
-        u32 ch = 2 * r + 1;
-        if (ch >= d) break;
-        if (ch + 1 < d && a[ch + 1] > a[ch]) ch++;
-        if (a[r] >= a[ch]) break;
-        u32 t = a[r]; a[r] = a[ch]; a[ch] = t;
-        r = ch;
-      }
-    }
-    for (u32 end = d - 1; end > 0; end--) {
-      u32 t = a[0]; a[0] = a[end]; a[end] = t;
-      u32 r = 0;
-      while (true) {
-        u32 ch = 2 * r + 1;
-        if (ch >= end) break;
-        if (ch + 1 < end && a[ch + 1] > a[ch]) ch++;
-        if (a[r] >= a[ch]) break;
-        u32 t2 = a[r]; a[r] = a[ch]; a[ch] = t2;
-        r = ch;
-      }
-    }
-  }
-}
-
-// --------------------------------------------------------------------------------
-// 4. connected components: sizes, and the split small / big
-// --------------------------------------------------------------------------------
-#define SMALL_COMP 32u      // components up to this many leaves are clustered by one lane, in registers
-
-// flatten the forest and count the leaves of every component at its root
-__global__ void k_comp_stats(const u32 *__restrict__ deg, u32 *P, u32 n, u32 *csize) {
-  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= n || deg[u] == 0) return;
-  const u32 root = uf_find(P, u);
-  P[u] = root;
-  atomicAdd(&csize[root], 1u);
-}
-
-// M = leaves with >= 1 neighbour, Mbig = those in components larger than SMALL_COMP
-__global__ void __launch_bounds__(256)
-k_comp_count(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *__restrict__ csize, u32 n,
-             ull *ctr) {
-  __shared__ u32 lds[4];
-  u32 m = 0, mb = 0;
-  for (u32 u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
-    if (deg[u]) {
-      m++;
-      if (csize[P[u]] > SMALL_COMP) mb++;              // P was flattened by k_comp_stats
-    }
-  }
-  const u32 tm = block_sum(m, lds);
-  const u32 tb = block_sum(mb, lds);
-  if (threadIdx.x == 0) {
-    if (tm) atomicAdd(&ctr[CTR_NONSINGLE], (ull)tm);
-    if (tb) atomicAdd(&ctr[CTR_MEMBERS], (ull)tb);
-  }
-}
-
-__global__ void k_iota(u32 *p, u32 n) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = i;
-}
-
-// explicit-graph entry point: union every CSR entry (u, nbr)
-__global__ void k_union_csr(const u32 *__restrict__ off, const u32 *__restrict__ idx, u32 n, u32 *P) {
-  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= n) return;
-  for (u32 k = off[u]; k < off[u + 1]; k++)
-    if (idx[k] != u) uf_union(P, u, idx[k]);
-}
-
-// members of the BIG components, keyed (root << 32 | rank); unordered, sorted afterwards
-__global__ void __launch_bounds__(256)
-k_member_keys(const u32 *__restrict__ deg, u32 *P, const u32 *__restrict__ csize, u32 n, u64 *mkeys,
-              ull *ctr) {
-  __shared__ u32 lds[8];
-  const u32 chunk = (n + gridDim.x - 1) / gridDim.x;
-  const u32 lo = blockIdx.x * chunk;
-  const u32 hi = (lo + chunk < n) ? lo + chunk : n;
-  u32 mine = 0;
-  for (u32 u = lo + threadIdx.x; u < hi; u += 256)
-    mine += (deg[u] && csize[uf_find(P, u)] > SMALL_COMP) ? 1u : 0u;
-  const u32 total = block_sum(mine, lds);
-  if (threadIdx.x == 0) lds[4] = total ? (u32)atomicAdd(&ctr[CTR_SPECIAL], (ull)total) : 0u;
-  __syncthreads();
-  u32 base = lds[4];
-  if (total == 0) return;
-  for (u32 u0 = lo; u0 < hi; u0 += 256) {
-    const u32 u = u0 + threadIdx.x;
-    u32 root = 0;
-    bool mem = (u < hi) && deg[u] != 0;
-    if (mem) { root = uf_find(P, u); mem = csize[root] > SMALL_COMP; }
-    u32 tot;
-    const u32 r = block_rank(mem, lds, &tot);
-    if (mem) mkeys[base + r] = ((u64)root << 32) | u;
-    base += tot;
-  }
-}
-
-// --------------------------------------------------------------------------------
-// 5. clustering
-// --------------------------------------------------------------------------------
-// singletons (no neighbours): the leaf creates its own cluster (src/humid.cc:179-187 with an
-// empty neighbour list: maxNeighbour_ returns the leaf, cluster.cc:39-51)
-__global__ void k_cluster_singletons(const u32 *__restrict__ deg, const u32 *__restrict__ cnt, u32 n,
-                                     u32 *cl_of, u32 *maxleaf, u64 *cl_size) {
-  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= n) return;
-  if (deg[u] == 0) {
-    cl_of[u] = u + 1;
-    maxleaf[u] = u;
-    cl_size[u] = cnt[u];
-  } else {
-    cl_of[u] = 0;
-  }
-}
-
-// The findClusters loop over the leaves of ONE connected component, ascending.  Literal
-// restatement of
-//   findClusters loop            /root/reference/src/humid.cc:176-189  (members ascending)
-//   maxNeighbour_                src/cluster.cc:39-51  (first qualifying neighbour, restart)
-//   assignDirectionalCluster_    src/cluster.cc:58-69  (pre-order flood, explicit stack)
-//   assignMaxCluster             src/cluster.cc:72-80
-// A cluster is named by its creating leaf (cl_of = creator rank + 1); ids come later from a
-// prefix sum over creators, which reproduces `id++` in walk order.  `st` holds 2 words per member.
-template <bool MAXIMUM, class MemberAt>
-__device__ __forceinline__ void cluster_one_component(MemberAt member_at, u32 n_members,
-                                                      const u32 *__restrict__ cnt,
-                                                      const u32 *__restrict__ off,
-                                                      const u32 *__restrict__ idx, u32 *cl_of,
-                                                      u32 *maxleaf, u64 *cl_size, u32 *st) {
-  for (u32 m = 0; m < n_members; m++) {
-    const u32 u = member_at(m);
-    if (cl_of[u] != 0) continue;                  // src/humid.cc:179
-    const u32 label = u + 1;                      // new Cluster, creator u
-    u32 start = u;
-    u32 best = u;
-    u32 bestc = 0;
-    if (!MAXIMUM) {
-      // maxNeighbour_
-      u32 leaf = u;
-      u32 k = off[leaf], kend = off[leaf + 1];
-      u64 lc = cnt[leaf];
-      while (k < kend) {
-        u32 nb = idx[k++];
-        if (cl_of[nb] == 0 && at_least_double(cnt[nb], lc)) {
-          leaf = nb; lc = cnt[leaf];
-          k = off[leaf]; kend = off[leaf + 1];
-        }
-      }
-      start = leaf;
-      best = leaf;                                // updateMaxCount_ once, cluster.cc:85
-    }
-    u64 size = 0;
-    u32 depth = 0;
-    // assignLeaf_(start)
-    cl_of[start] = label;
-    size += cnt[start];
-    if (MAXIMUM) { bestc = cnt[start]; best = start; }
-    st[0] = start; st[1] = off[start]; depth = 1;
-    while (depth) {
-      const u32 cur = st[2 * (depth - 1)];
-      u32 k = st[2 * (depth - 1) + 1];
-      const u32 kend = off[cur + 1];
-      const u64 cc = cnt[cur];
-      bool descended = false;
-      while (k < kend) {
-        const u32 nb = idx[k++];
-        if (cl_of[nb] != 0) continue;
-        if (!MAXIMUM && !at_least_double(cc, cnt[nb])) continue;
-        cl_of[nb] = label;
-        const u32 nc = cnt[nb];
-        size += nc;
-        if (MAXIMUM && nc > bestc) { bestc = nc; best = nb; }   // updateMaxCount_ strict >
-        st[2 * (depth - 1) + 1] = k;
-        st[2 * depth] = nb; st[2 * depth + 1] = off[nb];
-        depth++;
-        descended = true;
-        break;
-      }
-      if (!descended) depth--;
-    }
-    maxleaf[u] = best;
-    cl_size[u] = size;
-  }
-}
-
-// BIG components: one lane per component = the head of its run in the sorted member keys;
-// stack in HBM scratch (2 words per member of the run).
-template <bool MAXIMUM>
-__global__ void __launch_bounds__(64)
-k_cluster_components(const u64 *__restrict__ mkeys, u32 n_members, const u32 *__restrict__ cnt,
-                     const u32 *__restrict__ off, const u32 *__restrict__ idx, u32 *cl_of,
-                     u32 *maxleaf, u64 *cl_size, u32 *stk) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_members) return;
-  const u32 root = (u32)(mkeys[i] >> 32);
-  if (i > 0 && (u32)(mkeys[i - 1] >> 32) == root) return;   // not a component head
-  u32 len = 1;
-  while (i + len < n_members && (u32)(mkeys[i + len] >> 32) == root) len++;
-  cluster_one_component<MAXIMUM>([&](u32 m) { return (u32)mkeys[i + m]; }, len, cnt, off, idx, cl_of,
-                                 maxleaf, cl_size, stk + 2 * (u64)i);
-}
-
-// Components of exactly two leaves a < b (one centre + one satellite: the bulk of the non-trivial
-// components on UMI data) have a closed form of the same loop; no private arrays, no scratch.
-template <bool MAXIMUM>
-__global__ void __launch_bounds__(256)
-k_cluster_pairs(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *__restrict__ csize, u32 n,
-                const u32 *__restrict__ cnt, const u32 *__restrict__ off, const u32 *__restrict__ idx,
-                u32 *cl_of, u32 *maxleaf, u64 *cl_size) {
-  u32 a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= n || deg[a] == 0 || P[a] != a || csize[a] != 2) return;
-  const u32 b = idx[off[a]];
-  const u64 ca = cnt[a], cb = cnt[b];
-  if (MAXIMUM) {                                   // whole component, maxLeaf = first strict maximum
-    cl_of[a] = a + 1; cl_of[b] = a + 1;
-    maxleaf[a] = (cb > ca) ? b : a;
-    cl_size[a] = ca + cb;
-    return;
-  }
-  if (at_least_double(cb, ca)) {                   // a climbs to b, b floods back to a
-    cl_of[a] = a + 1; cl_of[b] = a + 1;
-    maxleaf[a] = b;
-    cl_size[a] = ca + cb;
-  } else if (at_least_double(ca, cb)) {            // a stays, absorbs b
-    cl_of[a] = a + 1; cl_of[b] = a + 1;
-    maxleaf[a] = a;
-    cl_size[a] = ca + cb;
-  } else {                                         // two clusters; b finds a already assigned
-    cl_of[a] = a + 1; maxleaf[a] = a; cl_size[a] = ca;
-    cl_of[b] = b + 1; maxleaf[b] = b; cl_size[b] = cb;
-  }
-}
-
-// SMALL components (<= SMALL_COMP leaves): one lane per component root collects the members by
-// a breadth-first walk, orders them, and runs the same loop with member list and stack in
-// private memory.  No sort, no scratch.
-template <bool MAXIMUM>
-__global__ void __launch_bounds__(128)
-k_cluster_small(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *__restrict__ csize,
-                u32 n, const u32 *__restrict__ cnt, const u32 *__restrict__ off,
-                const u32 *__restrict__ idx, u32 *cl_of, u32 *maxleaf, u64 *cl_size) {
-  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= n || deg[u] == 0 || P[u] != u) return;
-  const u32 target = csize[u];
-  if (target > SMALL_COMP || target == 2) return;   // pairs: k_cluster_pairs; big: k_cluster_components
-  u32 mem[SMALL_COMP];
-  u32 st[2 * SMALL_COMP];
-  u32 nm = 1;
-  mem[0] = u;
-  for (u32 q = 0; q < nm && nm < target; q++) {
-    const u32 v = mem[q];
-    for (u32 k = off[v]; k < off[v + 1] && nm < target; k++) {
-      const u32 nb = idx[k];
-      bool seen = false;
-      for (u32 t = 0; t < nm; t++) seen |= (mem[t] == nb);
-      if (!seen) mem[nm++] = nb;
-    }
-  }
-  for (u32 k = 1; k < nm; k++) {              // ascending = walk order inside the component
-    u32 x = mem[k];
-    u32 m = k;
-    while (m > 0 && mem[m - 1] > x) { mem[m] = mem[m - 1]; m--; }
-    mem[m] = x;
-  }
-  cluster_one_component<MAXIMUM>([&](u32 m) { return mem[m]; }, nm, cnt, off, idx, cl_of, maxleaf, cl_size, st);
-}
-
-__global__ void k_creator_flags(const u32 *__restrict__ cl_of, u32 n, u32 *flag) {
-  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u < n) flag[u] = (cl_of[u] == u + 1) ? 1u : 0u;
-}
-
-// per node: final cluster id (creators numbered in walk order) and maxLeaf flag
-__global__ void k_finalize_nodes(const u32 *__restrict__ cl_of, const u32 *__restrict__ pos,
-                                 const u32 *__restrict__ maxleaf, u32 n, u32 *__restrict__ cid,
-                                 u8 *__restrict__ ismax) {
-  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= n) return;
-  const u32 creator = cl_of[u] - 1;
-  cid[u] = pos[creator] + 1;
-  ismax[u] = (maxleaf[creator] == u) ? 1 : 0;
-}
-
-// per hash slot: (cluster id, read to keep) of the word it holds
-__global__ void k_slot_results(const u32 *__restrict__ l_cid, const u8 *__restrict__ l_ismax,
-                               const u32 *__restrict__ s_first, const u32 *__restrict__ s_slot, u32 n,
-                               u64 *__restrict__ slot_out) {
-  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= n) return;
-  slot_out[s_slot[u]] = ((u64)(l_ismax[u] ? s_first[u] : NONE32) << 32) | l_cid[u];
-}
-
-__global__ void k_export_clusters(const u32 *__restrict__ flag, const u32 *__restrict__ pos,
-                                  const u32 *__restrict__ maxleaf, const u64 *__restrict__ cl_size,
-                                  const u32 *__restrict__ cnt, u32 n, u64 *o_size, u32 *o_maxcount,
-                                  u32 *o_maxleaf) {
-  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= n || !flag[u]) return;
-  const u32 c = pos[u];
-  if (o_size) o_size[c] = cl_size[u];
-  if (o_maxleaf) o_maxleaf[c] = maxleaf[u];
-  if (o_maxcount) o_maxcount[c] = cnt[maxleaf[u]];
-}
-
-// --------------------------------------------------------------------------------
-// 6. per-read map: cluster id and the duplicate flag
-// --------------------------------------------------------------------------------
-// keep = this read is the first (input order) whose word is its cluster's maxLeaf
-// (/root/reference/src/humid.cc:224-231); cluster 0 for filtered reads (:272).
-__global__ void __launch_bounds__(256)
-k_read_map(const u32 *__restrict__ slot_of_read, const u64 *__restrict__ slot_out, u32 n_reads,
-           u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
-  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
-    const u32 s = slot_of_read[r];
-    u32 c = 0;
-    u8 k = 0;
-    if (s != NOSLOT) {
-      const u64 o = slot_out[s];
-      c = (u32)o;
-      k = ((u32)(o >> 32) == r) ? 1 : 0;
-    }
-    cluster_id[r] = c;
-    keep[r] = k;
-  }
-}
-
-// The same in PARTITION order (LDS-partitioned counts): position i of the partitioned arrays
-// holds read vals[i] and the slot of its word; the slot lookups are partition-local (cached).
-// The un-permute is ONE scattered 4-byte store per read (cluster id | keep << 31; ids < 2^31
-// because n_reads < 2^31); k_split_out then writes both output arrays coalesced.
-__global__ void __launch_bounds__(256)
-k_read_map_part(const u32 *__restrict__ vals, const u32 *__restrict__ pslot, const u64 *__restrict__ slot_out,
-                u32 n_reads, u32 *__restrict__ packed) {
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_reads; i += gridDim.x * blockDim.x) {
-    const u32 r = vals[i] & 0x7fffffffu;
-    if (r >= n_reads) continue;
-    const u32 s = pslot[i];
-    u32 c = 0;
-    if (s != NOSLOT) {
-      const u64 o = slot_out[s];
-      c = (u32)o | (((u32)(o >> 32) == r) ? 0x80000000u : 0u);
-    }
-    packed[r] = c;
-  }
-}
-
-__global__ void __launch_bounds__(256)
-k_split_out(const u32 *__restrict__ packed, u32 n_reads, u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
-  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
-    const u32 t = packed[r];
-    cluster_id[r] = t & 0x7fffffffu;
-    keep[r] = (u8)(t >> 31);
-  }
-}
-
-// --------------------------------------------------------------------------------
-// 7. multi-GPU result return: dense per-shard streams instead of N-sized arrays
-// --------------------------------------------------------------------------------
-#define MAX_RANKS 16
-struct OwnerRanges {            // value ranges of the ranks, by value, statically indexed
-  u64 lo[MAX_RANKS];
-  u64 hi[MAX_RANKS];
-};
-
-struct OwnedFlagOp {            // 1 for the reads this rank counted (global-table variant)
-  const u32 *slot_of_read;
-  u32 n;
-  __device__ u32 operator()(u32 i) const { return (i < n && slot_of_read[i] != NOSLOT) ? 1u : 0u; }
-};
-
-// packed result (cluster id | keep << 31) of every owned read, dense, in read order
-__global__ void __launch_bounds__(256)
-k_owned_results(const u32 *__restrict__ slot_of_read, const u32 *__restrict__ opos,
-                const u64 *__restrict__ slot_out, u32 n_reads, u32 *__restrict__ packed) {
-  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
-    const u32 s = slot_of_read[r];
-    if (s == NOSLOT) continue;
-    const u64 o = slot_out[s];
-    packed[opos[r]] = (u32)o | (((u32)(o >> 32) == r) ? 0x80000000u : 0u);
-  }
-}
-
-// owner rank of every local read (n_ranks = nobody: filtered reads)
-__global__ void __launch_bounds__(256)
-k_owner_of(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n, OwnerRanges rg,
-           u32 n_ranks, u8 *__restrict__ owner) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  u32 o = n_ranks;
-  if (!filtered[i]) {
-    const u64 w = words[i];
-#pragma unroll
-    for (u32 q = 0; q < MAX_RANKS; q++)
-      if (q < n_ranks && rg.lo[q] <= rg.hi[q] && w >= rg.lo[q] && w <= rg.hi[q]) o = q;
-  }
-  owner[i] = (u8)o;
-}
-
-// first position of every owner in the owner-sorted order (n_ranks + 2 boundaries)
-__global__ void k_owner_bounds(const u8 *__restrict__ sorted_owner, u32 n, u32 n_ranks, u32 *__restrict__ bounds) {
-  u32 q = threadIdx.x;
-  if (q > n_ranks + 1) return;
-  u32 lo = 0, hi = n;
-  while (lo < hi) {
-    u32 mid = lo + ((hi - lo) >> 1);
-    if (sorted_owner[mid] < q) lo = mid + 1; else hi = mid;
-  }
-  bounds[q] = lo;
-}
-
-// received dense stream (owner-major, read order inside) -> this shard's outputs
-__global__ void __launch_bounds__(256)
-k_scatter_results(const u32 *__restrict__ perm, const u32 *__restrict__ packed, u32 n_recv,
-                  u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
-  for (u32 k = blockIdx.x * blockDim.x + threadIdx.x; k < n_recv; k += gridDim.x * blockDim.x) {
-    const u32 r = perm[k];
-    const u32 t = packed[k];
-    cluster_id[r] = t & 0x7fffffffu;
-    keep[r] = (u8)(t >> 31);
-  }
-}
-
-__global__ void k_widen32(const u32 *__restrict__ in, u32 n, u64 *__restrict__ out) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = in[i];
-}
-
-__global__ void k_creator_sizes(const u32 *__restrict__ flag, const u32 *__restrict__ pos,
-                                const u64 *__restrict__ cl_size, u32 n, u64 *__restrict__ out) {
-  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u < n && flag[u]) out[pos[u]] = cl_size[u];
-}
-
-// reads per top-`bits` bin of the word (usable reads only): balanced range splitters for the
-// multi-GPU path.  LDS-privatised, fixed grid.
-__global__ void __launch_bounds__(256)
-k_top_hist(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n_reads, u32 shift,
-           u32 n_bins, u32 *hist) {
-  extern __shared__ u32 lh[];
-  for (u32 b = threadIdx.x; b < n_bins; b += blockDim.x) lh[b] = 0;
-  __syncthreads();
-  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x)
-    if (!filtered[r]) {
-      u32 b = (u32)(words[r] >> shift);
-      atomicAdd(&lh[b < n_bins ? b : n_bins - 1], 1u);   // malformed words cannot index out of LDS
-    }
-  __syncthreads();
-  for (u32 b = threadIdx.x; b < n_bins; b += blockDim.x)
-    if (lh[b]) atomicAdd(&hist[b], lh[b]);
-}
-
-__global__ void k_at_least_double(u64 a, u64 b, int *out) { *out = at_least_double(a, b) ? 1 : 0; }
+//   A. exact counts   kernels_count.hip.h   reads radix-partitioned by mix64(word), one LDS-resident
+//                     open-address table per bucket (k_dedup_lds); fallback: one table in HBM
+//                     (k_hash_insert).  Replaces Trie::add, /root/reference/src/humid.cc:95.
+//                     Unique words are then sorted: Trie::walk() order.
+//   B. graph          kernels_graph.hip.h   generalised pigeonhole buckets (k_combo_keys, k_pairs),
+//                     CSR rows through cursors + per-row sort, union-find components.  Replaces
+//                     walk x asymmetricHamming, src/humid.cc:113-130.
+//                     kernels_cluster.hip.h per component: the findClusters loop + src/cluster.cc,
+//                     order-exact (k_cluster_pairs / _small / _components); ids = prefix sum over
+//                     creators.  Replaces src/humid.cc:167-193.
+//   C. map            kernels_map.hip.h     per read (cluster_id, keep); replaces
+//                     trie.find()->leaf->cluster, src/humid.cc:223-231,276-277.  Also the
+//                     multi-GPU result return.
+// Sorts and scans are rocPRIM (header-only, compiled in).  No CPU fallback lives here: every
+// entry point either runs on the GPU or fails.
+#include "common.hip.h"
+#include "kernels_count.hip.h"
+#include "kernels_graph.hip.h"
+#include "kernels_cluster.hip.h"
+#include "kernels_map.hip.h"
 
 // --------------------------------------------------------------------------------
 // host side

@@ -1,0 +1,218 @@
+// kernels_cluster.hip.h -- order-exact directional / maximum clustering per component (src/cluster.cc)
+// Part of libhumid_hip.so (see humid_hip.hip for the pipeline and the C ABI).  Device code for
+// gfx950 only; included once, in this order, by humid_hip.hip.
+#ifndef HUMID_KERNELS_CLUSTER_HIP_H
+#define HUMID_KERNELS_CLUSTER_HIP_H
+
+#include "common.hip.h"
+#include "kernels_graph.hip.h"
+
+// --------------------------------------------------------------------------------
+// 5. clustering
+// --------------------------------------------------------------------------------
+// singletons (no neighbours): the leaf creates its own cluster (src/humid.cc:179-187 with an
+// empty neighbour list: maxNeighbour_ returns the leaf, cluster.cc:39-51)
+__global__ void k_cluster_singletons(const u32 *__restrict__ deg, const u32 *__restrict__ cnt, u32 n,
+                                     u32 *cl_of, u32 *maxleaf, u64 *cl_size) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  if (deg[u] == 0) {
+    cl_of[u] = u + 1;
+    maxleaf[u] = u;
+    cl_size[u] = cnt[u];
+  } else {
+    cl_of[u] = 0;
+  }
+}
+
+// The findClusters loop over the leaves of ONE connected component, ascending.  Literal
+// restatement of
+//   findClusters loop            /root/reference/src/humid.cc:176-189  (members ascending)
+//   maxNeighbour_                src/cluster.cc:39-51  (first qualifying neighbour, restart)
+//   assignDirectionalCluster_    src/cluster.cc:58-69  (pre-order flood, explicit stack)
+//   assignMaxCluster             src/cluster.cc:72-80
+// A cluster is named by its creating leaf (cl_of = creator rank + 1); ids come later from a
+// prefix sum over creators, which reproduces `id++` in walk order.  `st` holds 2 words per member.
+template <bool MAXIMUM, class MemberAt>
+__device__ __forceinline__ void cluster_one_component(MemberAt member_at, u32 n_members,
+                                                      const u32 *__restrict__ cnt,
+                                                      const u32 *__restrict__ off,
+                                                      const u32 *__restrict__ idx, u32 *cl_of,
+                                                      u32 *maxleaf, u64 *cl_size, u32 *st) {
+  for (u32 m = 0; m < n_members; m++) {
+    const u32 u = member_at(m);
+    if (cl_of[u] != 0) continue;                  // src/humid.cc:179
+    const u32 label = u + 1;                      // new Cluster, creator u
+    u32 start = u;
+    u32 best = u;
+    u32 bestc = 0;
+    if (!MAXIMUM) {
+      // maxNeighbour_
+      u32 leaf = u;
+      u32 k = off[leaf], kend = off[leaf + 1];
+      u64 lc = cnt[leaf];
+      while (k < kend) {
+        u32 nb = idx[k++];
+        if (cl_of[nb] == 0 && at_least_double(cnt[nb], lc)) {
+          leaf = nb; lc = cnt[leaf];
+          k = off[leaf]; kend = off[leaf + 1];
+        }
+      }
+      start = leaf;
+      best = leaf;                                // updateMaxCount_ once, cluster.cc:85
+    }
+    u64 size = 0;
+    u32 depth = 0;
+    // assignLeaf_(start)
+    cl_of[start] = label;
+    size += cnt[start];
+    if (MAXIMUM) { bestc = cnt[start]; best = start; }
+    st[0] = start; st[1] = off[start]; depth = 1;
+    while (depth) {
+      const u32 cur = st[2 * (depth - 1)];
+      u32 k = st[2 * (depth - 1) + 1];
+      const u32 kend = off[cur + 1];
+      const u64 cc = cnt[cur];
+      bool descended = false;
+      while (k < kend) {
+        const u32 nb = idx[k++];
+        if (cl_of[nb] != 0) continue;
+        if (!MAXIMUM && !at_least_double(cc, cnt[nb])) continue;
+        cl_of[nb] = label;
+        const u32 nc = cnt[nb];
+        size += nc;
+        if (MAXIMUM && nc > bestc) { bestc = nc; best = nb; }   // updateMaxCount_ strict >
+        st[2 * (depth - 1) + 1] = k;
+        st[2 * depth] = nb; st[2 * depth + 1] = off[nb];
+        depth++;
+        descended = true;
+        break;
+      }
+      if (!descended) depth--;
+    }
+    maxleaf[u] = best;
+    cl_size[u] = size;
+  }
+}
+
+// BIG components: one lane per component = the head of its run in the sorted member keys;
+// stack in HBM scratch (2 words per member of the run).
+template <bool MAXIMUM>
+__global__ void __launch_bounds__(64)
+k_cluster_components(const u64 *__restrict__ mkeys, u32 n_members, const u32 *__restrict__ cnt,
+                     const u32 *__restrict__ off, const u32 *__restrict__ idx, u32 *cl_of,
+                     u32 *maxleaf, u64 *cl_size, u32 *stk) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_members) return;
+  const u32 root = (u32)(mkeys[i] >> 32);
+  if (i > 0 && (u32)(mkeys[i - 1] >> 32) == root) return;   // not a component head
+  u32 len = 1;
+  while (i + len < n_members && (u32)(mkeys[i + len] >> 32) == root) len++;
+  cluster_one_component<MAXIMUM>([&](u32 m) { return (u32)mkeys[i + m]; }, len, cnt, off, idx, cl_of,
+                                 maxleaf, cl_size, stk + 2 * (u64)i);
+}
+
+// Components of exactly two leaves a < b (one centre + one satellite: the bulk of the non-trivial
+// components on UMI data) have a closed form of the same loop; no private arrays, no scratch.
+template <bool MAXIMUM>
+__global__ void __launch_bounds__(256)
+k_cluster_pairs(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *__restrict__ csize, u32 n,
+                const u32 *__restrict__ cnt, const u32 *__restrict__ off, const u32 *__restrict__ idx,
+                u32 *cl_of, u32 *maxleaf, u64 *cl_size) {
+  u32 a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n || deg[a] == 0 || P[a] != a || csize[a] != 2) return;
+  const u32 b = idx[off[a]];
+  const u64 ca = cnt[a], cb = cnt[b];
+  if (MAXIMUM) {                                   // whole component, maxLeaf = first strict maximum
+    cl_of[a] = a + 1; cl_of[b] = a + 1;
+    maxleaf[a] = (cb > ca) ? b : a;
+    cl_size[a] = ca + cb;
+    return;
+  }
+  if (at_least_double(cb, ca)) {                   // a climbs to b, b floods back to a
+    cl_of[a] = a + 1; cl_of[b] = a + 1;
+    maxleaf[a] = b;
+    cl_size[a] = ca + cb;
+  } else if (at_least_double(ca, cb)) {            // a stays, absorbs b
+    cl_of[a] = a + 1; cl_of[b] = a + 1;
+    maxleaf[a] = a;
+    cl_size[a] = ca + cb;
+  } else {                                         // two clusters; b finds a already assigned
+    cl_of[a] = a + 1; maxleaf[a] = a; cl_size[a] = ca;
+    cl_of[b] = b + 1; maxleaf[b] = b; cl_size[b] = cb;
+  }
+}
+
+// SMALL components (<= SMALL_COMP leaves): one lane per component root collects the members by
+// a breadth-first walk, orders them, and runs the same loop with member list and stack in
+// private memory.  No sort, no scratch.
+template <bool MAXIMUM>
+__global__ void __launch_bounds__(128)
+k_cluster_small(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *__restrict__ csize,
+                u32 n, const u32 *__restrict__ cnt, const u32 *__restrict__ off,
+                const u32 *__restrict__ idx, u32 *cl_of, u32 *maxleaf, u64 *cl_size) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n || deg[u] == 0 || P[u] != u) return;
+  const u32 target = csize[u];
+  if (target > SMALL_COMP || target == 2) return;   // pairs: k_cluster_pairs; big: k_cluster_components
+  u32 mem[SMALL_COMP];
+  u32 st[2 * SMALL_COMP];
+  u32 nm = 1;
+  mem[0] = u;
+  for (u32 q = 0; q < nm && nm < target; q++) {
+    const u32 v = mem[q];
+    for (u32 k = off[v]; k < off[v + 1] && nm < target; k++) {
+      const u32 nb = idx[k];
+      bool seen = false;
+      for (u32 t = 0; t < nm; t++) seen |= (mem[t] == nb);
+      if (!seen) mem[nm++] = nb;
+    }
+  }
+  for (u32 k = 1; k < nm; k++) {              // ascending = walk order inside the component
+    u32 x = mem[k];
+    u32 m = k;
+    while (m > 0 && mem[m - 1] > x) { mem[m] = mem[m - 1]; m--; }
+    mem[m] = x;
+  }
+  cluster_one_component<MAXIMUM>([&](u32 m) { return mem[m]; }, nm, cnt, off, idx, cl_of, maxleaf, cl_size, st);
+}
+
+__global__ void k_creator_flags(const u32 *__restrict__ cl_of, u32 n, u32 *flag) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < n) flag[u] = (cl_of[u] == u + 1) ? 1u : 0u;
+}
+
+// per node: final cluster id (creators numbered in walk order) and maxLeaf flag
+__global__ void k_finalize_nodes(const u32 *__restrict__ cl_of, const u32 *__restrict__ pos,
+                                 const u32 *__restrict__ maxleaf, u32 n, u32 *__restrict__ cid,
+                                 u8 *__restrict__ ismax) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  const u32 creator = cl_of[u] - 1;
+  cid[u] = pos[creator] + 1;
+  ismax[u] = (maxleaf[creator] == u) ? 1 : 0;
+}
+
+// per hash slot: (cluster id, read to keep) of the word it holds
+__global__ void k_slot_results(const u32 *__restrict__ l_cid, const u8 *__restrict__ l_ismax,
+                               const u32 *__restrict__ s_first, const u32 *__restrict__ s_slot, u32 n,
+                               u64 *__restrict__ slot_out) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  slot_out[s_slot[u]] = ((u64)(l_ismax[u] ? s_first[u] : NONE32) << 32) | l_cid[u];
+}
+
+__global__ void k_export_clusters(const u32 *__restrict__ flag, const u32 *__restrict__ pos,
+                                  const u32 *__restrict__ maxleaf, const u64 *__restrict__ cl_size,
+                                  const u32 *__restrict__ cnt, u32 n, u64 *o_size, u32 *o_maxcount,
+                                  u32 *o_maxleaf) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n || !flag[u]) return;
+  const u32 c = pos[u];
+  if (o_size) o_size[c] = cl_size[u];
+  if (o_maxleaf) o_maxleaf[c] = maxleaf[u];
+  if (o_maxcount) o_maxcount[c] = cnt[maxleaf[u]];
+}
+
+
+#endif  // HUMID_KERNELS_CLUSTER_HIP_H

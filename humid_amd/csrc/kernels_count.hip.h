@@ -1,0 +1,302 @@
+// kernels_count.hip.h -- exact counts: global HBM table and hash-partitioned LDS tables (Trie::add)
+// Part of libhumid_hip.so (see humid_hip.hip for the pipeline and the C ABI).  Device code for
+// gfx950 only; included once, in this order, by humid_hip.hip.
+#ifndef HUMID_KERNELS_COUNT_HIP_H
+#define HUMID_KERNELS_COUNT_HIP_H
+
+#include "common.hip.h"
+
+// --------------------------------------------------------------------------------
+// 1. exact counts: open-address hash of packed words
+// --------------------------------------------------------------------------------
+// One 16-byte slot per word so that the key probe and both atomics touch ONE line.
+// The table is initialised by a plain 0xff memset: key = EMPTY, cnt = 0xffffffff (count-1,
+// wraps to 0 on the first add), first = 0xffffffff (atomicMin identity).
+// tab[cap+1]: slot `cap` is reserved for the word that equals EMPTY_KEY (n = 32, all T).
+struct __attribute__((aligned(16))) Slot {
+  u64 key;
+  u32 cntm1;   // occurrences - 1; 0xffffffff = never touched
+  u32 first;   // smallest read index with this word
+};
+
+__global__ void __launch_bounds__(256)
+k_hash_insert(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n_reads,
+              Slot *tab, u32 cap_log2, u32 *__restrict__ slot_of_read, u64 range_lo, u64 range_hi,
+              u32 max_probe, ull *ctr) {
+  const u32 mask = (1u << cap_log2) - 1u;
+  const u32 cap = 1u << cap_log2;
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
+    if (filtered[r]) { slot_of_read[r] = NOSLOT; continue; }
+    const u64 w = words[r];
+    if (w < range_lo || w > range_hi) { slot_of_read[r] = NOSLOT; continue; }   // another rank's word
+    u32 s;
+    if (w == EMPTY_KEY) {
+      s = cap;
+    } else {
+      s = (u32)(mix64(w) >> (64 - cap_log2)) & mask;
+      u32 probes = 0;
+      while (true) {
+        u64 k = tab[s].key;
+        if (k == EMPTY_KEY) k = atomicCAS((ull *)&tab[s].key, EMPTY_KEY, (ull)w);
+        if (k == EMPTY_KEY || k == w) break;
+        s = (s + 1) & mask;
+        if (++probes > max_probe) { s = NOSLOT; break; }   // table (nearly) full: never spin forever
+      }
+      if (s == NOSLOT) { ctr[CTR_OVERFULL] = 1; slot_of_read[r] = NOSLOT; continue; }
+    }
+    atomicAdd(&tab[s].cntm1, 1u);
+    atomicMin(&tab[s].first, r);
+    slot_of_read[r] = s;
+  }
+}
+
+// A single-address global atomic costs ~12 ns and serialises (rocprof: 80 k of them = 1 ms), so
+// compaction kernels run a FIXED small grid; each block owns a contiguous chunk, counts its
+// items, reserves output space with ONE atomic, then writes in a second pass over the chunk
+// (L2-resident by then).
+#define COMPACT_BLOCKS 1024u
+
+// block-wide sum of a per-thread value (256 threads); result valid in all threads
+__device__ __forceinline__ u32 block_sum(u32 x, u32 *lds /* >= 4 u32 */) {
+#pragma unroll
+  for (u32 d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = x;
+  __syncthreads();
+  u32 t = lds[0] + lds[1] + lds[2] + lds[3];
+  __syncthreads();
+  return t;
+}
+
+// exclusive position of this thread's flag among the block's 256 flags; *total = block count
+__device__ __forceinline__ u32 block_rank(bool flag, u32 *lds /* >= 4 u32 */, u32 *total) {
+  const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const u64 m = __ballot(flag);
+  if (lane == 0) lds[wv] = (u32)__popcll(m);
+  __syncthreads();
+  u32 before = 0;
+  for (u32 k = 0; k < wv; k++) before += lds[k];
+  *total = lds[0] + lds[1] + lds[2] + lds[3];
+  __syncthreads();
+  return before + (u32)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+// occupied slots -> (word, slot) list in arbitrary order; also sums the usable reads
+__global__ void __launch_bounds__(256)
+k_compact_table(const Slot *__restrict__ tab, u32 n_slots, u64 *__restrict__ uniq_word,
+                u32 *__restrict__ uniq_slot, u32 uniq_cap, ull *ctr) {
+  __shared__ u32 lds[8];
+  const u32 chunk = (n_slots + gridDim.x - 1) / gridDim.x;
+  const u32 lo = blockIdx.x * chunk;
+  const u32 hi = (lo + chunk < n_slots) ? lo + chunk : n_slots;
+  u32 mine = 0, reads = 0;
+  for (u32 sidx = lo + threadIdx.x; sidx < hi; sidx += 256) {
+    const u32 c = tab[sidx].cntm1;
+    if (c != NONE32) { mine++; reads += c + 1u; }
+  }
+  const u32 total = block_sum(mine, lds);
+  const u32 total_reads = block_sum(reads, lds);
+  if (threadIdx.x == 0) {
+    lds[4] = total ? (u32)atomicAdd(&ctr[CTR_UNIQUE], (ull)total) : 0u;
+    if (total_reads) atomicAdd(&ctr[CTR_USABLE], (ull)total_reads);
+  }
+  __syncthreads();
+  u32 base = lds[4];
+  for (u32 s0 = lo; s0 < hi; s0 += 256) {
+    const u32 sidx = s0 + threadIdx.x;
+    Slot sl;
+    sl.cntm1 = NONE32;
+    if (sidx < hi) sl = tab[sidx];
+    u32 tot;
+    const u32 r = block_rank(sl.cntm1 != NONE32, lds, &tot);
+    if (sl.cntm1 != NONE32) {
+      if (base + r < uniq_cap) {
+        uniq_word[base + r] = sl.key;
+        uniq_slot[base + r] = sidx;
+      } else {
+        ctr[CTR_OVERFULL] = 1;
+      }
+    }
+    base += tot;
+  }
+}
+
+// --------------------------------------------------------------------------------
+// 1b. exact counts, partitioned: the reads are first bucketed by the top PB bits of mix64(word)
+// (radix partition; mix64 is a bijection, so equal keys <=> equal words), then every bucket is
+// counted by one workgroup in an LDS-resident open-address table.  No random HBM line traffic:
+// the only scattered access left is the 4-byte slot_of_read[r] store.
+// --------------------------------------------------------------------------------
+#define LDS_SLOTS 2048u          // 16-byte entries: 32 KiB of LDS per workgroup, 5 workgroups per CU
+#define LDS_FILL_LIMIT 1536u     // unique words a bucket may hold (75 % load)
+#define PART_TARGET 700u         // mean reads per bucket
+
+struct MixKeyOp {                // keys_input transform: word -> partition-ordered key
+  __host__ __device__ u64 operator()(u64 w) const { return mix64(w); }
+};
+struct ReadTagOp {               // values_input transform: read index | excluded << 31
+  const u64 *words;
+  const u8 *filtered;
+  u64 lo, hi;
+  __device__ u32 operator()(u32 r) const {
+    const u64 w = words[r];
+    const bool excl = filtered[r] != 0 || w < lo || w > hi;
+    return r | (excl ? 0x80000000u : 0u);
+  }
+};
+
+// first position of every bucket in the partitioned key array (binary search)
+__global__ void k_part_bounds(const u64 *__restrict__ keys, u32 n, u32 pb, u32 n_parts, u32 *__restrict__ pbeg,
+                              u32 *__restrict__ ucount) {
+  u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > n_parts) return;
+  if (p == n_parts) { pbeg[p] = n; ucount[p] = 0; return; }   // ucount tail: scan sentinel
+  const u64 target = (u64)p << (64 - pb);
+  u32 lo = 0, hi = n;
+  while (lo < hi) {
+    u32 mid = lo + ((hi - lo) >> 1);
+    if (keys[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  pbeg[p] = lo;
+}
+
+// One workgroup per bucket.  Entry s of the LDS table: lkey (mixed word), lcnt (occurrences, 0 =
+// empty), lfirst (smallest read index).  Entry LDS_SLOTS is reserved for the key that equals the
+// EMPTY sentinel.  Outputs, in a PADDED layout (bucket b owns positions [pbeg[b], pbeg[b+1]) of
+// N-sized arrays, its u unique words take the first u of them):
+//   pad_word/pad_cnt/pad_first, ucount[b], pusable[b]; slot_of_read[r] = padded position.
+__global__ void __launch_bounds__(256)
+k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u32 *__restrict__ pbeg,
+            u32 n_reads, u32 pb, u64 *__restrict__ pad_word, uint2 *__restrict__ pad_cf,
+            u32 *__restrict__ ucount, u32 *__restrict__ pusable, u32 *__restrict__ pslot, ull *ctr) {
+  __shared__ u64 lkey[LDS_SLOTS + 1];
+  __shared__ u32 lcnt[LDS_SLOTS + 1];
+  __shared__ u32 lfirst[LDS_SLOTS + 1];
+  __shared__ u32 lds[8];
+  const u32 b = blockIdx.x;
+  const u32 beg = pbeg[b], end = pbeg[b + 1];
+  if (beg >= end || end > n_reads) {
+    if (beg > end || end > n_reads) ctr[CTR_OVERFULL] = 1;   // malformed partition: never index with it
+    if (threadIdx.x == 0) { ucount[b] = 0; pusable[b] = 0; }
+    return;
+  }
+  for (u32 s = threadIdx.x; s <= LDS_SLOTS; s += 256) { lkey[s] = EMPTY_KEY; lcnt[s] = 0; lfirst[s] = NONE32; }
+  __syncthreads();
+  const u32 hshift = 64 - pb - 11;      // table index = the 11 key bits below the bucket bits
+  u32 usable = 0;
+  bool overflow = false;
+  for (u32 i = beg + threadIdx.x; i < end; i += 256) {
+    const u32 v = vals[i];
+    if ((v & 0x7fffffffu) >= n_reads) { overflow = true; break; }   // a malformed index is never used
+    if (v & 0x80000000u) { pslot[i] = NOSLOT; continue; }
+    usable++;
+    const u64 k = keys[i];
+    u32 s;
+    if (k == EMPTY_KEY) {
+      s = LDS_SLOTS;
+    } else {
+      s = (u32)(k >> hshift) & (LDS_SLOTS - 1);
+      u32 probes = 0;
+      while (true) {
+        u64 cur = lkey[s];
+        if (cur == EMPTY_KEY) cur = atomicCAS((ull *)&lkey[s], EMPTY_KEY, (ull)k);
+        if (cur == EMPTY_KEY || cur == k) break;
+        s = (s + 1) & (LDS_SLOTS - 1);
+        if (++probes >= LDS_SLOTS) { overflow = true; break; }
+      }
+      if (overflow) break;
+    }
+    atomicAdd(&lcnt[s], 1u);
+    atomicMin(&lfirst[s], v);
+  }
+  if (overflow) ctr[CTR_OVERFULL] = 1;
+  __syncthreads();
+  // compaction of the occupied entries -> padded arrays; lfirst[s] is then reused as slot -> index
+  u32 base = 0;
+  for (u32 s0 = 0; s0 <= LDS_SLOTS; s0 += 256) {
+    const u32 s = s0 + threadIdx.x;
+    const bool occ = (s <= LDS_SLOTS) && lcnt[s] != 0;
+    u32 tot;
+    const u32 r = block_rank(occ, lds, &tot);
+    if (occ) {
+      const u32 li = base + r;           // li < unique words <= reads of the bucket = padded room
+      pad_word[beg + li] = unmix64(lkey[s]);
+      pad_cf[beg + li] = make_uint2(lcnt[s], lfirst[s]);
+      lfirst[s] = li;
+    }
+    base += tot;
+  }
+  if (threadIdx.x == 0) ucount[b] = base;
+  const u32 tu = block_sum(usable, lds);
+  if (threadIdx.x == 0) pusable[b] = tu;
+  __syncthreads();
+  // second pass: every position learns the padded slot of its word (coalesced store; the
+  // per-read outputs are produced later in this same partition order, see k_read_map_part)
+  for (u32 i = beg + threadIdx.x; i < end; i += 256) {
+    const u32 v = vals[i];
+    if (v >= n_reads) continue;          // excluded read (bit 31) or malformed index
+    const u64 k = keys[i];
+    u32 s;
+    if (k == EMPTY_KEY) {
+      s = LDS_SLOTS;
+    } else {
+      s = (u32)(k >> hshift) & (LDS_SLOTS - 1);
+      u32 probes = 0;
+      while (lkey[s] != k && probes++ < LDS_SLOTS) s = (s + 1) & (LDS_SLOTS - 1);
+    }
+    const u32 li = lfirst[s];
+    pslot[i] = (li < end - beg) ? beg + li : NOSLOT;
+  }
+}
+
+// totals over the buckets: U = sum ucount, usable = sum pusable (one block)
+__global__ void __launch_bounds__(256)
+k_part_totals(const u32 *__restrict__ ucount, const u32 *__restrict__ pusable, u32 n_parts, ull *ctr) {
+  __shared__ u32 lds[4];
+  ull u = 0, us = 0;
+  for (u32 p = threadIdx.x; p < n_parts; p += 256) { u += ucount[p]; us += pusable[p]; }
+  // 64-bit block sums via two 32-bit halves are unnecessary: both totals are < 2^32
+  const u32 tu = block_sum((u32)u, lds);
+  const u32 ts = block_sum((u32)us, lds);
+  if (threadIdx.x == 0) { ctr[CTR_UNIQUE] = tu; ctr[CTR_USABLE] = ts; }
+}
+
+// padded -> dense unique list (word, padded position); order = bucket order (sorted afterwards)
+__global__ void __launch_bounds__(256)
+k_compact_padded(const u64 *__restrict__ pad_word, const u32 *__restrict__ pbeg, const u32 *__restrict__ ucount,
+                 const u32 *__restrict__ ubase, u32 n_parts, u64 *__restrict__ uniq_word,
+                 u32 *__restrict__ uniq_slot) {
+  // one wave per bucket
+  const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const u32 lane = threadIdx.x & 63;
+  if (wave >= n_parts) return;
+  const u32 beg = pbeg[wave], uc = ucount[wave], ub = ubase[wave];
+  for (u32 j = lane; j < uc; j += 64) {
+    uniq_word[ub + j] = pad_word[beg + j];
+    uniq_slot[ub + j] = beg + j;
+  }
+}
+
+// after the sort, padded variant: gather count / first read of rank i (one 8-byte gather)
+__global__ void k_post_sort_padded(const u32 *__restrict__ s_slot, const uint2 *__restrict__ pad_cf, u32 n,
+                                   u32 *__restrict__ s_cnt, u32 *__restrict__ s_first) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint2 cf = pad_cf[s_slot[i]];
+    s_cnt[i] = cf.x;
+    s_first[i] = cf.y;
+  }
+}
+
+// after the sort: per rank i gather count / first read from the table
+__global__ void k_post_sort(const u32 *__restrict__ s_slot, const Slot *__restrict__ tab, u32 n,
+                            u32 *__restrict__ s_cnt, u32 *__restrict__ s_first) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const Slot sl = tab[s_slot[i]];
+    s_cnt[i] = sl.cntm1 + 1u;
+    s_first[i] = sl.first;
+  }
+}
+
+
+#endif  // HUMID_KERNELS_COUNT_HIP_H

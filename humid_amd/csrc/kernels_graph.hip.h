@@ -1,0 +1,326 @@
+// kernels_graph.hip.h -- neighbour search (generalised pigeonhole), CSR, union-find components
+// Part of libhumid_hip.so (see humid_hip.hip for the pipeline and the C ABI).  Device code for
+// gfx950 only; included once, in this order, by humid_hip.hip.
+#ifndef HUMID_KERNELS_GRAPH_HIP_H
+#define HUMID_KERNELS_GRAPH_HIP_H
+
+#include "common.hip.h"
+
+// --------------------------------------------------------------------------------
+// 3. neighbour search: pigeonhole segments
+// --------------------------------------------------------------------------------
+// Generalised pigeonhole: the n nucleotides are cut into s segments; two words within
+// Hamming distance d agree exactly on at least s-d of them, so every pair is found in the bucket
+// of some COMBINATION of s-d segments.  d=1: s=2, 2 combos of 12 nt (n=24).  d=2: s=4, 6 combos
+// of 12 nt -- not 3 segments of 8 nt, whose 65 536 buckets hold hundreds of words each.
+// Combo 0 is always the top s-d segments, i.e. a prefix: its buckets are runs of the sorted
+// unique array and need no sort.  mask[c] = bits of combo c; a pair is emitted from the FIRST
+// combo it agrees on.
+#define MAX_COMBOS 20
+#define MAX_FIELDS 8
+struct ComboPlan {
+  u32 ncombo;
+  u32 key_bits;                       // bits of a combo key (sum of its field widths)
+  u64 mask[MAX_COMBOS];
+  u8 nfield[MAX_COMBOS];
+  u8 shift[MAX_COMBOS][MAX_FIELDS];   // fields from most to least significant
+  u8 width[MAX_COMBOS][MAX_FIELDS];
+};
+
+// bucket key of combo `cb` for every unique word (fields concatenated, most significant first)
+// Kernel arguments derived from the plan are passed BY VALUE in small structs and indexed
+// STATICALLY (unrolled loops with a predicate).  A 1 KB plan struct indexed dynamically in the
+// kernarg segment -- and equally a plan freshly uploaded to device memory and read through
+// wave-uniform (scalar) loads -- returned stale fields for single waves on gfx950 / ROCm 7.2
+// (5-25 of 219 k edges lost at 10 M reads, tools/det_check.py), so neither form is used.
+struct EarlierMasks {
+  u64 m[MAX_COMBOS];
+};
+
+// fields of ONE combo
+struct ComboFields {
+  u32 nf;
+  u8 shift[MAX_FIELDS];
+  u8 width[MAX_FIELDS];
+};
+
+template <class KeyT>
+__global__ void k_combo_keys(const u64 *__restrict__ s_word, u32 n, ComboFields cf,
+                             KeyT *__restrict__ key, u32 *__restrict__ val) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 w = s_word[i];
+  u64 k = 0;
+#pragma unroll
+  for (u32 f = 0; f < MAX_FIELDS; f++) {
+    if (f < cf.nf) {
+      const u32 wd = cf.width[f];
+      k = (k << wd) | ((w >> cf.shift[f]) & ((wd >= 64) ? ~0ull : ((1ull << wd) - 1ull)));
+    }
+  }
+  key[i] = (KeyT)k;
+  val[i] = i;
+}
+
+// --------------------------------------------------------------------------------
+// 4. connected components (lock-free union-find, smaller index wins => root = min rank)
+// --------------------------------------------------------------------------------
+__device__ __forceinline__ u32 uf_find(const u32 *P, u32 x) {
+  u32 p = ld_agent(&P[x]);
+  while (p != x) { x = p; p = ld_agent(&P[x]); }
+  return x;
+}
+
+__device__ __forceinline__ void uf_union(u32 *P, u32 a, u32 b) {
+  while (true) {
+    a = uf_find(P, a);
+    b = uf_find(P, b);
+    if (a == b) return;
+    if (a > b) { u32 t = a; a = b; b = t; }
+    if (atomicCAS(&P[b], b, a) == b) return;
+  }
+}
+
+// One thread per position i of the bucket-sorted order (V = ranks in that order; combo 0 uses
+// the sorted unique array itself); compares with the following elements of its bucket: the
+// bucket ends at the first j whose word differs inside the combo mask.  Ranks ascend inside a
+// bucket, so (ri < rj) always.  A pair is emitted only from the FIRST combo it agrees on.
+// Two phases with identical control flow and no shared append counter:
+//   FILL = false: deg[] += 1 per endpoint, union(ri, rj) in the component forest
+//   FILL = true : writes rj into ri's CSR row and ri into rj's (per-row cursors; the rows are
+//                 put in ascending order afterwards by k_sort_lists)
+// MODE: what happens to a found pair
+//   PM_COUNT      deg[] += 1 per endpoint, union(ri, rj)            (single-GPU phase A)
+//   PM_FILL       both directions into the CSR rows via cursors      (single-GPU phase B)
+//   PM_EMIT_COUNT pc[t] = pairs found by this thread                 (multi-GPU share, phase A)
+//   PM_EMIT_FILL  edge (min << 32 | max) at poff[t] + k              (multi-GPU share, phase B)
+// i0/n_i: the thread block covers positions [i0, i0 + n_i) as the first element of a pair; the
+// second runs on to the end of the bucket anywhere in [0, n).
+enum { PM_COUNT = 0, PM_FILL = 1, PM_EMIT_COUNT = 2, PM_EMIT_FILL = 3 };
+
+template <bool PASS0, int MODE>
+__global__ void __launch_bounds__(256)
+k_pairs(const u64 *__restrict__ s_word, const u32 *__restrict__ V, u32 n, u32 i0, u32 n_i, u64 mask,
+        EarlierMasks em, u32 cb, u32 distance, u32 *deg, u32 *parent,
+        const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, u32 *__restrict__ pc,
+        const u32 *__restrict__ poff, u64 *__restrict__ edges) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_i) return;
+  const u32 i = i0 + t;
+  const u32 ri = PASS0 ? i : V[i];
+  const u64 wi = s_word[ri];
+  u32 found = 0;
+  u64 e = (MODE == PM_EMIT_FILL) ? (u64)poff[t] : 0;
+  for (u32 j = i + 1; j < n; j++) {
+    const u32 rj = PASS0 ? j : V[j];
+    const u64 x = wi ^ s_word[rj];
+    if (x & mask) break;                           // left the bucket
+    if (nt_mismatch(x) > distance) continue;
+    bool first = true;
+#pragma unroll
+    for (u32 q = 0; q < MAX_COMBOS; q++)
+      first = first && !(q < cb && (x & em.m[q]) == 0);
+    if (!first) continue;
+    if (MODE == PM_FILL) {
+      nbr_idx[nbr_off[ri] + atomicAdd(&cur[ri], 1u)] = rj;
+      nbr_idx[nbr_off[rj] + atomicAdd(&cur[rj], 1u)] = ri;
+    } else if (MODE == PM_COUNT) {
+      found++;
+      atomicAdd(&deg[rj], 1u);
+      uf_union(parent, ri, rj);
+    } else if (MODE == PM_EMIT_COUNT) {
+      found++;
+    } else {
+      edges[e++] = ri < rj ? (((u64)ri << 32) | rj) : (((u64)rj << 32) | ri);
+    }
+  }
+  if (MODE == PM_COUNT && found) atomicAdd(&deg[ri], found);
+  if (MODE == PM_EMIT_COUNT) pc[t] = found;
+}
+
+// the same two phases driven by an explicit edge list (multi-GPU: the ranks' shares, all-gathered)
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+k_edges_apply(const u64 *__restrict__ edges, u64 n_edges, u32 n_nodes, u32 *deg, u32 *parent,
+              const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, ull *ctr) {
+  for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n_edges; k += (u64)gridDim.x * blockDim.x) {
+    const u64 ed = edges[k];
+    const u32 a = (u32)(ed >> 32), b = (u32)ed;
+    if (a >= n_nodes || b >= n_nodes || a == b) { ctr[CTR_OVERFULL] = 1; continue; }   // malformed edge
+    if (FILL) {
+      nbr_idx[nbr_off[a] + atomicAdd(&cur[a], 1u)] = b;
+      nbr_idx[nbr_off[b] + atomicAdd(&cur[b], 1u)] = a;
+    } else {
+      atomicAdd(&deg[a], 1u);
+      atomicAdd(&deg[b], 1u);
+      uf_union(parent, a, b);
+    }
+  }
+}
+
+// multi-GPU share of a sorted combo: the unique words whose combo key lies in [klo, khi]
+// (key, rank) appended in arbitrary order; fixed grid, one global atomic per block
+template <class KeyT>
+__global__ void __launch_bounds__(256)
+k_select_keyrange(const u64 *__restrict__ s_word, u32 n, ComboFields cf, u64 klo, u64 khi,
+                  KeyT *__restrict__ key_out, u32 *__restrict__ val_out, ull *ctr) {
+  __shared__ u32 lds[8];
+  const u32 chunk = (n + gridDim.x - 1) / gridDim.x;
+  const u32 lo = blockIdx.x * chunk;
+  const u32 hi = (lo + chunk < n) ? lo + chunk : n;
+  auto key_of = [&](u32 i) {
+    const u64 w = s_word[i];
+    u64 k = 0;
+#pragma unroll
+    for (u32 f = 0; f < MAX_FIELDS; f++) {
+      if (f < cf.nf) {
+        const u32 wd = cf.width[f];
+        k = (k << wd) | ((w >> cf.shift[f]) & ((wd >= 64) ? ~0ull : ((1ull << wd) - 1ull)));
+      }
+    }
+    return k;
+  };
+  u32 mine = 0;
+  for (u32 i = lo + threadIdx.x; i < hi; i += 256) {
+    const u64 k = key_of(i);
+    mine += (k >= klo && k <= khi) ? 1u : 0u;
+  }
+  const u32 total = block_sum(mine, lds);
+  if (threadIdx.x == 0) lds[4] = total ? (u32)atomicAdd(&ctr[CTR_SPECIAL], (ull)total) : 0u;
+  __syncthreads();
+  u32 base = lds[4];
+  if (total == 0) return;
+  for (u32 i0 = lo; i0 < hi; i0 += 256) {
+    const u32 i = i0 + threadIdx.x;
+    u64 k = 0;
+    bool sel = false;
+    if (i < hi) { k = key_of(i); sel = (k >= klo && k <= khi); }
+    u32 tot;
+    const u32 r = block_rank(sel, lds, &tot);
+    if (sel) { key_out[base + r] = (KeyT)k; val_out[base + r] = i; }
+    base += tot;
+  }
+}
+
+// every CSR row ascending (the order NLeaf::neighbours has under the trie hypotheses H1+H2)
+__global__ void __launch_bounds__(256)
+k_sort_lists(const u32 *__restrict__ off, u32 n, u32 *idx) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  const u32 b = off[u], d = off[u + 1] - b;
+  if (d < 2) return;
+  u32 *a = idx + b;
+  if (d <= 32) {
+    u32 v[32];
+    for (u32 k = 0; k < d; k++) v[k] = a[k];
+    for (u32 k = 1; k < d; k++) {          // insertion sort
+      u32 x = v[k];
+      u32 m = k;
+      while (m > 0 && v[m - 1] > x) { v[m] = v[m - 1]; m--; }
+      v[m] = x;
+    }
+    for (u32 k = 0; k < d; k++) a[k] = v[k];
+  } else {                                 // heap sort in place
+    for (u32 start = d / 2; start-- > 0;) {
+      u32 r = start;
+      while (true) {
+        u32 ch = 2 * r + 1;
+        if (ch >= d) break;
+        if (ch + 1 < d && a[ch + 1] > a[ch]) ch++;
+        if (a[r] >= a[ch]) break;
+        u32 t = a[r]; a[r] = a[ch]; a[ch] = t;
+        r = ch;
+      }
+    }
+    for (u32 end = d - 1; end > 0; end--) {
+      u32 t = a[0]; a[0] = a[end]; a[end] = t;
+      u32 r = 0;
+      while (true) {
+        u32 ch = 2 * r + 1;
+        if (ch >= end) break;
+        if (ch + 1 < end && a[ch + 1] > a[ch]) ch++;
+        if (a[r] >= a[ch]) break;
+        u32 t2 = a[r]; a[r] = a[ch]; a[ch] = t2;
+        r = ch;
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------
+// 4. connected components: sizes, and the split small / big
+// --------------------------------------------------------------------------------
+#define SMALL_COMP 32u      // components up to this many leaves are clustered by one lane, in registers
+
+// flatten the forest and count the leaves of every component at its root
+__global__ void k_comp_stats(const u32 *__restrict__ deg, u32 *P, u32 n, u32 *csize) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n || deg[u] == 0) return;
+  const u32 root = uf_find(P, u);
+  P[u] = root;
+  atomicAdd(&csize[root], 1u);
+}
+
+// M = leaves with >= 1 neighbour, Mbig = those in components larger than SMALL_COMP
+__global__ void __launch_bounds__(256)
+k_comp_count(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *__restrict__ csize, u32 n,
+             ull *ctr) {
+  __shared__ u32 lds[4];
+  u32 m = 0, mb = 0;
+  for (u32 u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
+    if (deg[u]) {
+      m++;
+      if (csize[P[u]] > SMALL_COMP) mb++;              // P was flattened by k_comp_stats
+    }
+  }
+  const u32 tm = block_sum(m, lds);
+  const u32 tb = block_sum(mb, lds);
+  if (threadIdx.x == 0) {
+    if (tm) atomicAdd(&ctr[CTR_NONSINGLE], (ull)tm);
+    if (tb) atomicAdd(&ctr[CTR_MEMBERS], (ull)tb);
+  }
+}
+
+__global__ void k_iota(u32 *p, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
+// explicit-graph entry point: union every CSR entry (u, nbr)
+__global__ void k_union_csr(const u32 *__restrict__ off, const u32 *__restrict__ idx, u32 n, u32 *P) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  for (u32 k = off[u]; k < off[u + 1]; k++)
+    if (idx[k] != u) uf_union(P, u, idx[k]);
+}
+
+// members of the BIG components, keyed (root << 32 | rank); unordered, sorted afterwards
+__global__ void __launch_bounds__(256)
+k_member_keys(const u32 *__restrict__ deg, u32 *P, const u32 *__restrict__ csize, u32 n, u64 *mkeys,
+              ull *ctr) {
+  __shared__ u32 lds[8];
+  const u32 chunk = (n + gridDim.x - 1) / gridDim.x;
+  const u32 lo = blockIdx.x * chunk;
+  const u32 hi = (lo + chunk < n) ? lo + chunk : n;
+  u32 mine = 0;
+  for (u32 u = lo + threadIdx.x; u < hi; u += 256)
+    mine += (deg[u] && csize[uf_find(P, u)] > SMALL_COMP) ? 1u : 0u;
+  const u32 total = block_sum(mine, lds);
+  if (threadIdx.x == 0) lds[4] = total ? (u32)atomicAdd(&ctr[CTR_SPECIAL], (ull)total) : 0u;
+  __syncthreads();
+  u32 base = lds[4];
+  if (total == 0) return;
+  for (u32 u0 = lo; u0 < hi; u0 += 256) {
+    const u32 u = u0 + threadIdx.x;
+    u32 root = 0;
+    bool mem = (u < hi) && deg[u] != 0;
+    if (mem) { root = uf_find(P, u); mem = csize[root] > SMALL_COMP; }
+    u32 tot;
+    const u32 r = block_rank(mem, lds, &tot);
+    if (mem) mkeys[base + r] = ((u64)root << 32) | u;
+    base += tot;
+  }
+}
+
+
+#endif  // HUMID_KERNELS_GRAPH_HIP_H

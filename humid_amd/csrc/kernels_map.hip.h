@@ -1,0 +1,159 @@
+// kernels_map.hip.h -- per-read outputs, multi-GPU result return, histograms
+// Part of libhumid_hip.so (see humid_hip.hip for the pipeline and the C ABI).  Device code for
+// gfx950 only; included once, in this order, by humid_hip.hip.
+#ifndef HUMID_KERNELS_MAP_HIP_H
+#define HUMID_KERNELS_MAP_HIP_H
+
+#include "common.hip.h"
+
+// --------------------------------------------------------------------------------
+// 6. per-read map: cluster id and the duplicate flag
+// --------------------------------------------------------------------------------
+// keep = this read is the first (input order) whose word is its cluster's maxLeaf
+// (/root/reference/src/humid.cc:224-231); cluster 0 for filtered reads (:272).
+__global__ void __launch_bounds__(256)
+k_read_map(const u32 *__restrict__ slot_of_read, const u64 *__restrict__ slot_out, u32 n_reads,
+           u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
+    const u32 s = slot_of_read[r];
+    u32 c = 0;
+    u8 k = 0;
+    if (s != NOSLOT) {
+      const u64 o = slot_out[s];
+      c = (u32)o;
+      k = ((u32)(o >> 32) == r) ? 1 : 0;
+    }
+    cluster_id[r] = c;
+    keep[r] = k;
+  }
+}
+
+// The same in PARTITION order (LDS-partitioned counts): position i of the partitioned arrays
+// holds read vals[i] and the slot of its word; the slot lookups are partition-local (cached).
+// The un-permute is ONE scattered 4-byte store per read (cluster id | keep << 31; ids < 2^31
+// because n_reads < 2^31); k_split_out then writes both output arrays coalesced.
+__global__ void __launch_bounds__(256)
+k_read_map_part(const u32 *__restrict__ vals, const u32 *__restrict__ pslot, const u64 *__restrict__ slot_out,
+                u32 n_reads, u32 *__restrict__ packed) {
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_reads; i += gridDim.x * blockDim.x) {
+    const u32 r = vals[i] & 0x7fffffffu;
+    if (r >= n_reads) continue;
+    const u32 s = pslot[i];
+    u32 c = 0;
+    if (s != NOSLOT) {
+      const u64 o = slot_out[s];
+      c = (u32)o | (((u32)(o >> 32) == r) ? 0x80000000u : 0u);
+    }
+    packed[r] = c;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_split_out(const u32 *__restrict__ packed, u32 n_reads, u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
+    const u32 t = packed[r];
+    cluster_id[r] = t & 0x7fffffffu;
+    keep[r] = (u8)(t >> 31);
+  }
+}
+
+// --------------------------------------------------------------------------------
+// 7. multi-GPU result return: dense per-shard streams instead of N-sized arrays
+// --------------------------------------------------------------------------------
+#define MAX_RANKS 16
+struct OwnerRanges {            // value ranges of the ranks, by value, statically indexed
+  u64 lo[MAX_RANKS];
+  u64 hi[MAX_RANKS];
+};
+
+struct OwnedFlagOp {            // 1 for the reads this rank counted (global-table variant)
+  const u32 *slot_of_read;
+  u32 n;
+  __device__ u32 operator()(u32 i) const { return (i < n && slot_of_read[i] != NOSLOT) ? 1u : 0u; }
+};
+
+// packed result (cluster id | keep << 31) of every owned read, dense, in read order
+__global__ void __launch_bounds__(256)
+k_owned_results(const u32 *__restrict__ slot_of_read, const u32 *__restrict__ opos,
+                const u64 *__restrict__ slot_out, u32 n_reads, u32 *__restrict__ packed) {
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
+    const u32 s = slot_of_read[r];
+    if (s == NOSLOT) continue;
+    const u64 o = slot_out[s];
+    packed[opos[r]] = (u32)o | (((u32)(o >> 32) == r) ? 0x80000000u : 0u);
+  }
+}
+
+// owner rank of every local read (n_ranks = nobody: filtered reads)
+__global__ void __launch_bounds__(256)
+k_owner_of(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n, OwnerRanges rg,
+           u32 n_ranks, u8 *__restrict__ owner) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 o = n_ranks;
+  if (!filtered[i]) {
+    const u64 w = words[i];
+#pragma unroll
+    for (u32 q = 0; q < MAX_RANKS; q++)
+      if (q < n_ranks && rg.lo[q] <= rg.hi[q] && w >= rg.lo[q] && w <= rg.hi[q]) o = q;
+  }
+  owner[i] = (u8)o;
+}
+
+// first position of every owner in the owner-sorted order (n_ranks + 2 boundaries)
+__global__ void k_owner_bounds(const u8 *__restrict__ sorted_owner, u32 n, u32 n_ranks, u32 *__restrict__ bounds) {
+  u32 q = threadIdx.x;
+  if (q > n_ranks + 1) return;
+  u32 lo = 0, hi = n;
+  while (lo < hi) {
+    u32 mid = lo + ((hi - lo) >> 1);
+    if (sorted_owner[mid] < q) lo = mid + 1; else hi = mid;
+  }
+  bounds[q] = lo;
+}
+
+// received dense stream (owner-major, read order inside) -> this shard's outputs
+__global__ void __launch_bounds__(256)
+k_scatter_results(const u32 *__restrict__ perm, const u32 *__restrict__ packed, u32 n_recv,
+                  u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
+  for (u32 k = blockIdx.x * blockDim.x + threadIdx.x; k < n_recv; k += gridDim.x * blockDim.x) {
+    const u32 r = perm[k];
+    const u32 t = packed[k];
+    cluster_id[r] = t & 0x7fffffffu;
+    keep[r] = (u8)(t >> 31);
+  }
+}
+
+__global__ void k_widen32(const u32 *__restrict__ in, u32 n, u64 *__restrict__ out) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+
+__global__ void k_creator_sizes(const u32 *__restrict__ flag, const u32 *__restrict__ pos,
+                                const u64 *__restrict__ cl_size, u32 n, u64 *__restrict__ out) {
+  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < n && flag[u]) out[pos[u]] = cl_size[u];
+}
+
+// reads per top-`bits` bin of the word (usable reads only): balanced range splitters for the
+// multi-GPU path.  LDS-privatised, fixed grid.
+__global__ void __launch_bounds__(256)
+k_top_hist(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n_reads, u32 shift,
+           u32 n_bins, u32 *hist) {
+  extern __shared__ u32 lh[];
+  for (u32 b = threadIdx.x; b < n_bins; b += blockDim.x) lh[b] = 0;
+  __syncthreads();
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x)
+    if (!filtered[r]) {
+      u32 b = (u32)(words[r] >> shift);
+      atomicAdd(&lh[b < n_bins ? b : n_bins - 1], 1u);   // malformed words cannot index out of LDS
+    }
+  __syncthreads();
+  for (u32 b = threadIdx.x; b < n_bins; b += blockDim.x)
+    if (lh[b]) atomicAdd(&hist[b], lh[b]);
+}
+
+__global__ void k_at_least_double(u64 a, u64 b, int *out) { *out = at_least_double(a, b) ? 1 : 0; }
+
+
+#endif  // HUMID_KERNELS_MAP_HIP_H
