@@ -61,6 +61,9 @@ SYMBOLS = {
                                     C.POINTER(C.c_void_p), C.POINTER(HumidSummary)]),
     "humid_stage_map": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                   C.c_void_p]),
+    "humid_stage_count_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                          C.c_uint64, C.c_uint64, u64p, C.c_uint32, u64p, u64p, u64p]),
+    "humid_stage_map_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), u64p]),
     "humid_stage_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                     C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), u64p]),
     "humid_stage_graph_edges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,

@@ -55,6 +55,8 @@ struct humid_ctx {
   DBuf pk_keys, pk_vals, pbeg, ucount, pusable, ubase, pad_word, pad_cf, pslot;   // partitioned counts
   DBuf opos, own_packed, owner, owner_sorted, perm, small;                        // multi-GPU result return
   DBuf pc, poff, share_edges;                                                     // multi-GPU pair-search share
+  DBuf own_words;                                                                 // multi-GPU dense count
+  bool dense_mode = false;   // last count ran on a compacted list of this rank's reads
   int count_mode = 0;        // 0: hash-partitioned LDS tables (default), 1: one global HBM table
   u32 force_segments = 0;    // 0: automatic pigeonhole plan; else the number of segments s
   bool last_count_lds = false;
@@ -702,6 +704,7 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
   c->have_run = false;
   c->graph_mode = false;
   c->have_graph = false;
+  c->dense_mode = false;
   TRY(check_run_args(c, n_reads, word_nt, method));
   if (n_reads && (!d_words || !d_filt || !d_cid || !d_keep)) return fail(c, HUMID_E_INVALID, "null buffer");
   HIPCHK(hipSetDevice(c->device));
@@ -812,7 +815,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
-                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->csize, &c->cur, &c->plan_dev, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -1101,6 +1104,7 @@ int humid_stage_count(humid_ctx *c, const uint64_t *d_words, const uint8_t *d_fi
   if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
   c->have_run = c->have_graph = false;
   c->graph_mode = false;
+  c->dense_mode = false;
   TRY(check_run_args(c, n_reads, word_nt, 0));
   if (n_reads && (!d_words || !d_filtered)) return fail(c, HUMID_E_INVALID, "null buffer");
   HIPCHK(hipSetDevice(c->device));
@@ -1112,6 +1116,94 @@ int humid_stage_count(humid_ctx *c, const uint64_t *d_words, const uint8_t *d_fi
   HIPCHK(hipStreamSynchronize(c->stream));
   if (n_unique) *n_unique = c->U;
   if (n_usable) *n_usable = c->usable;
+  return HUMID_OK;
+}
+
+// Dense variant for a multi-GPU rank: the usable reads of [range_lo, range_hi] are first compacted
+// (in read order) and then counted by the LDS-partitioned path like a single-GPU read set.  The
+// dense order IS the order of the per-shard result streams (humid_stage_map_dense), and
+// counts[q] = owned reads in [shard_begin[q], shard_begin[q+1]) are the all-to-all split sizes.
+int humid_stage_count_dense(humid_ctx *c, const uint64_t *d_words, const uint8_t *d_filtered,
+                            uint64_t n_reads, uint32_t word_nt, uint64_t range_lo, uint64_t range_hi,
+                            const uint64_t *shard_begin, uint32_t n_shards, uint64_t *counts,
+                            uint64_t *n_unique, uint64_t *n_usable) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  c->have_run = c->have_graph = false;
+  c->graph_mode = false;
+  c->dense_mode = false;
+  TRY(check_run_args(c, n_reads, word_nt, 0));
+  if (!shard_begin || !counts || n_shards == 0 || n_shards > 4096) return fail(c, HUMID_E_INVALID, "bad argument");
+  if (n_reads && (!d_words || !d_filtered)) return fail(c, HUMID_E_INVALID, "null buffer");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const u32 N = (u32)n_reads;
+  for (u32 q = 0; q <= n_shards; q++)
+    if (shard_begin[q] > N || (q && shard_begin[q] < shard_begin[q - 1])) return fail(c, HUMID_E_INVALID, "shard_begin must ascend within [0, n_reads]");
+  if (shard_begin[0] != 0 || shard_begin[n_shards] != N) return fail(c, HUMID_E_INVALID, "shards must cover [0, n_reads)");
+  humid_summary s;
+  memset(&s, 0, sizeof s);
+  c->N = c->U = c->E = c->M = c->C = c->usable = 0;
+  c->word_nt = word_nt;
+  for (u32 q = 0; q < n_shards; q++) counts[q] = 0;
+  if (n_unique) *n_unique = 0;
+  if (n_usable) *n_usable = 0;
+  c->dense_mode = true;
+  if (N == 0) return HUMID_OK;
+  ENSURE(c->opos, ((size_t)N + 1) * 4);
+  {
+    auto fin = rocprim::make_transform_iterator(rocprim::counting_iterator<u32>(0),
+                                                OwnedRangeFlagOp{d_words, d_filtered, range_lo, range_hi, N});
+    size_t bytes = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, bytes, fin, c->opos.as<u32>(), 0u, (size_t)N + 1, rocprim::plus<u32>(), st));
+    ENSURE(c->tmp, bytes);
+    HIPCHK(rocprim::exclusive_scan(c->tmp.p, bytes, fin, c->opos.as<u32>(), 0u, (size_t)N + 1, rocprim::plus<u32>(), st));
+  }
+  std::vector<u32> got(n_shards + 1);
+  for (u32 q = 0; q <= n_shards; q++)
+    HIPCHK(hipMemcpyAsync(&got[q], c->opos.as<u32>() + shard_begin[q], 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const u32 n_own = got[n_shards];
+  for (u32 q = 0; q < n_shards; q++) counts[q] = got[q + 1] - got[q];
+  c->N = n_own;
+  if (n_own == 0) return HUMID_OK;
+  ENSURE(c->own_words, (size_t)n_own * 8);
+  hipLaunchKernelGGL(k_gather_owned, dim3(grid_stride_blocks(N)), dim3(256), 0, st, d_words, d_filtered,
+                     c->opos.as<u32>(), range_lo, range_hi, N, c->own_words.as<u64>());
+  HIPCHK(hipGetLastError());
+  TRY(stage_count(c, c->own_words.as<u64>(), nullptr, n_own, word_nt, 0ull, ~0ull, 0, s));
+  HIPCHK(hipStreamSynchronize(st));
+  if (n_unique) *n_unique = c->U;
+  if (n_usable) *n_usable = c->usable;
+  return HUMID_OK;
+}
+
+// The result stream of the dense variant: packed (cluster_id | keep << 31) of this rank's reads in
+// dense (= read) order, n = sum of the counts humid_stage_count_dense returned.
+int humid_stage_map_dense(humid_ctx *c, const uint32_t *d_local_cluster_id, const uint8_t *d_local_is_max,
+                          const uint32_t **d_packed, uint64_t *n_packed) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (!c->dense_mode) return fail(c, HUMID_E_STATE, "no preceding humid_stage_count_dense");
+  if (!d_packed || !n_packed) return fail(c, HUMID_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const u32 N = (u32)c->N, U = (u32)c->U;
+  *d_packed = nullptr;
+  *n_packed = N;
+  if (N == 0) return HUMID_OK;
+  if (U && (!d_local_cluster_id || !d_local_is_max)) return fail(c, HUMID_E_INVALID, "null buffer");
+  if (U > 0)
+    hipLaunchKernelGGL(k_slot_results, dim3(blocks_for(U)), dim3(256), 0, st, d_local_cluster_id, d_local_is_max,
+                       c->s_first.as<u32>(), c->s_slot.as<u32>(), U, c->slot_out.as<u64>());
+  ENSURE(c->own_packed, ((size_t)N + 1) * 4);
+  if (c->last_count_lds)
+    hipLaunchKernelGGL(k_read_map_part, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->pk_vals.as<u32>(),
+                       c->pslot.as<u32>(), c->slot_out.as<u64>(), N, c->own_packed.as<u32>());
+  else
+    hipLaunchKernelGGL(k_read_map_packed, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->slot_of_read.as<u32>(),
+                       c->slot_out.as<u64>(), N, c->own_packed.as<u32>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  *d_packed = c->own_packed.as<u32>();
   return HUMID_OK;
 }
 

@@ -26,7 +26,7 @@ k_hash_insert(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u3
   const u32 mask = (1u << cap_log2) - 1u;
   const u32 cap = 1u << cap_log2;
   for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
-    if (filtered[r]) { slot_of_read[r] = NOSLOT; continue; }
+    if (filtered && filtered[r]) { slot_of_read[r] = NOSLOT; continue; }   // filtered == null: none
     const u64 w = words[r];
     if (w < range_lo || w > range_hi) { slot_of_read[r] = NOSLOT; continue; }   // another rank's word
     u32 s;
@@ -139,7 +139,7 @@ struct ReadTagOp {               // values_input transform: read index | exclude
   u64 lo, hi;
   __device__ u32 operator()(u32 r) const {
     const u64 w = words[r];
-    const bool excl = filtered[r] != 0 || w < lo || w > hi;
+    const bool excl = (filtered && filtered[r] != 0) || w < lo || w > hi;   // filtered == null: none
     return r | (excl ? 0x80000000u : 0u);
   }
 };

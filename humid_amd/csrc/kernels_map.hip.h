@@ -48,6 +48,21 @@ k_read_map_part(const u32 *__restrict__ vals, const u32 *__restrict__ pslot, con
   }
 }
 
+// global-table variant with the packed result word as output (every read is owned and usable)
+__global__ void __launch_bounds__(256)
+k_read_map_packed(const u32 *__restrict__ slot_of_read, const u64 *__restrict__ slot_out, u32 n_reads,
+                  u32 *__restrict__ packed) {
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
+    const u32 s = slot_of_read[r];
+    u32 c = 0;
+    if (s != NOSLOT) {
+      const u64 o = slot_out[s];
+      c = (u32)o | (((u32)(o >> 32) == r) ? 0x80000000u : 0u);
+    }
+    packed[r] = c;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 k_split_out(const u32 *__restrict__ packed, u32 n_reads, u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
   for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
@@ -65,6 +80,29 @@ struct OwnerRanges {            // value ranges of the ranks, by value, statical
   u64 lo[MAX_RANKS];
   u64 hi[MAX_RANKS];
 };
+
+struct OwnedRangeFlagOp {       // 1 for the usable reads whose word lies in [lo, hi]
+  const u64 *words;
+  const u8 *filtered;
+  u64 lo, hi;
+  u32 n;
+  __device__ u32 operator()(u32 i) const {
+    if (i >= n || filtered[i]) return 0u;
+    const u64 w = words[i];
+    return (w >= lo && w <= hi) ? 1u : 0u;
+  }
+};
+
+// dense copy of the owned reads' words, in read order
+__global__ void __launch_bounds__(256)
+k_gather_owned(const u64 *__restrict__ words, const u8 *__restrict__ filtered, const u32 *__restrict__ opos,
+               u64 lo, u64 hi, u32 n_reads, u64 *__restrict__ own_words) {
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
+    if (filtered[r]) continue;
+    const u64 w = words[r];
+    if (w >= lo && w <= hi) own_words[opos[r]] = w;
+  }
+}
 
 struct OwnedFlagOp {            // 1 for the reads this rank counted (global-table variant)
   const u32 *slot_of_read;

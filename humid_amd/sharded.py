@@ -56,7 +56,6 @@ class HipStageOps(Context):
     def __init__(self, device: int):
         self.device = torch.device("cuda", device)
         super().__init__(device=device)
-        self.set_option("count_mode", 1)      # a rank counts a value range: global-table variant
 
     def histogram(self, g_w, g_f, word_nt, bits):
         hist = torch.zeros(1 << bits, dtype=torch.int32, device=self.device)
@@ -66,7 +65,30 @@ class HipStageOps(Context):
                                                     bits, C.c_void_p(hist.data_ptr())))
         return hist
 
+    def count_dense(self, g_w, g_f, word_nt, lo, hi, shard_begin):
+        """compact this rank's reads, count them with the LDS tables; also the send split sizes"""
+        n = len(shard_begin) - 1
+        sb = (C.c_uint64 * (n + 1))(*shard_begin)
+        counts = (C.c_uint64 * n)()
+        nu, ns = C.c_uint64(), C.c_uint64()
+        torch.cuda.current_stream(self.device).synchronize()
+        self.set_option("count_mode", 0)
+        self._check(self._lib.humid_stage_count_dense(
+            self._h, C.c_void_p(g_w.data_ptr()), C.c_void_p(g_f.data_ptr()), g_w.numel(), word_nt,
+            C.c_uint64(lo), C.c_uint64(hi), sb, n, counts, C.byref(nu), C.byref(ns)))
+        self._u = nu.value
+        return nu.value, ns.value, [int(x) for x in counts]
+
+    def map_dense(self, l_cid, l_ismax):
+        pp = C.c_void_p()
+        n = C.c_uint64()
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check(self._lib.humid_stage_map_dense(self._h, C.c_void_p(l_cid.data_ptr()),
+                                                    C.c_void_p(l_ismax.data_ptr()), C.byref(pp), C.byref(n)))
+        return _wrap(pp.value, n.value, "<i4", torch.int32, self.device)
+
     def count(self, g_w, g_f, word_nt, lo, hi, expected):
+        self.set_option("count_mode", 1)      # partial range + slot_of_read over N: global table
         nu, ns = C.c_uint64(), C.c_uint64()
         self._n_reads = g_w.numel()
         self._check(self._lib.humid_stage_count(self._h, C.c_void_p(g_w.data_ptr()),
@@ -284,7 +306,14 @@ class ShardedDedup:
         ranges = splitters_from_hist(hist.cpu().numpy(), P, self.word_nt, self.bits)
         lo, hi, exp = ranges[r]
         # ---- 3. exact counts of this rank's range ----
-        u_local, usable_local = self.ops.count(g_w, g_f, self.word_nt, lo, hi, max(exp, 1))
+        shard_begin = [q * n_max for q in range(P + 1)]
+        use_dense = (self.dense_return and hasattr(self.ops, "count_dense")
+                     and P <= getattr(self.ops, "max_ranks_dense", 0))
+        send_counts = None
+        if use_dense:
+            u_local, usable_local, send_counts = self.ops.count_dense(g_w, g_f, self.word_nt, lo, hi, shard_begin)
+        else:
+            u_local, usable_local = self.ops.count(g_w, g_f, self.word_nt, lo, hi, max(exp, 1))
         meta = torch.tensor([u_local, usable_local], dtype=torch.int64, device=dev)
         metas = torch.empty(2 * P, dtype=torch.int64, device=dev)
         _all_gather_flat(dist, metas, meta, P)
@@ -339,9 +368,11 @@ class ShardedDedup:
             if dense:
                 # ---- 6. owners emit dense per-shard result streams; one all-to-all; home ranks
                 #         scatter them (both sides derive the split sizes from the value ranges)
-                shard_begin = [q * n_max for q in range(P + 1)]
-                packed, send_counts = self.ops.owned_results(cid_g[goff:goff + u_local],
-                                                             ismax_g[goff:goff + u_local], shard_begin)
+                if use_dense:
+                    packed = self.ops.map_dense(cid_g[goff:goff + u_local], ismax_g[goff:goff + u_local])
+                else:
+                    packed, send_counts = self.ops.owned_results(cid_g[goff:goff + u_local],
+                                                                 ismax_g[goff:goff + u_local], shard_begin)
                 perm, recv_counts = self.ops.owner_perm(d_w, d_f, ranges)
                 recv = torch.empty(sum(recv_counts), dtype=torch.int32, device=dev)
                 _all_to_all_v(dist, recv, packed, recv_counts, send_counts, P, r)

@@ -172,6 +172,21 @@ int humid_stage_map(humid_ctx *ctx, const uint32_t *d_local_cluster_id,
                     const uint8_t *d_local_is_max, uint64_t n_reads, uint32_t *d_cluster_id,
                     uint8_t *d_keep);
 
+/* Dense variant of humid_stage_count for a rank of a multi-GPU run: the usable reads of the rank's
+ * value range are compacted in read order and counted with the LDS-partitioned tables, exactly like
+ * a single-GPU read set.  shard_begin[n_shards+1] (host): the home shards of the gathered reads;
+ * counts[q] (host, out) = this rank's reads in shard q = split sizes of the result all-to-all.
+ * humid_stage_unique / humid_stage_graph* follow as usual; humid_stage_map_dense then yields the
+ * packed results (cluster_id | keep << 31) of those reads in the same dense order, i.e. already
+ * laid out as the per-shard streams. */
+int humid_stage_count_dense(humid_ctx *ctx, const uint64_t *d_words, const uint8_t *d_filtered,
+                            uint64_t n_reads, uint32_t word_nt, uint64_t range_lo, uint64_t range_hi,
+                            const uint64_t *shard_begin, uint32_t n_shards, uint64_t *counts,
+                            uint64_t *n_unique, uint64_t *n_usable);
+int humid_stage_map_dense(humid_ctx *ctx, const uint32_t *d_local_cluster_id,
+                          const uint8_t *d_local_is_max, const uint32_t **d_packed,
+                          uint64_t *n_packed);
+
 /* Partitioned neighbour search.  Every rank holds the whole ascending unique array (after the
  * all-gather of the per-range arrays); rank part_rank of part_world finds the pairs whose first
  * element lies in its slice -- an equal slice of the positions for the prefix combination, the

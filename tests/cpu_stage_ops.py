@@ -58,6 +58,18 @@ class CpuStageOps:
         out_cid.numpy()[self.read_idx] = cid
         out_keep.numpy()[self.read_idx] = keep.astype(np.uint8)
 
+    # ---- dense count / map ----
+    def count_dense(self, g_w, g_f, word_nt, lo, hi, shard_begin):
+        u, usable = self.count(g_w, g_f, word_nt, lo, hi, len(g_w))
+        idx = self.read_idx
+        counts = [int(((idx >= shard_begin[q]) & (idx < shard_begin[q + 1])).sum())
+                  for q in range(len(shard_begin) - 1)]
+        return u, usable, counts
+
+    def map_dense(self, l_cid, l_ismax):
+        pk, _ = self.owned_results(l_cid, l_ismax, [0, 1 << 62])
+        return pk
+
     # ---- partitioned pair search ----
     def pairs(self, g_word, word_nt, distance, part_rank, part_world):
         uw = g_word.numpy().view(np.uint64)

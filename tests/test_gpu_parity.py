@@ -419,6 +419,17 @@ def test_stage_functions_with_virtual_ranks(P, cfg):
         ops[q].scatter(perm, recv, oc, ok)
         assert np.array_equal(oc.cpu().numpy().view(np.uint32), ocid[bounds[q]:bounds[q + 1]])
         assert np.array_equal(ok.cpu().numpy(), okeep[bounds[q]:bounds[q + 1]])
+    # dense count variant (owned reads compacted, LDS tables): same unique arrays, same streams
+    off = 0
+    for r in range(P):
+        lo, hi, exp = ranges[r]
+        u, us, cnts = ops[r].count_dense(g_w, g_f, n, lo, hi, bounds)
+        assert u == u_all[r] and cnts == send[r]
+        w, c = ops[r].unique()
+        assert torch.equal(w, uw[r]) and torch.equal(c, uc[r])
+        pk = ops[r].map_dense(cid_g[off:off + u].clone(), ismax_g[off:off + u].clone())
+        assert torch.equal(pk, packed[r])
+        off += u
     for o in ops:
         o.close()
 
