@@ -11,7 +11,7 @@
 //                     CSR rows through cursors + per-row sort, union-find components.  Replaces
 //                     walk x asymmetricHamming, src/humid.cc:113-130.
 //                     kernels_cluster.hip.h per component: the findClusters loop + src/cluster.cc,
-//                     order-exact (k_cluster_pairs / _small / _components); ids = prefix sum over
+//                     order-exact (k_cluster_trivial / _small / _components); ids = prefix sum over
 //                     creators.  Replaces src/humid.cc:167-193.
 //   C. map            kernels_map.hip.h     per read (cluster_id, keep); replaces
 //                     trie.find()->leaf->cluster, src/humid.cc:223-231,276-277.  Also the
@@ -57,6 +57,7 @@ struct humid_ctx {
   DBuf pc, poff, share_edges;                                                     // multi-GPU pair-search share
   DBuf own_words;                                                                 // multi-GPU dense count
   bool dense_mode = false;   // last count ran on a compacted list of this rank's reads
+  bool slots_done = false;   // slot_out already written by k_finalize_nodes (one-GPU fusion)
   int count_mode = 0;        // 0: hash-partitioned LDS tables (default), 1: one global HBM table
   u32 force_segments = 0;    // 0: automatic pigeonhole plan; else the number of segments s
   bool last_count_lds = false;
@@ -231,18 +232,16 @@ static int cluster_stage(humid_ctx *c, const u32 *g_cnt, u32 U, u64 M, u64 Mbig,
   ENSURE(c->pos, (size_t)(U + 1) * 4);
   ENSURE(c->cid, (size_t)U * 4);
   ENSURE(c->ismax, (size_t)U);
-  hipLaunchKernelGGL(k_cluster_singletons, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
-                     g_cnt, U, c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
+  HIPCHK(hipEventRecord(c->kev[2], st));
+  if (method == HUMID_METHOD_MAXIMUM)
+    hipLaunchKernelGGL(k_cluster_trivial<true>, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
+                       c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
+                       c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
+  else
+    hipLaunchKernelGGL(k_cluster_trivial<false>, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
+                       c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
+                       c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
   if (M > 0) {
-    HIPCHK(hipEventRecord(c->kev[2], st));
-    if (method == HUMID_METHOD_MAXIMUM)
-      hipLaunchKernelGGL(k_cluster_pairs<true>, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
-                         c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
-                         c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
-    else
-      hipLaunchKernelGGL(k_cluster_pairs<false>, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
-                         c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
-                         c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
     if (method == HUMID_METHOD_MAXIMUM)
       hipLaunchKernelGGL(k_cluster_small<true>, dim3(blocks_for(U, 128)), dim3(128), 0, st, c->deg.as<u32>(),
                          c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
@@ -270,8 +269,8 @@ static int cluster_stage(humid_ctx *c, const u32 *g_cnt, u32 U, u64 M, u64 Mbig,
                            c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(),
                            c->cl_size.as<u64>(), c->stk.as<u32>());
     }
-    HIPCHK(hipEventRecord(c->kev[3], st));
   }
+  HIPCHK(hipEventRecord(c->kev[3], st));
   hipLaunchKernelGGL(k_creator_flags, dim3(blocks_for(U)), dim3(256), 0, st, c->cl_of.as<u32>(), U,
                      c->flag.as<u32>());
   TRY(exscan_u32(c, c->flag.as<u32>(), c->pos.as<u32>(), U));
@@ -442,11 +441,10 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
   ENSURE(c->nbr_off, (size_t)(U + 1) * 4);
   ENSURE(c->parent, (size_t)U * 4);
   ENSURE(c->csize, (size_t)U * 4);
-  HIPCHK(hipMemsetAsync(c->deg.p, 0, (size_t)(U + 1) * 4, st));
-  HIPCHK(hipMemsetAsync(c->csize.p, 0, (size_t)U * 4, st));
-  HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_NONSINGLE], 0, 2 * sizeof(ull), st));   // NONSINGLE, MEMBERS
-  HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_OVERFULL], 0, sizeof(ull), st));
-  hipLaunchKernelGGL(k_iota, dim3(blocks_for(U)), dim3(256), 0, st, c->parent.as<u32>(), U);
+  ENSURE(c->cur, (size_t)U * 4);
+  HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_NONSINGLE], 0, (CTR_OVERFULL - CTR_NONSINGLE + 1) * sizeof(ull), st));
+  hipLaunchKernelGGL(k_graph_init, dim3(blocks_for((u64)U + 1)), dim3(256), 0, st, c->parent.as<u32>(),
+                     c->deg.as<u32>(), c->csize.as<u32>(), c->cur.as<u32>(), U);
   u64 E = 0, M = 0, Mbig = 0;
   u32 n_pair_segs = 0;
   c->h_plan = make_plan(word_nt, distance, U, c->force_segments);
@@ -526,8 +524,6 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
   s.nonsingle = c->M = M;
   ENSURE(c->nbr_idx, (size_t)(2 * E + 1) * 4);
   if (E > 0) {
-    ENSURE(c->cur, (size_t)U * 4);
-    HIPCHK(hipMemsetAsync(c->cur.p, 0, (size_t)U * 4, st));
     if (given)
       hipLaunchKernelGGL(k_edges_apply<true>, dim3(grid_stride_blocks(n_ext_edges)), dim3(256), 0, st, ext_edges,
                          n_ext_edges, U, (u32 *)nullptr, (u32 *)nullptr, c->nbr_off.as<u32>(),
@@ -556,8 +552,15 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
 
   // clusters
   TRY(cluster_stage(c, g_cnt, U, M, Mbig, method));
+  // one GPU: the graph is over this context's own unique words, so the per-slot result words can
+  // be written in the same pass (stage C then skips k_slot_results)
+  const bool own = (g_word == c->s_word.as<u64>()) && U == (u32)c->U && !given;
   hipLaunchKernelGGL(k_finalize_nodes, dim3(blocks_for(U)), dim3(256), 0, st, c->cl_of.as<u32>(),
-                     c->pos.as<u32>(), c->maxleaf.as<u32>(), U, c->cid.as<u32>(), c->ismax.as<u8>());
+                     c->pos.as<u32>(), c->maxleaf.as<u32>(), U, c->cid.as<u32>(), c->ismax.as<u8>(),
+                     own ? c->s_first.as<u32>() : (const u32 *)nullptr,
+                     own ? c->s_slot.as<u32>() : (const u32 *)nullptr,
+                     own ? c->slot_out.as<u64>() : (u64 *)nullptr);
+  c->slots_done = own;
   HIPCHK(hipGetLastError());
   n_pair_segs_out = n_pair_segs;
   return HUMID_OK;
@@ -670,7 +673,9 @@ static int stage_pairs_share(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt
 static int stage_map(humid_ctx *c, const u32 *l_cid, const u8 *l_ismax, u32 N, u32 *d_cid, u8 *d_keep) {
   hipStream_t st = c->stream;
   const u32 U = (u32)c->U;
-  if (U > 0)
+  const bool fused = c->slots_done && l_cid == c->cid.as<u32>() && l_ismax == c->ismax.as<u8>();
+  c->slots_done = false;
+  if (U > 0 && !fused)
     hipLaunchKernelGGL(k_slot_results, dim3(blocks_for(U)), dim3(256), 0, st, l_cid, l_ismax,
                        c->s_first.as<u32>(), c->s_slot.as<u32>(), U, c->slot_out.as<u64>());
   HIPCHK(hipEventRecord(c->ev[3], st));
@@ -742,7 +747,7 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
   if (c->last_count_lds) HIPCHK(hipEventElapsedTime(&s.ms_k_map, c->ev[3], c->kev[36]));   // k_read_map_part alone
   else s.ms_k_map = s.ms_map;   // ev[3]..ev[4] bracket exactly the k_read_map launch
   s.count_mode_used = c->last_count_lds ? 0u : 1u;
-  if (M > 0) HIPCHK(hipEventElapsedTime(&s.ms_k_cluster, c->kev[2], c->kev[3]));
+  HIPCHK(hipEventElapsedTime(&s.ms_k_cluster, c->kev[2], c->kev[3]));
   for (u32 g = 0; g < n_pair_segs; g++) {
     float t = 0;
     HIPCHK(hipEventElapsedTime(&t, c->kev[20 + 2 * g], c->kev[21 + 2 * g]));   // count phase
@@ -1060,7 +1065,8 @@ int humid_cluster_graph(humid_ctx *c, const uint32_t *count, const uint32_t *nbr
   TRY(read_counters(c));   // also drains the stream: hdeg is a host temporary
   TRY(cluster_stage(c, c->s_cnt.as<u32>(), U, c->h_ctr[CTR_NONSINGLE], c->h_ctr[CTR_MEMBERS], method));
   hipLaunchKernelGGL(k_finalize_nodes, dim3(blocks_for(U)), dim3(256), 0, st, c->cl_of.as<u32>(),
-                     c->pos.as<u32>(), c->maxleaf.as<u32>(), U, c->cid.as<u32>(), c->ismax.as<u8>());
+                     c->pos.as<u32>(), c->maxleaf.as<u32>(), U, c->cid.as<u32>(), c->ismax.as<u8>(),
+                     (const u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr);
   HIPCHK(hipGetLastError());
   u64 C = 0;
   TRY(n_clusters_from_scan(c, U, &C));

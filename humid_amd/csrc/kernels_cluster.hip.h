@@ -10,21 +10,6 @@
 // --------------------------------------------------------------------------------
 // 5. clustering
 // --------------------------------------------------------------------------------
-// singletons (no neighbours): the leaf creates its own cluster (src/humid.cc:179-187 with an
-// empty neighbour list: maxNeighbour_ returns the leaf, cluster.cc:39-51)
-__global__ void k_cluster_singletons(const u32 *__restrict__ deg, const u32 *__restrict__ cnt, u32 n,
-                                     u32 *cl_of, u32 *maxleaf, u64 *cl_size) {
-  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= n) return;
-  if (deg[u] == 0) {
-    cl_of[u] = u + 1;
-    maxleaf[u] = u;
-    cl_size[u] = cnt[u];
-  } else {
-    cl_of[u] = 0;
-  }
-}
-
 // The findClusters loop over the leaves of ONE connected component, ascending.  Literal
 // restatement of
 //   findClusters loop            /root/reference/src/humid.cc:176-189  (members ascending)
@@ -112,15 +97,24 @@ k_cluster_components(const u64 *__restrict__ mkeys, u32 n_members, const u32 *__
                                  maxleaf, cl_size, stk + 2 * (u64)i);
 }
 
-// Components of exactly two leaves a < b (one centre + one satellite: the bulk of the non-trivial
-// components on UMI data) have a closed form of the same loop; no private arrays, no scratch.
+// The two trivial cases in one pass over the leaves, every cl_of entry written by exactly one
+// lane:
+//  * no neighbours: the leaf creates its own cluster (src/humid.cc:179-187 with an empty list:
+//    maxNeighbour_ returns the leaf, cluster.cc:39-51);
+//  * components of exactly two leaves a < b (one centre + one satellite: the bulk of the
+//    non-trivial components on UMI data): closed form of the same loop, done by a's lane;
+//  * every other leaf is marked unassigned for k_cluster_small / k_cluster_components.
 template <bool MAXIMUM>
 __global__ void __launch_bounds__(256)
-k_cluster_pairs(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *__restrict__ csize, u32 n,
-                const u32 *__restrict__ cnt, const u32 *__restrict__ off, const u32 *__restrict__ idx,
-                u32 *cl_of, u32 *maxleaf, u64 *cl_size) {
+k_cluster_trivial(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *__restrict__ csize, u32 n,
+                  const u32 *__restrict__ cnt, const u32 *__restrict__ off, const u32 *__restrict__ idx,
+                  u32 *cl_of, u32 *maxleaf, u64 *cl_size) {
   u32 a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= n || deg[a] == 0 || P[a] != a || csize[a] != 2) return;
+  if (a >= n) return;
+  if (deg[a] == 0) { cl_of[a] = a + 1; maxleaf[a] = a; cl_size[a] = cnt[a]; return; }
+  const u32 root = P[a];                           // flattened by k_comp_stats
+  if (csize[root] != 2) { cl_of[a] = 0; return; }
+  if (root != a) return;                           // b: written by a's lane
   const u32 b = idx[off[a]];
   const u64 ca = cnt[a], cb = cnt[b];
   if (MAXIMUM) {                                   // whole component, maxLeaf = first strict maximum
@@ -154,7 +148,7 @@ k_cluster_small(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u3
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n || deg[u] == 0 || P[u] != u) return;
   const u32 target = csize[u];
-  if (target > SMALL_COMP || target == 2) return;   // pairs: k_cluster_pairs; big: k_cluster_components
+  if (target > SMALL_COMP || target == 2) return;   // pairs: k_cluster_trivial; big: k_cluster_components
   u32 mem[SMALL_COMP];
   u32 st[2 * SMALL_COMP];
   u32 nm = 1;
@@ -182,15 +176,20 @@ __global__ void k_creator_flags(const u32 *__restrict__ cl_of, u32 n, u32 *flag)
   if (u < n) flag[u] = (cl_of[u] == u + 1) ? 1u : 0u;
 }
 
-// per node: final cluster id (creators numbered in walk order) and maxLeaf flag
+// per node: final cluster id (creators numbered in walk order) and maxLeaf flag; on one GPU also
+// the per-slot result word (slot_out != null), which saves the separate k_slot_results pass
 __global__ void k_finalize_nodes(const u32 *__restrict__ cl_of, const u32 *__restrict__ pos,
                                  const u32 *__restrict__ maxleaf, u32 n, u32 *__restrict__ cid,
-                                 u8 *__restrict__ ismax) {
+                                 u8 *__restrict__ ismax, const u32 *__restrict__ s_first,
+                                 const u32 *__restrict__ s_slot, u64 *__restrict__ slot_out) {
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n) return;
   const u32 creator = cl_of[u] - 1;
-  cid[u] = pos[creator] + 1;
-  ismax[u] = (maxleaf[creator] == u) ? 1 : 0;
+  const u32 c = pos[creator] + 1;
+  const bool mx = maxleaf[creator] == u;
+  cid[u] = c;
+  ismax[u] = mx ? 1 : 0;
+  if (slot_out) slot_out[s_slot[u]] = ((u64)(mx ? s_first[u] : NONE32) << 32) | c;
 }
 
 // per hash slot: (cluster id, read to keep) of the word it holds

@@ -281,6 +281,15 @@ k_comp_count(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *
   }
 }
 
+// one pass instead of three memsets and an iota: parent[i] = i, deg = csize = cur = 0 (deg has
+// n + 1 entries: the extra one is the sentinel of the exclusive scan)
+__global__ void k_graph_init(u32 *__restrict__ parent, u32 *__restrict__ deg, u32 *__restrict__ csize,
+                             u32 *__restrict__ cur, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { parent[i] = i; deg[i] = 0; csize[i] = 0; cur[i] = 0; }
+  if (i == n) deg[i] = 0;
+}
+
 __global__ void k_iota(u32 *p, u32 n) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
