@@ -19,6 +19,7 @@
 
 #include "../../../include/humid_hip.h"
 #include "fastq_io.hpp"
+#include "fastq_mmap.hpp"
 #include "words.hpp"
 
 using namespace humid_host;
@@ -137,11 +138,35 @@ int main(int argc, char **argv) {
   for (size_t i = 0; i < a.files.size(); i++) log << "\n  " << a.files[i] << ": " << plan.take[i];
   log << "\n";
 
+  // ---- fast path: plain canonical FastQ files are mapped and indexed on all cores ----
+  const unsigned threads = host_threads();
+  std::vector<MappedFastq> maps(a.files.size());
+  bool fast = a.files.size() <= 64 && getenv("HUMID_HOST_SLOW") == nullptr;
+  for (size_t f = 0; fast && f < a.files.size(); f++) fast = maps[f].open(a.files[f], threads);
+
   // ---- pass 1: readData (src/humid.cc:89-100) ----
   t = start_message(log, "Reading data");
   std::vector<uint64_t> words;
   std::vector<uint8_t> filtered;
-  {
+  if (fast) {
+    size_t n = maps[0].records();
+    for (auto &m : maps) n = m.records() < n ? m.records() : n;     // stop at the shortest file
+    words.resize(n);
+    filtered.resize(n);
+    const size_t nf = maps.size();
+    parallel_ranges(n, threads, [&](size_t b, size_t e, unsigned) {
+      std::string_view seqs[64], name0, nm, st, ql;
+      for (size_t i = b; i < e; i++) {
+        for (size_t f = 0; f < nf; f++) {
+          maps[f].lines(i, nm, seqs[f], st, ql);
+          if (f == 0) name0 = nm;
+        }
+        uint64_t w;
+        filtered[i] = make_word(name0, seqs, nf, plan, w) ? 1 : 0;
+        words[i] = w;
+      }
+    });
+  } else {
     MultiReader in(a.files);
     if (!in.ok()) { std::fprintf(stderr, "humid: cannot open %s\n", in.bad_file().c_str()); return 1; }
     std::vector<FastqRecord> recs;
@@ -203,6 +228,43 @@ int main(int argc, char **argv) {
     for (FastqWriter *w : dedup) ok = ok && w->ok();
     for (FastqWriter *w : annot) ok = ok && w->ok();
     if (!ok) { std::fprintf(stderr, "humid: cannot create output files in %s\n", a.dir_name.c_str()); return 1; }
+    if (fast) {
+      // records come straight from the mappings; batches are formatted on all cores and written
+      // in order
+      const size_t nf = maps.size();
+      const size_t batch = 1u << 20;
+      std::vector<std::string> bufs(threads);
+      for (size_t b0 = 0; b0 < N; b0 += batch) {
+        const size_t b1 = b0 + batch < N ? b0 + batch : N;
+        for (size_t f = 0; f < nf; f++) {
+          for (int what = 0; what < 2; what++) {           // 0 = dedup, 1 = annotated
+            if ((what == 0 && !a.filter) || (what == 1 && !a.annotate)) continue;
+            parallel_ranges(b1 - b0, threads, [&](size_t rb, size_t re, unsigned w) {
+              std::string &o = bufs[w];
+              o.clear();
+              std::string_view nm, sq, st, ql;
+              for (size_t i = b0 + rb; i < b0 + re; i++) {
+                if (what == 0) {
+                  if (keep[i]) { std::string_view r = maps[f].raw(i); o.append(r.data(), r.size()); }
+                } else {
+                  maps[f].lines(i, nm, sq, st, ql);
+                  o.append(nm.data(), nm.size());
+                  o.push_back(':');
+                  o.append(std::to_string(cluster_id[i]));   // src/humid.cc:281
+                  o.push_back('\n');
+                  o.append(sq.data(), sq.size()).push_back('\n');
+                  o.append(st.data(), st.size()).push_back('\n');
+                  o.append(ql.data(), ql.size()).push_back('\n');
+                }
+              }
+            });
+            FastqWriter *wr = what == 0 ? dedup[f] : annot[f];
+            const unsigned used = (threads <= 1 || b1 - b0 < 4096) ? 1 : threads;
+            for (unsigned w = 0; w < used; w++) wr->write(bufs[w].data(), bufs[w].size());
+          }
+        }
+      }
+    } else {
     MultiReader in(a.files);
     std::vector<FastqRecord> recs;
     std::string s;
@@ -225,6 +287,7 @@ int main(int argc, char **argv) {
         }
       }
       i++;
+    }
     }
     for (FastqWriter *w : dedup) delete w;
     for (FastqWriter *w : annot) delete w;

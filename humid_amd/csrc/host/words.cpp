@@ -63,13 +63,21 @@ static inline void push_symbols(std::string_view s, size_t want, uint64_t &w, bo
   }
 }
 
-bool make_word(const std::vector<FastqRecord> &recs, const WordPlan &plan, uint64_t &word) {
+bool make_word(std::string_view first_header, const std::string_view *seqs, size_t n_files,
+               const WordPlan &plan, uint64_t &word) {
   uint64_t w = 0;
   bool filtered = false;
-  if (plan.header_umi > 0) push_symbols(header_umi(recs.front().name), plan.header_umi, w, filtered);
-  for (size_t f = 0; f < recs.size(); f++) push_symbols(recs[f].seq, plan.take[f], w, filtered);
+  if (plan.header_umi > 0) push_symbols(header_umi(first_header), plan.header_umi, w, filtered);
+  for (size_t f = 0; f < n_files; f++) push_symbols(seqs[f], plan.take[f], w, filtered);
   word = w;
   return filtered;
+}
+
+bool make_word(const std::vector<FastqRecord> &recs, const WordPlan &plan, uint64_t &word) {
+  std::string_view seqs[64];
+  const size_t n = recs.size() < 64 ? recs.size() : 64;
+  for (size_t f = 0; f < n; f++) seqs[f] = recs[f].seq;
+  return make_word(recs.front().name, seqs, n, plan, word);
 }
 
 std::string make_file_name(const std::string &path, const std::string &dir, const std::string &suffix) {

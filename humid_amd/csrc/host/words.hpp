@@ -34,6 +34,9 @@ WordPlan make_plan(size_t first_header_umi, size_t n_files, size_t word_nt);
 // filtered (a symbol outside ACGT, including 'N' padding of short UMIs/reads; coded as 'G').
 // Requires plan.word_nt <= 32.
 bool make_word(const std::vector<FastqRecord> &recs, const WordPlan &plan, uint64_t &word);
+// the same on views (fast path: records read straight from the file mapping)
+bool make_word(std::string_view first_header, const std::string_view *seqs, size_t n_files,
+               const WordPlan &plan, uint64_t &word);
 
 // <dir>/<basename with _suffix inserted before the first '.'>
 std::string make_file_name(const std::string &path, const std::string &dir, const std::string &suffix);

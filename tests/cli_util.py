@@ -35,10 +35,12 @@ def expected_words(files, word_nt):
     return words, filt, recs, (hdr, take)
 
 
-def dump_words(files, word_nt, tmp):
+def dump_words(files, word_nt, tmp, env=None):
     out = os.path.join(tmp, "words.bin")
+    e = dict(os.environ)
+    e.update(env or {})
     subprocess.check_call([HUMID, "-n", str(word_nt), "-l", os.path.join(tmp, "log.txt"),
-                           "--dump-words", out] + list(files))
+                           "--dump-words", out] + list(files), env=e)
     raw = open(out, "rb").read()
     n = int(np.frombuffer(raw[:8], dtype=np.uint64)[0])
     words = np.frombuffer(raw[8:8 + 8 * n], dtype=np.uint64)

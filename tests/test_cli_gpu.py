@@ -79,3 +79,18 @@ def test_cli_gz_roundtrip_and_q_flag(tmp_path):
     out2 = str(tmp_path / "o2")
     subprocess.check_call([HUMID, "-q", "-d", out2, "-l", "/dev/null", gz])
     assert not os.path.exists(os.path.join(out2, "reads_dedup.fastq.gz"))
+
+
+def test_fast_and_streaming_host_paths_write_identical_files(tmp_path):
+    files = synth_fastq(str(tmp_path / "in"), 30000, 321, n_files=2, umi_len=8, read_len=40, p_sub=4e-3,
+                        p_n=2e-3)
+    outs = []
+    for name, env in (("fast", {"HUMID_THREADS": "5"}), ("slow", {"HUMID_HOST_SLOW": "1"})):
+        out = str(tmp_path / name)
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.check_call([HUMID, "-d", out, "-l", "/dev/null", "-a", "-s"] + files, env=e)
+        outs.append(out)
+    for fn in sorted(os.listdir(outs[0])):
+        assert open(os.path.join(outs[0], fn), "rb").read() == open(os.path.join(outs[1], fn), "rb").read(), fn
+    assert len(os.listdir(outs[0])) == 8     # 2 dedup + 2 annotated + 4 .dat

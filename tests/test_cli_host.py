@@ -77,3 +77,30 @@ def test_cli_errors(tmp_path):
     assert subprocess.call([HUMID, "-n", "40"] + files, stderr=subprocess.DEVNULL) == 2
     assert subprocess.call([HUMID], stderr=subprocess.DEVNULL) == 2
     assert subprocess.call([HUMID, str(tmp_path / "missing.fastq")], stderr=subprocess.DEVNULL) == 1
+
+
+@pytest.mark.parametrize("threads", ["1", "3", "8"])
+def test_mapped_fast_path_equals_streaming_path(threads, tmp_path):
+    """plain canonical files are indexed and parsed on several threads; same words as the streaming
+    reader, for every thread count (chunk boundaries fall inside records)"""
+    files = synth_fastq(str(tmp_path), 20000, 77, n_files=2, umi_len=8, read_len=37, p_sub=5e-3,
+                        p_n=3e-3, short_frac=0.05)
+    w_fast, f_fast = dump_words(files, 24, str(tmp_path), env={"HUMID_THREADS": threads})
+    w_slow, f_slow = dump_words(files, 24, str(tmp_path), env={"HUMID_HOST_SLOW": "1"})
+    assert len(w_fast) == 20000
+    assert np.array_equal(w_fast, w_slow) and np.array_equal(f_fast, f_slow)
+
+
+def test_quality_lines_starting_with_at_sign(tmp_path):
+    """'@' is a legal first quality character: the record-start detection of the parallel indexer
+    must not be fooled (line+2 of a true header starts with '+')"""
+    path = str(tmp_path / "tricky.fastq")
+    rng = np.random.default_rng(1)
+    with open(path, "w") as fh:
+        for i in range(30000):
+            seq = "".join("ACGT"[x] for x in rng.integers(0, 4, size=30))
+            qual = ("@" if i % 3 == 0 else "I") + "@+I" * 9 + "I" * 2
+            fh.write("@r%d_%s\n%s\n+\n%s\n" % (i, seq[:8], seq, qual[:30]))
+    w_fast, f_fast = dump_words([path], 24, str(tmp_path), env={"HUMID_THREADS": "7"})
+    w_slow, f_slow = dump_words([path], 24, str(tmp_path), env={"HUMID_HOST_SLOW": "1"})
+    assert len(w_fast) == 30000 and np.array_equal(w_fast, w_slow) and np.array_equal(f_fast, f_slow)
