@@ -56,10 +56,12 @@ struct humid_ctx {
   DBuf opos, own_packed, owner, owner_sorted, perm, small;                        // multi-GPU result return
   DBuf pc, poff, share_edges;                                                     // multi-GPU pair-search share
   DBuf own_words;                                                                 // multi-GPU dense count
+  DBuf heads;                                                                     // big-component heads
   bool dense_mode = false;   // last count ran on a compacted list of this rank's reads
   bool slots_done = false;   // slot_out already written by k_finalize_nodes (one-GPU fusion)
   int count_mode = 0;        // 0: hash-partitioned LDS tables (default), 1: one global HBM table
   u32 force_segments = 0;    // 0: automatic pigeonhole plan; else the number of segments s
+  bool coop_big = true;      // big components: workgroup-cooperative kernel (directional method)
   bool last_count_lds = false;
   DBuf uniq_word, s_word, s_slot, s_cnt, s_first;            // unique words (walk order)
   DBuf deg, nbr_off, nbr_idx, seg_k0, seg_v0, seg_ks, seg_vs, csize, cur, plan_dev;
@@ -258,16 +260,28 @@ static int cluster_stage(humid_ctx *c, const u32 *g_cnt, u32 U, u64 M, u64 Mbig,
       hipLaunchKernelGGL(k_member_keys, dim3(COMPACT_BLOCKS), dim3(256), 0, st, c->deg.as<u32>(),
                          c->parent.as<u32>(), c->csize.as<u32>(), U, c->mk0.as<u64>(), c->d_ctr);
       TRY(sort_keys<u64>(c, c->mk0.as<u64>(), c->mk1.as<u64>(), Mbig, 0, 32 + bits_for(U)));
-      if (method == HUMID_METHOD_MAXIMUM)
+      if (method == HUMID_METHOD_MAXIMUM) {
+        // maxLeaf ties are broken by depth-first pre-order: one lane per component
         hipLaunchKernelGGL(k_cluster_components<true>, dim3(blocks_for(Mbig, 64)), dim3(64), 0, st,
                            c->mk1.as<u64>(), (u32)Mbig, g_cnt, c->nbr_off.as<u32>(),
                            c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(),
                            c->cl_size.as<u64>(), c->stk.as<u32>());
-      else
+      } else if (c->coop_big) {
+        // one workgroup per component, flood as a parallel BFS
+        ENSURE(c->heads, (size_t)Mbig * 4);
+        HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_SPECIAL], 0, sizeof(ull), st));
+        hipLaunchKernelGGL(k_comp_heads, dim3(COMPACT_BLOCKS), dim3(256), 0, st, c->mk1.as<u64>(), (u32)Mbig,
+                           c->heads.as<u32>(), c->d_ctr);
+        const u32 grid = (u32)(Mbig / (SMALL_COMP + 1) + 1 < 2048 ? Mbig / (SMALL_COMP + 1) + 1 : 2048);
+        hipLaunchKernelGGL(k_cluster_big_coop, dim3(grid), dim3(256), 0, st, c->mk1.as<u64>(), (u32)Mbig,
+                           c->heads.as<u32>(), c->d_ctr, g_cnt, c->nbr_off.as<u32>(), c->nbr_idx.as<u32>(),
+                           c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>(), c->stk.as<u32>());
+      } else {
         hipLaunchKernelGGL(k_cluster_components<false>, dim3(blocks_for(Mbig, 64)), dim3(64), 0, st,
                            c->mk1.as<u64>(), (u32)Mbig, g_cnt, c->nbr_off.as<u32>(),
                            c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(),
                            c->cl_size.as<u64>(), c->stk.as<u32>());
+      }
     }
   }
   HIPCHK(hipEventRecord(c->kev[3], st));
@@ -820,7 +834,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
-                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->csize, &c->cur, &c->plan_dev, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -840,6 +854,10 @@ int humid_ctx_set_option(humid_ctx *c, const char *key, int64_t value) {
   if (strcmp(key, "count_mode") == 0) {
     if (value != 0 && value != 1) return fail(c, HUMID_E_INVALID, "count_mode must be 0 (LDS-partitioned) or 1 (global table)");
     c->count_mode = (int)value;
+    return HUMID_OK;
+  }
+  if (strcmp(key, "coop_big") == 0) {
+    c->coop_big = value != 0;
     return HUMID_OK;
   }
   if (strcmp(key, "plan_segments") == 0) {

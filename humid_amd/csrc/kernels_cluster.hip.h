@@ -6,6 +6,7 @@
 
 #include "common.hip.h"
 #include "kernels_graph.hip.h"
+#include "kernels_count.hip.h"
 
 // --------------------------------------------------------------------------------
 // 5. clustering
@@ -95,6 +96,137 @@ k_cluster_components(const u64 *__restrict__ mkeys, u32 n_members, const u32 *__
   while (i + len < n_members && (u32)(mkeys[i + len] >> 32) == root) len++;
   cluster_one_component<MAXIMUM>([&](u32 m) { return (u32)mkeys[i + m]; }, len, cnt, off, idx, cl_of,
                                  maxleaf, cl_size, stk + 2 * (u64)i);
+}
+
+// BIG components, directional method, one WORKGROUP per component.  The sequential loop of the
+// reference is kept where order matters (members ascending, the climb hop by hop, first
+// qualifying neighbour in list order) and parallelised where it does not: the flood is the
+// closure of "cnt[cur] >= 2 cnt[nb]" over unassigned leaves -- the same set in any visiting order
+// (src/cluster.cc:58-69), its size a commutative sum -- so it runs as a level-synchronous BFS
+// with the neighbour lists scanned by whole waves.  A dense 100 k-leaf component costs
+// O(edges / 256) here instead of O(edges) dependent loads on one lane.
+// heads[h] = position in mkeys of the first member of component h; fr = 2 words of scratch per
+// member.  cl_of is claimed with atomicCAS and read with agent-scope loads.
+__global__ void __launch_bounds__(256)
+k_cluster_big_coop(const u64 *__restrict__ mkeys, u32 n_members, const u32 *__restrict__ heads,
+                   const ull *__restrict__ ctr, const u32 *__restrict__ cnt, const u32 *__restrict__ off,
+                   const u32 *__restrict__ idx, u32 *cl_of, u32 *maxleaf, u64 *cl_size, u32 *fr) {
+  __shared__ u32 s_min;         // block-wide minimum (next unassigned member / first qualifying neighbour)
+  __shared__ u32 s_next;        // size of the next BFS frontier
+  __shared__ ull s_size;        // reads in the cluster being flooded
+  const u32 n_heads = (u32)ctr[CTR_SPECIAL];
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (u32 h = blockIdx.x; h < n_heads; h += gridDim.x) {
+    const u32 i0 = heads[h];
+    const u32 root = (u32)(mkeys[i0] >> 32);
+    // length of the run of this component's members
+    u32 len = 0;
+    for (u32 base = i0;; base += 256) {
+      if (threadIdx.x == 0) s_min = NONE32;
+      __syncthreads();
+      const u32 p = base + threadIdx.x;
+      if (p >= n_members || (u32)(mkeys[p] >> 32) != root) atomicMin(&s_min, p);
+      __syncthreads();
+      const u32 e = s_min;
+      __syncthreads();
+      if (e != NONE32) { len = e - i0; break; }
+    }
+    u32 *fa = fr + 2 * (u64)i0, *fb = fa + len;
+    u32 pos = 0;
+    while (true) {
+      // next unassigned member at or after pos (src/humid.cc:178-179)
+      u32 hit = NONE32;
+      for (; pos < len; pos += 256) {
+        if (threadIdx.x == 0) s_min = NONE32;
+        __syncthreads();
+        const u32 m = pos + threadIdx.x;
+        if (m < len && ld_agent(&cl_of[(u32)mkeys[i0 + m]]) == 0) atomicMin(&s_min, m);
+        __syncthreads();
+        hit = s_min;
+        __syncthreads();
+        if (hit != NONE32) break;
+      }
+      if (hit == NONE32) break;
+      pos = hit;
+      const u32 u = (u32)mkeys[i0 + pos];
+      const u32 label = u + 1;
+      // maxNeighbour_: hop to the FIRST unassigned neighbour (list order) with >= 2x the count
+      u32 leaf = u;
+      while (true) {
+        if (threadIdx.x == 0) s_min = NONE32;
+        __syncthreads();
+        const u32 b = off[leaf], e = off[leaf + 1];
+        const u64 lc = cnt[leaf];
+        for (u32 k = b + threadIdx.x; k < e; k += 256) {
+          const u32 nb = idx[k];
+          if (ld_agent(&cl_of[nb]) == 0 && at_least_double(cnt[nb], lc)) { atomicMin(&s_min, k - b); break; }
+        }
+        __syncthreads();
+        const u32 kmin = s_min;
+        __syncthreads();
+        if (kmin == NONE32) break;
+        leaf = idx[b + kmin];
+      }
+      // flood from `leaf`
+      if (threadIdx.x == 0) {
+        atomicExch(&cl_of[leaf], label);
+        fa[0] = leaf;
+        s_size = cnt[leaf];
+        s_next = 0;
+      }
+      __syncthreads();
+      u32 nfr = 1;
+      u32 *cur_f = fa, *nxt_f = fb;
+      while (nfr) {
+        for (u32 f = wave; f < nfr; f += 4) {
+          const u32 cu = cur_f[f];
+          const u64 cc = cnt[cu];
+          for (u32 k = off[cu] + lane; k < off[cu + 1]; k += 64) {
+            const u32 nb = idx[k];
+            const u32 nc = cnt[nb];
+            if (at_least_double(cc, nc) && ld_agent(&cl_of[nb]) == 0 && atomicCAS(&cl_of[nb], 0u, label) == 0u) {
+              nxt_f[atomicAdd(&s_next, 1u)] = nb;
+              atomicAdd(&s_size, (ull)nc);
+            }
+          }
+        }
+        __syncthreads();
+        nfr = s_next;
+        __syncthreads();
+        if (threadIdx.x == 0) s_next = 0;
+        u32 *t = cur_f; cur_f = nxt_f; nxt_f = t;
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) { maxleaf[u] = leaf; cl_size[u] = s_size; }
+      __syncthreads();
+      pos++;
+    }
+  }
+}
+
+// heads of the runs of equal root in the sorted member keys (fixed grid, one atomic per block)
+__global__ void __launch_bounds__(256)
+k_comp_heads(const u64 *__restrict__ mkeys, u32 n_members, u32 *__restrict__ heads, ull *ctr) {
+  __shared__ u32 lds[8];
+  const u32 chunk = (n_members + gridDim.x - 1) / gridDim.x;
+  const u32 lo = blockIdx.x * chunk;
+  const u32 hi = (lo + chunk < n_members) ? lo + chunk : n_members;
+  auto is_head = [&](u32 i) { return i == 0 || (u32)(mkeys[i] >> 32) != (u32)(mkeys[i - 1] >> 32); };
+  u32 mine = 0;
+  for (u32 i = lo + threadIdx.x; i < hi; i += 256) mine += is_head(i) ? 1u : 0u;
+  const u32 total = block_sum(mine, lds);
+  if (threadIdx.x == 0) lds[4] = total ? (u32)atomicAdd(&ctr[CTR_SPECIAL], (ull)total) : 0u;
+  __syncthreads();
+  u32 base = lds[4];
+  if (total == 0) return;
+  for (u32 i0 = lo; i0 < hi; i0 += 256) {
+    const u32 i = i0 + threadIdx.x;
+    const bool hd = (i < hi) && is_head(i);
+    u32 tot;
+    const u32 r = block_rank(hd, lds, &tot);
+    if (hd) heads[base + r] = i;
+    base += tot;
+  }
 }
 
 // The two trivial cases in one pass over the leaves, every cl_of entry written by exactly one

@@ -77,7 +77,9 @@ const char *humid_last_error(const humid_ctx *ctx);   /* ctx may be NULL */
  * LDS-resident tables (default; falls back to 1 by itself when a bucket overflows), 1 = one
  * open-address table in HBM.  Environment HUMID_COUNT_MODE presets it.
  * "plan_segments": 0 = automatic choice of the pigeonhole plan (s segments, buckets on every
- * combination of s-d of them), else force s (ignored when illegal for the given n, d). */
+ * combination of s-d of them), else force s (ignored when illegal for the given n, d).
+ * "coop_big": 1 (default) = components of more than 32 leaves are clustered by one workgroup each
+ * (parallel flood), 0 = by one lane each (the literal sequential loop). */
 int  humid_ctx_set_option(humid_ctx *ctx, const char *key, int64_t value);
 
 /* ---- the whole hot path ----------------------------------------------------

@@ -223,6 +223,29 @@ def test_forced_pigeonhole_plans(dd, d, s):
         dd.set_option("plan_segments", 0)
 
 
+@pytest.mark.parametrize("coop", [1, 0])
+def test_big_components_both_kernels(dd, coop):
+    """dense components far above 32 leaves: workgroup-cooperative flood vs the one-lane loop"""
+    dd.set_option("coop_big", coop)
+    try:
+        rng = np.random.default_rng(17)
+        # saturated 6-nt space: 4096 words, one component, geometric counts (deep climbs, wide floods)
+        w = rng.integers(0, 4 ** 6, size=40000, dtype=np.uint64)
+        w = np.concatenate([w, np.repeat(rng.integers(0, 4 ** 6, size=200, dtype=np.uint64), 50)])
+        check_against_oracle(dd, w, np.zeros(len(w), np.uint8), 6, 1, False)
+        check_against_oracle(dd, w, np.zeros(len(w), np.uint8), 6, 2, False)
+        # many mid-sized components (40-400 leaves): d=2 over a few hundred seeds of 12 nt
+        seeds = rng.integers(0, 4 ** 12, size=300, dtype=np.uint64)
+        ws = np.repeat(seeds, 300)
+        for _ in range(2):
+            pos = rng.integers(0, 12, size=len(ws)).astype(np.uint64) * np.uint64(2)
+            v = rng.integers(0, 4, size=len(ws)).astype(np.uint64)
+            ws = (ws & ~(np.uint64(3) << pos)) | (v << pos)
+        check_against_oracle(dd, ws, np.zeros(len(ws), np.uint8), 12, 2, False)
+    finally:
+        dd.set_option("coop_big", 1)
+
+
 def test_repeatable_at_scale(dd):
     """same input, same answer, run after run (guards the stale-kernel-argument bug recorded in
     humid_hip.hip: single waves lost their edges 5-25 times per 219 k)"""
