@@ -180,6 +180,12 @@ def test_edge_cases(dd):
     w = np.array([2 ** 64 - 1, 2 ** 64 - 1, 2 ** 64 - 2, 2 ** 64 - 5, 7, 2 ** 64 - 1], dtype=np.uint64)
     check_against_oracle(dd, w, np.zeros(6, np.uint8), 32, 1, False)
     check_against_oracle(dd, w, np.zeros(6, np.uint8), 32, 1, True)
+    # n = 32 with the word whose mix64() equals the LDS table's EMPTY sentinel (unmix64(~0))
+    sp = 0xcf9a04affa6badc0
+    w = np.array([sp, sp, sp ^ 1, sp ^ 3, 9, sp, 2 ** 64 - 1], dtype=np.uint64)
+    check_against_oracle(dd, w, np.zeros(len(w), np.uint8), 32, 1, False)
+    big = np.concatenate([np.full(5000, sp, np.uint64), np.arange(3000, dtype=np.uint64) * np.uint64(977)])
+    check_against_oracle(dd, big, np.zeros(len(big), np.uint8), 32, 1, True)
     # distance 0: exact duplicates only
     words, filt = synth_words(20000, 3, 24, p_sub=1e-2)
     check_against_oracle(dd, words, filt, 24, 0, False)
