@@ -64,7 +64,7 @@ struct humid_ctx {
   bool coop_big = true;      // big components: workgroup-cooperative kernel (directional method)
   bool last_count_lds = false;
   DBuf uniq_word, s_word, s_slot, s_cnt, s_first;            // unique words (walk order)
-  DBuf deg, nbr_off, nbr_idx, seg_k0, seg_v0, seg_ks, seg_vs, csize, cur, plan_dev;
+  DBuf deg, nbr_off, nbr_idx, seg_k0, seg_v0, seg_ks, seg_vs, seg_ws, csize, cur, plan_dev;
   ComboPlan h_plan;          // host copy of the plan in flight (source of the async upload)
   DBuf parent, mk0, mk1, cl_of, maxleaf, cl_size, flag, pos, cid, ismax, stk, tmp, scratch;
   hipEvent_t ev[6] = {};
@@ -490,6 +490,7 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
       ENSURE(c->seg_v0, (size_t)U * 4);
       ENSURE(c->seg_ks, (size_t)U * 8);                     // sorted keys: scratch, not kept
       ENSURE(c->seg_vs, (size_t)(nseg - 1) * U * 4);        // ranks in bucket order, per combo
+      ENSURE(c->seg_ws, (size_t)(nseg - 1) * U * 8);        // words in bucket order, per combo
     }
     // phase A: bucket order per combo; degrees and component forest
     for (u32 seg = 0; seg < nseg; seg++) {
@@ -511,8 +512,10 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
                              c->seg_k0.as<u64>(), c->seg_v0.as<u32>());
           TRY(sort_pairs<u64, u32>(c, c->seg_k0.as<u64>(), c->seg_ks.as<u64>(), c->seg_v0.as<u32>(), vs, U, 0, kb));
         }
+        u64 *ws = c->seg_ws.as<u64>() + (size_t)(seg - 1) * U;
+        hipLaunchKernelGGL(k_gather_bucket_words, dim3(blocks_for(U)), dim3(256), 0, st, g_word, vs, U, ws);
         if (seg < 8) HIPCHK(hipEventRecord(c->kev[20 + 2 * seg], st));
-        hipLaunchKernelGGL((k_pairs<false, PM_COUNT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
+        hipLaunchKernelGGL((k_pairs<false, PM_COUNT>), dim3(blocks_for(U)), dim3(256), 0, st, ws,
                            vs, U, 0u, U, plan.mask[seg], d_masks, seg, distance, c->deg.as<u32>(), c->parent.as<u32>(),
                            (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
                            (const u32 *)nullptr, (u64 *)nullptr);
@@ -552,7 +555,8 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
                            (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr);
       } else {
         const u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
-        hipLaunchKernelGGL((k_pairs<false, PM_FILL>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
+        const u64 *ws = c->seg_ws.as<u64>() + (size_t)(seg - 1) * U;
+        hipLaunchKernelGGL((k_pairs<false, PM_FILL>), dim3(blocks_for(U)), dim3(256), 0, st, ws,
                            vs, U, 0u, U, plan.mask[seg], d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
                            c->nbr_off.as<u32>(), c->cur.as<u32>(), c->nbr_idx.as<u32>(),
                            (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr);
@@ -612,6 +616,7 @@ static int stage_pairs_share(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt
     ENSURE(c->seg_v0, (size_t)U * 4);
     ENSURE(c->seg_ks, (size_t)U * 8);
     ENSURE(c->seg_vs, (size_t)(nseg - 1) * U * 4);
+    ENSURE(c->seg_ws, (size_t)(nseg - 1) * U * 8);
   }
   // key range of this rank: [floor(r 2^kb / P), floor((r+1) 2^kb / P) - 1]
   const unsigned __int128 span = (unsigned __int128)1 << kb;
@@ -632,7 +637,12 @@ static int stage_pairs_share(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt
     if (n_sel[seg] > 1) {
       if (kb <= 32) TRY(sort_pairs<u32, u32>(c, c->seg_k0.as<u32>(), c->seg_ks.as<u32>(), c->seg_v0.as<u32>(), vs, n_sel[seg], 0, kb));
       else TRY(sort_pairs<u64, u32>(c, c->seg_k0.as<u64>(), c->seg_ks.as<u64>(), c->seg_v0.as<u32>(), vs, n_sel[seg], 0, kb));
+    } else if (n_sel[seg] == 1) {
+      HIPCHK(hipMemcpyAsync(vs, c->seg_v0.p, 4, hipMemcpyDeviceToDevice, st));
     }
+    if (n_sel[seg])
+      hipLaunchKernelGGL(k_gather_bucket_words, dim3(blocks_for(n_sel[seg])), dim3(256), 0, st, g_word, vs,
+                         n_sel[seg], c->seg_ws.as<u64>() + (size_t)(seg - 1) * U);
   }
   u64 T = 0;
   std::vector<u64> base(nseg, 0);
@@ -648,6 +658,7 @@ static int stage_pairs_share(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt
       u32 *pcs = c->pc.as<u32>() + base[seg];
       const u32 *pos = c->poff.as<u32>() + base[seg];
       const u32 *vs = seg ? c->seg_vs.as<u32>() + (size_t)(seg - 1) * U : nullptr;
+      const u64 *ws = seg ? c->seg_ws.as<u64>() + (size_t)(seg - 1) * U : g_word;
       u64 *ed = c->share_edges.as<u64>();
       const dim3 grid(blocks_for(n_sel[seg])), blk(256);
       if (seg == 0 && phase == 0)
@@ -659,11 +670,11 @@ static int stage_pairs_share(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt
                            d_masks, 0u, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr,
                            (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed);
       else if (phase == 0)
-        hipLaunchKernelGGL((k_pairs<false, PM_EMIT_COUNT>), grid, blk, 0, st, g_word, vs, n_sel[seg], 0u, n_sel[seg],
+        hipLaunchKernelGGL((k_pairs<false, PM_EMIT_COUNT>), grid, blk, 0, st, ws, vs, n_sel[seg], 0u, n_sel[seg],
                            plan.mask[seg], d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
                            (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed);
       else
-        hipLaunchKernelGGL((k_pairs<false, PM_EMIT_FILL>), grid, blk, 0, st, g_word, vs, n_sel[seg], 0u, n_sel[seg],
+        hipLaunchKernelGGL((k_pairs<false, PM_EMIT_FILL>), grid, blk, 0, st, ws, vs, n_sel[seg], 0u, n_sel[seg],
                            plan.mask[seg], d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
                            (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed);
     }
@@ -837,7 +848,7 @@ void humid_ctx_destroy(humid_ctx *c) {
                   &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
-                  &c->seg_v0, &c->seg_vs, &c->csize, &c->cur, &c->plan_dev, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
+                  &c->seg_v0, &c->seg_vs, &c->seg_ws, &c->csize, &c->cur, &c->plan_dev, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
                   &c->maxleaf, &c->cl_size, &c->flag, &c->pos, &c->cid, &c->ismax, &c->stk, &c->tmp,
                   &c->scratch};
   for (DBuf *b : bufs) b->release();

@@ -100,20 +100,22 @@ enum { PM_COUNT = 0, PM_FILL = 1, PM_EMIT_COUNT = 2, PM_EMIT_FILL = 3 };
 
 template <bool PASS0, int MODE>
 __global__ void __launch_bounds__(256)
-k_pairs(const u64 *__restrict__ s_word, const u32 *__restrict__ V, u32 n, u32 i0, u32 n_i, u64 mask,
+k_pairs(const u64 *__restrict__ W, const u32 *__restrict__ V, u32 n, u32 i0, u32 n_i, u64 mask,
         EarlierMasks em, u32 cb, u32 distance, u32 *deg, u32 *parent,
         const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, u32 *__restrict__ pc,
         const u32 *__restrict__ poff, u64 *__restrict__ edges) {
+  // W: the words IN THE ORDER WALKED (the sorted unique array for the prefix combo, a gathered
+  // copy in bucket order for the sorted combos), so the inner loop is one sequential, coalesced
+  // stream; the ranks V[] are only loaded for the pairs that are found.
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_i) return;
   const u32 i = i0 + t;
+  const u64 wi = W[i];
   const u32 ri = PASS0 ? i : V[i];
-  const u64 wi = s_word[ri];
   u32 found = 0;
   u64 e = (MODE == PM_EMIT_FILL) ? (u64)poff[t] : 0;
   for (u32 j = i + 1; j < n; j++) {
-    const u32 rj = PASS0 ? j : V[j];
-    const u64 x = wi ^ s_word[rj];
+    const u64 x = wi ^ W[j];
     if (x & mask) break;                           // left the bucket
     if (nt_mismatch(x) > distance) continue;
     bool first = true;
@@ -121,6 +123,7 @@ k_pairs(const u64 *__restrict__ s_word, const u32 *__restrict__ V, u32 n, u32 i0
     for (u32 q = 0; q < MAX_COMBOS; q++)
       first = first && !(q < cb && (x & em.m[q]) == 0);
     if (!first) continue;
+    const u32 rj = PASS0 ? j : V[j];
     if (MODE == PM_FILL) {
       nbr_idx[nbr_off[ri] + atomicAdd(&cur[ri], 1u)] = rj;
       nbr_idx[nbr_off[rj] + atomicAdd(&cur[rj], 1u)] = ri;
@@ -136,6 +139,13 @@ k_pairs(const u64 *__restrict__ s_word, const u32 *__restrict__ V, u32 n, u32 i0
   }
   if (MODE == PM_COUNT && found) atomicAdd(&deg[ri], found);
   if (MODE == PM_EMIT_COUNT) pc[t] = found;
+}
+
+// words of a sorted combo in bucket order (one gather per combo instead of one per comparison)
+__global__ void k_gather_bucket_words(const u64 *__restrict__ s_word, const u32 *__restrict__ V, u32 n,
+                                      u64 *__restrict__ wv) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) wv[i] = s_word[V[i]];
 }
 
 // the same two phases driven by an explicit edge list (multi-GPU: the ranks' shares, all-gathered)
