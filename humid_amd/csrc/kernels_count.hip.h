@@ -171,6 +171,8 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
   __shared__ u64 lkey[LDS_SLOTS + 1];
   __shared__ u32 lcnt[LDS_SLOTS + 1];
   __shared__ u32 lfirst[LDS_SLOTS + 1];
+  __shared__ unsigned short lslot_of[LDS_SLOTS + 1];   // unique index (claim order) -> table entry
+  __shared__ u32 lcount;                               // unique words claimed so far
   __shared__ u32 lds[8];
   const u32 b = blockIdx.x;
   const u32 beg = pbeg[b], end = pbeg[b + 1];
@@ -180,6 +182,7 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
     return;
   }
   for (u32 s = threadIdx.x; s <= LDS_SLOTS; s += 256) { lkey[s] = EMPTY_KEY; lcnt[s] = 0; lfirst[s] = NONE32; }
+  if (threadIdx.x == 0) lcount = 0;
   __syncthreads();
   const u32 hshift = 64 - pb - 11;      // table index = the 11 key bits below the bucket bits
   u32 usable = 0;
@@ -205,27 +208,23 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
       }
       if (overflow) break;
     }
-    atomicAdd(&lcnt[s], 1u);
+    // the first add to an entry (old count 0) registers it: its index is the claim order, so no
+    // compaction scan over the table is needed afterwards
+    if (atomicAdd(&lcnt[s], 1u) == 0u) lslot_of[atomicAdd(&lcount, 1u)] = (unsigned short)s;
     atomicMin(&lfirst[s], v);
   }
   if (overflow) ctr[CTR_OVERFULL] = 1;
   __syncthreads();
-  // compaction of the occupied entries -> padded arrays; lfirst[s] is then reused as slot -> index
-  u32 base = 0;
-  for (u32 s0 = 0; s0 <= LDS_SLOTS; s0 += 256) {
-    const u32 s = s0 + threadIdx.x;
-    const bool occ = (s <= LDS_SLOTS) && lcnt[s] != 0;
-    u32 tot;
-    const u32 r = block_rank(occ, lds, &tot);
-    if (occ) {
-      const u32 li = base + r;           // li < unique words <= reads of the bucket = padded room
-      pad_word[beg + li] = unmix64(lkey[s]);
-      pad_cf[beg + li] = make_uint2(lcnt[s], lfirst[s]);
-      lfirst[s] = li;
-    }
-    base += tot;
+  // registered entries -> padded arrays (index < unique words <= reads of the bucket = padded
+  // room); lfirst[s] is then reused as entry -> index
+  const u32 n_uniq = lcount;
+  for (u32 li = threadIdx.x; li < n_uniq; li += 256) {
+    const u32 s = lslot_of[li];
+    pad_word[beg + li] = unmix64(lkey[s]);
+    pad_cf[beg + li] = make_uint2(lcnt[s], lfirst[s]);
+    lfirst[s] = li;
   }
-  if (threadIdx.x == 0) ucount[b] = base;
+  if (threadIdx.x == 0) ucount[b] = n_uniq;
   const u32 tu = block_sum(usable, lds);
   if (threadIdx.x == 0) pusable[b] = tu;
   __syncthreads();
