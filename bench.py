@@ -127,7 +127,7 @@ def main():
 
     # ---- roofline of the dominant kernel (HIP events around its single launch, live) ----
     # candidates: the two N-proportional single-launch kernels (13 B/read x N is their unit)
-    lds = int(last.get("count_mode_used", 0)) == 0 and world == 1 and not a.force_sharded
+    lds = int(last.get("count_mode_used", 0)) in (0, 2) and world == 1 and not a.force_sharded
     kern = {("k_dedup_lds" if lds else "k_hash_insert"): ks["ms_k_insert"],
             ("k_read_map_part" if lds else "k_read_map"): ks["ms_k_map"]}
     dom = max(kern, key=lambda k: kern[k])

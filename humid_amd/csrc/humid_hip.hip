@@ -63,6 +63,8 @@ struct humid_ctx {
   u32 force_segments = 0;    // 0: automatic pigeonhole plan; else the number of segments s
   bool coop_big = true;      // big components: workgroup-cooperative kernel (directional method)
   bool last_count_lds = false;
+  bool last_count_ordered = false;
+  int count_order = -1;      // LDS buckets by word prefix: -1 automatic (uniform prefix), 0 never, 1 always
   DBuf uniq_word, s_word, s_slot, s_cnt, s_first;            // unique words (walk order)
   DBuf deg, nbr_off, nbr_idx, seg_k0, seg_v0, seg_ks, seg_vs, seg_ws, csize, cur, plan_dev;
   ComboPlan h_plan;          // host copy of the plan in flight (source of the async upload)
@@ -351,16 +353,24 @@ static int stage_count_global(humid_ctx *c, const u64 *d_words, const u8 *d_filt
   return HUMID_OK;
 }
 
+// bucket bits of the partitioned count: 2^pb buckets of about PART_TARGET reads
+static inline u32 part_bits(u32 N) {
+  u32 pb = 1;
+  while (pb < 26 && ((u64)PART_TARGET << pb) < (u64)N) pb++;
+  return pb;
+}
+
 // Partitioned variant of stage A (see section 1b of the kernels).  Returns HUMID_OK with
 // *overflowed = true when a bucket held more unique words than its LDS table (the caller then
 // runs the global-table variant; results are never taken from an overflowed run).
 static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N, u32 word_nt,
-                           u64 range_lo, u64 range_hi, humid_summary &s, bool *overflowed) {
+                           u64 range_lo, u64 range_hi, bool ordered, humid_summary &s, bool *overflowed) {
   hipStream_t st = c->stream;
   *overflowed = false;
   c->last_count_lds = true;
-  u32 pb = 1;
-  while (pb < 26 && ((u64)PART_TARGET << pb) < (u64)N) pb++;
+  c->last_count_ordered = ordered;
+  const u32 lshift = 64 - 2 * word_nt;
+  const u32 pb = part_bits(N);
   const u32 n_parts = 1u << pb;
   ENSURE(c->pk_keys, (size_t)N * 8);
   ENSURE(c->pk_vals, (size_t)N * 4);
@@ -377,7 +387,7 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   HIPCHK(hipEventRecord(c->ev[0], st));
   HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_N * sizeof(ull), st));
   {
-    auto kin = rocprim::make_transform_iterator(d_words, MixKeyOp{});
+    auto kin = rocprim::make_transform_iterator(d_words, PartKeyOp{ordered ? 1u : 0u, lshift});
     auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<u32>(0),
                                                 ReadTagOp{d_words, d_filt, range_lo, range_hi});
     // MergeSortLimit = 0: block sort up to 1024 items, Onesweep above (never the merge path)
@@ -393,9 +403,14 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   hipLaunchKernelGGL(k_part_bounds, dim3(blocks_for(n_parts + 1)), dim3(256), 0, st, c->pk_keys.as<u64>(), N,
                      pb, n_parts, c->pbeg.as<u32>(), c->ucount.as<u32>());
   HIPCHK(hipEventRecord(c->kev[0], st));
-  hipLaunchKernelGGL(k_dedup_lds, dim3(n_parts), dim3(256), 0, st, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(),
-                     c->pbeg.as<u32>(), N, pb, c->pad_word.as<u64>(), c->pad_cf.as<uint2>(),
-                     c->ucount.as<u32>(), c->pusable.as<u32>(), c->pslot.as<u32>(), c->d_ctr);
+  if (ordered)
+    hipLaunchKernelGGL(k_dedup_lds<true>, dim3(n_parts), dim3(256), 0, st, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(),
+                       c->pbeg.as<u32>(), N, pb, lshift, c->pad_word.as<u64>(), c->pad_cf.as<uint2>(),
+                       c->ucount.as<u32>(), c->pusable.as<u32>(), c->pslot.as<u32>(), c->d_ctr);
+  else
+    hipLaunchKernelGGL(k_dedup_lds<false>, dim3(n_parts), dim3(256), 0, st, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(),
+                       c->pbeg.as<u32>(), N, pb, lshift, c->pad_word.as<u64>(), c->pad_cf.as<uint2>(),
+                       c->ucount.as<u32>(), c->pusable.as<u32>(), c->pslot.as<u32>(), c->d_ctr);
   HIPCHK(hipEventRecord(c->kev[1], st));
   hipLaunchKernelGGL(k_part_totals, dim3(1), dim3(256), 0, st, c->ucount.as<u32>(), c->pusable.as<u32>(),
                      n_parts, c->d_ctr);
@@ -411,15 +426,63 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   ENSURE(c->s_slot, (size_t)U * 4);
   ENSURE(c->s_cnt, (size_t)U * 4);
   ENSURE(c->s_first, (size_t)U * 4);
-  hipLaunchKernelGGL(k_compact_padded, dim3(blocks_for((u64)n_parts * 64)), dim3(256), 0, st,
-                     c->pad_word.as<u64>(), c->pbeg.as<u32>(), c->ucount.as<u32>(), c->ubase.as<u32>(), n_parts,
-                     c->uniq_word.as<u64>(), c->uniq_slot.as<u32>());
-  TRY(sort_pairs<u64, u32>(c, c->uniq_word.as<u64>(), c->s_word.as<u64>(), c->uniq_slot.as<u32>(),
-                           c->s_slot.as<u32>(), U, 0, 2 * word_nt));
-  hipLaunchKernelGGL(k_post_sort_padded, dim3(blocks_for(U)), dim3(256), 0, st, c->s_slot.as<u32>(),
-                     c->pad_cf.as<uint2>(), U, c->s_cnt.as<u32>(), c->s_first.as<u32>());
+  if (ordered) {
+    // buckets are runs of the word order and sorted inside: squeezing out the holes IS the sort
+    hipLaunchKernelGGL(k_compact_padded<true>, dim3(blocks_for((u64)n_parts * 64)), dim3(256), 0, st,
+                       c->pad_word.as<u64>(), c->pad_cf.as<uint2>(), c->pbeg.as<u32>(), c->ucount.as<u32>(),
+                       c->ubase.as<u32>(), n_parts, c->s_word.as<u64>(), c->s_slot.as<u32>(),
+                       c->s_cnt.as<u32>(), c->s_first.as<u32>());
+  } else {
+    hipLaunchKernelGGL(k_compact_padded<false>, dim3(blocks_for((u64)n_parts * 64)), dim3(256), 0, st,
+                       c->pad_word.as<u64>(), c->pad_cf.as<uint2>(), c->pbeg.as<u32>(), c->ucount.as<u32>(),
+                       c->ubase.as<u32>(), n_parts, c->uniq_word.as<u64>(), c->uniq_slot.as<u32>(),
+                       (u32 *)nullptr, (u32 *)nullptr);
+    TRY(sort_pairs<u64, u32>(c, c->uniq_word.as<u64>(), c->s_word.as<u64>(), c->uniq_slot.as<u32>(),
+                             c->s_slot.as<u32>(), U, 0, 2 * word_nt));
+    hipLaunchKernelGGL(k_post_sort_padded, dim3(blocks_for(U)), dim3(256), 0, st, c->s_slot.as<u32>(),
+                       c->pad_cf.as<uint2>(), U, c->s_cnt.as<u32>(), c->s_first.as<u32>());
+  }
   HIPCHK(hipEventRecord(c->ev[1], st));
   HIPCHK(hipGetLastError());
+  return HUMID_OK;
+}
+
+// Would word-ordered buckets fit their LDS tables?  Histogram of the top (up to 12) word bits over
+// a sample of the reads, folded / scaled to the 2^pb buckets the partition will use: the fullest
+// bucket, with a 1.5x margin, must stay below the table's fill limit (a bucket's unique words
+// cannot exceed its reads).  UMI-first layouts pass; read-prefix-first amplicon or low-complexity
+// data does not and keeps the hashed buckets.  A wrong "yes" only costs the overflow fallback.
+static int prefix_fits_ordered(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N, u32 word_nt, bool *fits) {
+  *fits = false;
+  const u32 bits = 2 * word_nt < 12 ? 2 * word_nt : 12;
+  const u32 n_bins = 1u << bits;
+  if (N < 65536) return HUMID_OK;                              // small inputs: not worth a decision
+  // a sample is enough: the first ~1 M reads (FastQ order is unrelated to the word value)
+  const u32 n_sample = N < (1u << 20) ? N : (1u << 20);
+  ENSURE(c->small, (size_t)n_bins * 4);
+  HIPCHK(hipMemsetAsync(c->small.p, 0, (size_t)n_bins * 4, c->stream));
+  hipLaunchKernelGGL(k_top_hist, dim3(256), dim3(256), n_bins * 4, c->stream, d_words, d_filt, n_sample,
+                     2 * word_nt - bits, n_bins, c->small.as<u32>());
+  std::vector<u32> h(n_bins);
+  HIPCHK(hipMemcpyAsync(h.data(), c->small.p, (size_t)n_bins * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const u32 pb = part_bits(N);
+  double worst = 0;
+  if (pb >= bits) {                    // several buckets per bin: assume the bin splits evenly
+    u32 mx = 0;
+    for (u32 v : h) if (v > mx) mx = v;
+    worst = (double)mx / (double)(1u << (pb - bits));
+  } else {                             // several bins per bucket: fold
+    const u32 per = 1u << (bits - pb);
+    for (u32 b = 0; b < n_bins; b += per) {
+      u64 t = 0;
+      for (u32 k = 0; k < per; k++) t += h[b + k];
+      if ((double)t > worst) worst = (double)t;
+    }
+  }
+  worst *= (double)N / (double)n_sample;
+  *fits = worst * 1.5 <= (double)LDS_FILL_LIMIT;
   return HUMID_OK;
 }
 
@@ -430,7 +493,13 @@ static int stage_count(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N
   const bool full_range = (range_lo == 0 && range_hi == ~0ull);
   if (c->count_mode == 0 && full_range) {
     bool overflowed = false;
-    TRY(stage_count_lds(c, d_words, d_filt, N, word_nt, range_lo, range_hi, s, &overflowed));
+    bool ordered = c->count_order == 1;
+    if (c->count_order < 0) TRY(prefix_fits_ordered(c, d_words, d_filt, N, word_nt, &ordered));
+    if (ordered) {
+      TRY(stage_count_lds(c, d_words, d_filt, N, word_nt, range_lo, range_hi, true, s, &overflowed));
+      if (!overflowed) return HUMID_OK;
+    }
+    TRY(stage_count_lds(c, d_words, d_filt, N, word_nt, range_lo, range_hi, false, s, &overflowed));
     if (!overflowed) return HUMID_OK;
   }
   return stage_count_global(c, d_words, d_filt, N, word_nt, range_lo, range_hi, expected_reads, s);
@@ -771,7 +840,7 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
   HIPCHK(hipEventElapsedTime(&s.ms_k_insert, c->kev[0], c->kev[1]));
   if (c->last_count_lds) HIPCHK(hipEventElapsedTime(&s.ms_k_map, c->ev[3], c->kev[36]));   // k_read_map_part alone
   else s.ms_k_map = s.ms_map;   // ev[3]..ev[4] bracket exactly the k_read_map launch
-  s.count_mode_used = c->last_count_lds ? 0u : 1u;
+  s.count_mode_used = c->last_count_lds ? (c->last_count_ordered ? 2u : 0u) : 1u;
   HIPCHK(hipEventElapsedTime(&s.ms_k_cluster, c->kev[2], c->kev[3]));
   for (u32 g = 0; g < n_pair_segs; g++) {
     float t = 0;
@@ -865,6 +934,11 @@ int humid_ctx_set_option(humid_ctx *c, const char *key, int64_t value) {
   if (strcmp(key, "count_mode") == 0) {
     if (value != 0 && value != 1) return fail(c, HUMID_E_INVALID, "count_mode must be 0 (LDS-partitioned) or 1 (global table)");
     c->count_mode = (int)value;
+    return HUMID_OK;
+  }
+  if (strcmp(key, "count_order") == 0) {
+    if (value < -1 || value > 1) return fail(c, HUMID_E_INVALID, "count_order must be -1 (auto), 0 or 1");
+    c->count_order = (int)value;
     return HUMID_OK;
   }
   if (strcmp(key, "coop_big") == 0) {

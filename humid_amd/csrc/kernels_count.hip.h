@@ -130,8 +130,13 @@ k_compact_table(const Slot *__restrict__ tab, u32 n_slots, u64 *__restrict__ uni
 #define LDS_FILL_LIMIT 1536u     // unique words a bucket may hold (75 % load)
 #define PART_TARGET 700u         // mean reads per bucket
 
-struct MixKeyOp {                // keys_input transform: word -> partition-ordered key
-  __host__ __device__ u64 operator()(u64 w) const { return mix64(w); }
+// keys_input transform: word -> partition key.  Hashed: mix64(word) (a bijection; robust to any
+// word distribution).  Ordered: the word itself, left-aligned, so that buckets are runs of the
+// word order -- used when the top word bits are uniform (UMI first), see stage_count.
+struct PartKeyOp {
+  u32 ordered;
+  u32 lshift;                    // 64 - 2n
+  __host__ __device__ u64 operator()(u64 w) const { return ordered ? (w << lshift) : mix64(w); }
 };
 struct ReadTagOp {               // values_input transform: read index | excluded << 31
   const u64 *words;
@@ -164,14 +169,19 @@ __global__ void k_part_bounds(const u64 *__restrict__ keys, u32 n, u32 pb, u32 n
 // EMPTY sentinel.  Outputs, in a PADDED layout (bucket b owns positions [pbeg[b], pbeg[b+1]) of
 // N-sized arrays, its u unique words take the first u of them):
 //   pad_word/pad_cnt/pad_first, ucount[b], pusable[b]; slot_of_read[r] = padded position.
+// ORDERED: the partition key is the left-aligned word; the bucket's unique words are additionally
+// sorted (bitonic sort of the claim-order index by key, in LDS), so the padded arrays are in
+// word order bucket after bucket = Trie::walk() order once the holes are squeezed out.
+template <bool ORDERED>
 __global__ void __launch_bounds__(256)
 k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u32 *__restrict__ pbeg,
-            u32 n_reads, u32 pb, u64 *__restrict__ pad_word, uint2 *__restrict__ pad_cf,
+            u32 n_reads, u32 pb, u32 lshift, u64 *__restrict__ pad_word, uint2 *__restrict__ pad_cf,
             u32 *__restrict__ ucount, u32 *__restrict__ pusable, u32 *__restrict__ pslot, ull *ctr) {
   __shared__ u64 lkey[LDS_SLOTS + 1];
   __shared__ u32 lcnt[LDS_SLOTS + 1];
   __shared__ u32 lfirst[LDS_SLOTS + 1];
   __shared__ unsigned short lslot_of[LDS_SLOTS + 1];   // unique index (claim order) -> table entry
+  __shared__ unsigned short lorder[ORDERED ? 512 : 1]; // ORDERED, small buckets: entries by rank
   __shared__ u32 lcount;                               // unique words claimed so far
   __shared__ u32 lds[8];
   const u32 b = blockIdx.x;
@@ -218,9 +228,46 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
   // registered entries -> padded arrays (index < unique words <= reads of the bucket = padded
   // room); lfirst[s] is then reused as entry -> index
   const u32 n_uniq = lcount;
+  if (ORDERED && n_uniq <= 512) {
+    // small bucket (the normal case): rank of an entry = number of smaller keys, counted directly
+    // -- n_uniq broadcast LDS reads per thread, no barrier per step (a bitonic network costs 36
+    // barriers at 256 entries)
+    for (u32 li = threadIdx.x; li < n_uniq; li += 256) {
+      const u32 s = lslot_of[li];
+      const u64 k = lkey[s];
+      u32 r = 0;
+      for (u32 j = 0; j < n_uniq; j++) r += (lkey[lslot_of[j]] < k) ? 1u : 0u;
+      lorder[r] = (unsigned short)s;            // keys are distinct: ranks are a permutation
+    }
+    __syncthreads();
+    for (u32 li = threadIdx.x; li < n_uniq; li += 256) lslot_of[li] = lorder[li];
+    __syncthreads();
+  } else if (ORDERED) {
+    if (n_uniq > LDS_SLOTS) ctr[CTR_OVERFULL] = 1;             // table + special entry all in use
+    u32 npow = 1;
+    while (npow < n_uniq) npow <<= 1;
+    if (npow > LDS_SLOTS) npow = LDS_SLOTS;
+    for (u32 i = n_uniq + threadIdx.x; i < npow; i += 256) lslot_of[i] = 0xffff;   // padding: +infinity
+    __syncthreads();
+    for (u32 k = 2; k <= npow; k <<= 1) {
+      for (u32 j = k >> 1; j > 0; j >>= 1) {
+        for (u32 t = threadIdx.x; t < npow; t += 256) {
+          const u32 x = t ^ j;
+          if (x > t) {
+            const u32 a = lslot_of[t], bb = lslot_of[x];
+            const bool pa = a == 0xffff, pbd = bb == 0xffff;
+            const u64 ka = pa ? 0 : lkey[a], kb = pbd ? 0 : lkey[bb];
+            const bool gt = pa ? !pbd : (!pbd && ka > kb);     // a > b, padding above every key
+            if (gt == ((t & k) == 0)) { lslot_of[t] = (unsigned short)bb; lslot_of[x] = (unsigned short)a; }
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
   for (u32 li = threadIdx.x; li < n_uniq; li += 256) {
     const u32 s = lslot_of[li];
-    pad_word[beg + li] = unmix64(lkey[s]);
+    pad_word[beg + li] = ORDERED ? (lkey[s] >> lshift) : unmix64(lkey[s]);
     pad_cf[beg + li] = make_uint2(lcnt[s], lfirst[s]);
     lfirst[s] = li;
   }
@@ -259,12 +306,15 @@ k_part_totals(const u32 *__restrict__ ucount, const u32 *__restrict__ pusable, u
   if (threadIdx.x == 0) { ctr[CTR_UNIQUE] = tu; ctr[CTR_USABLE] = ts; }
 }
 
-// padded -> dense unique list (word, padded position); order = bucket order (sorted afterwards)
+// padded -> dense unique list (word, padded position), one wave per bucket.  Hashed buckets: the
+// list is in bucket order and sorted afterwards.  Ordered buckets: it IS walk order, so count and
+// first read are copied along and no sort follows.
+template <bool ORDERED>
 __global__ void __launch_bounds__(256)
-k_compact_padded(const u64 *__restrict__ pad_word, const u32 *__restrict__ pbeg, const u32 *__restrict__ ucount,
+k_compact_padded(const u64 *__restrict__ pad_word, const uint2 *__restrict__ pad_cf,
+                 const u32 *__restrict__ pbeg, const u32 *__restrict__ ucount,
                  const u32 *__restrict__ ubase, u32 n_parts, u64 *__restrict__ uniq_word,
-                 u32 *__restrict__ uniq_slot) {
-  // one wave per bucket
+                 u32 *__restrict__ uniq_slot, u32 *__restrict__ s_cnt, u32 *__restrict__ s_first) {
   const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const u32 lane = threadIdx.x & 63;
   if (wave >= n_parts) return;
@@ -272,6 +322,11 @@ k_compact_padded(const u64 *__restrict__ pad_word, const u32 *__restrict__ pbeg,
   for (u32 j = lane; j < uc; j += 64) {
     uniq_word[ub + j] = pad_word[beg + j];
     uniq_slot[ub + j] = beg + j;
+    if (ORDERED) {
+      const uint2 cf = pad_cf[beg + j];
+      s_cnt[ub + j] = cf.x;
+      s_first[ub + j] = cf.y;
+    }
   }
 }
 

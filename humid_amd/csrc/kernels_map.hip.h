@@ -182,7 +182,7 @@ k_top_hist(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n
   for (u32 b = threadIdx.x; b < n_bins; b += blockDim.x) lh[b] = 0;
   __syncthreads();
   for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x)
-    if (!filtered[r]) {
+    if (!(filtered && filtered[r])) {
       u32 b = (u32)(words[r] >> shift);
       atomicAdd(&lh[b < n_bins ? b : n_bins - 1], 1u);   // malformed words cannot index out of LDS
     }

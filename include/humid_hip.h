@@ -62,7 +62,8 @@ typedef struct humid_summary {
   float ms_k_pairs;     /* sum over the 2(d+1) k_pairs launches (count + fill)      */
   float ms_k_cluster;   /* k_cluster_pairs + _small (+ _components): 2-3 launches   */
   float ms_k_map;       /* k_read_map_part or k_read_map (one launch)               */
-  uint32_t count_mode_used;  /* 0 = LDS-partitioned tables, 1 = global HBM table (option or fallback) */
+  uint32_t count_mode_used;  /* 0 = LDS tables, hashed buckets; 2 = LDS tables, word-ordered buckets;
+                              * 1 = global HBM table (option or fallback)                        */
 } humid_summary;
 
 uint32_t humid_abi_version(void);
@@ -78,6 +79,10 @@ const char *humid_last_error(const humid_ctx *ctx);   /* ctx may be NULL */
  * open-address table in HBM.  Environment HUMID_COUNT_MODE presets it.
  * "plan_segments": 0 = automatic choice of the pigeonhole plan (s segments, buckets on every
  * combination of s-d of them), else force s (ignored when illegal for the given n, d).
+ * "count_order": LDS buckets formed on the word prefix instead of its hash, which makes the unique
+ * sort unnecessary: -1 (default) = when a sampled histogram of the top word bits says the fullest
+ * bucket fits its LDS table (UMI-first layouts), 0 = never, 1 = always (either way a bucket
+ * overflow falls back to hashed buckets).
  * "coop_big": 1 (default) = components of more than 32 leaves are clustered by one workgroup each
  * (parallel flood), 0 = by one lane each (the literal sequential loop). */
 int  humid_ctx_set_option(humid_ctx *ctx, const char *key, int64_t value);

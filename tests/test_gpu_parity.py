@@ -12,12 +12,16 @@ from oracle import pyoracle as orc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["lds_partitioned", "global_table"])
+@pytest.fixture(scope="module", params=[(0, 0), (0, 1), (1, 0)],
+                ids=["lds_hashed_buckets", "lds_ordered_buckets", "global_table"])
 def dd(request):
-    """every parity test runs with both exact-count variants (humid_ctx_set_option count_mode)"""
+    """every parity test runs with all exact-count variants (humid_ctx_set_option count_mode /
+    count_order; the ordered variant falls back to hashed buckets by itself on skewed words)"""
     d = humid_amd.Dedup()
-    d.set_option("count_mode", request.param)
-    d.count_mode = request.param
+    d.set_option("count_mode", request.param[0])
+    d.set_option("count_order", request.param[1])
+    d.count_mode = request.param[0]
+    d.count_order = request.param[1]
     yield d
     d.close()
 
@@ -209,11 +213,20 @@ def test_bucket_overflow_falls_back_to_global_table(dd):
     words = np.unique(cand[top == 7])[:20000]
     assert len(words) == 20000
     s = check_against_oracle(dd, words, np.zeros(len(words), np.uint8), 24, 1, False)
-    assert s["count_mode_used"] == 1                   # fallback (or the forced global mode)
+    if dd.count_order == 1:
+        assert s["count_mode_used"] == 2               # word-ordered buckets spread these words out
+        # ... but 20000 distinct words sharing their top 5 word bits overflow an ORDERED bucket:
+        # the run is redone with hashed buckets
+        same_prefix = (words & np.uint64((1 << 43) - 1)) | (np.uint64(13) << np.uint64(43))
+        same_prefix = np.unique(same_prefix)
+        s2 = check_against_oracle(dd, same_prefix, np.zeros(len(same_prefix), np.uint8), 24, 1, False)
+        assert s2["count_mode_used"] == 0
+    else:
+        assert s["count_mode_used"] == 1               # fallback (or the forced global mode)
     # the same amount of reads, but duplicates of few words: no overflow, LDS path is used
     few = np.repeat(words[:100], 200)
     s = check_against_oracle(dd, few, np.zeros(len(few), np.uint8), 24, 1, False)
-    assert s["count_mode_used"] == dd.count_mode
+    assert s["count_mode_used"] in ((1,) if dd.count_mode == 1 else (0, 2))
 
 
 @pytest.mark.parametrize("d,s", [(1, 2), (1, 3), (1, 4), (2, 3), (2, 4), (2, 5), (3, 4), (3, 6)])
@@ -250,6 +263,21 @@ def test_big_components_both_kernels(dd, coop):
         check_against_oracle(dd, ws, np.zeros(len(ws), np.uint8), 12, 2, False)
     finally:
         dd.set_option("coop_big", 1)
+
+
+def test_ordered_buckets_are_chosen_for_uniform_prefixes_only():
+    d = humid_amd.Dedup()
+    words, filt = synth_words(400_000, 9, 24)                      # UMI first: uniform top bits
+    cid, keep, s = d.run(words, filt)
+    assert s["count_mode_used"] == 2
+    ocid, okeep, _, _ = orc.dedup_run(words, filt, 24, 1, 0)
+    assert np.array_equal(cid, ocid) and np.array_equal(keep, okeep)
+    skew = (words & np.uint64((1 << 30) - 1)) | (np.uint64(0x2aaaa) << np.uint64(30))   # one read prefix
+    cid, keep, s = d.run(skew, filt)
+    assert s["count_mode_used"] == 0
+    ocid, okeep, _, _ = orc.dedup_run(skew, filt, 24, 1, 0)
+    assert np.array_equal(cid, ocid) and np.array_equal(keep, okeep)
+    d.close()
 
 
 def test_repeatable_at_scale(dd):
