@@ -136,7 +136,10 @@ def main():
     traffic = None
     tj = a.traffic_json or os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj):
-        traffic = json.load(open(tj)).get(dom)
+        tr = json.load(open(tj))
+        traffic = tr.get(dom)
+        if traffic is None:                       # template instantiations: k_dedup_lds<true>
+            traffic = next((v for k, v in tr.items() if k.split("<")[0] == dom), None)
     roofline = {"bound": "hbm", "kernel": dom, "kernel_ms": round(dom_ms, 4),
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
