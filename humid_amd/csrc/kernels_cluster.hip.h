@@ -11,6 +11,8 @@
 // --------------------------------------------------------------------------------
 // 5. clustering
 // --------------------------------------------------------------------------------
+#define MAX_CLIMB 40u   // hops of maxNeighbour_: counts >= 1 double per hop, so 32 suffice; see below
+
 // The findClusters loop over the leaves of ONE connected component, ascending.  Literal
 // restatement of
 //   findClusters loop            /root/reference/src/humid.cc:176-189  (members ascending)
@@ -37,11 +39,13 @@ __device__ __forceinline__ void cluster_one_component(MemberAt member_at, u32 n_
       u32 leaf = u;
       u32 k = off[leaf], kend = off[leaf + 1];
       u64 lc = cnt[leaf];
-      while (k < kend) {
-        u32 nb = idx[k++];
-        if (cl_of[nb] == 0 && at_least_double(cnt[nb], lc)) {
+      u32 hops = 0;                               // every hop at least doubles a count >= 1: a
+      while (k < kend) {                          // 32-bit count allows 32; the cap only matters
+        u32 nb = idx[k++];                        // for a caller's zero counts (never spin)
+        if (cl_of[nb] == 0 && at_least_double(cnt[nb], lc) && hops < MAX_CLIMB) {
           leaf = nb; lc = cnt[leaf];
           k = off[leaf]; kend = off[leaf + 1];
+          hops++;
         }
       }
       start = leaf;
@@ -152,7 +156,7 @@ k_cluster_big_coop(const u64 *__restrict__ mkeys, u32 n_members, const u32 *__re
       const u32 label = u + 1;
       // maxNeighbour_: hop to the FIRST unassigned neighbour (list order) with >= 2x the count
       u32 leaf = u;
-      while (true) {
+      for (u32 hops = 0; hops < MAX_CLIMB; hops++) {
         if (threadIdx.x == 0) s_min = NONE32;
         __syncthreads();
         const u32 b = off[leaf], e = off[leaf + 1];
