@@ -67,12 +67,17 @@ class Dedup(Context):
     """The whole hot path on one GPU."""
 
     def run(self, words, filtered, word_nt=24, distance=1, method=DIRECTIONAL):
-        """Host numpy buffers in, (cluster_id u32[N], keep u8[N], summary dict) out."""
+        """Host numpy buffers in, (cluster_id u32[N], keep u8[N], summary dict) out.
+
+        word_nt <= 32: words is u64[N].  33 <= word_nt <= 64: words is u64[N, 2], [:, 0] = the
+        first word_nt-32 nucleotides, [:, 1] = the last 32 (include/humid_hip.h)."""
         w = np.ascontiguousarray(words, dtype=np.uint64)
         f = np.ascontiguousarray(filtered, dtype=np.uint8)
-        if w.shape != f.shape or w.ndim != 1:
-            raise ValueError("words and filtered must be 1-D and of equal length")
-        n = len(w)
+        want = (len(f), 2) if word_nt > 32 else (len(f),)
+        if f.ndim != 1 or w.shape != want:
+            raise ValueError("words must have shape %r for word_nt=%d (filtered: %r)" % (want, word_nt, f.shape))
+        n = len(f)
+        self._wide = word_nt > 32
         cid = np.zeros(n, dtype=np.uint32)
         keep = np.zeros(n, dtype=np.uint8)
         s = _lib.HumidSummary()
@@ -89,11 +94,13 @@ class Dedup(Context):
             self._h, C.c_void_p(d_words), C.c_void_p(d_filtered), n_reads, word_nt, distance,
             method, C.c_void_p(d_cluster_id), C.c_void_p(d_keep), C.byref(s)))
         self.summary = s.asdict()
+        self._wide = word_nt > 32
         return self.summary
 
     def leaves(self):
         u = int(self.summary["unique"])
-        out = dict(word=np.zeros(u, np.uint64), count=np.zeros(u, np.uint32),
+        wshape = (u, 2) if getattr(self, "_wide", False) else u
+        out = dict(word=np.zeros(wshape, np.uint64), count=np.zeros(u, np.uint32),
                    first_read=np.zeros(u, np.uint32), degree=np.zeros(u, np.uint32),
                    cluster_id=np.zeros(u, np.uint32), is_max_leaf=np.zeros(u, np.uint8))
         self._check(self._lib.humid_get_leaves(self._h, _vp(out["word"]), _vp(out["count"]),

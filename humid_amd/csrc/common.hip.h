@@ -57,6 +57,32 @@ __device__ __forceinline__ u32 nt_mismatch(u64 x) {
   return (u32)__popcll((x | (x >> 1)) & 0x5555555555555555ull);
 }
 
+// Wide words (33 <= n <= 64 nucleotides): hi = the first n-32 nucleotides (right-aligned), lo =
+// the last 32.  (hi, lo) lexicographic order == word order.  The graph kernels are templates over
+// the word type (u64 or W2) through these helpers.
+struct __attribute__((aligned(16))) W2 {
+  u64 hi, lo;
+};
+__host__ __device__ __forceinline__ u64 w_xor(u64 a, u64 b) { return a ^ b; }
+__host__ __device__ __forceinline__ W2 w_xor(W2 a, W2 b) { return W2{a.hi ^ b.hi, a.lo ^ b.lo}; }
+__host__ __device__ __forceinline__ bool w_hits(u64 x, u64 m) { return (x & m) != 0; }
+__host__ __device__ __forceinline__ bool w_hits(W2 x, W2 m) { return ((x.hi & m.hi) | (x.lo & m.lo)) != 0; }
+__device__ __forceinline__ u32 w_mismatch(u64 x) { return nt_mismatch(x); }
+__device__ __forceinline__ u32 w_mismatch(W2 x) { return nt_mismatch(x.hi) + nt_mismatch(x.lo); }
+// bits [shift, shift + width) of the word, width <= 64
+__host__ __device__ __forceinline__ u64 w_field(u64 w, u32 shift, u32 width) {
+  return (w >> shift) & ((width >= 64) ? ~0ull : ((1ull << width) - 1ull));
+}
+__host__ __device__ __forceinline__ u64 w_field(W2 w, u32 shift, u32 width) {
+  const unsigned __int128 v = ((unsigned __int128)w.hi << 64) | w.lo;
+  return (u64)(v >> shift) & ((width >= 64) ? ~0ull : ((1ull << width) - 1ull));
+}
+__host__ __device__ __forceinline__ bool w_less(W2 a, W2 b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+__host__ __device__ __forceinline__ bool w_eq(W2 a, W2 b) { return a.hi == b.hi && a.lo == b.lo; }
+template <class WT> __host__ __device__ __forceinline__ WT w_from(W2 m);
+template <> __host__ __device__ __forceinline__ u64 w_from<u64>(W2 m) { return m.lo; }
+template <> __host__ __device__ __forceinline__ W2 w_from<W2>(W2 m) { return m; }
+
 __device__ __forceinline__ u32 ld_agent(const u32 *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -117,8 +117,8 @@ int main(int argc, char **argv) {
     std::fprintf(stderr, "humid: edit distance (-e) is not supported by the HIP path (Hamming only)\n");
     return 2;
   }
-  if (a.word_length == 0 || a.word_length > 32) {
-    std::fprintf(stderr, "humid: word length %zu is not supported by the HIP path (1..32)\n", a.word_length);
+  if (a.word_length == 0 || a.word_length > 64) {
+    std::fprintf(stderr, "humid: word length %zu is not supported by the HIP path (1..64)\n", a.word_length);
     return 2;
   }
   std::ofstream log(a.log_name.c_str(), std::ios::out | std::ios::binary);
@@ -146,12 +146,13 @@ int main(int argc, char **argv) {
 
   // ---- pass 1: readData (src/humid.cc:89-100) ----
   t = start_message(log, "Reading data");
+  const size_t wpr = a.word_length > 32 ? 2 : 1;   // uint64 per word (include/humid_hip.h)
   std::vector<uint64_t> words;
   std::vector<uint8_t> filtered;
   if (fast) {
     size_t n = maps[0].records();
     for (auto &m : maps) n = m.records() < n ? m.records() : n;     // stop at the shortest file
-    words.resize(n);
+    words.resize(n * wpr);
     filtered.resize(n);
     const size_t nf = maps.size();
     parallel_ranges(n, threads, [&](size_t b, size_t e, unsigned) {
@@ -161,9 +162,13 @@ int main(int argc, char **argv) {
           maps[f].lines(i, nm, seqs[f], st, ql);
           if (f == 0) name0 = nm;
         }
-        uint64_t w;
-        filtered[i] = make_word(name0, seqs, nf, plan, w) ? 1 : 0;
-        words[i] = w;
+        if (wpr == 2) {
+          filtered[i] = make_word_wide(name0, seqs, nf, plan, &words[2 * i]) ? 1 : 0;
+        } else {
+          uint64_t w;
+          filtered[i] = make_word(name0, seqs, nf, plan, w) ? 1 : 0;
+          words[i] = w;
+        }
       }
     });
   } else {
@@ -171,19 +176,20 @@ int main(int argc, char **argv) {
     if (!in.ok()) { std::fprintf(stderr, "humid: cannot open %s\n", in.bad_file().c_str()); return 1; }
     std::vector<FastqRecord> recs;
     while (in.next(recs)) {
-      uint64_t w;
-      bool f = make_word(recs, plan, w);
-      words.push_back(w);
+      uint64_t w[2];
+      bool f = wpr == 2 ? make_word_wide(recs, plan, w) : make_word(recs, plan, w[0]);
+      words.push_back(w[0]);
+      if (wpr == 2) words.push_back(w[1]);
       filtered.push_back(f ? 1 : 0);
     }
   }
   end_message(log, t);
-  const uint64_t N = words.size();
+  const uint64_t N = filtered.size();
 
   if (!a.dump_words.empty()) {   // development aid: host-side parsing can be checked without a GPU
     std::ofstream out(a.dump_words, std::ios::out | std::ios::binary);
     out.write((const char *)&N, 8);
-    out.write((const char *)words.data(), (std::streamsize)(N * 8));
+    out.write((const char *)words.data(), (std::streamsize)(N * 8 * wpr));
     out.write((const char *)filtered.data(), (std::streamsize)N);
     return 0;
   }

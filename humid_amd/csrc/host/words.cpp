@@ -50,12 +50,13 @@ WordPlan make_plan(size_t first_header_umi, size_t n_files, size_t word_nt) {
 }
 
 // appends `want` symbols of `s` (cut or padded with a non-ACGT symbol) to the packed word
-static inline void push_symbols(std::string_view s, size_t want, uint64_t &w, bool &filtered) {
+template <class Acc>
+static inline void push_symbols(std::string_view s, size_t want, Acc &w, bool &filtered) {
   size_t have = s.size() < want ? s.size() : want;
   for (size_t i = 0; i < have; i++) {
     int c = code_of(s[i]);
     if (c < 0) { c = 2; filtered = true; }       // unknown base: code of 'G', word filtered
-    w = (w << 2) | (uint64_t)c;
+    w = (w << 2) | (Acc)c;
   }
   for (size_t i = have; i < want; i++) {         // 'N' padding of a short UMI / read
     w = (w << 2) | 2u;
@@ -71,6 +72,24 @@ bool make_word(std::string_view first_header, const std::string_view *seqs, size
   for (size_t f = 0; f < n_files; f++) push_symbols(seqs[f], plan.take[f], w, filtered);
   word = w;
   return filtered;
+}
+
+bool make_word_wide(std::string_view first_header, const std::string_view *seqs, size_t n_files,
+                    const WordPlan &plan, uint64_t word[2]) {
+  unsigned __int128 w = 0;
+  bool filtered = false;
+  if (plan.header_umi > 0) push_symbols(header_umi(first_header), plan.header_umi, w, filtered);
+  for (size_t f = 0; f < n_files; f++) push_symbols(seqs[f], plan.take[f], w, filtered);
+  word[0] = (uint64_t)(w >> 64);     // the first word_nt - 32 symbols
+  word[1] = (uint64_t)w;             // the last 32
+  return filtered;
+}
+
+bool make_word_wide(const std::vector<FastqRecord> &recs, const WordPlan &plan, uint64_t word[2]) {
+  std::string_view seqs[64];
+  const size_t n = recs.size() < 64 ? recs.size() : 64;
+  for (size_t f = 0; f < n; f++) seqs[f] = recs[f].seq;
+  return make_word_wide(recs.front().name, seqs, n, plan, word);
 }
 
 bool make_word(const std::vector<FastqRecord> &recs, const WordPlan &plan, uint64_t &word) {

@@ -38,6 +38,11 @@ bool make_word(const std::vector<FastqRecord> &recs, const WordPlan &plan, uint6
 bool make_word(std::string_view first_header, const std::string_view *seqs, size_t n_files,
                const WordPlan &plan, uint64_t &word);
 
+// 33 <= plan.word_nt <= 64: two uint64, [0] = the first word_nt-32 symbols, [1] = the last 32
+bool make_word_wide(const std::vector<FastqRecord> &recs, const WordPlan &plan, uint64_t word[2]);
+bool make_word_wide(std::string_view first_header, const std::string_view *seqs, size_t n_files,
+                    const WordPlan &plan, uint64_t word[2]);
+
 // <dir>/<basename with _suffix inserted before the first '.'>
 std::string make_file_name(const std::string &path, const std::string &dir, const std::string &suffix);
 

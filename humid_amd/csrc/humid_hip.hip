@@ -23,6 +23,7 @@
 #include "kernels_graph.hip.h"
 #include "kernels_cluster.hip.h"
 #include "kernels_map.hip.h"
+#include "kernels_wide.hip.h"
 
 // --------------------------------------------------------------------------------
 // host side
@@ -57,6 +58,9 @@ struct humid_ctx {
   DBuf pc, poff, share_edges;                                                     // multi-GPU pair-search share
   DBuf own_words;                                                                 // multi-GPU dense count
   DBuf heads;                                                                     // big-component heads
+  DBuf w_sorted, w_head, w_hpos, w_start;                                         // wide-word (sorted) counts
+  bool last_count_sorted = false;                                                 // last count was the wide-word sort
+  u32 g_wpr = 1;                                                                  // uint64 per word of g_word
   bool dense_mode = false;   // last count ran on a compacted list of this rank's reads
   bool slots_done = false;   // slot_out already written by k_finalize_nodes (one-GPU fusion)
   int count_mode = 0;        // 0: hash-partitioned LDS tables (default), 1: one global HBM table
@@ -74,7 +78,7 @@ struct humid_ctx {
   bool have_run = false;     // a full dedup run completed (all accessors valid)
   bool have_graph = false;   // stage B completed (leaf/adjacency/cluster accessors valid)
   bool graph_mode = false;   // last call was humid_cluster_graph
-  const u64 *g_word = nullptr;   // arrays stage B ran on
+  const void *g_word = nullptr;  // arrays stage B ran on (u64 or W2 per word)
   const u32 *g_cnt = nullptr;
   u32 gU = 0;
   u32 cap_log2 = 0;
@@ -167,7 +171,7 @@ static u64 n_choose_k(u32 n, u32 k) {
 static ComboPlan make_plan(u32 n, u32 d, u64 U, u32 force_segments) {
   ComboPlan p;
   memset(&p, 0, sizeof p);
-  if (d >= n) { p.ncombo = 1; p.key_bits = 0; p.mask[0] = 0; p.nfield[0] = 0; return p; }
+  if (d >= n) { p.ncombo = 1; p.key_bits = 0; p.mask[0] = W2{0, 0}; p.nfield[0] = 0; return p; }
   u32 want = 1;                                  // nucleotides of key wanted: 4^want >= U
   while (want < n && ((u64)1 << (2 * want)) < U) want++;
   u32 best_s = d + 1, best_len = 0;
@@ -200,17 +204,23 @@ static ComboPlan make_plan(u32 n, u32 d, u64 U, u32 force_segments) {
   for (u32 t = 0; t < k; t++) idx[t] = t;
   u32 c = 0, maxbits = 0;
   while (true) {
-    u64 m = 0;
-    u32 bits = 0;
-    for (u32 t = 0; t < k; t++) {
+    // A combo key holds at most 64 bits (only wide words can exceed that): the last field is cut
+    // to its top bits and later fields are dropped.  Two words within distance d still agree on the
+    // shortened mask of some combo, so the search stays complete; it only compares a few more pairs.
+    unsigned __int128 m = 0;
+    u32 bits = 0, nf = 0;
+    for (u32 t = 0; t < k && bits < 64; t++) {
       const u32 sg = idx[t];
-      p.shift[c][t] = (u8)seg_shift[sg];
-      p.width[c][t] = (u8)seg_width[sg];
-      m |= ((seg_width[sg] >= 64) ? ~0ull : (((u64)1 << seg_width[sg]) - 1)) << seg_shift[sg];
-      bits += seg_width[sg];
+      u32 wd = seg_width[sg], sh = seg_shift[sg];
+      if (bits + wd > 64) { const u32 cut = bits + wd - 64; wd -= cut; sh += cut; }
+      p.shift[c][nf] = (u8)sh;
+      p.width[c][nf] = (u8)wd;
+      m |= ((wd >= 64) ? (unsigned __int128)~0ull : (((unsigned __int128)1 << wd) - 1)) << sh;
+      bits += wd;
+      nf++;
     }
-    p.mask[c] = m;
-    p.nfield[c] = (u8)k;
+    p.mask[c] = W2{(u64)(m >> 64), (u64)m};
+    p.nfield[c] = (u8)nf;
     if (bits > maxbits) maxbits = bits;
     c++;
     int t = (int)k - 1;
@@ -311,6 +321,7 @@ static int stage_count_global(humid_ctx *c, const u64 *d_words, const u8 *d_filt
                               u64 range_lo, u64 range_hi, u64 expected_reads, humid_summary &s) {
   hipStream_t st = c->stream;
   c->last_count_lds = false;
+  c->last_count_sorted = false;
   if (expected_reads == 0 || expected_reads > N) expected_reads = N;
   u32 cap_log2 = 10;
   while (((u64)1 << cap_log2) < expected_reads + expected_reads / 2) cap_log2++;
@@ -368,6 +379,7 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   hipStream_t st = c->stream;
   *overflowed = false;
   c->last_count_lds = true;
+  c->last_count_sorted = false;
   c->last_count_ordered = ordered;
   const u32 lshift = 64 - 2 * word_nt;
   const u32 pb = part_bits(N);
@@ -505,17 +517,80 @@ static int stage_count(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N
   return stage_count_global(c, d_words, d_filt, N, word_nt, range_lo, range_hi, expected_reads, s);
 }
 
+// Stage A for wide words (two uint64 per read): counts by sorting, see kernels_wide.hip.h.
+// Leaves s_word (W2)/s_cnt/s_first/s_slot and, for stage C, the partition-order arrays
+// pk_vals/pslot in the context.
+static int stage_count_wide(humid_ctx *c, const W2 *d_words, const u8 *d_filt, u32 N, u32 word_nt, humid_summary &s) {
+  hipStream_t st = c->stream;
+  c->last_count_lds = true;          // stage C walks pk_vals/pslot (k_read_map_part)
+  c->last_count_ordered = false;
+  c->last_count_sorted = true;
+  const u32 hbits = 2 * (word_nt - 32);
+  const u32 grid = grid_stride_blocks(N);
+  ENSURE(c->pk_keys, (size_t)N * 8);
+  ENSURE(c->pad_word, (size_t)N * 8);
+  ENSURE(c->pk_vals, (size_t)N * 4);
+  ENSURE(c->uniq_slot, (size_t)N * 4 + 4);
+  ENSURE(c->pslot, (size_t)N * 4);
+  ENSURE(c->w_sorted, (size_t)N * sizeof(W2));
+  ENSURE(c->w_head, ((size_t)N + 1) * 4);
+  ENSURE(c->w_hpos, ((size_t)N + 1) * 4);
+  HIPCHK(hipEventRecord(c->ev[0], st));
+  HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_N * sizeof(ull), st));
+  HIPCHK(hipEventRecord(c->kev[0], st));
+  u64 *k0 = c->pk_keys.as<u64>(), *k1 = c->pad_word.as<u64>();
+  u32 *va = c->uniq_slot.as<u32>(), *vb = c->pk_vals.as<u32>();
+  hipLaunchKernelGGL(k_wide_keys_lo, dim3(grid), dim3(256), 0, st, d_words, d_filt, N, k0, va, c->d_ctr);
+  TRY(sort_pairs<u64, u32>(c, k0, k1, va, vb, N, 0, 64));                       // by lo
+  hipLaunchKernelGGL(k_wide_keys_hi, dim3(grid), dim3(256), 0, st, d_words, d_filt, vb, N, hbits, k0);
+  TRY(sort_pairs<u64, u32>(c, k0, k1, vb, va, N, 0, hbits < 64 ? hbits + 1 : 64));   // by (filtered,) hi
+  u32 *v = va;
+  if (hbits == 64) {                                                            // n = 64: no spare key bit
+    hipLaunchKernelGGL(k_wide_keys_flag, dim3(grid), dim3(256), 0, st, d_filt, va, N, (u32 *)k0);
+    TRY(sort_pairs<u32, u32>(c, (u32 *)k0, (u32 *)k1, va, vb, N, 0, 1));
+    v = vb;
+  }
+  HIPCHK(hipEventRecord(c->kev[1], st));
+  hipLaunchKernelGGL(k_wide_gather, dim3(grid), dim3(256), 0, st, d_words, v, N, hbits, c->w_sorted.as<W2>());
+  hipLaunchKernelGGL(k_wide_heads, dim3(grid), dim3(256), 0, st, c->w_sorted.as<W2>(), N, c->d_ctr,
+                     c->w_head.as<u32>());
+  TRY(exscan_u32(c, c->w_head.as<u32>(), c->w_hpos.as<u32>(), (u64)N + 1));
+  HIPCHK(hipGetLastError());
+  TRY(read_counters(c, c->w_hpos.as<u32>() + N));                               // h_ctr[CTR_N-1] = U
+  const u32 U = (u32)(c->h_ctr[CTR_N - 1] & 0xffffffffull);
+  s.usable = c->usable = c->h_ctr[CTR_USABLE];
+  s.unique = c->U = U;
+  ENSURE(c->s_word, (size_t)(U + 1) * sizeof(W2));
+  ENSURE(c->s_slot, (size_t)(U + 1) * 4);
+  ENSURE(c->s_cnt, (size_t)(U + 1) * 4);
+  ENSURE(c->s_first, (size_t)(U + 1) * 4);
+  ENSURE(c->w_start, (size_t)(U + 2) * 4);
+  ENSURE(c->slot_out, (size_t)(U + 1) * 8);
+  hipLaunchKernelGGL(k_wide_unique, dim3(grid), dim3(256), 0, st, c->w_sorted.as<W2>(), v, c->w_head.as<u32>(),
+                     c->w_hpos.as<u32>(), N, c->d_ctr, c->s_word.as<W2>(), c->s_first.as<u32>(),
+                     c->w_start.as<u32>(), c->pslot.as<u32>(), c->pk_vals.as<u32>());
+  if (U)
+    hipLaunchKernelGGL(k_wide_counts, dim3(blocks_for(U)), dim3(256), 0, st, c->w_start.as<u32>(), U,
+                       c->s_cnt.as<u32>(), c->s_slot.as<u32>());
+  HIPCHK(hipEventRecord(c->ev[1], st));
+  HIPCHK(hipGetLastError());
+  return HUMID_OK;
+}
+
 // ---- stage B: neighbours + clusters over a sorted unique array ---------------------------
 // g_word[U] ascending, g_cnt[U] (device; the context's own arrays on one GPU, the gathered
 // arrays of all ranks on several).  Leaves deg/nbr_off/nbr_idx/cl_of/maxleaf/cl_size/flag/
 // pos/cid/ismax in the context.
 // ext_edges != nullptr: the neighbour pairs are GIVEN (multi-GPU: every rank searched its share,
 // humid_stage_pairs, and the shares were all-gathered); otherwise they are searched here.
-static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U, u32 word_nt,
+// WT: u64 (n <= 32) or W2 (33 <= n <= 64, two uint64 per word).
+template <class WT>
+static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, u32 word_nt,
                        u32 distance, u32 method, humid_summary &s, u32 &n_pair_segs_out,
                        const u64 *ext_edges = nullptr, u64 n_ext_edges = 0) {
   hipStream_t st = c->stream;
   c->g_word = g_word;
+  c->g_wpr = (u32)(sizeof(WT) / 8);
   c->g_cnt = g_cnt;
   c->gU = U;
   // ---------------- 3. neighbours -----------------
@@ -532,8 +607,8 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
   u32 n_pair_segs = 0;
   c->h_plan = make_plan(word_nt, distance, U, c->force_segments);
   const ComboPlan &plan = c->h_plan;
-  EarlierMasks d_masks;                              // masks of all combos, for the first-combo rule
-  for (u32 t = 0; t < MAX_COMBOS; t++) d_masks.m[t] = plan.mask[t];
+  EarlierMasksT<WT> d_masks;                         // masks of all combos, for the first-combo rule
+  for (u32 t = 0; t < MAX_COMBOS; t++) d_masks.m[t] = w_from<WT>(plan.mask[t]);
   auto fields_of = [&](u32 cb) {
     ComboFields cf;
     cf.nf = plan.nfield[cb];
@@ -559,33 +634,33 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
       ENSURE(c->seg_v0, (size_t)U * 4);
       ENSURE(c->seg_ks, (size_t)U * 8);                     // sorted keys: scratch, not kept
       ENSURE(c->seg_vs, (size_t)(nseg - 1) * U * 4);        // ranks in bucket order, per combo
-      ENSURE(c->seg_ws, (size_t)(nseg - 1) * U * 8);        // words in bucket order, per combo
+      ENSURE(c->seg_ws, (size_t)(nseg - 1) * U * sizeof(WT));   // words in bucket order, per combo
     }
     // phase A: bucket order per combo; degrees and component forest
     for (u32 seg = 0; seg < nseg; seg++) {
       if (seg == 0) {
         HIPCHK(hipEventRecord(c->kev[20], st));
-        hipLaunchKernelGGL((k_pairs<true, PM_COUNT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
-                           (const u32 *)nullptr, U, 0u, U, plan.mask[seg], d_masks, seg, distance, c->deg.as<u32>(),
+        hipLaunchKernelGGL((k_pairs<true, PM_COUNT, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
+                           (const u32 *)nullptr, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, c->deg.as<u32>(),
                            c->parent.as<u32>(), (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
                            (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr);
       } else {
         u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
         const u32 kb = plan.key_bits ? plan.key_bits : 1;
         if (kb <= 32) {
-          hipLaunchKernelGGL(k_combo_keys<u32>, dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, fields_of(seg),
+          hipLaunchKernelGGL((k_combo_keys<u32, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, fields_of(seg),
                              c->seg_k0.as<u32>(), c->seg_v0.as<u32>());
           TRY(sort_pairs<u32, u32>(c, c->seg_k0.as<u32>(), c->seg_ks.as<u32>(), c->seg_v0.as<u32>(), vs, U, 0, kb));
         } else {
-          hipLaunchKernelGGL(k_combo_keys<u64>, dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, fields_of(seg),
+          hipLaunchKernelGGL((k_combo_keys<u64, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, fields_of(seg),
                              c->seg_k0.as<u64>(), c->seg_v0.as<u32>());
           TRY(sort_pairs<u64, u32>(c, c->seg_k0.as<u64>(), c->seg_ks.as<u64>(), c->seg_v0.as<u32>(), vs, U, 0, kb));
         }
-        u64 *ws = c->seg_ws.as<u64>() + (size_t)(seg - 1) * U;
-        hipLaunchKernelGGL(k_gather_bucket_words, dim3(blocks_for(U)), dim3(256), 0, st, g_word, vs, U, ws);
+        WT *ws = c->seg_ws.as<WT>() + (size_t)(seg - 1) * U;
+        hipLaunchKernelGGL(k_gather_bucket_words<WT>, dim3(blocks_for(U)), dim3(256), 0, st, g_word, vs, U, ws);
         if (seg < 8) HIPCHK(hipEventRecord(c->kev[20 + 2 * seg], st));
-        hipLaunchKernelGGL((k_pairs<false, PM_COUNT>), dim3(blocks_for(U)), dim3(256), 0, st, ws,
-                           vs, U, 0u, U, plan.mask[seg], d_masks, seg, distance, c->deg.as<u32>(), c->parent.as<u32>(),
+        hipLaunchKernelGGL((k_pairs<false, PM_COUNT, WT>), dim3(blocks_for(U)), dim3(256), 0, st, ws,
+                           vs, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, c->deg.as<u32>(), c->parent.as<u32>(),
                            (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
                            (const u32 *)nullptr, (u64 *)nullptr);
       }
@@ -618,15 +693,15 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
     for (u32 seg = 0; !given && seg < plan.ncombo; seg++) {
       if (seg < 8) HIPCHK(hipEventRecord(c->kev[4 + 2 * seg], st));
       if (seg == 0) {
-        hipLaunchKernelGGL((k_pairs<true, PM_FILL>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
-                           (const u32 *)nullptr, U, 0u, U, plan.mask[seg], d_masks, seg, distance, (u32 *)nullptr,
+        hipLaunchKernelGGL((k_pairs<true, PM_FILL, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
+                           (const u32 *)nullptr, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, (u32 *)nullptr,
                            (u32 *)nullptr, c->nbr_off.as<u32>(), c->cur.as<u32>(), c->nbr_idx.as<u32>(),
                            (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr);
       } else {
         const u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
-        const u64 *ws = c->seg_ws.as<u64>() + (size_t)(seg - 1) * U;
-        hipLaunchKernelGGL((k_pairs<false, PM_FILL>), dim3(blocks_for(U)), dim3(256), 0, st, ws,
-                           vs, U, 0u, U, plan.mask[seg], d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
+        const WT *ws = c->seg_ws.as<WT>() + (size_t)(seg - 1) * U;
+        hipLaunchKernelGGL((k_pairs<false, PM_FILL, WT>), dim3(blocks_for(U)), dim3(256), 0, st, ws,
+                           vs, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
                            c->nbr_off.as<u32>(), c->cur.as<u32>(), c->nbr_idx.as<u32>(),
                            (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr);
       }
@@ -641,7 +716,7 @@ static int stage_graph(humid_ctx *c, const u64 *g_word, const u32 *g_cnt, u32 U,
   TRY(cluster_stage(c, g_cnt, U, M, Mbig, method));
   // one GPU: the graph is over this context's own unique words, so the per-slot result words can
   // be written in the same pass (stage C then skips k_slot_results)
-  const bool own = (g_word == c->s_word.as<u64>()) && U == (u32)c->U && !given;
+  const bool own = ((const void *)g_word == c->s_word.p) && U == (u32)c->U && !given;
   hipLaunchKernelGGL(k_finalize_nodes, dim3(blocks_for(U)), dim3(256), 0, st, c->cl_of.as<u32>(),
                      c->pos.as<u32>(), c->maxleaf.as<u32>(), U, c->cid.as<u32>(), c->ismax.as<u8>(),
                      own ? c->s_first.as<u32>() : (const u32 *)nullptr,
@@ -666,8 +741,8 @@ static int stage_pairs_share(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt
   if (distance == 0 || U < 2) return HUMID_OK;
   c->h_plan = make_plan(word_nt, distance, U, c->force_segments);
   const ComboPlan &plan = c->h_plan;
-  EarlierMasks d_masks;
-  for (u32 t = 0; t < MAX_COMBOS; t++) d_masks.m[t] = plan.mask[t];
+  EarlierMasksT<u64> d_masks;
+  for (u32 t = 0; t < MAX_COMBOS; t++) d_masks.m[t] = plan.mask[t].lo;
   auto fields_of = [&](u32 cb) {
     ComboFields cf;
     cf.nf = plan.nfield[cb];
@@ -710,7 +785,7 @@ static int stage_pairs_share(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt
       HIPCHK(hipMemcpyAsync(vs, c->seg_v0.p, 4, hipMemcpyDeviceToDevice, st));
     }
     if (n_sel[seg])
-      hipLaunchKernelGGL(k_gather_bucket_words, dim3(blocks_for(n_sel[seg])), dim3(256), 0, st, g_word, vs,
+      hipLaunchKernelGGL(k_gather_bucket_words<u64>, dim3(blocks_for(n_sel[seg])), dim3(256), 0, st, g_word, vs,
                          n_sel[seg], c->seg_ws.as<u64>() + (size_t)(seg - 1) * U);
   }
   u64 T = 0;
@@ -731,20 +806,20 @@ static int stage_pairs_share(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt
       u64 *ed = c->share_edges.as<u64>();
       const dim3 grid(blocks_for(n_sel[seg])), blk(256);
       if (seg == 0 && phase == 0)
-        hipLaunchKernelGGL((k_pairs<true, PM_EMIT_COUNT>), grid, blk, 0, st, g_word, vs, U, p_lo, n_sel[0], plan.mask[0],
+        hipLaunchKernelGGL((k_pairs<true, PM_EMIT_COUNT, u64>), grid, blk, 0, st, g_word, vs, U, p_lo, n_sel[0], plan.mask[0].lo,
                            d_masks, 0u, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr,
                            (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed);
       else if (seg == 0)
-        hipLaunchKernelGGL((k_pairs<true, PM_EMIT_FILL>), grid, blk, 0, st, g_word, vs, U, p_lo, n_sel[0], plan.mask[0],
+        hipLaunchKernelGGL((k_pairs<true, PM_EMIT_FILL, u64>), grid, blk, 0, st, g_word, vs, U, p_lo, n_sel[0], plan.mask[0].lo,
                            d_masks, 0u, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr,
                            (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed);
       else if (phase == 0)
-        hipLaunchKernelGGL((k_pairs<false, PM_EMIT_COUNT>), grid, blk, 0, st, ws, vs, n_sel[seg], 0u, n_sel[seg],
-                           plan.mask[seg], d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
+        hipLaunchKernelGGL((k_pairs<false, PM_EMIT_COUNT, u64>), grid, blk, 0, st, ws, vs, n_sel[seg], 0u, n_sel[seg],
+                           plan.mask[seg].lo, d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
                            (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed);
       else
-        hipLaunchKernelGGL((k_pairs<false, PM_EMIT_FILL>), grid, blk, 0, st, ws, vs, n_sel[seg], 0u, n_sel[seg],
-                           plan.mask[seg], d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
+        hipLaunchKernelGGL((k_pairs<false, PM_EMIT_FILL, u64>), grid, blk, 0, st, ws, vs, n_sel[seg], 0u, n_sel[seg],
+                           plan.mask[seg].lo, d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
                            (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed);
     }
     if (phase == 0) {
@@ -788,23 +863,27 @@ static int stage_map(humid_ctx *c, const u32 *l_cid, const u8 *l_ismax, u32 N, u
   return HUMID_OK;
 }
 
-static int check_run_args(humid_ctx *c, u64 n_reads, u32 word_nt, u32 method) {
+static int check_run_args(humid_ctx *c, u64 n_reads, u32 word_nt, u32 method, u32 max_nt = 32) {
   if (word_nt == 0) return fail(c, HUMID_E_INVALID, "word_nt must be >= 1");
-  if (word_nt > 32) return fail(c, HUMID_E_UNSUPPORTED, "word_nt %u > 32 is not supported by the HIP path", word_nt);
+  if (word_nt > max_nt) return fail(c, HUMID_E_UNSUPPORTED, "word_nt %u > %u is not supported by this entry point", word_nt, max_nt);
   if (method > 1) return fail(c, HUMID_E_INVALID, "method must be 0 (directional) or 1 (maximum)");
   if (n_reads > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "n_reads %llu exceeds 2^31-1", (ull)n_reads);
   return HUMID_OK;
 }
 
 // ---- the full pipeline on device buffers (one GPU) -------------------------------------------
-static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_reads, u32 word_nt,
+// WT = u64: word_nt <= 32, one uint64 per read.  WT = W2: 33 <= word_nt <= 64, two per read.
+template <class WT>
+static int run_device(humid_ctx *c, const WT *d_words, const u8 *d_filt, u64 n_reads, u32 word_nt,
                       u32 distance, u32 method, u32 *d_cid, u8 *d_keep, humid_summary *sum) {
   if (!c) return HUMID_E_INVALID;
+  constexpr bool WIDE = sizeof(WT) == 16;
   c->have_run = false;
   c->graph_mode = false;
   c->have_graph = false;
   c->dense_mode = false;
-  TRY(check_run_args(c, n_reads, word_nt, method));
+  TRY(check_run_args(c, n_reads, word_nt, method, 64));
+  if (WIDE != (word_nt > 32)) return fail(c, HUMID_E_INVALID, "word layout does not match word_nt");
   if (n_reads && (!d_words || !d_filt || !d_cid || !d_keep)) return fail(c, HUMID_E_INVALID, "null buffer");
   HIPCHK(hipSetDevice(c->device));
   hipStream_t st = c->stream;
@@ -816,7 +895,8 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
   c->word_nt = word_nt; c->distance = distance; c->method = method;
   c->gU = 0;
   if (N == 0) { if (sum) *sum = s; c->have_run = c->have_graph = true; return HUMID_OK; }
-  TRY(stage_count(c, d_words, d_filt, N, word_nt, 0ull, ~0ull, 0, s));
+  if constexpr (WIDE) TRY(stage_count_wide(c, d_words, d_filt, N, word_nt, s));
+  else TRY(stage_count(c, d_words, d_filt, N, word_nt, 0ull, ~0ull, 0, s));
   const u32 U = (u32)c->U;
   if (U == 0) {   // everything filtered
     HIPCHK(hipMemsetAsync(d_cid, 0, (size_t)N * 4, st));
@@ -827,7 +907,7 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
     return HUMID_OK;
   }
   u32 n_pair_segs = 0;
-  TRY(stage_graph(c, c->s_word.as<u64>(), c->s_cnt.as<u32>(), U, word_nt, distance, method, s, n_pair_segs));
+  TRY(stage_graph<WT>(c, c->s_word.as<WT>(), c->s_cnt.as<u32>(), U, word_nt, distance, method, s, n_pair_segs));
   TRY(stage_map(c, c->cid.as<u32>(), c->ismax.as<u8>(), N, d_cid, d_keep));
   TRY(n_clusters_from_scan(c, U, &c->C));
   s.clusters = c->C;
@@ -840,7 +920,7 @@ static int run_device(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u64 n_
   HIPCHK(hipEventElapsedTime(&s.ms_k_insert, c->kev[0], c->kev[1]));
   if (c->last_count_lds) HIPCHK(hipEventElapsedTime(&s.ms_k_map, c->ev[3], c->kev[36]));   // k_read_map_part alone
   else s.ms_k_map = s.ms_map;   // ev[3]..ev[4] bracket exactly the k_read_map launch
-  s.count_mode_used = c->last_count_lds ? (c->last_count_ordered ? 2u : 0u) : 1u;
+  s.count_mode_used = c->last_count_sorted ? 3u : c->last_count_lds ? (c->last_count_ordered ? 2u : 0u) : 1u;
   HIPCHK(hipEventElapsedTime(&s.ms_k_cluster, c->kev[2], c->kev[3]));
   for (u32 g = 0; g < n_pair_segs; g++) {
     float t = 0;
@@ -914,7 +994,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
-                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->seg_ws, &c->csize, &c->cur, &c->plan_dev, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -957,7 +1037,9 @@ int humid_dedup_run_device(humid_ctx *c, const uint64_t *d_words, const uint8_t 
                            uint64_t n_reads, uint32_t word_nt, uint32_t distance, uint32_t method,
                            uint32_t *d_cluster_id, uint8_t *d_keep, humid_summary *summary) {
   if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
-  return run_device(c, d_words, d_filtered, n_reads, word_nt, distance, method, d_cluster_id, d_keep, summary);
+  if (word_nt > 32)
+    return run_device<W2>(c, (const W2 *)d_words, d_filtered, n_reads, word_nt, distance, method, d_cluster_id, d_keep, summary);
+  return run_device<u64>(c, d_words, d_filtered, n_reads, word_nt, distance, method, d_cluster_id, d_keep, summary);
 }
 
 int humid_dedup_run(humid_ctx *c, const uint64_t *words, const uint8_t *filtered, uint64_t n_reads,
@@ -974,18 +1056,22 @@ int humid_dedup_run(humid_ctx *c, const uint64_t *words, const uint8_t *filtered
   hipEvent_t e1, e2, e3;
   HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2)); HIPCHK(hipEventCreate(&e3));
   size_t n = (size_t)n_reads;
-  ENSURE(c->in_words, n * 8 + 8);
+  const size_t wbytes = word_nt > 32 ? 16 : 8;
+  ENSURE(c->in_words, n * wbytes + 16);
   ENSURE(c->in_filt, n + 8);
   ENSURE(c->out_cid, n * 4 + 8);
   ENSURE(c->out_keep, n + 8);
   HIPCHK(hipEventRecord(e0, st));
   if (n) {
-    HIPCHK(hipMemcpyAsync(c->in_words.p, words, n * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->in_words.p, words, n * wbytes, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->in_filt.p, filtered, n, hipMemcpyHostToDevice, st));
   }
   HIPCHK(hipEventRecord(e1, st));
-  int rc = run_device(c, c->in_words.as<u64>(), c->in_filt.as<u8>(), n_reads, word_nt, distance, method,
-                      c->out_cid.as<u32>(), c->out_keep.as<u8>(), &s);
+  int rc = word_nt > 32
+               ? run_device<W2>(c, c->in_words.as<W2>(), c->in_filt.as<u8>(), n_reads, word_nt, distance, method,
+                                c->out_cid.as<u32>(), c->out_keep.as<u8>(), &s)
+               : run_device<u64>(c, c->in_words.as<u64>(), c->in_filt.as<u8>(), n_reads, word_nt, distance, method,
+                                 c->out_cid.as<u32>(), c->out_keep.as<u8>(), &s);
   if (rc == HUMID_OK) {
     hipError_t he = hipEventRecord(e2, st);
     if (he == hipSuccess && n) he = hipMemcpyAsync(cluster_id, c->out_cid.p, n * 4, hipMemcpyDeviceToHost, st);
@@ -1018,7 +1104,7 @@ int humid_get_leaves(humid_ctx *c, uint64_t *word, uint32_t *count, uint32_t *fi
   if (U == 0) return HUMID_OK;
   if (first_read && !c->have_run)
     return fail(c, HUMID_E_STATE, "first_read is only available after a single-GPU humid_dedup_run*");
-  D2H(word, c->g_word, U * 8);
+  D2H(word, c->g_word, U * 8 * c->g_wpr);
   D2H(count, c->g_cnt, U * 4);
   D2H(first_read, c->s_first.p, U * 4);
   D2H(degree, c->deg.p, U * 4);

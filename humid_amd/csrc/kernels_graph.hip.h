@@ -21,7 +21,7 @@
 struct ComboPlan {
   u32 ncombo;
   u32 key_bits;                       // bits of a combo key (sum of its field widths)
-  u64 mask[MAX_COMBOS];
+  W2 mask[MAX_COMBOS];                // hi = 0 for one-word plans; at most 64 bits set (= the key)
   u8 nfield[MAX_COMBOS];
   u8 shift[MAX_COMBOS][MAX_FIELDS];   // fields from most to least significant
   u8 width[MAX_COMBOS][MAX_FIELDS];
@@ -33,8 +33,9 @@ struct ComboPlan {
 // kernarg segment -- and equally a plan freshly uploaded to device memory and read through
 // wave-uniform (scalar) loads -- returned stale fields for single waves on gfx950 / ROCm 7.2
 // (5-25 of 219 k edges lost at 10 M reads, tools/det_check.py), so neither form is used.
-struct EarlierMasks {
-  u64 m[MAX_COMBOS];
+template <class WT>
+struct EarlierMasksT {
+  WT m[MAX_COMBOS];
 };
 
 // fields of ONE combo
@@ -44,18 +45,18 @@ struct ComboFields {
   u8 width[MAX_FIELDS];
 };
 
-template <class KeyT>
-__global__ void k_combo_keys(const u64 *__restrict__ s_word, u32 n, ComboFields cf,
+template <class KeyT, class WT>
+__global__ void k_combo_keys(const WT *__restrict__ s_word, u32 n, ComboFields cf,
                              KeyT *__restrict__ key, u32 *__restrict__ val) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const u64 w = s_word[i];
+  const WT w = s_word[i];
   u64 k = 0;
 #pragma unroll
   for (u32 f = 0; f < MAX_FIELDS; f++) {
     if (f < cf.nf) {
       const u32 wd = cf.width[f];
-      k = (k << wd) | ((w >> cf.shift[f]) & ((wd >= 64) ? ~0ull : ((1ull << wd) - 1ull)));
+      k = ((wd >= 64) ? 0ull : (k << wd)) | w_field(w, cf.shift[f], wd);
     }
   }
   key[i] = (KeyT)k;
@@ -98,10 +99,10 @@ __device__ __forceinline__ void uf_union(u32 *P, u32 a, u32 b) {
 // second runs on to the end of the bucket anywhere in [0, n).
 enum { PM_COUNT = 0, PM_FILL = 1, PM_EMIT_COUNT = 2, PM_EMIT_FILL = 3 };
 
-template <bool PASS0, int MODE>
+template <bool PASS0, int MODE, class WT>
 __global__ void __launch_bounds__(256)
-k_pairs(const u64 *__restrict__ W, const u32 *__restrict__ V, u32 n, u32 i0, u32 n_i, u64 mask,
-        EarlierMasks em, u32 cb, u32 distance, u32 *deg, u32 *parent,
+k_pairs(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, u32 i0, u32 n_i, WT mask,
+        EarlierMasksT<WT> em, u32 cb, u32 distance, u32 *deg, u32 *parent,
         const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, u32 *__restrict__ pc,
         const u32 *__restrict__ poff, u64 *__restrict__ edges) {
   // W: the words IN THE ORDER WALKED (the sorted unique array for the prefix combo, a gathered
@@ -110,18 +111,18 @@ k_pairs(const u64 *__restrict__ W, const u32 *__restrict__ V, u32 n, u32 i0, u32
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_i) return;
   const u32 i = i0 + t;
-  const u64 wi = W[i];
+  const WT wi = W[i];
   const u32 ri = PASS0 ? i : V[i];
   u32 found = 0;
   u64 e = (MODE == PM_EMIT_FILL) ? (u64)poff[t] : 0;
   for (u32 j = i + 1; j < n; j++) {
-    const u64 x = wi ^ W[j];
-    if (x & mask) break;                           // left the bucket
-    if (nt_mismatch(x) > distance) continue;
+    const WT x = w_xor(wi, W[j]);
+    if (w_hits(x, mask)) break;                    // left the bucket
+    if (w_mismatch(x) > distance) continue;
     bool first = true;
 #pragma unroll
     for (u32 q = 0; q < MAX_COMBOS; q++)
-      first = first && !(q < cb && (x & em.m[q]) == 0);
+      first = first && !(q < cb && !w_hits(x, em.m[q]));
     if (!first) continue;
     const u32 rj = PASS0 ? j : V[j];
     if (MODE == PM_FILL) {
@@ -142,8 +143,9 @@ k_pairs(const u64 *__restrict__ W, const u32 *__restrict__ V, u32 n, u32 i0, u32
 }
 
 // words of a sorted combo in bucket order (one gather per combo instead of one per comparison)
-__global__ void k_gather_bucket_words(const u64 *__restrict__ s_word, const u32 *__restrict__ V, u32 n,
-                                      u64 *__restrict__ wv) {
+template <class WT>
+__global__ void k_gather_bucket_words(const WT *__restrict__ s_word, const u32 *__restrict__ V, u32 n,
+                                      WT *__restrict__ wv) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) wv[i] = s_word[V[i]];
 }
@@ -185,7 +187,7 @@ k_select_keyrange(const u64 *__restrict__ s_word, u32 n, ComboFields cf, u64 klo
     for (u32 f = 0; f < MAX_FIELDS; f++) {
       if (f < cf.nf) {
         const u32 wd = cf.width[f];
-        k = (k << wd) | ((w >> cf.shift[f]) & ((wd >= 64) ? ~0ull : ((1ull << wd) - 1ull)));
+        k = ((wd >= 64) ? 0ull : (k << wd)) | w_field(w, cf.shift[f], wd);
       }
     }
     return k;

@@ -14,7 +14,7 @@ import os
 
 import numpy as np
 
-__all__ = ["synth_words", "synth_fastq", "CONFIG_SEEDS", "pack_bases"]
+__all__ = ["synth_words", "synth_wide_words", "synth_fastq", "CONFIG_SEEDS", "pack_bases"]
 
 CONFIG_SEEDS = {1: 1001, 2: 1002, 3: 1003, 4: 1004, 5: 1005}
 
@@ -101,6 +101,57 @@ def synth_words(n_reads: int, seed: int, word_nt: int = 24, p_sub: float = 1e-3,
         shift = (2 * (word_nt - 1 - pos)).astype(np.uint64)
         for r, s in zip(rd.tolist(), shift.tolist()):
             words[r] = (int(words[r]) & ~(3 << s)) | (2 << s)
+    if shuffle and n_reads:
+        perm = rng.permutation(n_reads)
+        words = words[perm]
+        filtered = filtered[perm]
+    return np.ascontiguousarray(words), np.ascontiguousarray(filtered)
+
+
+def _rand_bits(rng, bits, size):
+    """uniform integers of `bits` (<= 64) bits as uint64"""
+    if bits == 0:
+        return np.zeros(size, dtype=np.uint64)
+    if bits < 64:
+        return rng.integers(0, 1 << bits, size=size, dtype=np.uint64)
+    return rng.integers(0, 1 << 63, size=size, dtype=np.uint64) * np.uint64(2) + \
+        rng.integers(0, 2, size=size, dtype=np.uint64)
+
+
+def synth_wide_words(n_reads: int, seed: int, word_nt: int = 48, p_sub: float = 1e-3,
+                     p_n: float = 1e-4, shuffle: bool = True):
+    """`synth_words` mode "umi" for 33 <= word_nt <= 64: u64[N, 2] words ([:, 0] = the first
+    word_nt-32 nucleotides, [:, 1] = the last 32) + filtered flags."""
+    if not (33 <= word_nt <= 64):
+        raise ValueError("word_nt must be 33..64")
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mol, n_mol = _family_of_read(rng, n_reads)
+    nh = word_nt - 32
+    words = np.stack([_rand_bits(rng, 2 * nh, n_mol)[mol], _rand_bits(rng, 64, n_mol)[mol]], axis=1) \
+        if n_reads else np.zeros((0, 2), dtype=np.uint64)
+    total_bases = n_reads * word_nt
+
+    def place(pos):   # nucleotide position -> (column, bit shift)
+        col = (pos >= nh).astype(np.int64)
+        shift = np.where(pos < nh, 2 * (nh - 1 - pos), 2 * (word_nt - 1 - pos)).astype(np.uint64)
+        return col, shift
+
+    k = int(rng.binomial(total_bases, p_sub)) if total_bases else 0
+    if k:
+        idx = rng.integers(0, total_bases, size=k)
+        rd, (col, shift) = idx // word_nt, place(idx % word_nt)
+        delta = rng.integers(1, 4, size=k).astype(np.uint64)
+        for r, c, sh, dl in zip(rd.tolist(), col.tolist(), shift.tolist(), delta.tolist()):
+            old = (int(words[r, c]) >> sh) & 3
+            words[r, c] = int(words[r, c]) ^ ((old ^ ((old + dl) & 3)) << sh)
+    filtered = np.zeros(n_reads, dtype=np.uint8)
+    k2 = int(rng.binomial(total_bases, p_n)) if total_bases else 0
+    if k2:
+        idx = rng.integers(0, total_bases, size=k2)
+        rd, (col, shift) = idx // word_nt, place(idx % word_nt)
+        filtered[rd] = 1
+        for r, c, sh in zip(rd.tolist(), col.tolist(), shift.tolist()):   # code of 'G', src/fastq.cc:156
+            words[r, c] = (int(words[r, c]) & ~(3 << sh)) | (2 << sh)
     if shuffle and n_reads:
         perm = rng.permutation(n_reads)
         words = words[perm]

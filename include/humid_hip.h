@@ -14,8 +14,12 @@
  * Packed word: nucleotide i (A0 C1 G2 T3, src/fastq.cc:12) of an n-symbol word
  * (n = -n word length, src/humid.cc:419) occupies bits [2(n-1-i), 2(n-1-i)+1] of a
  * uint64, so unsigned integer order == lexicographic order == Trie::walk() order.
- * This library handles n <= 32 (one uint64 per read); n > 32 returns
- * HUMID_E_UNSUPPORTED (all BASELINE.json configs use n = 24).
+ * n <= 32: one uint64 per read (all BASELINE.json configs use n = 24).
+ * 33 <= n <= 64 ("wide" words): TWO uint64 per read, [2r] = the first n-32 nucleotides packed the
+ * same way (right-aligned), [2r+1] = the last 32; every words / word array of the single-GPU entry
+ * points (humid_dedup_run, humid_dedup_run_device, humid_get_leaves) then holds 2 entries per
+ * read / leaf, 16-byte aligned on the device.  n > 64, and n > 32 in the multi-GPU humid_stage_*
+ * entry points, return HUMID_E_UNSUPPORTED.
  */
 #ifndef HUMID_HIP_H
 #define HUMID_HIP_H
@@ -29,7 +33,7 @@ extern "C" {
 
 #define HUMID_OK             0
 #define HUMID_E_INVALID     -1   /* bad argument                                    */
-#define HUMID_E_UNSUPPORTED -2   /* word_nt > 32, edit distance (-e)                */
+#define HUMID_E_UNSUPPORTED -2   /* word_nt > 64 (stages: > 32), edit distance (-e)  */
 #define HUMID_E_NOMEM       -3   /* device or host allocation failed                */
 #define HUMID_E_HIP         -4   /* HIP runtime error (text in humid_last_error)    */
 #define HUMID_E_OVERFLOW    -5   /* an index exceeded 32 bits (reads, 2*edges)      */
@@ -63,7 +67,7 @@ typedef struct humid_summary {
   float ms_k_cluster;   /* k_cluster_pairs + _small (+ _components): 2-3 launches   */
   float ms_k_map;       /* k_read_map_part or k_read_map (one launch)               */
   uint32_t count_mode_used;  /* 0 = LDS tables, hashed buckets; 2 = LDS tables, word-ordered buckets;
-                              * 1 = global HBM table (option or fallback)                        */
+                              * 1 = global HBM table (option or fallback); 3 = sorted (wide words) */
 } humid_summary;
 
 uint32_t humid_abi_version(void);
@@ -93,7 +97,7 @@ int  humid_ctx_set_option(humid_ctx *ctx, const char *key, int64_t value);
  *   findHammingNeighbours(trie, d)      src/humid.cc:113-130 (lib/trie walk x asymmetricHamming)
  *   findClusters(trie, maximum)         src/humid.cc:167-193 + src/cluster.cc:10-87
  *   trie.find(word)->leaf->cluster ...  src/humid.cc:223-231 (keep), :276-277 (cluster id)
- * words[N], filtered[N] in; cluster_id[N] (0 = filtered, ids 1.. in the order
+ * words[N] (2N uint64 when word_nt > 32), filtered[N] in; cluster_id[N] (0 = filtered, ids 1.. in the order
  * src/humid.cc:177-180 hands them out) and keep[N] (1 = the record writeFiltered
  * emits: the first read, in input order, whose word is its cluster's maxLeaf) out.
  * Host buffers, caller-owned; summary may be NULL. */

@@ -380,6 +380,7 @@ static void arena_free(Arena *a) {
 
 struct orc_ctx {
   uint32_t n;          /* word length in nucleotides */
+  uint32_t wpr;        /* uint64 per word: 1 (n <= 32) or 2 */
   ONode *root;
   Arena nodes, leaves;
   uint64_t total, usable, unique, edges;
@@ -388,23 +389,29 @@ struct orc_ctx {
   size_t n_clusters, cap_clusters;
 };
 
-static inline unsigned sym(uint64_t w, uint32_t n, uint32_t i) {
-  return (unsigned)((w >> (2u * (n - 1u - i))) & 3u);
+/* symbol i (0 = first nucleotide) of a packed word.  n <= 32: one uint64.  33 <= n <= 64: two,
+ * w[0] = the first n-32 nucleotides (right-aligned), w[1] = the last 32 (the C ABI's layout). */
+static inline unsigned sym(const uint64_t *w, uint32_t n, uint32_t i) {
+  if (n <= 32) return (unsigned)((w[0] >> (2u * (n - 1u - i))) & 3u);
+  const uint32_t nh = n - 32;
+  if (i < nh) return (unsigned)((w[0] >> (2u * (nh - 1u - i))) & 3u);
+  return (unsigned)((w[1] >> (2u * (n - 1u - i))) & 3u);
 }
 
 orc_ctx *orc_create(uint32_t n) {
-  if (n == 0 || n > 32) return NULL;
+  if (n == 0 || n > 64) return NULL;
   orc_ctx *c = (orc_ctx *)xcalloc(1, sizeof(*c));
   c->n = n;
+  c->wpr = n > 32 ? 2 : 1;
   c->nodes.item = sizeof(ONode);
   c->leaves.item = sizeof(OLeaf);
   c->root = (ONode *)arena_new(&c->nodes);
   return c;
 }
 
-static void walk_leaves(const orc_ctx *c, void (*fn)(OLeaf *, uint64_t, void *), void *arg);
+static void walk_leaves(const orc_ctx *c, void (*fn)(OLeaf *, const uint64_t *, void *), void *arg);
 
-static void free_leaf_cb(OLeaf *l, uint64_t w, void *arg) {
+static void free_leaf_cb(OLeaf *l, const uint64_t *w, void *arg) {
   (void)w; (void)arg;
   free(l->nbr);
 }
@@ -420,7 +427,7 @@ void orc_destroy(orc_ctx *c) {
 }
 
 /* Trie::add (call site src/humid.cc:95): descend/create n nodes, leaf->count++ */
-static OLeaf *trie_add(orc_ctx *c, uint64_t w) {
+static OLeaf *trie_add(orc_ctx *c, const uint64_t *w) {
   ONode *node = c->root;
   for (uint32_t i = 0; i < c->n; i++) {
     unsigned s = sym(w, c->n, i);
@@ -436,7 +443,7 @@ static OLeaf *trie_add(orc_ctx *c, uint64_t w) {
 }
 
 /* Trie::find (call sites src/humid.cc:223,276) */
-static OLeaf *trie_find(const orc_ctx *c, uint64_t w) {
+static OLeaf *trie_find(const orc_ctx *c, const uint64_t *w) {
   const ONode *node = c->root;
   for (uint32_t i = 0; i < c->n; i++) {
     node = node->child[sym(w, c->n, i)];
@@ -447,17 +454,22 @@ static OLeaf *trie_find(const orc_ctx *c, uint64_t w) {
 
 /* Trie::walk (call sites src/humid.cc:117,178,307): depth-first, children in
  * index order 0..3 => ascending lexicographic == ascending packed word. */
-static void walk_leaves(const orc_ctx *c, void (*fn)(OLeaf *, uint64_t, void *), void *arg) {
-  const ONode *stack_node[34];
-  unsigned stack_next[34];
-  uint64_t path = 0;
+static void walk_leaves(const orc_ctx *c, void (*fn)(OLeaf *, const uint64_t *, void *), void *arg) {
+  const ONode *stack_node[66];
+  unsigned stack_next[66];
+  unsigned __int128 path = 0;
   int depth = 0;
   stack_node[0] = c->root;
   stack_next[0] = 0;
   while (depth >= 0) {
     const ONode *node = stack_node[depth];
     if ((uint32_t)depth == c->n) {
-      if (node->leaf) fn(node->leaf, path, arg);
+      if (node->leaf) {
+        uint64_t w[2];
+        if (c->wpr == 1) { w[0] = (uint64_t)path; w[1] = 0; }
+        else { w[0] = (uint64_t)(path >> 64); w[1] = (uint64_t)path; }
+        fn(node->leaf, w, arg);
+      }
       depth--;
       path >>= 2;
       continue;
@@ -485,7 +497,7 @@ static void walk_leaves(const orc_ctx *c, void (*fn)(OLeaf *, uint64_t, void *),
  * src/humid.cc:120). */
 typedef struct {
   const orc_ctx *c;
-  uint64_t word;
+  const uint64_t *word;
   OLeaf *from;
   uint64_t pairs;
 } HamArg;
@@ -512,7 +524,7 @@ static void asym_hamming_(HamArg *a, const ONode *node, uint32_t position, int d
 void orc_read_data(orc_ctx *c, const uint64_t *words, const uint8_t *filtered, uint64_t n_reads) {
   for (uint64_t r = 0; r < n_reads; r++) {       /* src/humid.cc:92-99 */
     if (!(filtered && filtered[r])) {
-      trie_add(c, words[r]);
+      trie_add(c, words + r * c->wpr);
       c->usable++;
     }
     c->total++;
@@ -520,13 +532,13 @@ void orc_read_data(orc_ctx *c, const uint64_t *words, const uint8_t *filtered, u
 }
 
 typedef struct { orc_ctx *c; uint32_t distance; size_t k; } NbArg;
-static void collect_cb(OLeaf *l, uint64_t w, void *arg) {
+static void collect_cb(OLeaf *l, const uint64_t *w, void *arg) {
   (void)w;
   NbArg *a = (NbArg *)arg;
   l->rank = (uint32_t)a->k;
   a->c->walk[a->k++] = l;
 }
-static void neighbours_cb(OLeaf *l, uint64_t w, void *arg) {
+static void neighbours_cb(OLeaf *l, const uint64_t *w, void *arg) {
   NbArg *a = (NbArg *)arg;
   HamArg h = {a->c, w, l, 0};
   asym_hamming_(&h, a->c->root, 0, (int)a->distance, 0);
@@ -545,7 +557,7 @@ uint64_t orc_find_hamming_neighbours(orc_ctx *c, uint32_t distance) {
 }
 
 typedef struct { orc_ctx *c; int maximum; size_t id; } ClArg;
-static void clusters_cb(OLeaf *l, uint64_t w, void *arg) {
+static void clusters_cb(OLeaf *l, const uint64_t *w, void *arg) {
   (void)w;
   ClArg *a = (ClArg *)arg;
   orc_ctx *c = a->c;
@@ -577,7 +589,7 @@ void orc_map_reads(orc_ctx *c, const uint64_t *words, const uint8_t *filtered,
     uint32_t id = 0;            /* :272 cluster 0 = could not be clustered */
     uint8_t k = 0;
     if (!(filtered && filtered[r])) {
-      OLeaf *leaf = trie_find(c, words[r]);
+      OLeaf *leaf = trie_find(c, words + r * c->wpr);
       if (!leaf->cluster->visited && leaf->cluster->maxLeaf == leaf) {  /* :224-226 */
         k = 1;
         leaf->cluster->visited = 1;                                     /* :231 */
@@ -596,12 +608,12 @@ uint64_t orc_n_clusters(const orc_ctx *c) { return c->n_clusters; }
 uint64_t orc_n_edges(const orc_ctx *c) { return c->edges; }
 
 typedef struct {
-  uint64_t *word, *count; uint32_t *degree, *cluster_id; uint8_t *is_max; size_t k;
+  uint64_t *word, *count; uint32_t *degree, *cluster_id; uint8_t *is_max; size_t k; uint32_t wpr;
 } ExArg;
-static void export_cb(OLeaf *l, uint64_t w, void *arg) {
+static void export_cb(OLeaf *l, const uint64_t *w, void *arg) {
   ExArg *a = (ExArg *)arg;
   size_t k = a->k++;
-  if (a->word) a->word[k] = w;
+  if (a->word) { for (uint32_t q = 0; q < a->wpr; q++) a->word[k * a->wpr + q] = w[q]; }
   if (a->count) a->count[k] = l->count;
   if (a->degree) a->degree[k] = (uint32_t)l->nn;
   if (a->cluster_id) a->cluster_id[k] = l->cluster ? (uint32_t)l->cluster->id : 0;
@@ -609,7 +621,7 @@ static void export_cb(OLeaf *l, uint64_t w, void *arg) {
 }
 void orc_export_leaves(const orc_ctx *c, uint64_t *word, uint64_t *count,
                        uint32_t *degree, uint32_t *cluster_id, uint8_t *is_max_leaf) {
-  ExArg a = {word, count, degree, cluster_id, is_max_leaf, 0};
+  ExArg a = {word, count, degree, cluster_id, is_max_leaf, 0, c->wpr};
   walk_leaves(c, export_cb, &a);
 }
 

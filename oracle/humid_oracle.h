@@ -27,6 +27,8 @@
  * Packed-word layout (the C-ABI's, not the reference's): nucleotide i of an
  * n-symbol word (A0 C1 G2 T3, src/fastq.cc:12) sits in bits [2(n-1-i), 2(n-1-i)+1]
  * of a uint64 (n <= 32), so integer order == lexicographic order == trie order.
+ * 33 <= n <= 64: two uint64 per word, [0] = the first n-32 nucleotides (right-aligned),
+ * [1] = the last 32; every `words` array then holds 2 entries per read / leaf.
  */
 #ifndef HUMID_ORACLE_H
 #define HUMID_ORACLE_H

@@ -201,7 +201,8 @@ class Pipeline:
     def __init__(self, word_nt):
         self.h = lib().orc_create(word_nt)
         if not self.h:
-            raise ValueError("word_nt must be 1..32")
+            raise ValueError("word_nt must be 1..64")
+        self.wpr = 2 if word_nt > 32 else 1   # wide words: (N, 2) uint64 arrays, [hi, lo]
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -209,8 +210,9 @@ class Pipeline:
             self.h = None
 
     def read_data(self, words, filtered):
-        self._w = np.ascontiguousarray(words, dtype=np.uint64)
+        self._w = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1, self.wpr)
         self._f = np.ascontiguousarray(filtered, dtype=np.uint8)
+        assert len(self._f) == len(self._w)
         lib().orc_read_data(self.h, _p(self._w, u64p), _p(self._f, u8p), len(self._w))
 
     def find_hamming_neighbours(self, distance):
@@ -247,7 +249,7 @@ class Pipeline:
 
     def leaves(self):
         u = self.unique
-        word = np.zeros(u, dtype=np.uint64)
+        word = np.zeros(u if self.wpr == 1 else (u, 2), dtype=np.uint64)
         count = np.zeros(u, dtype=np.uint64)
         deg = np.zeros(u, dtype=np.uint32)
         cid = np.zeros(u, dtype=np.uint32)
@@ -274,9 +276,10 @@ class Pipeline:
 
 def dedup_run(words, filtered, word_nt, distance=1, method=0):
     """One-call oracle run.  Returns (cluster_id, keep, summary dict, phase seconds)."""
-    w = np.ascontiguousarray(words, dtype=np.uint64)
+    w = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1, 2 if word_nt > 32 else 1)
     f = np.ascontiguousarray(filtered, dtype=np.uint8)
     n = len(w)
+    assert len(f) == n
     cid = np.zeros(n, dtype=np.uint32)
     keep = np.zeros(n, dtype=np.uint8)
     s = np.zeros(4, dtype=np.uint64)

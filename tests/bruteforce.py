@@ -25,7 +25,12 @@ def nt_hamming(a, b):
 
 
 def unique_counts(words, filtered):
+    """1-D words (n <= 32) or (N, 2) [hi, lo] wide words: rows sort lexicographically."""
     w = np.asarray(words, dtype=np.uint64)[np.asarray(filtered) == 0]
+    if w.ndim == 2:
+        if len(w) == 0:
+            return w.reshape(0, 2), np.zeros(0, dtype=np.int64)
+        return np.unique(w, axis=0, return_counts=True)
     return np.unique(w, return_counts=True)
 
 
@@ -35,7 +40,10 @@ def adjacency(uw, distance):
     out = []
     if u == 0:
         return out
-    d = nt_hamming(uw[:, None], uw[None, :])
+    if uw.ndim == 2:
+        d = nt_hamming(uw[:, None, 0], uw[None, :, 0]) + nt_hamming(uw[:, None, 1], uw[None, :, 1])
+    else:
+        d = nt_hamming(uw[:, None], uw[None, :])
     for i in range(u):
         nb = np.nonzero((d[i] <= distance) & (np.arange(u) != i))[0]
         out.append(nb.tolist())
@@ -102,7 +110,8 @@ def dedup(words, filtered, distance=1, maximum=False):
     uw, cnt = unique_counts(words, filtered)
     nbrs = adjacency(uw, distance)
     cl, info = cluster(cnt, nbrs, maximum)
-    rank = {int(w): i for i, w in enumerate(uw.tolist())}
+    key = (lambda w: tuple(int(x) for x in w)) if words.ndim == 2 else int
+    rank = {key(w): i for i, w in enumerate(uw.tolist())}
     n = len(words)
     cid = np.zeros(n, dtype=np.uint32)
     keep = np.zeros(n, dtype=np.uint8)
@@ -110,7 +119,7 @@ def dedup(words, filtered, distance=1, maximum=False):
     for r in range(n):
         if filtered[r]:
             continue
-        l = rank[int(words[r])]
+        l = rank[key(words[r])]
         c = cl[l]
         cid[r] = c
         if c not in visited and info[c]["maxLeaf"] == l:

@@ -25,12 +25,17 @@ def expected_words(files, word_nt):
     n = min(len(r) for r in recs)
     first_umi = len(orc.extract_umi(recs[0][0][0])) if n else 0
     hdr, take = orc.pre_compute(first_umi, len(files), word_nt)
-    words = np.zeros(n, dtype=np.uint64)
+    wide = word_nt > 32      # two uint64 per word: [first word_nt-32 symbols, last 32]
+    words = np.zeros((n, 2) if wide else n, dtype=np.uint64)
     filt = np.zeros(n, dtype=np.uint8)
     for i in range(n):
         nuc = orc.get_nucleotides(recs[0][i][0], [r[i][1] for r in recs], take, hdr)
         data, fl = orc.make_word(nuc)
-        words[i] = orc.pack_word(data)
+        if wide:
+            words[i, 0] = orc.pack_word(data[:word_nt - 32])
+            words[i, 1] = orc.pack_word(data[word_nt - 32:])
+        else:
+            words[i] = orc.pack_word(data)
         filt[i] = fl
     return words, filt, recs, (hdr, take)
 
@@ -43,6 +48,9 @@ def dump_words(files, word_nt, tmp, env=None):
                            "--dump-words", out] + list(files), env=e)
     raw = open(out, "rb").read()
     n = int(np.frombuffer(raw[:8], dtype=np.uint64)[0])
-    words = np.frombuffer(raw[8:8 + 8 * n], dtype=np.uint64)
-    filt = np.frombuffer(raw[8 + 8 * n:8 + 9 * n], dtype=np.uint8)
+    wpr = 2 if word_nt > 32 else 1
+    words = np.frombuffer(raw[8:8 + 8 * n * wpr], dtype=np.uint64)
+    if wpr == 2:
+        words = words.reshape(n, 2)
+    filt = np.frombuffer(raw[8 + 8 * n * wpr:8 + 8 * n * wpr + n], dtype=np.uint8)
     return words, filt

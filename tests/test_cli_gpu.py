@@ -32,6 +32,8 @@ def dat(path):
     dict(n_files=2, umi_len=8, umi_in_header=True, word_nt=24, d=1, x=False, n=3000),
     dict(n_files=2, umi_len=12, umi_in_header=False, umi_file=True, word_nt=24, d=1, x=True, n=2000),
     dict(n_files=2, umi_len=0, umi_in_header=False, word_nt=12, d=2, x=False, n=2000),
+    dict(n_files=2, umi_len=8, umi_in_header=True, word_nt=48, d=1, x=False, n=3000),   # wide words
+    dict(n_files=2, umi_len=12, umi_in_header=False, umi_file=True, word_nt=64, d=2, x=True, n=2000),
 ])
 def test_cli_end_to_end(case, tmp_path):
     case = dict(case)

@@ -27,6 +27,9 @@ CASES = [
     dict(n_files=1, umi_len=8, umi_in_header=True, word_nt=6),                       # UMI longer than word
     dict(n_files=1, umi_len=8, umi_in_header=True, word_nt=32, header_style=":"),    # BCL style
     dict(n_files=2, umi_len=8, umi_in_header=True, word_nt=24, short_frac=0.2),      # N padding
+    dict(n_files=2, umi_len=8, umi_in_header=True, word_nt=40),                      # wide word (2 x uint64)
+    dict(n_files=2, umi_len=12, umi_in_header=False, umi_file=True, word_nt=64, short_frac=0.1),
+    dict(n_files=1, umi_len=8, umi_in_header=True, word_nt=33),
 ]
 
 
@@ -74,7 +77,7 @@ def test_log_reports_plan(tmp_path):
 def test_cli_errors(tmp_path):
     files = synth_fastq(str(tmp_path), 4, 8, n_files=1, read_len=30)
     assert subprocess.call([HUMID, "-e"] + files, stderr=subprocess.DEVNULL) == 2
-    assert subprocess.call([HUMID, "-n", "40"] + files, stderr=subprocess.DEVNULL) == 2
+    assert subprocess.call([HUMID, "-n", "65"] + files, stderr=subprocess.DEVNULL) == 2
     assert subprocess.call([HUMID], stderr=subprocess.DEVNULL) == 2
     assert subprocess.call([HUMID, str(tmp_path / "missing.fastq")], stderr=subprocess.DEVNULL) == 1
 

@@ -296,7 +296,7 @@ def test_unsupported_and_invalid(dd):
     w = np.zeros(4, np.uint64)
     f = np.zeros(4, np.uint8)
     with pytest.raises(humid_amd.HumidError) as e:
-        dd.run(w, f, word_nt=33)
+        dd.run(np.zeros((4, 2), np.uint64), f, word_nt=65)     # wide words stop at 64 nt
     assert e.value.code == -2
     with pytest.raises(humid_amd.HumidError) as e:
         dd.run(w, f, word_nt=0)

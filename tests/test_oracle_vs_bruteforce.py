@@ -90,3 +90,30 @@ def test_deep_chain_no_stack_overflow():
     for i in range(n - 1):
         g.link(i, i + 1)
     assert g.find_clusters(True) == 1
+
+
+@pytest.mark.parametrize("n", [33, 40, 48, 63, 64])
+@pytest.mark.parametrize("d", [0, 1, 2])
+@pytest.mark.parametrize("maximum", [False, True])
+def test_wide_words(n, d, maximum):
+    """33 <= n <= 64: two uint64 per word ([hi, lo], oracle/humid_oracle.h)"""
+    from humid_amd.synth import synth_wide_words
+    words, filt = synth_wide_words(500, 7 + n, n, p_sub=0.02, p_n=0.01)
+    p, cid, keep = run_oracle(words, filt, n, d, maximum)
+    bcid, bkeep, det = bf.dedup(words, filt, d, maximum)
+    assert np.array_equal(cid, bcid) and np.array_equal(keep, bkeep)
+    lv = p.leaves()
+    assert np.array_equal(lv["word"], det["unique"])
+    assert np.array_equal(lv["count"], det["count"].astype(np.uint64))
+    off, idx = p.adjacency()
+    flat = [x for row in det["nbrs"] for x in row]
+    assert idx.tolist() == flat
+
+
+def test_wide_matches_one_word_embedding():
+    """a constant prefix in front of 32-nt words changes nothing"""
+    lo, filt = synth_words(2000, 3, word_nt=32, p_sub=0.01)
+    wide = np.stack([np.full(len(lo), 0x2d, dtype=np.uint64), lo], axis=1)
+    _, c1, k1 = run_oracle(lo, filt, 32, 1, False)
+    _, c2, k2 = run_oracle(wide, filt, 36, 1, False)
+    assert np.array_equal(c1, c2) and np.array_equal(k1, k2)
