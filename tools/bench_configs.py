@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 import humid_amd  # noqa: E402
-from humid_amd.synth import synth_words  # noqa: E402
+from humid_amd.synth import synth_wide_words, synth_words  # noqa: E402
 
 CONFIGS = [
     # name, reads, word_nt, distance, mode
@@ -22,6 +22,8 @@ CONFIGS = [
     ("C3 50M PE+UMI file d1", 50_000_000, 24, 1, "umi"),
     ("C4 shard 25M UMI8 d1", 25_000_000, 24, 1, "umi"),
     ("C5 50M PE no-UMI d2", 50_000_000, 24, 2, "genome"),
+    ("W6 10M wide 48 nt d1", 10_000_000, 48, 1, "wide"),      # two uint64 per word (sorted count stage)
+    ("W7 10M wide 64 nt d2", 10_000_000, 64, 2, "wide"),
 ]
 
 
@@ -33,7 +35,10 @@ def main():
         if only and str(ci + 1) not in only:
             continue
         t0 = time.time()
-        words, filt = synth_words(n, 1001 + ci, nt, mode=mode)
+        if mode == "wide":
+            words, filt = synth_wide_words(n, 1001 + ci, nt)
+        else:
+            words, filt = synth_words(n, 1001 + ci, nt, mode=mode)
         tg = time.time() - t0
         d_w = torch.from_numpy(words.view(np.int64)).to(dev)
         d_f = torch.from_numpy(filt).to(dev)
