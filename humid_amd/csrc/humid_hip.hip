@@ -58,6 +58,7 @@ struct humid_ctx {
   DBuf pc, poff, share_edges;                                                     // multi-GPU pair-search share
   DBuf own_words;                                                                 // multi-GPU dense count
   DBuf heads;                                                                     // big-component heads
+  DBuf x_items, x_w, x_id, x_ids, x_ends, x_ends_s, x_head, x_hpos, x_nodes, x_cedges;   // multi-GPU exchange mode
   DBuf w_sorted, w_head, w_hpos, w_start;                                         // wide-word (sorted) counts
   bool last_count_sorted = false;                                                 // last count was the wide-word sort
   u32 g_wpr = 1;                                                                  // uint64 per word of g_word
@@ -994,7 +995,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
-                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->seg_ws, &c->csize, &c->cur, &c->plan_dev, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -1502,6 +1503,216 @@ int humid_stage_graph_edges(humid_ctx *c, const uint64_t *d_g_word, const uint32
   HIPCHK(hipStreamSynchronize(c->stream));
   if (summary) *summary = s;
   c->have_graph = true;
+  return HUMID_OK;
+}
+
+// ---- multi-GPU exchange mode (humid_amd/sharded.py, mode "exchange") -------------------------
+// Words travel to the rank that owns their VALUE range (all-to-all) instead of every word to every
+// rank; each rank counts its range, and for every non-prefix combination the unique words travel
+// once more, to the rank that owns their combination key.  Pairs carry global unique indices.
+static u32 min_prefix_bits(u32 n, u32 d, u32 force_segments) {
+  if (d >= n) return 0;
+  u32 best = ~0u;
+  for (u32 sgm = d + 1; sgm <= n && sgm <= d + MAX_FIELDS; sgm++) {
+    if (n_choose_k(sgm, sgm - d) > MAX_COMBOS) break;
+    if (force_segments && sgm != force_segments) continue;
+    const u32 base = n / sgm, rem = n % sgm, k = sgm - d;
+    u32 len = 0;
+    for (u32 t = 0; t < k; t++) len += base + (t < rem ? 1 : 0);
+    if (2 * len < best) best = 2 * len;
+  }
+  if (best == ~0u) best = 2 * (n / (d + 1));     // forced s not legal: make_plan falls back to d + 1
+  return best > 64 ? 64 : best;
+}
+
+int humid_stage_plan_info(humid_ctx *c, uint32_t word_nt, uint32_t distance, uint64_t plan_unique,
+                          uint32_t *n_combos, uint32_t *prefix_bits) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  TRY(check_run_args(c, 0, word_nt, 0));
+  const ComboPlan plan = make_plan(word_nt, distance, plan_unique, c->force_segments);
+  if (n_combos) *n_combos = plan.ncombo;
+  if (prefix_bits) {
+    const u32 mp = min_prefix_bits(word_nt, distance, c->force_segments);
+    *prefix_bits = mp < (u32)__builtin_popcountll(plan.mask[0].lo) ? mp : (u32)__builtin_popcountll(plan.mask[0].lo);
+  }
+  return HUMID_OK;
+}
+
+static ComboFields plan_fields(const ComboPlan &plan, u32 cb) {
+  ComboFields cf;
+  cf.nf = plan.nfield[cb];
+  for (u32 f = 0; f < MAX_FIELDS; f++) { cf.shift[f] = plan.shift[cb][f]; cf.width[f] = plan.width[cb][f]; }
+  return cf;
+}
+
+int humid_stage_combo_route(humid_ctx *c, const uint64_t *d_word, uint64_t n_unique, uint64_t id_base,
+                            uint32_t word_nt, uint32_t distance, uint64_t plan_unique, uint32_t combo,
+                            uint32_t n_ranks, const uint64_t **d_items, uint64_t *counts) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (!d_items || !counts || n_ranks == 0) return fail(c, HUMID_E_INVALID, "bad argument");
+  if (n_ranks > 255) return fail(c, HUMID_E_UNSUPPORTED, "more than 255 ranks");
+  TRY(check_run_args(c, n_unique, word_nt, 0));
+  if (id_base + n_unique > 0xffffffffull) return fail(c, HUMID_E_OVERFLOW, "global unique index exceeds 32 bits");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const ComboPlan plan = make_plan(word_nt, distance, plan_unique, c->force_segments);
+  if (combo >= plan.ncombo) return fail(c, HUMID_E_INVALID, "combo %u out of range (%u)", combo, plan.ncombo);
+  *d_items = nullptr;
+  for (u32 q = 0; q < n_ranks; q++) counts[q] = 0;
+  const u32 n = (u32)n_unique;
+  if (n == 0) return HUMID_OK;
+  if (!d_word) return fail(c, HUMID_E_INVALID, "null buffer");
+  ENSURE(c->owner, (size_t)n);
+  ENSURE(c->owner_sorted, (size_t)n);
+  ENSURE(c->x_ids, (size_t)n * 4);
+  ENSURE(c->x_items, (size_t)n * 16);
+  hipLaunchKernelGGL(k_combo_owner, dim3(blocks_for(n)), dim3(256), 0, st, d_word, n, plan_fields(plan, combo),
+                     n_ranks, c->owner.as<u8>());
+  {
+    using part_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                rocprim::default_config, 0>;   // never the merge path
+    rocprim::counting_iterator<u32> vin(0);
+    size_t bytes = 0;
+    HIPCHK(rocprim::radix_sort_pairs<part_cfg>(nullptr, bytes, c->owner.as<u8>(), c->owner_sorted.as<u8>(), vin,
+                                               c->x_ids.as<u32>(), (size_t)n, 0, 8, st));
+    ENSURE(c->tmp, bytes);
+    HIPCHK(rocprim::radix_sort_pairs<part_cfg>(c->tmp.p, bytes, c->owner.as<u8>(), c->owner_sorted.as<u8>(), vin,
+                                               c->x_ids.as<u32>(), (size_t)n, 0, 8, st));
+  }
+  ENSURE(c->small, (size_t)(n_ranks + 2) * 4);
+  hipLaunchKernelGGL(k_owner_bounds, dim3(1), dim3(256), 0, st, c->owner_sorted.as<u8>(), n, n_ranks,
+                     c->small.as<u32>());
+  hipLaunchKernelGGL(k_route_items, dim3(blocks_for(n)), dim3(256), 0, st, d_word, c->x_ids.as<u32>(), n,
+                     (u64)id_base, c->x_items.as<ulonglong2>());
+  std::vector<u32> b(n_ranks + 2);
+  HIPCHK(hipMemcpyAsync(b.data(), c->small.p, (n_ranks + 2) * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  for (u32 q = 0; q < n_ranks; q++) counts[q] = b[q + 1] - b[q];
+  *d_items = c->x_items.as<u64>();
+  return HUMID_OK;
+}
+
+// pairs among W[0, n) walked in bucket order of combination cb (ids V) -> c->share_edges
+static int emit_pairs(humid_ctx *c, const u64 *W, const u32 *V, u32 n, const ComboPlan &plan, u32 cb,
+                      u32 distance, u64 *E_out) {
+  hipStream_t st = c->stream;
+  *E_out = 0;
+  EarlierMasksT<u64> d_masks;
+  for (u32 t = 0; t < MAX_COMBOS; t++) d_masks.m[t] = plan.mask[t].lo;
+  ENSURE(c->pc, ((size_t)n + 1) * 4);
+  ENSURE(c->poff, ((size_t)n + 1) * 4);
+  HIPCHK(hipMemsetAsync(c->pc.as<u32>() + n, 0, 4, st));
+  const dim3 grid(blocks_for(n)), blk(256);
+  hipLaunchKernelGGL((k_pairs<false, PM_EMIT_COUNT, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
+                     cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
+                     (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>());
+  TRY(exscan_u32(c, c->pc.as<u32>(), c->poff.as<u32>(), (u64)n + 1));
+  HIPCHK(hipGetLastError());
+  TRY(read_counters(c, c->poff.as<u32>() + n));
+  const u64 E = c->h_ctr[CTR_N - 1] & 0xffffffffull;
+  *E_out = E;
+  if (E == 0) return HUMID_OK;
+  ENSURE(c->share_edges, (size_t)E * 8);
+  hipLaunchKernelGGL((k_pairs<false, PM_EMIT_FILL, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
+                     cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
+                     (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>());
+  HIPCHK(hipGetLastError());
+  return HUMID_OK;
+}
+
+int humid_stage_pairs_keyed(humid_ctx *c, const uint64_t *d_items, uint64_t n_items, int interleaved,
+                            uint64_t id_base, uint32_t word_nt, uint32_t distance, uint64_t plan_unique,
+                            uint32_t combo, const uint64_t **d_edges, uint64_t *n_edges) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (!d_edges || !n_edges) return fail(c, HUMID_E_INVALID, "bad argument");
+  TRY(check_run_args(c, n_items, word_nt, 0));
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  *d_edges = nullptr;
+  *n_edges = 0;
+  const u32 n = (u32)n_items;
+  if (n < 2 || distance == 0) return HUMID_OK;
+  if (!d_items) return fail(c, HUMID_E_INVALID, "null buffer");
+  const ComboPlan plan = make_plan(word_nt, distance, plan_unique, c->force_segments);
+  if (combo >= plan.ncombo) return fail(c, HUMID_E_INVALID, "combo %u out of range (%u)", combo, plan.ncombo);
+  if (!interleaved && combo != 0) return fail(c, HUMID_E_INVALID, "a plain word array is in bucket order for combination 0 only");
+  if (!interleaved && id_base + n_items > 0xffffffffull) return fail(c, HUMID_E_OVERFLOW, "global unique index exceeds 32 bits");
+  u64 E = 0;
+  ENSURE(c->x_id, (size_t)n * 4);
+  if (!interleaved) {
+    hipLaunchKernelGGL(k_iota_base, dim3(blocks_for(n)), dim3(256), 0, st, c->x_id.as<u32>(), n, (u32)id_base);
+    TRY(emit_pairs(c, d_items, c->x_id.as<u32>(), n, plan, 0, distance, &E));
+  } else {
+    ENSURE(c->x_w, (size_t)n * 8);
+    ENSURE(c->seg_k0, (size_t)n * 8);
+    ENSURE(c->seg_v0, (size_t)n * 4);
+    ENSURE(c->seg_ks, (size_t)n * 8);
+    ENSURE(c->seg_vs, (size_t)n * 4);
+    ENSURE(c->seg_ws, (size_t)n * 8);
+    ENSURE(c->x_ids, (size_t)n * 4);
+    hipLaunchKernelGGL(k_split_items, dim3(blocks_for(n)), dim3(256), 0, st, (const ulonglong2 *)d_items, n,
+                       c->x_w.as<u64>(), c->x_id.as<u32>());
+    const u32 kb = plan.key_bits ? plan.key_bits : 1;
+    if (kb <= 32) {
+      hipLaunchKernelGGL((k_combo_keys<u32, u64>), dim3(blocks_for(n)), dim3(256), 0, st, c->x_w.as<u64>(), n,
+                         plan_fields(plan, combo), c->seg_k0.as<u32>(), c->seg_v0.as<u32>());
+      TRY(sort_pairs<u32, u32>(c, c->seg_k0.as<u32>(), c->seg_ks.as<u32>(), c->seg_v0.as<u32>(), c->seg_vs.as<u32>(), n, 0, kb));
+    } else {
+      hipLaunchKernelGGL((k_combo_keys<u64, u64>), dim3(blocks_for(n)), dim3(256), 0, st, c->x_w.as<u64>(), n,
+                         plan_fields(plan, combo), c->seg_k0.as<u64>(), c->seg_v0.as<u32>());
+      TRY(sort_pairs<u64, u32>(c, c->seg_k0.as<u64>(), c->seg_ks.as<u64>(), c->seg_v0.as<u32>(), c->seg_vs.as<u32>(), n, 0, kb));
+    }
+    hipLaunchKernelGGL(k_gather_bucket_words<u64>, dim3(blocks_for(n)), dim3(256), 0, st, c->x_w.as<u64>(),
+                       c->seg_vs.as<u32>(), n, c->seg_ws.as<u64>());
+    hipLaunchKernelGGL(k_gather_u32, dim3(blocks_for(n)), dim3(256), 0, st, c->x_id.as<u32>(), c->seg_vs.as<u32>(), n,
+                       c->x_ids.as<u32>());
+    TRY(emit_pairs(c, c->seg_ws.as<u64>(), c->x_ids.as<u32>(), n, plan, combo, distance, &E));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  *n_edges = E;
+  *d_edges = E ? c->share_edges.as<u64>() : nullptr;
+  return HUMID_OK;
+}
+
+// distinct endpoints of an edge list, ascending, and the edges relabelled to positions in that list
+int humid_stage_compact_nodes(humid_ctx *c, const uint64_t *d_edges, uint64_t n_edges, const uint32_t **d_nodes,
+                              uint64_t *n_nodes, const uint64_t **d_compact_edges) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (!d_nodes || !n_nodes || !d_compact_edges) return fail(c, HUMID_E_INVALID, "bad argument");
+  if (n_edges >= 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "2*edges exceeds 32 bits");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  *d_nodes = nullptr;
+  *d_compact_edges = nullptr;
+  *n_nodes = 0;
+  const u32 E = (u32)n_edges;
+  if (E == 0) return HUMID_OK;
+  if (!d_edges) return fail(c, HUMID_E_INVALID, "null buffer");
+  const u32 n2 = 2 * E;
+  ENSURE(c->x_ends, (size_t)n2 * 4);
+  ENSURE(c->x_ends_s, (size_t)n2 * 4);
+  ENSURE(c->x_head, ((size_t)n2 + 1) * 4);
+  ENSURE(c->x_hpos, ((size_t)n2 + 1) * 4);
+  hipLaunchKernelGGL(k_edge_ends, dim3(blocks_for(E)), dim3(256), 0, st, d_edges, E, c->x_ends.as<u32>());
+  TRY(sort_keys<u32>(c, c->x_ends.as<u32>(), c->x_ends_s.as<u32>(), n2, 0, 32));
+  hipLaunchKernelGGL(k_heads_u32, dim3(blocks_for((u64)n2 + 1)), dim3(256), 0, st, c->x_ends_s.as<u32>(), n2,
+                     c->x_head.as<u32>());
+  TRY(exscan_u32(c, c->x_head.as<u32>(), c->x_hpos.as<u32>(), (u64)n2 + 1));
+  HIPCHK(hipGetLastError());
+  TRY(read_counters(c, c->x_hpos.as<u32>() + n2));
+  const u32 M = (u32)(c->h_ctr[CTR_N - 1] & 0xffffffffull);
+  ENSURE(c->x_nodes, ((size_t)M + 1) * 4);
+  ENSURE(c->x_cedges, (size_t)E * 8);
+  hipLaunchKernelGGL(k_compact_heads_u32, dim3(blocks_for(n2)), dim3(256), 0, st, c->x_ends_s.as<u32>(),
+                     c->x_head.as<u32>(), c->x_hpos.as<u32>(), n2, c->x_nodes.as<u32>());
+  hipLaunchKernelGGL(k_relabel_edges, dim3(blocks_for(E)), dim3(256), 0, st, d_edges, E, c->x_nodes.as<u32>(), M,
+                     c->x_cedges.as<u64>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  *d_nodes = c->x_nodes.as<u32>();
+  *n_nodes = M;
+  *d_compact_edges = c->x_cedges.as<u64>();
   return HUMID_OK;
 }
 

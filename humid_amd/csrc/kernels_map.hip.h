@@ -5,6 +5,7 @@
 #define HUMID_KERNELS_MAP_HIP_H
 
 #include "common.hip.h"
+#include "kernels_graph.hip.h"
 
 // --------------------------------------------------------------------------------
 // 6. per-read map: cluster id and the duplicate flag
@@ -160,6 +161,98 @@ k_scatter_results(const u32 *__restrict__ perm, const u32 *__restrict__ packed, 
     cluster_id[r] = t & 0x7fffffffu;
     keep[r] = (u8)(t >> 31);
   }
+}
+
+// --------------------------------------------------------------------------------
+// 8. multi-GPU exchange mode: routing of unique words by combination key, compact node lists
+// --------------------------------------------------------------------------------
+// owner rank of a unique word for combination `cf`: a hash of its key, so that all words of one
+// bucket meet on one rank whatever the key distribution is
+__global__ void __launch_bounds__(256)
+k_combo_owner(const u64 *__restrict__ words, u32 n, ComboFields cf, u32 n_ranks, u8 *__restrict__ owner) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 w = words[i];
+  u64 k = 0;
+#pragma unroll
+  for (u32 f = 0; f < MAX_FIELDS; f++) {
+    if (f < cf.nf) {
+      const u32 wd = cf.width[f];
+      k = ((wd >= 64) ? 0ull : (k << wd)) | w_field(w, cf.shift[f], wd);
+    }
+  }
+  const u64 h = mix64(k ^ 0x9e3779b97f4a7c15ull);
+  owner[i] = (u8)(((h >> 32) * (u64)n_ranks) >> 32);
+}
+
+// (word, id) items in routed order: id = id_base + index in the local unique array
+__global__ void __launch_bounds__(256)
+k_route_items(const u64 *__restrict__ words, const u32 *__restrict__ perm, u32 n, u64 id_base,
+              ulonglong2 *__restrict__ items) {
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const u32 i = perm[k];
+  items[k] = make_ulonglong2(words[i], id_base + i);
+}
+
+__global__ void k_split_items(const ulonglong2 *__restrict__ items, u32 n, u64 *__restrict__ w, u32 *__restrict__ id) {
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const ulonglong2 it = items[k];
+  w[k] = it.x;
+  id[k] = (u32)it.y;
+}
+
+__global__ void k_iota_base(u32 *p, u32 n, u32 base) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = base + i;
+}
+
+__global__ void k_gather_u32(const u32 *__restrict__ src, const u32 *__restrict__ idx, u32 n, u32 *__restrict__ dst) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+
+// both endpoints of every edge (smaller << 32 | larger)
+__global__ void k_edge_ends(const u64 *__restrict__ edges, u32 n_edges, u32 *__restrict__ ends) {
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_edges) return;
+  const u64 e = edges[k];
+  ends[2 * k] = (u32)(e >> 32);
+  ends[2 * k + 1] = (u32)e;
+}
+
+// head[i] = 1 where a new value starts in the sorted array; head[n] = 0 (scan sentinel)
+__global__ void k_heads_u32(const u32 *__restrict__ sorted, u32 n, u32 *__restrict__ head) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  head[i] = (i < n && (i == 0 || sorted[i] != sorted[i - 1])) ? 1u : 0u;
+}
+
+__global__ void k_compact_heads_u32(const u32 *__restrict__ sorted, const u32 *__restrict__ head,
+                                    const u32 *__restrict__ hpos, u32 n, u32 *__restrict__ out) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && head[i]) out[hpos[i]] = sorted[i];
+}
+
+// edges over node ids -> edges over positions in the ascending node list
+__global__ void k_relabel_edges(const u64 *__restrict__ edges, u32 n_edges, const u32 *__restrict__ nodes,
+                                u32 n_nodes, u64 *__restrict__ out) {
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_edges) return;
+  const u64 e = edges[k];
+  u32 r[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const u32 id = q == 0 ? (u32)(e >> 32) : (u32)e;
+    u32 lo = 0, hi = n_nodes;
+    while (lo < hi) {
+      const u32 mid = lo + ((hi - lo) >> 1);
+      if (nodes[mid] < id) lo = mid + 1; else hi = mid;
+    }
+    r[q] = lo;
+  }
+  out[k] = ((u64)r[0] << 32) | r[1];
 }
 
 __global__ void k_widen32(const u32 *__restrict__ in, u32 n, u64 *__restrict__ out) {

@@ -1,6 +1,26 @@
 """Multi-GPU driver of the hot path: one process per GPU, torch.distributed over RCCL/xGMI.
 
-The read set is sharded over the ranks in input order.  Per pass:
+The read set is sharded over the ranks in input order.  Two orchestrations share the stage entry
+points of include/humid_hip.h:
+
+mode "exchange" (default, 2..16 ranks) -- every word travels to the rank that owns its VALUE range;
+per-rank work and traffic stay constant as ranks are added (weak scaling):
+
+  1. local histogram of the top word bits + all-reduce (16 KB) -> P ordered, balanced value ranges,
+     cut at boundaries of the prefix combination of the pigeonhole plan;
+  2. all-to-all of the usable words to their range owners (8 B per read leaves the rank once);
+  3. the owner counts its words (LDS tables, as on one GPU); its ascending unique array is a slice
+     of Trie::walk() order, global index = sum of the lower ranks' unique counts + local index;
+  4. neighbour pairs: the prefix combination is local to a range; for each other combination the
+     unique words go to the rank that owns their combination key (all-to-all of (word, index),
+     12..16 B per unique word) and are compared there; pairs come out in global indices;
+  5. all-gather of the pairs (~2 % of the reads) -> compact graph over the pairs' endpoints only,
+     counts of the endpoints all-gathered, clustered replicated (singletons never enter: a singleton
+     is its own cluster and its own maxLeaf); cluster ids from closed-form prefix counts;
+  6. per-read results at the owner (humid_stage_map_dense), all-to-all back (4 B per read), scatter.
+
+mode "allgather" (BASELINE.json's literal wording; also the fallback for > 16 ranks and for plans
+without a usable prefix) -- every rank sees every word.  Per pass:
 
   1. RCCL all-gather of the packed words (+ filtered flags): every rank sees every candidate
      neighbour (BASELINE.json north_star).  This is the path's one real exchange step.
@@ -175,6 +195,46 @@ class HipStageOps(Context):
 
     max_ranks_dense = 16
 
+    # ---- exchange mode ----
+    def plan_info(self, word_nt, distance, plan_unique):
+        nc, pb = C.c_uint32(), C.c_uint32()
+        self._check(self._lib.humid_stage_plan_info(self._h, word_nt, distance, plan_unique,
+                                                    C.byref(nc), C.byref(pb)))
+        return nc.value, pb.value
+
+    def combo_route(self, l_word, id_base, word_nt, distance, plan_unique, combo, n_ranks):
+        """(word, id) items of the local unique array in destination-major order: int64[n, 2]"""
+        pi = C.c_void_p()
+        counts = (C.c_uint64 * n_ranks)()
+        n = l_word.numel()
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check(self._lib.humid_stage_combo_route(
+            self._h, C.c_void_p(l_word.data_ptr()), n, id_base, word_nt, distance, plan_unique, combo,
+            n_ranks, C.byref(pi), counts))
+        return _wrap(pi.value, 2 * n, "<i8", torch.int64, self.device).view(-1, 2), [int(x) for x in counts]
+
+    def pairs_keyed(self, items, interleaved, id_base, word_nt, distance, plan_unique, combo):
+        """pairs (smaller id << 32 | larger id) among the items; a VIEW of ctx memory that the next
+        call overwrites"""
+        pe = C.c_void_p()
+        ne = C.c_uint64()
+        n = items.shape[0]
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check(self._lib.humid_stage_pairs_keyed(
+            self._h, C.c_void_p(items.data_ptr()) if n else None, n, int(interleaved), id_base, word_nt,
+            distance, plan_unique, combo, C.byref(pe), C.byref(ne)))
+        return _wrap(pe.value, ne.value, "<i8", torch.int64, self.device)
+
+    def compact_nodes(self, edges):
+        pn, pc = C.c_void_p(), C.c_void_p()
+        nn = C.c_uint64()
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check(self._lib.humid_stage_compact_nodes(
+            self._h, C.c_void_p(edges.data_ptr()) if edges.numel() else None, edges.numel(),
+            C.byref(pn), C.byref(nn), C.byref(pc)))
+        return (_wrap(pn.value, nn.value, "<i4", torch.int32, self.device),
+                _wrap(pc.value, edges.numel(), "<i8", torch.int64, self.device))
+
     def map(self, l_cid, l_ismax, out_cid, out_keep):
         torch.cuda.current_stream(self.device).synchronize()
         self._check(self._lib.humid_stage_map(self._h, C.c_void_p(l_cid.data_ptr()),
@@ -208,8 +268,12 @@ def _reduce_scatter_sum(dist, out, inp, world, rank):
 
 
 def _all_to_all_v(dist, out, inp, out_splits, in_splits, world, rank):
-    """variable all-to-all of 1-D tensors; emulated with an all-gather where the backend (gloo)
-    has no all_to_all"""
+    """variable all-to-all along dim 0 (rows of a contiguous [n, k] tensor count as one element);
+    emulated with an all-gather where the backend (gloo) has no all_to_all"""
+    if inp.dim() == 2:
+        k = inp.shape[1]
+        return _all_to_all_v(dist, out.view(-1), inp.reshape(-1), [x * k for x in out_splits],
+                             [x * k for x in in_splits], world, rank)
     try:
         dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits)
         return
@@ -232,6 +296,23 @@ def _all_to_all_v(dist, out, inp, out_splits, in_splits, world, rank):
         cnt = int(metas[src, rank])
         out[o:o + cnt] = allb[src * m + off: src * m + off + cnt]
         o += cnt
+
+
+def _all_gather_var(dist, t, world, fill=0):
+    """all-gather of 1-D tensors of different lengths -> (concatenation in rank order, lengths)"""
+    dev = t.device
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=dev)
+    ns = torch.empty(world, dtype=torch.int64, device=dev)
+    _all_gather_flat(dist, ns, n, world)
+    ns = ns.cpu().tolist()
+    m = max(max(ns), 1)
+    pad = torch.full((m,), fill, dtype=t.dtype, device=dev)
+    pad[:t.numel()] = t
+    allb = torch.empty(world * m, dtype=t.dtype, device=dev)
+    _all_gather_flat(dist, allb, pad, world)
+    if all(x == m for x in ns):
+        return allb, ns
+    return torch.cat([allb[q * m:q * m + ns[q]] for q in range(world)]), ns
 
 
 def splitters_from_hist(hist: np.ndarray, world: int, word_nt: int, bits: int):
@@ -264,8 +345,13 @@ class ShardedDedup:
     """Global deduplication of a read set sharded over the ranks of the default process group."""
 
     def __init__(self, device: int = 0, word_nt: int = 24, distance: int = 1, method: int = 0,
-                 ops=None, dist=None, dense_return: bool = True, partition_search: bool = True):
+                 ops=None, dist=None, dense_return: bool = True, partition_search: bool = True,
+                 mode: str = None):
+        import os
         import torch.distributed as tdist
+        self.mode = mode or os.environ.get("HUMID_SHARD_MODE", "exchange")
+        if self.mode not in ("exchange", "allgather"):
+            raise ValueError("mode must be 'exchange' or 'allgather'")
         self.dist = dist or tdist
         self.world = self.dist.get_world_size()
         self.rank = self.dist.get_rank()
@@ -279,6 +365,112 @@ class ShardedDedup:
     def run(self, d_w, d_f, d_cid, d_keep):
         """d_w int64[n_local] packed words, d_f uint8[n_local]; writes d_cid int32[n_local] and
         d_keep uint8[n_local] (torch tensors on this rank's device).  Returns a summary dict."""
+        if self.mode == "exchange" and hasattr(self.ops, "combo_route") and \
+                self.world <= getattr(self.ops, "max_ranks_dense", 0):
+            _, pbits = self.ops.plan_info(self.word_nt, self.distance, 1)
+            if pbits >= 1:          # d >= n has no prefix to cut the value ranges at
+                self.mode_used = "exchange"
+                return self._run_exchange(d_w, d_f, d_cid, d_keep, min(self.bits, pbits))
+        self.mode_used = "allgather"
+        return self._run_allgather(d_w, d_f, d_cid, d_keep)
+
+    def _run_exchange(self, d_w, d_f, d_cid, d_keep, bits):
+        dist, P, r, ops = self.dist, self.world, self.rank, self.ops
+        dev = d_w.device
+        n_local = d_w.numel()
+        i64 = dict(dtype=torch.int64, device=dev)
+        # ---- 1. global histogram -> balanced ordered value ranges (cut at prefix boundaries) ----
+        hist = ops.histogram(d_w, d_f, self.word_nt, bits)
+        dist.all_reduce(hist)
+        ranges = splitters_from_hist(hist.cpu().numpy(), P, self.word_nt, bits)
+        # ---- 2. usable words -> owner of their range ----
+        perm, send_counts = ops.owner_perm(d_w, d_f, ranges)          # owner-major, filtered reads last
+        n_send = sum(send_counts)
+        send_w = d_w[perm[:n_send].long()] if n_send else torch.empty(0, **i64)
+        cm = torch.empty(P * P, **i64)
+        _all_gather_flat(dist, cm, torch.tensor(send_counts, **i64), P)
+        recv_counts = cm.cpu().view(P, P)[:, r].tolist()
+        n_recv = sum(recv_counts)
+        recv_w = torch.empty(n_recv, **i64)
+        _all_to_all_v(dist, recv_w, send_w, recv_counts, send_counts, P, r)
+        # ---- 3. exact counts of the received words (all usable, all in this rank's range) ----
+        zf = torch.zeros(max(n_recv, 1), dtype=torch.uint8, device=dev)
+        u_local, usable_local, _ = ops.count_dense(recv_w, zf[:n_recv], self.word_nt, 0, (1 << 64) - 1, [0, n_recv])
+        metas = torch.empty(3 * P, **i64)
+        _all_gather_flat(dist, metas, torch.tensor([u_local, usable_local, n_local], **i64), P)
+        metas = metas.cpu().view(P, 3)
+        u_all = metas[:, 0].tolist()
+        u_total, goff = sum(u_all), sum(u_all[:r])
+        summ = dict(total=int(metas[:, 2].sum()), usable=int(metas[:, 1].sum()), unique=u_total,
+                    clusters=u_total, edges=0, nonsingle=0)
+        if u_total >= (1 << 32) - 1:
+            raise HumidError(-5, "more than 2^32-2 unique words in total")
+        lw, lc = ops.unique() if u_local else (torch.empty(0, **i64), torch.empty(0, dtype=torch.int32, device=dev))
+        # ---- 4. neighbour pairs in global unique indices ----
+        e_parts = []
+        if self.distance > 0 and u_total > 1:
+            n_combos, _ = ops.plan_info(self.word_nt, self.distance, u_total)
+            if u_local > 1:
+                e_parts.append(ops.pairs_keyed(lw, False, goff, self.word_nt, self.distance, u_total, 0).clone())
+            for cb in range(1, n_combos):
+                items, sc = ops.combo_route(lw, goff, self.word_nt, self.distance, u_total, cb, P)
+                cm = torch.empty(P * P, **i64)
+                _all_gather_flat(dist, cm, torch.tensor(sc, **i64), P)
+                rc = cm.cpu().view(P, P)[:, r].tolist()
+                got = torch.empty((sum(rc), 2), **i64)
+                _all_to_all_v(dist, got, items, rc, sc, P, r)
+                if got.shape[0] > 1:
+                    e_parts.append(ops.pairs_keyed(got, True, 0, self.word_nt, self.distance, u_total, cb).clone())
+        e_loc = torch.cat(e_parts) if e_parts else torch.empty(0, **i64)
+        e_all, _ = _all_gather_var(dist, e_loc, P)
+        # ---- 5. compact graph over the pairs' endpoints; ids by closed-form prefix counts ----
+        g = goff + torch.arange(u_local, **i64)
+        if e_all.numel():
+            nodes, cedges = ops.compact_nodes(e_all)                  # ascending global indices, int32
+            nodes = nodes.clone()
+            cedges = cedges.clone()
+            M = nodes.numel()
+            nodes64 = nodes.long() & 0xffffffff
+            bounds = torch.searchsorted(nodes64, torch.tensor([goff, goff + u_local], **i64)).tolist()
+            s0, s1 = bounds
+            li = nodes64[s0:s1] - goff                                # local indices of this rank's endpoints
+            own_cnt = lc[li] if s1 > s0 else torch.empty(0, dtype=torch.int32, device=dev)
+            cnt_c, _ = _all_gather_var(dist, own_cnt, P)
+            ccid, cismax, gs = ops.graph_edges(nodes, cnt_c, cedges, self.word_nt, self.distance, self.method)
+            C_c = int(gs["clusters"])
+            ccid64 = ccid.long()
+            creator = torch.full((C_c,), M, **i64).scatter_reduce_(0, ccid64 - 1, torch.arange(M, **i64), "amin")
+            creator_g = nodes64[creator]                              # ascending: ids follow creators
+            base_id = creator_g - creator + torch.arange(C_c, **i64)  # global cluster id - 1
+            is_c = torch.zeros(u_local, **i64)
+            is_c[li] = 1
+            nb = s0 + torch.cumsum(is_c, 0) - is_c
+            cr = torch.searchsorted(creator_g, torch.tensor([goff, goff + u_local], **i64)).tolist()
+            is_cr = torch.zeros(u_local, **i64)
+            is_cr[creator_g[cr[0]:cr[1]] - goff] = 1
+            cb_ = cr[0] + torch.cumsum(is_cr, 0) - is_cr
+            l_cid = 1 + g - nb + cb_
+            l_cid[li] = 1 + base_id[ccid64[s0:s1] - 1]
+            l_ismax = torch.ones(u_local, dtype=torch.uint8, device=dev)
+            l_ismax[li] = cismax[s0:s1]
+            summ.update(clusters=u_total - M + C_c, edges=int(e_all.numel()), nonsingle=M)
+            for k, v in gs.items():
+                if k.startswith("ms_"):
+                    summ[k] = v
+        else:
+            l_cid = 1 + g
+            l_ismax = torch.ones(u_local, dtype=torch.uint8, device=dev)
+        if summ["clusters"] >= (1 << 31):
+            raise HumidError(-5, "cluster ids exceed 31 bits")
+        # ---- 6. per-read results at the owner, back to the home shards ----
+        packed = ops.map_dense(l_cid.to(torch.int32), l_ismax)
+        ret = torch.empty(n_send, dtype=torch.int32, device=dev)
+        _all_to_all_v(dist, ret, packed, send_counts, recv_counts, P, r)
+        ops.scatter(perm, ret, d_cid, d_keep)
+        self.summary = summ
+        return summ
+
+    def _run_allgather(self, d_w, d_f, d_cid, d_keep):
         dist, P, r = self.dist, self.world, self.rank
         dev = d_w.device
         n_local = d_w.numel()

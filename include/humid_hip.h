@@ -236,6 +236,39 @@ int humid_stage_owner_perm(humid_ctx *ctx, const uint64_t *d_words, const uint8_
 int humid_stage_scatter(humid_ctx *ctx, const uint32_t *d_perm, const uint32_t *d_packed,
                         uint64_t n_recv, uint64_t n_reads, uint32_t *d_cluster_id, uint8_t *d_keep);
 
+/* ---- exchange mode: words travel to the owner of their VALUE range --------------------------
+ * (humid_amd/sharded.py, mode "exchange".)  Instead of the all-gather of every word to every
+ * rank, each usable read's word goes to the rank that owns its value range (all-to-all, ranges
+ * from an all-reduced histogram), that rank counts it (humid_stage_count_dense over the received
+ * array), and candidate neighbours meet per pigeonhole combination: the prefix combination is
+ * local to a value range (ranges are cut at prefix boundaries: use at most *prefix_bits histogram
+ * bits), for every other combination the unique words travel once more, to the rank that owns
+ * their combination key (hash of the key; a bucket is never split).  Pairs carry GLOBAL unique
+ * indices (rank offset + local walk index); only the pairs -- about 2 % of the reads -- and the
+ * counts of their endpoints are replicated, and clustered as a compact graph.
+ *   humid_stage_plan_info:   combinations of the pigeonhole plan for plan_unique words in total (all
+ *     ranks pass the same number) and the bits of the shortest prefix combination.
+ *   humid_stage_combo_route: (word, id_base + index) items of this rank's ascending unique array in
+ *     destination-major order, *d_items[2k] = word, [2k+1] = id; counts[q] = items for rank q.
+ *   humid_stage_pairs_keyed: the neighbour pairs among n_items items that share the bucket of
+ *     `combo` and were not already found by an earlier combination, as
+ *     (smaller id << 32 | larger id).  interleaved = 1: d_items as above (any order);
+ *     interleaved = 0: a plain ascending word array with ids id_base + index (combination 0 only).
+ *   humid_stage_compact_nodes: the distinct endpoints of an edge list (ascending) and the same
+ *     edges over positions in that list -- the input of humid_stage_graph_edges for a graph that
+ *     leaves out the singletons (every singleton is its own cluster and its own maxLeaf). */
+int humid_stage_plan_info(humid_ctx *ctx, uint32_t word_nt, uint32_t distance, uint64_t plan_unique,
+                          uint32_t *n_combos, uint32_t *prefix_bits);
+int humid_stage_combo_route(humid_ctx *ctx, const uint64_t *d_word, uint64_t n_unique, uint64_t id_base,
+                            uint32_t word_nt, uint32_t distance, uint64_t plan_unique, uint32_t combo,
+                            uint32_t n_ranks, const uint64_t **d_items, uint64_t *counts);
+int humid_stage_pairs_keyed(humid_ctx *ctx, const uint64_t *d_items, uint64_t n_items, int interleaved,
+                            uint64_t id_base, uint32_t word_nt, uint32_t distance, uint64_t plan_unique,
+                            uint32_t combo, const uint64_t **d_edges, uint64_t *n_edges);
+int humid_stage_compact_nodes(humid_ctx *ctx, const uint64_t *d_edges, uint64_t n_edges,
+                              const uint32_t **d_nodes, uint64_t *n_nodes,
+                              const uint64_t **d_compact_edges);
+
 /* src/cluster.cc:31-33 atLeastDouble_, evaluated on the device (parity probe). */
 int humid_at_least_double(humid_ctx *ctx, uint64_t a, uint64_t b, int *result);
 

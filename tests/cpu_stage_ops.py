@@ -98,6 +98,74 @@ class CpuStageOps:
         return (torch.from_numpy(lc.astype(np.int32)), torch.from_numpy(ismax),
                 dict(clusters=nc, edges=len(e), nonsingle=nonsingle))
 
+    # ---- exchange mode: a plain pigeonhole plan of d+1 single-segment combinations ----
+    @staticmethod
+    def _segments(word_nt, distance):
+        k = distance + 1
+        base, rem = divmod(word_nt, k)
+        segs, pos = [], 0
+        for t in range(k):
+            ln = base + (1 if t < rem else 0)
+            segs.append((2 * (word_nt - pos - ln), 2 * ln))       # (shift, width in bits)
+            pos += ln
+        return segs
+
+    def plan_info(self, word_nt, distance, plan_unique):
+        if distance >= word_nt:
+            return 1, 0
+        segs = self._segments(word_nt, distance)
+        return len(segs), segs[0][1]
+
+    @staticmethod
+    def _seg_key(w, seg):
+        shift, width = seg
+        return (w >> np.uint64(shift)) & np.uint64((1 << width) - 1)
+
+    def combo_route(self, l_word, id_base, word_nt, distance, plan_unique, combo, n_ranks):
+        w = l_word.numpy().view(np.uint64)
+        key = self._seg_key(w, self._segments(word_nt, distance)[combo])
+        owner = ((key * np.uint64(0x9e3779b97f4a7c15)) >> np.uint64(40)) % np.uint64(n_ranks)
+        order = np.argsort(owner, kind="stable")
+        items = np.stack([w[order].view(np.int64), (id_base + order).astype(np.int64)], axis=1)
+        counts = [int((owner == q).sum()) for q in range(n_ranks)]
+        return torch.from_numpy(np.ascontiguousarray(items)), counts
+
+    def pairs_keyed(self, items, interleaved, id_base, word_nt, distance, plan_unique, combo):
+        if interleaved:
+            a = items.numpy()
+            w, ids = a[:, 0].view(np.uint64), a[:, 1].astype(np.int64)
+        else:
+            assert combo == 0
+            w = items.numpy().view(np.uint64)
+            ids = id_base + np.arange(len(w), dtype=np.int64)
+        segs = self._segments(word_nt, distance)
+        key = self._seg_key(w, segs[combo])
+        order = np.argsort(key, kind="stable")
+        w, ids, key = w[order], ids[order], key[order]
+        out = []
+        start = 0
+        m55 = np.uint64(0x5555555555555555)
+        for end in list(np.nonzero(key[1:] != key[:-1])[0] + 1) + [len(w)]:
+            for i in range(start, end):
+                x = w[i] ^ w[i + 1:end]
+                y = (x | (x >> np.uint64(1))) & m55
+                ham = np.array([bin(int(v)).count("1") for v in y], dtype=np.int64)
+                ok = ham <= distance
+                for q in range(combo):                                   # found by an earlier combination
+                    ok &= self._seg_key(x, segs[q]) != 0
+                for j in np.nonzero(ok)[0]:
+                    a_, b_ = int(ids[i]), int(ids[i + 1 + j])
+                    out.append((min(a_, b_) << 32) | max(a_, b_))
+            start = end
+        return torch.from_numpy(np.array(out, dtype=np.int64))
+
+    def compact_nodes(self, edges):
+        e = edges.numpy().astype(np.int64)
+        a, b = e >> 32, e & 0xffffffff
+        nodes = np.unique(np.concatenate([a, b]))
+        ce = (np.searchsorted(nodes, a) << 32) | np.searchsorted(nodes, b)
+        return torch.from_numpy(nodes.astype(np.uint32).view(np.int32)), torch.from_numpy(ce.astype(np.int64))
+
     # ---- dense result return ----
     max_ranks_dense = 16
 

@@ -35,6 +35,8 @@ def _worker(rank, world, port, case, q):
         from humid_amd.synth import synth_words
         from oracle import pyoracle as orc
         n_reads, n, d, method, sizes, mode, p_sub, dense = case
+        shard_mode = "exchange" if dense == "exchange" else "allgather"
+        dense = bool(dense)
         words, filt = synth_words(n_reads, 4242, n, p_sub=p_sub, p_n=2e-3, mode=mode, genome_bp=3000)
         ocid, okeep, osum, _ = orc.dedup_run(words, filt, n, d, method)
         if sizes is None:
@@ -46,12 +48,14 @@ def _worker(rank, world, port, case, q):
         cid = torch.zeros(sizes[rank], dtype=torch.int32)
         keep = torch.zeros(sizes[rank], dtype=torch.uint8)
         sd = ShardedDedup(word_nt=n, distance=d, method=method, ops=CpuStageOps(), dense_return=dense,
-                          partition_search=dense)   # old pair: replicated search + reduce-scatter
+                          partition_search=dense,   # old pair: replicated search + reduce-scatter
+                          mode=shard_mode)
         for _ in range(2):          # second pass re-uses the instance (cached shard sizes)
             s = sd.run(w, f, cid, keep)
         ok = (np.array_equal(cid.numpy().view(np.uint32), ocid[off:off + sizes[rank]]) and
               np.array_equal(keep.numpy(), okeep[off:off + sizes[rank]]))
         ok = ok and all(s[k] == osum[k] for k in ("total", "usable", "unique", "clusters"))
+        ok = ok and (sd.mode_used == shard_mode or (shard_mode == "exchange" and d >= n))
         q.put((rank, bool(ok), {k: s[k] for k in ("total", "usable", "unique", "clusters")}, osum))
     except Exception as e:  # pragma: no cover
         import traceback
@@ -68,11 +72,14 @@ CASES = [
     (3001, 8, 1, 0, "uneven", "umi", 1e-2),
     (300, 32, 1, 0, None, "umi", 1e-2),
     (40, 3, 1, 0, None, "umi", 0.0),       # tiny word space: most ranges empty
+    (500, 2, 2, 0, None, "umi", 0.0),      # d >= n: no prefix, exchange mode falls back to the all-gather
+    (3000, 16, 3, 1, None, "umi", 2e-2),   # four combinations
 ]
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("dense", [True, False], ids=["dense_all_to_all", "reduce_scatter"])
+@pytest.mark.parametrize("dense", ["exchange", True, False],
+                         ids=["exchange", "allgather_dense_return", "allgather_reduce_scatter"])
 @pytest.mark.parametrize("case", CASES)
 def test_sharded_matches_single_process(world, case, dense):
     case = list(case) + [dense]
