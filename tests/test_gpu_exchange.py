@@ -1,0 +1,124 @@
+"""-m gpu: the multi-GPU orchestration (humid_amd/sharded.py) with the REAL HIP stage ops for
+P = 1..8 ranks on one GPU -- the ranks are threads, collectives come from tests/fake_dist.py.
+Every rank's shard must be bit-identical to a single-process oracle run over the whole read set."""
+import threading
+
+import numpy as np
+import pytest
+
+from humid_amd.synth import synth_words
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def run_ranks(P, words, filt, n, d, method, mode, sizes=None, plan_segments=0, passes=1):
+    import torch
+    from fake_dist import FakeDist, FakeWorld
+    from humid_amd.sharded import HipStageOps, ShardedDedup
+    dev = torch.device("cuda:0")
+    N = len(words)
+    if sizes is None:
+        sizes = [N // P] * (P - 1) + [N - (N // P) * (P - 1)]
+    offs = [sum(sizes[:q]) for q in range(P + 1)]
+    world = FakeWorld(P)
+    out, errs = [None] * P, []
+
+    def rank_main(r):
+        try:
+            torch.cuda.set_device(0)
+            ops = HipStageOps(0)
+            if plan_segments:
+                ops.set_option("plan_segments", plan_segments)
+            sd = ShardedDedup(device=0, word_nt=n, distance=d, method=method, ops=ops,
+                              dist=FakeDist(world, r), mode=mode)
+            w = torch.from_numpy(words[offs[r]:offs[r + 1]].view(np.int64).copy()).to(dev)
+            f = torch.from_numpy(filt[offs[r]:offs[r + 1]].copy()).to(dev)
+            c = torch.zeros(sizes[r], dtype=torch.int32, device=dev)
+            k = torch.zeros(sizes[r], dtype=torch.uint8, device=dev)
+            for _ in range(passes):
+                s = sd.run(w, f, c, k)
+            torch.cuda.synchronize()
+            out[r] = (c.cpu().numpy().view(np.uint32), k.cpu().numpy(), s, sd.mode_used)
+            ops.close()
+        except Exception:  # pragma: no cover
+            import traceback
+            errs.append((r, traceback.format_exc()))
+            world.barrier.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not errs, errs[0][1]
+    return out, offs
+
+
+def check(P, words, filt, n, d, method, mode="exchange", expect_mode=None, **kw):
+    ocid, okeep, osum, _ = orc.dedup_run(words, filt, n, d, method)
+    p = orc.Pipeline(n)
+    p.read_data(words, filt)
+    edges = p.find_hamming_neighbours(d)
+    out, offs = run_ranks(P, words, filt, n, d, method, mode, **kw)
+    for r in range(P):
+        cid, keep, s, used = out[r]
+        assert used == (expect_mode or mode)
+        assert np.array_equal(cid, ocid[offs[r]:offs[r + 1]]), ("cluster_id", r)
+        assert np.array_equal(keep, okeep[offs[r]:offs[r + 1]]), ("keep", r)
+        for k in ("total", "usable", "unique", "clusters"):
+            assert s[k] == osum[k], (k, s[k], osum[k])
+        assert s["edges"] == p.n_edges
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("cfg", [(200_000, 24, 1, "umi", 0), (60_000, 12, 2, "umi", 1),
+                                 (50_000, 32, 1, "umi", 0), (3000, 4, 1, "umi", 0),
+                                 (80_000, 24, 2, "genome", 0), (40_000, 16, 3, "umi", 0)])
+def test_exchange_mode_virtual_ranks(P, cfg):
+    n_reads, n, d, mode, method = cfg
+    words, filt = synth_words(n_reads, 177 + P, n, p_sub=5e-3, p_n=1e-3, mode=mode, genome_bp=20000)
+    check(P, words, filt, n, d, method)
+
+
+def test_exchange_uneven_shards_and_reuse():
+    words, filt = synth_words(100_003, 5, 24, p_sub=5e-3, p_n=1e-3)
+    check(4, words, filt, 24, 1, 0, sizes=[50_000, 3, 0, 50_000], passes=2)
+
+
+def test_exchange_skewed_words():
+    """nearly all words in one value range / one combination bucket: owners are unbalanced, results
+    must not change"""
+    rng = np.random.default_rng(3)
+    base = np.uint64(0x00ab_cdef_0123)
+    w = np.full(30_000, base, dtype=np.uint64)
+    for pos in (0, 5, 13, 22):
+        sh = np.uint64(2 * pos)
+        w = (w & ~(np.uint64(3) << sh)) | (rng.integers(0, 4, size=len(w)).astype(np.uint64) << sh)
+    w[::50] = rng.integers(0, 1 << 48, size=len(w[::50]), dtype=np.uint64)
+    f = (rng.random(len(w)) < 0.01).astype(np.uint8)
+    check(4, w, f, 24, 1, 0)
+    check(3, w, f, 24, 2, 1)
+
+
+def test_exchange_all_filtered_and_tiny():
+    w = np.zeros(40, dtype=np.uint64)
+    check(2, w, np.ones(40, np.uint8), 24, 1, 0)
+    check(4, np.arange(3, dtype=np.uint64), np.zeros(3, np.uint8), 24, 1, 0)
+    check(2, w, np.zeros(40, np.uint8), 24, 0, 0)        # d = 0: no pairs at all
+
+
+def test_exchange_falls_back_without_prefix():
+    words, filt = synth_words(2000, 9, 2, p_sub=0.0)
+    check(2, words, filt, 2, 3, 0, expect_mode="allgather")
+
+
+@pytest.mark.parametrize("segs", [3, 4, 6])
+def test_exchange_forced_plans(segs):
+    words, filt = synth_words(60_000, 21 + segs, 24, p_sub=1e-2, p_n=1e-3)
+    check(3, words, filt, 24, 2, 0, plan_segments=segs)
+
+
+def test_allgather_mode_virtual_ranks():
+    words, filt = synth_words(120_000, 8, 24, p_sub=5e-3, p_n=1e-3)
+    check(3, words, filt, 24, 1, 0, mode="allgather")
