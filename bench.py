@@ -78,7 +78,8 @@ def main():
     d_keep = torch.zeros(n_local, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
-    if world == 1 and not a.force_sharded:
+    world_sharded = not (world == 1 and not a.force_sharded)
+    if not world_sharded:
         dd = humid_amd.Dedup(device=local_rank)
 
         def step():
@@ -98,6 +99,8 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    if world_sharded and getattr(sd, "trace", None) is not None:
+        sd.trace.clear()
     barrier()
     t0 = time.perf_counter()
     ks = {"ms_k_insert": 0.0, "ms_k_pairs": 0.0, "ms_k_cluster": 0.0, "ms_k_map": 0.0,
@@ -116,6 +119,9 @@ def main():
     for k in ks:
         ks[k] /= max(a.steps, 1)
 
+    if rank == 0 and world_sharded and getattr(sd, "trace", None):
+        print("shard trace (ms per timed pass): %s" %
+              {k: round(v / a.steps, 3) for k, v in sorted(sd.trace.items())}, file=sys.stderr)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()

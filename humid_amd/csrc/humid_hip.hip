@@ -58,7 +58,8 @@ struct humid_ctx {
   DBuf pc, poff, share_edges;                                                     // multi-GPU pair-search share
   DBuf own_words;                                                                 // multi-GPU dense count
   DBuf heads;                                                                     // big-component heads
-  DBuf x_items, x_w, x_id, x_ids, x_ends, x_ends_s, x_head, x_hpos, x_nodes, x_cedges;   // multi-GPU exchange mode
+  DBuf x_route, x_creator, x_base, x_mark, x_markcr, x_scan, x_lcid, x_lismax,
+       x_items, x_w, x_id, x_ids, x_ends, x_ends_s, x_head, x_hpos, x_nodes, x_cedges;   // multi-GPU exchange mode
   DBuf w_sorted, w_head, w_hpos, w_start;                                         // wide-word (sorted) counts
   bool last_count_sorted = false;                                                 // last count was the wide-word sort
   u32 g_wpr = 1;                                                                  // uint64 per word of g_word
@@ -995,7 +996,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
-                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->seg_ws, &c->csize, &c->cur, &c->plan_dev, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -1290,8 +1291,7 @@ int humid_stage_histogram(humid_ctx *c, const uint64_t *d_words, const uint8_t *
     hipLaunchKernelGGL(k_top_hist, dim3(512), dim3(256), n_bins * 4, c->stream, d_words, d_filtered,
                        (u32)n_reads, 2 * word_nt - bits, n_bins, d_hist);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(c->stream));
-  return HUMID_OK;
+  return HUMID_OK;              // queued on the context's stream; no host value is returned
 }
 
 int humid_stage_count(humid_ctx *c, const uint64_t *d_words, const uint8_t *d_filtered, uint64_t n_reads,
@@ -1329,7 +1329,10 @@ int humid_stage_count_dense(humid_ctx *c, const uint64_t *d_words, const uint8_t
   c->dense_mode = false;
   TRY(check_run_args(c, n_reads, word_nt, 0));
   if (!shard_begin || !counts || n_shards == 0 || n_shards > 4096) return fail(c, HUMID_E_INVALID, "bad argument");
-  if (n_reads && (!d_words || !d_filtered)) return fail(c, HUMID_E_INVALID, "null buffer");
+  // d_filtered == NULL with the full value range: every read is owned (exchange mode: the reads
+  // were routed here because they are); the array is counted as it stands, no compaction pass
+  const bool all_owned = d_filtered == nullptr && range_lo == 0 && range_hi == ~0ull;
+  if (n_reads && (!d_words || (!d_filtered && !all_owned))) return fail(c, HUMID_E_INVALID, "null buffer");
   HIPCHK(hipSetDevice(c->device));
   hipStream_t st = c->stream;
   const u32 N = (u32)n_reads;
@@ -1345,6 +1348,15 @@ int humid_stage_count_dense(humid_ctx *c, const uint64_t *d_words, const uint8_t
   if (n_usable) *n_usable = 0;
   c->dense_mode = true;
   if (N == 0) return HUMID_OK;
+  if (all_owned) {
+    for (u32 q = 0; q < n_shards; q++) counts[q] = shard_begin[q + 1] - shard_begin[q];
+    c->N = N;
+    TRY(stage_count(c, d_words, nullptr, N, word_nt, 0ull, ~0ull, 0, s));
+    HIPCHK(hipStreamSynchronize(st));
+    if (n_unique) *n_unique = c->U;
+    if (n_usable) *n_usable = c->usable;
+    return HUMID_OK;
+  }
   ENSURE(c->opos, ((size_t)N + 1) * 4);
   {
     auto fin = rocprim::make_transform_iterator(rocprim::counting_iterator<u32>(0),
@@ -1398,8 +1410,7 @@ int humid_stage_map_dense(humid_ctx *c, const uint32_t *d_local_cluster_id, cons
     hipLaunchKernelGGL(k_read_map_packed, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->slot_of_read.as<u32>(),
                        c->slot_out.as<u64>(), N, c->own_packed.as<u32>());
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(st));
-  *d_packed = c->own_packed.as<u32>();
+  *d_packed = c->own_packed.as<u32>();     // queued on the context's stream
   return HUMID_OK;
 }
 
@@ -1716,6 +1727,81 @@ int humid_stage_compact_nodes(humid_ctx *c, const uint64_t *d_edges, uint64_t n_
   return HUMID_OK;
 }
 
+// words of this rank's usable reads in the owner-major order humid_stage_owner_perm just computed
+int humid_stage_route_words(humid_ctx *c, const uint64_t *d_words, uint64_t n_send, const uint64_t **d_routed) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (!d_routed) return fail(c, HUMID_E_INVALID, "bad argument");
+  *d_routed = nullptr;
+  if (n_send == 0) return HUMID_OK;
+  if (!d_words) return fail(c, HUMID_E_INVALID, "null buffer");
+  if (n_send * 4 > c->perm.cap) return fail(c, HUMID_E_STATE, "no preceding humid_stage_owner_perm of at least n_send reads");
+  HIPCHK(hipSetDevice(c->device));
+  ENSURE(c->x_route, (size_t)n_send * 8);
+  hipLaunchKernelGGL(k_route_words, dim3(grid_stride_blocks(n_send)), dim3(256), 0, c->stream, d_words,
+                     c->perm.as<u32>(), (u32)n_send, c->x_route.as<u64>());
+  HIPCHK(hipGetLastError());
+  *d_routed = c->x_route.as<u64>();
+  return HUMID_OK;
+}
+
+// Cluster id and maxLeaf flag of this rank's u_local unique words (global walk indices
+// id_base .. id_base + u_local - 1) from the replicated compact graph: d_nodes[n_nodes] ascending
+// global indices of the leaves that have neighbours, d_ccid / d_cismax their results from
+// humid_stage_graph_edges (compact ids 1..n_clusters in creator order).  A leaf outside the compact
+// graph is a singleton: its own cluster, its own maxLeaf.  Ids follow src/humid.cc:177-180: 1 + the
+// number of cluster-creating leaves before it in the walk.  No host synchronisation.
+int humid_stage_exchange_ids(humid_ctx *c, const uint32_t *d_nodes, const uint32_t *d_ccid,
+                             const uint8_t *d_cismax, uint64_t n_nodes, uint64_t n_clusters, uint64_t id_base,
+                             uint64_t u_local, const uint32_t **d_l_cid, const uint8_t **d_l_ismax) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (!d_l_cid || !d_l_ismax) return fail(c, HUMID_E_INVALID, "bad argument");
+  if (id_base + u_local > 0xffffffffull || n_nodes > 0xfffffffeull || n_clusters > n_nodes)
+    return fail(c, HUMID_E_OVERFLOW, "index out of range");
+  *d_l_cid = nullptr;
+  *d_l_ismax = nullptr;
+  if (u_local == 0) return HUMID_OK;
+  if (n_nodes && (!d_nodes || !d_ccid || !d_cismax)) return fail(c, HUMID_E_INVALID, "null buffer");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const u32 M = (u32)n_nodes, Cc = (u32)n_clusters, goff = (u32)id_base, U = (u32)u_local;
+  ENSURE(c->x_creator, ((size_t)Cc + 1) * 4);
+  ENSURE(c->x_base, ((size_t)Cc + 1) * 4);
+  ENSURE(c->x_mark, (size_t)U * 4);
+  ENSURE(c->x_markcr, (size_t)U * 4);
+  ENSURE(c->x_scan, ((size_t)U + 1) * 8);
+  ENSURE(c->x_lcid, (size_t)U * 4);
+  ENSURE(c->x_lismax, (size_t)U);
+  ENSURE(c->small, 64);
+  HIPCHK(hipMemsetAsync(c->x_mark.p, 0, (size_t)U * 4, st));
+  HIPCHK(hipMemsetAsync(c->x_markcr.p, 0, (size_t)U * 4, st));
+  HIPCHK(hipMemsetAsync(c->small.p, 0, 8, st));
+  if (M) {
+    HIPCHK(hipMemsetAsync(c->x_creator.p, 0xff, ((size_t)Cc + 1) * 4, st));
+    hipLaunchKernelGGL(k_xid_creators, dim3(blocks_for(M)), dim3(256), 0, st, d_ccid, M, Cc, c->x_creator.as<u32>());
+    if (Cc)
+      hipLaunchKernelGGL(k_xid_base, dim3(blocks_for(Cc)), dim3(256), 0, st, d_nodes, c->x_creator.as<u32>(), M, Cc,
+                         goff, U, c->x_base.as<u32>(), c->x_markcr.as<u32>());
+    hipLaunchKernelGGL(k_xid_mark, dim3(blocks_for(M)), dim3(256), 0, st, d_nodes, M, goff, U, c->x_mark.as<u32>());
+    hipLaunchKernelGGL(k_xid_first, dim3(1), dim3(64), 0, st, d_nodes, c->x_creator.as<u32>(), M, Cc, goff,
+                       c->small.as<u32>());
+  }
+  {
+    auto fin = rocprim::make_transform_iterator(rocprim::counting_iterator<u32>(0),
+                                                XidFlagOp{c->x_mark.as<u32>(), c->x_markcr.as<u32>(), U});
+    size_t bytes = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, bytes, fin, c->x_scan.as<u64>(), (u64)0, (size_t)U, rocprim::plus<u64>(), st));
+    ENSURE(c->tmp, bytes);
+    HIPCHK(rocprim::exclusive_scan(c->tmp.p, bytes, fin, c->x_scan.as<u64>(), (u64)0, (size_t)U, rocprim::plus<u64>(), st));
+  }
+  hipLaunchKernelGGL(k_xid_assign, dim3(blocks_for(U)), dim3(256), 0, st, c->x_mark.as<u32>(), c->x_scan.as<u64>(),
+                     c->small.as<u32>(), d_ccid, d_cismax, c->x_base.as<u32>(), Cc, goff, U, c->x_lcid.as<u32>(),
+                     c->x_lismax.as<u8>());
+  HIPCHK(hipGetLastError());
+  *d_l_cid = c->x_lcid.as<u32>();
+  *d_l_ismax = c->x_lismax.as<u8>();
+  return HUMID_OK;
+}
+
 // ---- multi-GPU result return ------------------------------------------------------------------
 int humid_stage_owned_results(humid_ctx *c, const uint32_t *d_local_cluster_id, const uint8_t *d_local_is_max,
                               const uint64_t *shard_begin, uint32_t n_shards, const uint32_t **d_packed,
@@ -1825,8 +1911,7 @@ int humid_stage_scatter(humid_ctx *c, const uint32_t *d_perm, const uint32_t *d_
                        (u32)n_recv, d_cluster_id, d_keep);
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(st));
-  return HUMID_OK;
+  return HUMID_OK;              // queued on the context's stream
 }
 
 }  // extern "C"

@@ -255,6 +255,89 @@ __global__ void k_relabel_edges(const u64 *__restrict__ edges, u32 n_edges, cons
   out[k] = ((u64)r[0] << 32) | r[1];
 }
 
+// routed copy of the usable reads' words (owner-major order of humid_stage_owner_perm)
+__global__ void __launch_bounds__(256)
+k_route_words(const u64 *__restrict__ words, const u32 *__restrict__ perm, u32 n, u64 *__restrict__ out) {
+  for (u32 k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) out[k] = words[perm[k]];
+}
+
+// ---- cluster ids of one rank's unique words from the replicated compact graph ----
+// creator (smallest member = the leaf whose walk step created the cluster) of every compact cluster
+__global__ void k_xid_creators(const u32 *__restrict__ ccid, u32 n_nodes, u32 n_clusters, u32 *creator) {
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_nodes) return;
+  const u32 c = ccid[k];
+  if (c >= 1 && c <= n_clusters) atomicMin(&creator[c - 1], k);
+}
+
+// base_id[c] = global cluster id - 1 of compact cluster c: creators before it in the whole walk =
+// singletons before its creator (global index - compact position) + compact creators before it (c)
+__global__ void k_xid_base(const u32 *__restrict__ nodes, const u32 *__restrict__ creator, u32 n_nodes,
+                           u32 n_clusters, u32 goff, u32 u_local, u32 *__restrict__ base_id,
+                           u32 *__restrict__ mark_cr) {
+  u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_clusters) return;
+  const u32 k = creator[c];
+  if (k >= n_nodes) { base_id[c] = 0; return; }            // malformed ids: never index with them
+  const u32 g = nodes[k];
+  base_id[c] = g - k + c;
+  if (g >= goff && g - goff < u_local) mark_cr[g - goff] = 1u;
+}
+
+// mark[i] = compact position + 1 of local unique word i (0 = singleton)
+__global__ void k_xid_mark(const u32 *__restrict__ nodes, u32 n_nodes, u32 goff, u32 u_local, u32 *__restrict__ mark) {
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_nodes) return;
+  const u32 g = nodes[k];
+  if (g >= goff && g - goff < u_local) mark[g - goff] = k + 1u;
+}
+
+// first[0] = compact nodes below goff, first[1] = compact creators below goff (binary searches)
+__global__ void k_xid_first(const u32 *__restrict__ nodes, const u32 *__restrict__ creator, u32 n_nodes,
+                            u32 n_clusters, u32 goff, u32 *__restrict__ first) {
+  if (threadIdx.x == 0) {
+    u32 lo = 0, hi = n_nodes;
+    while (lo < hi) { const u32 mid = lo + ((hi - lo) >> 1); if (nodes[mid] < goff) lo = mid + 1; else hi = mid; }
+    first[0] = lo;
+  } else if (threadIdx.x == 1) {
+    u32 lo = 0, hi = n_clusters;               // creators ascend with the cluster id
+    while (lo < hi) {
+      const u32 mid = lo + ((hi - lo) >> 1);
+      const u32 k = creator[mid];
+      if (k < n_nodes && nodes[k] < goff) lo = mid + 1; else hi = mid;
+    }
+    first[1] = lo;
+  }
+}
+
+struct XidFlagOp {               // (is compact) | (is compact creator) << 32, scanned in one pass
+  const u32 *mark, *mark_cr;
+  u32 n;
+  __device__ u64 operator()(u32 i) const {
+    if (i >= n) return 0ull;
+    return (u64)(mark[i] != 0u) | ((u64)(mark_cr[i] != 0u) << 32);
+  }
+};
+
+__global__ void __launch_bounds__(256)
+k_xid_assign(const u32 *__restrict__ mark, const u64 *__restrict__ scan, const u32 *__restrict__ first,
+             const u32 *__restrict__ ccid, const u8 *__restrict__ cismax, const u32 *__restrict__ base_id,
+             u32 n_clusters, u32 goff, u32 u_local, u32 *__restrict__ l_cid, u8 *__restrict__ l_ismax) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= u_local) return;
+  const u32 m = mark[i];
+  if (m) {
+    const u32 c = ccid[m - 1];
+    l_cid[i] = (c >= 1 && c <= n_clusters) ? 1u + base_id[c - 1] : 0u;
+    l_ismax[i] = cismax[m - 1];
+  } else {
+    const u64 sc = scan[i];
+    const u32 nb = first[0] + (u32)sc, cb = first[1] + (u32)(sc >> 32);
+    l_cid[i] = 1u + (goff + i) - nb + cb;     // creators before it: singletons + compact creators
+    l_ismax[i] = 1;
+  }
+}
+
 __global__ void k_widen32(const u32 *__restrict__ in, u32 n, u64 *__restrict__ out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i];

@@ -75,52 +75,70 @@ class HipStageOps(Context):
 
     def __init__(self, device: int):
         self.device = torch.device("cuda", device)
-        super().__init__(device=device)
+        # The context works on a torch stream of its own.  ShardedDedup.run makes it the current
+        # stream, so torch ops, collectives and the library's kernels are ordered by the stream
+        # itself; a caller on another stream is ordered through events (_enter / _exit) -- no host
+        # synchronisation either way.
+        self.tstream = torch.cuda.Stream(self.device)
+        super().__init__(device=device, stream=self.tstream.cuda_stream)
+
+    def _enter(self):
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.tstream:
+            self.tstream.wait_stream(cur)
+
+    def _exit(self):
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.tstream:
+            cur.wait_stream(self.tstream)
+
+    def _call(self, fn, *args):
+        """one stage entry point, ordered after the caller's stream and before its next op"""
+        self._enter()
+        self._check(fn(self._h, *args))
+        self._exit()
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
 
     def histogram(self, g_w, g_f, word_nt, bits):
         hist = torch.zeros(1 << bits, dtype=torch.int32, device=self.device)
-        torch.cuda.current_stream(self.device).synchronize()
-        self._check(self._lib.humid_stage_histogram(self._h, C.c_void_p(g_w.data_ptr()),
-                                                    C.c_void_p(g_f.data_ptr()), g_w.numel(), word_nt,
-                                                    bits, C.c_void_p(hist.data_ptr())))
+        self._call(self._lib.humid_stage_histogram, self._p(g_w), self._p(g_f), g_w.numel(), word_nt, bits,
+                   C.c_void_p(hist.data_ptr()))
         return hist
 
     def count_dense(self, g_w, g_f, word_nt, lo, hi, shard_begin):
-        """compact this rank's reads, count them with the LDS tables; also the send split sizes"""
+        """compact this rank's reads, count them with the LDS tables; also the send split sizes.
+        g_f None (with the full value range): every read is owned, no compaction pass"""
         n = len(shard_begin) - 1
         sb = (C.c_uint64 * (n + 1))(*shard_begin)
         counts = (C.c_uint64 * n)()
         nu, ns = C.c_uint64(), C.c_uint64()
-        torch.cuda.current_stream(self.device).synchronize()
         self.set_option("count_mode", 0)
-        self._check(self._lib.humid_stage_count_dense(
-            self._h, C.c_void_p(g_w.data_ptr()), C.c_void_p(g_f.data_ptr()), g_w.numel(), word_nt,
-            C.c_uint64(lo), C.c_uint64(hi), sb, n, counts, C.byref(nu), C.byref(ns)))
+        self._call(self._lib.humid_stage_count_dense, self._p(g_w), self._p(g_f), g_w.numel(), word_nt,
+                   C.c_uint64(lo), C.c_uint64(hi), sb, n, counts, C.byref(nu), C.byref(ns))
         self._u = nu.value
         return nu.value, ns.value, [int(x) for x in counts]
 
     def map_dense(self, l_cid, l_ismax):
         pp = C.c_void_p()
         n = C.c_uint64()
-        torch.cuda.current_stream(self.device).synchronize()
-        self._check(self._lib.humid_stage_map_dense(self._h, C.c_void_p(l_cid.data_ptr()),
-                                                    C.c_void_p(l_ismax.data_ptr()), C.byref(pp), C.byref(n)))
+        self._call(self._lib.humid_stage_map_dense, self._p(l_cid), self._p(l_ismax), C.byref(pp), C.byref(n))
         return _wrap(pp.value, n.value, "<i4", torch.int32, self.device)
 
     def count(self, g_w, g_f, word_nt, lo, hi, expected):
         self.set_option("count_mode", 1)      # partial range + slot_of_read over N: global table
         nu, ns = C.c_uint64(), C.c_uint64()
         self._n_reads = g_w.numel()
-        self._check(self._lib.humid_stage_count(self._h, C.c_void_p(g_w.data_ptr()),
-                                                C.c_void_p(g_f.data_ptr()), g_w.numel(), word_nt,
-                                                C.c_uint64(lo), C.c_uint64(hi), expected,
-                                                C.byref(nu), C.byref(ns)))
+        self._call(self._lib.humid_stage_count, self._p(g_w), self._p(g_f), g_w.numel(), word_nt,
+                   C.c_uint64(lo), C.c_uint64(hi), expected, C.byref(nu), C.byref(ns))
         self._u = nu.value
         return nu.value, ns.value
 
     def unique(self):
         pw, pc, pf = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        self._check(self._lib.humid_stage_unique(self._h, C.byref(pw), C.byref(pc), C.byref(pf)))
+        self._call(self._lib.humid_stage_unique, C.byref(pw), C.byref(pc), C.byref(pf))
         w = _wrap(pw.value, self._u, "<i8", torch.int64, self.device)
         c = _wrap(pc.value, self._u, "<i4", torch.int32, self.device)
         return w, c
@@ -129,10 +147,8 @@ class HipStageOps(Context):
         pc, pm = C.c_void_p(), C.c_void_p()
         s = _lib.HumidSummary()
         n = g_word.numel()
-        torch.cuda.current_stream(self.device).synchronize()
-        self._check(self._lib.humid_stage_graph(self._h, C.c_void_p(g_word.data_ptr()),
-                                                C.c_void_p(g_cnt.data_ptr()), n, word_nt, distance,
-                                                method, C.byref(pc), C.byref(pm), C.byref(s)))
+        self._call(self._lib.humid_stage_graph, self._p(g_word), self._p(g_cnt), n, word_nt, distance,
+                   method, C.byref(pc), C.byref(pm), C.byref(s))
         cid = _wrap(pc.value, n, "<i4", torch.int32, self.device)
         ismax = _wrap(pm.value, n, "|u1", torch.uint8, self.device)
         return cid, ismax, s.asdict()
@@ -141,21 +157,16 @@ class HipStageOps(Context):
         """this rank's share of the neighbour pairs: int64 tensor of (smaller << 32 | larger)"""
         pe = C.c_void_p()
         ne = C.c_uint64()
-        torch.cuda.current_stream(self.device).synchronize()
-        self._check(self._lib.humid_stage_pairs(self._h, C.c_void_p(g_word.data_ptr()), g_word.numel(),
-                                                word_nt, distance, part_rank, part_world,
-                                                C.byref(pe), C.byref(ne)))
+        self._call(self._lib.humid_stage_pairs, self._p(g_word), g_word.numel(), word_nt, distance,
+                   part_rank, part_world, C.byref(pe), C.byref(ne))
         return _wrap(pe.value, ne.value, "<i8", torch.int64, self.device)
 
     def graph_edges(self, g_word, g_cnt, edges, word_nt, distance, method):
         pc, pm = C.c_void_p(), C.c_void_p()
         s = _lib.HumidSummary()
         n = g_word.numel()
-        torch.cuda.current_stream(self.device).synchronize()
-        self._check(self._lib.humid_stage_graph_edges(
-            self._h, C.c_void_p(g_word.data_ptr()), C.c_void_p(g_cnt.data_ptr()), n,
-            C.c_void_p(edges.data_ptr()) if edges.numel() else None, edges.numel(), word_nt, distance,
-            method, C.byref(pc), C.byref(pm), C.byref(s)))
+        self._call(self._lib.humid_stage_graph_edges, self._p(g_word), self._p(g_cnt), n, self._p(edges),
+                   edges.numel(), word_nt, distance, method, C.byref(pc), C.byref(pm), C.byref(s))
         cid = _wrap(pc.value, n, "<i4", torch.int32, self.device)
         ismax = _wrap(pm.value, n, "|u1", torch.uint8, self.device)
         return cid, ismax, s.asdict()
@@ -166,10 +177,8 @@ class HipStageOps(Context):
         sb = (C.c_uint64 * (n + 1))(*shard_begin)
         counts = (C.c_uint64 * n)()
         pp = C.c_void_p()
-        torch.cuda.current_stream(self.device).synchronize()
-        self._check(self._lib.humid_stage_owned_results(
-            self._h, C.c_void_p(l_cid.data_ptr()), C.c_void_p(l_ismax.data_ptr()), sb, n,
-            C.byref(pp), counts))
+        self._call(self._lib.humid_stage_owned_results, self._p(l_cid), self._p(l_ismax), sb, n,
+                   C.byref(pp), counts)
         counts = [int(x) for x in counts]
         return _wrap(pp.value, sum(counts), "<i4", torch.int32, self.device), counts
 
@@ -180,18 +189,14 @@ class HipStageOps(Context):
         hi = (C.c_uint64 * P)(*[r[1] for r in ranges])
         counts = (C.c_uint64 * P)()
         pp = C.c_void_p()
-        torch.cuda.current_stream(self.device).synchronize()
-        self._check(self._lib.humid_stage_owner_perm(
-            self._h, C.c_void_p(d_w.data_ptr()), C.c_void_p(d_f.data_ptr()), d_w.numel(), lo, hi, P,
-            C.byref(pp), counts))
+        self._call(self._lib.humid_stage_owner_perm, self._p(d_w), self._p(d_f), d_w.numel(), lo, hi, P,
+                   C.byref(pp), counts)
         counts = [int(x) for x in counts]
         return _wrap(pp.value, d_w.numel(), "<i4", torch.int32, self.device), counts
 
     def scatter(self, perm, recv, out_cid, out_keep):
-        torch.cuda.current_stream(self.device).synchronize()
-        self._check(self._lib.humid_stage_scatter(
-            self._h, C.c_void_p(perm.data_ptr()), C.c_void_p(recv.data_ptr()), recv.numel(),
-            out_cid.numel(), C.c_void_p(out_cid.data_ptr()), C.c_void_p(out_keep.data_ptr())))
+        self._call(self._lib.humid_stage_scatter, self._p(perm), self._p(recv), recv.numel(),
+                   out_cid.numel(), self._p(out_cid), self._p(out_keep))
 
     max_ranks_dense = 16
 
@@ -202,15 +207,19 @@ class HipStageOps(Context):
                                                     C.byref(nc), C.byref(pb)))
         return nc.value, pb.value
 
+    def route_words(self, d_w, n_send):
+        """words of the usable reads in the owner-major order of the preceding owner_perm"""
+        pr = C.c_void_p()
+        self._call(self._lib.humid_stage_route_words, self._p(d_w), n_send, C.byref(pr))
+        return _wrap(pr.value, n_send, "<i8", torch.int64, self.device)
+
     def combo_route(self, l_word, id_base, word_nt, distance, plan_unique, combo, n_ranks):
         """(word, id) items of the local unique array in destination-major order: int64[n, 2]"""
         pi = C.c_void_p()
         counts = (C.c_uint64 * n_ranks)()
         n = l_word.numel()
-        torch.cuda.current_stream(self.device).synchronize()
-        self._check(self._lib.humid_stage_combo_route(
-            self._h, C.c_void_p(l_word.data_ptr()), n, id_base, word_nt, distance, plan_unique, combo,
-            n_ranks, C.byref(pi), counts))
+        self._call(self._lib.humid_stage_combo_route, self._p(l_word), n, id_base, word_nt, distance,
+                   plan_unique, combo, n_ranks, C.byref(pi), counts)
         return _wrap(pi.value, 2 * n, "<i8", torch.int64, self.device).view(-1, 2), [int(x) for x in counts]
 
     def pairs_keyed(self, items, interleaved, id_base, word_nt, distance, plan_unique, combo):
@@ -218,29 +227,30 @@ class HipStageOps(Context):
         call overwrites"""
         pe = C.c_void_p()
         ne = C.c_uint64()
-        n = items.shape[0]
-        torch.cuda.current_stream(self.device).synchronize()
-        self._check(self._lib.humid_stage_pairs_keyed(
-            self._h, C.c_void_p(items.data_ptr()) if n else None, n, int(interleaved), id_base, word_nt,
-            distance, plan_unique, combo, C.byref(pe), C.byref(ne)))
+        self._call(self._lib.humid_stage_pairs_keyed, self._p(items), items.shape[0], int(interleaved),
+                   id_base, word_nt, distance, plan_unique, combo, C.byref(pe), C.byref(ne))
         return _wrap(pe.value, ne.value, "<i8", torch.int64, self.device)
 
     def compact_nodes(self, edges):
         pn, pc = C.c_void_p(), C.c_void_p()
         nn = C.c_uint64()
-        torch.cuda.current_stream(self.device).synchronize()
-        self._check(self._lib.humid_stage_compact_nodes(
-            self._h, C.c_void_p(edges.data_ptr()) if edges.numel() else None, edges.numel(),
-            C.byref(pn), C.byref(nn), C.byref(pc)))
+        self._call(self._lib.humid_stage_compact_nodes, self._p(edges), edges.numel(), C.byref(pn),
+                   C.byref(nn), C.byref(pc))
         return (_wrap(pn.value, nn.value, "<i4", torch.int32, self.device),
                 _wrap(pc.value, edges.numel(), "<i8", torch.int64, self.device))
 
+    def exchange_ids(self, nodes, ccid, cismax, n_clusters, id_base, u_local):
+        """cluster id (int32) + maxLeaf flag (uint8) of the local unique words; views of ctx memory"""
+        pc, pm = C.c_void_p(), C.c_void_p()
+        m = nodes.numel() if nodes is not None else 0
+        self._call(self._lib.humid_stage_exchange_ids, self._p(nodes), self._p(ccid), self._p(cismax), m,
+                   n_clusters, id_base, u_local, C.byref(pc), C.byref(pm))
+        return (_wrap(pc.value, u_local, "<i4", torch.int32, self.device),
+                _wrap(pm.value, u_local, "|u1", torch.uint8, self.device))
+
     def map(self, l_cid, l_ismax, out_cid, out_keep):
-        torch.cuda.current_stream(self.device).synchronize()
-        self._check(self._lib.humid_stage_map(self._h, C.c_void_p(l_cid.data_ptr()),
-                                              C.c_void_p(l_ismax.data_ptr()), out_cid.numel(),
-                                              C.c_void_p(out_cid.data_ptr()),
-                                              C.c_void_p(out_keep.data_ptr())))
+        self._call(self._lib.humid_stage_map, self._p(l_cid), self._p(l_ismax), out_cid.numel(),
+                   self._p(out_cid), self._p(out_keep))
 
 
 # ------------------------------------------------------------------------------------------
@@ -315,6 +325,36 @@ def _all_gather_var(dist, t, world, fill=0):
     return torch.cat([allb[q * m:q * m + ns[q]] for q in range(world)]), ns
 
 
+def _exchange_ids_torch(nodes, ccid, cismax, n_clusters, goff, u_local, dev):
+    """humid_stage_exchange_ids restated with torch ops (ops objects without the entry point: the
+    CPU stand-in of the gloo tests).  Cluster id = 1 + cluster-creating leaves before it in the whole
+    walk = singletons before it + compact creators before it."""
+    i64 = dict(dtype=torch.int64, device=dev)
+    g = goff + torch.arange(u_local, **i64)
+    if nodes is None or nodes.numel() == 0:
+        return (1 + g).to(torch.int32), torch.ones(u_local, dtype=torch.uint8, device=dev)
+    M = nodes.numel()
+    nodes64 = nodes.long() & 0xffffffff
+    s0, s1 = torch.searchsorted(nodes64, torch.tensor([goff, goff + u_local], **i64)).tolist()
+    li = nodes64[s0:s1] - goff                                # local indices of this rank's endpoints
+    ccid64 = ccid.long()
+    creator = torch.full((n_clusters,), M, **i64).scatter_reduce_(0, ccid64 - 1, torch.arange(M, **i64), "amin")
+    creator_g = nodes64[creator]                              # ascending: ids follow creators
+    base_id = creator_g - creator + torch.arange(n_clusters, **i64)   # global cluster id - 1
+    is_c = torch.zeros(u_local, **i64)
+    is_c[li] = 1
+    nb = s0 + torch.cumsum(is_c, 0) - is_c
+    cr = torch.searchsorted(creator_g, torch.tensor([goff, goff + u_local], **i64)).tolist()
+    is_cr = torch.zeros(u_local, **i64)
+    is_cr[creator_g[cr[0]:cr[1]] - goff] = 1
+    cb = cr[0] + torch.cumsum(is_cr, 0) - is_cr
+    l_cid = 1 + g - nb + cb
+    l_cid[li] = 1 + base_id[ccid64[s0:s1] - 1]
+    l_ismax = torch.ones(u_local, dtype=torch.uint8, device=dev)
+    l_ismax[li] = cismax[s0:s1]
+    return l_cid.to(torch.int32), l_ismax
+
+
 def splitters_from_hist(hist: np.ndarray, world: int, word_nt: int, bits: int):
     """P ordered, disjoint, covering value ranges with balanced usable-read counts.
     Returns [(lo, hi_inclusive, expected_reads)] -- identical on every rank."""
@@ -361,10 +401,24 @@ class ShardedDedup:
         self.dense_return = dense_return
         self.partition_search = partition_search
         self._n_max = None
+        self.trace = {} if os.environ.get("HUMID_SHARD_TRACE") else None
 
     def run(self, d_w, d_f, d_cid, d_keep):
         """d_w int64[n_local] packed words, d_f uint8[n_local]; writes d_cid int32[n_local] and
         d_keep uint8[n_local] (torch tensors on this rank's device).  Returns a summary dict."""
+        ts = getattr(self.ops, "tstream", None)
+        if ts is None:
+            return self._run(d_w, d_f, d_cid, d_keep)
+        # the library's stream becomes the current stream for the whole pass: torch ops, RCCL
+        # collectives and the stage kernels are then ordered by the stream, without host syncs
+        cur = torch.cuda.current_stream(d_w.device)
+        ts.wait_stream(cur)
+        with torch.cuda.stream(ts):
+            summ = self._run(d_w, d_f, d_cid, d_keep)
+        cur.wait_stream(ts)
+        return summ
+
+    def _run(self, d_w, d_f, d_cid, d_keep):
         if self.mode == "exchange" and hasattr(self.ops, "combo_route") and \
                 self.world <= getattr(self.ops, "max_ranks_dense", 0):
             _, pbits = self.ops.plan_info(self.word_nt, self.distance, 1)
@@ -379,23 +433,42 @@ class ShardedDedup:
         dev = d_w.device
         n_local = d_w.numel()
         i64 = dict(dtype=torch.int64, device=dev)
+        trace = self.trace
+        if trace is not None:
+            import time
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            t_last = [time.perf_counter()]
+
+        def mark(name):                                   # HUMID_SHARD_TRACE=1: per-phase wall ms
+            if trace is None:
+                return
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            now = time.perf_counter()
+            trace[name] = trace.get(name, 0.0) + 1e3 * (now - t_last[0])
+            t_last[0] = now
         # ---- 1. global histogram -> balanced ordered value ranges (cut at prefix boundaries) ----
         hist = ops.histogram(d_w, d_f, self.word_nt, bits)
         dist.all_reduce(hist)
         ranges = splitters_from_hist(hist.cpu().numpy(), P, self.word_nt, bits)
+        mark("1_ranges")
         # ---- 2. usable words -> owner of their range ----
         perm, send_counts = ops.owner_perm(d_w, d_f, ranges)          # owner-major, filtered reads last
         n_send = sum(send_counts)
-        send_w = d_w[perm[:n_send].long()] if n_send else torch.empty(0, **i64)
+        if hasattr(ops, "route_words"):
+            send_w = ops.route_words(d_w, n_send)
+        else:
+            send_w = d_w[perm[:n_send].long()] if n_send else torch.empty(0, **i64)
         cm = torch.empty(P * P, **i64)
         _all_gather_flat(dist, cm, torch.tensor(send_counts, **i64), P)
         recv_counts = cm.cpu().view(P, P)[:, r].tolist()
         n_recv = sum(recv_counts)
         recv_w = torch.empty(n_recv, **i64)
         _all_to_all_v(dist, recv_w, send_w, recv_counts, send_counts, P, r)
+        mark("2_route_words")
         # ---- 3. exact counts of the received words (all usable, all in this rank's range) ----
-        zf = torch.zeros(max(n_recv, 1), dtype=torch.uint8, device=dev)
-        u_local, usable_local, _ = ops.count_dense(recv_w, zf[:n_recv], self.word_nt, 0, (1 << 64) - 1, [0, n_recv])
+        u_local, usable_local, _ = ops.count_dense(recv_w, None, self.word_nt, 0, (1 << 64) - 1, [0, n_recv])
         metas = torch.empty(3 * P, **i64)
         _all_gather_flat(dist, metas, torch.tensor([u_local, usable_local, n_local], **i64), P)
         metas = metas.cpu().view(P, 3)
@@ -406,6 +479,7 @@ class ShardedDedup:
         if u_total >= (1 << 32) - 1:
             raise HumidError(-5, "more than 2^32-2 unique words in total")
         lw, lc = ops.unique() if u_local else (torch.empty(0, **i64), torch.empty(0, dtype=torch.int32, device=dev))
+        mark("3_count")
         # ---- 4. neighbour pairs in global unique indices ----
         e_parts = []
         if self.distance > 0 and u_total > 1:
@@ -423,50 +497,39 @@ class ShardedDedup:
                     e_parts.append(ops.pairs_keyed(got, True, 0, self.word_nt, self.distance, u_total, cb).clone())
         e_loc = torch.cat(e_parts) if e_parts else torch.empty(0, **i64)
         e_all, _ = _all_gather_var(dist, e_loc, P)
+        mark("4_pairs")
         # ---- 5. compact graph over the pairs' endpoints; ids by closed-form prefix counts ----
-        g = goff + torch.arange(u_local, **i64)
         if e_all.numel():
             nodes, cedges = ops.compact_nodes(e_all)                  # ascending global indices, int32
-            nodes = nodes.clone()
-            cedges = cedges.clone()
             M = nodes.numel()
+            # counts of the endpoints: every rank contributes the slice it owns (ranks own
+            # contiguous index ranges, so the slices concatenate to the node order)
             nodes64 = nodes.long() & 0xffffffff
-            bounds = torch.searchsorted(nodes64, torch.tensor([goff, goff + u_local], **i64)).tolist()
-            s0, s1 = bounds
-            li = nodes64[s0:s1] - goff                                # local indices of this rank's endpoints
-            own_cnt = lc[li] if s1 > s0 else torch.empty(0, dtype=torch.int32, device=dev)
+            s0, s1 = torch.searchsorted(nodes64, torch.tensor([goff, goff + u_local], **i64)).tolist()
+            own_cnt = lc[nodes64[s0:s1] - goff] if s1 > s0 else torch.empty(0, dtype=torch.int32, device=dev)
             cnt_c, _ = _all_gather_var(dist, own_cnt, P)
             ccid, cismax, gs = ops.graph_edges(nodes, cnt_c, cedges, self.word_nt, self.distance, self.method)
             C_c = int(gs["clusters"])
-            ccid64 = ccid.long()
-            creator = torch.full((C_c,), M, **i64).scatter_reduce_(0, ccid64 - 1, torch.arange(M, **i64), "amin")
-            creator_g = nodes64[creator]                              # ascending: ids follow creators
-            base_id = creator_g - creator + torch.arange(C_c, **i64)  # global cluster id - 1
-            is_c = torch.zeros(u_local, **i64)
-            is_c[li] = 1
-            nb = s0 + torch.cumsum(is_c, 0) - is_c
-            cr = torch.searchsorted(creator_g, torch.tensor([goff, goff + u_local], **i64)).tolist()
-            is_cr = torch.zeros(u_local, **i64)
-            is_cr[creator_g[cr[0]:cr[1]] - goff] = 1
-            cb_ = cr[0] + torch.cumsum(is_cr, 0) - is_cr
-            l_cid = 1 + g - nb + cb_
-            l_cid[li] = 1 + base_id[ccid64[s0:s1] - 1]
-            l_ismax = torch.ones(u_local, dtype=torch.uint8, device=dev)
-            l_ismax[li] = cismax[s0:s1]
             summ.update(clusters=u_total - M + C_c, edges=int(e_all.numel()), nonsingle=M)
             for k, v in gs.items():
                 if k.startswith("ms_"):
                     summ[k] = v
         else:
-            l_cid = 1 + g
-            l_ismax = torch.ones(u_local, dtype=torch.uint8, device=dev)
+            nodes = ccid = cismax = None
+            C_c = 0
+        if hasattr(ops, "exchange_ids"):
+            l_cid, l_ismax = ops.exchange_ids(nodes, ccid, cismax, C_c, goff, u_local)
+        else:
+            l_cid, l_ismax = _exchange_ids_torch(nodes, ccid, cismax, C_c, goff, u_local, dev)
         if summ["clusters"] >= (1 << 31):
             raise HumidError(-5, "cluster ids exceed 31 bits")
+        mark("5_clusters")
         # ---- 6. per-read results at the owner, back to the home shards ----
-        packed = ops.map_dense(l_cid.to(torch.int32), l_ismax)
+        packed = ops.map_dense(l_cid, l_ismax)
         ret = torch.empty(n_send, dtype=torch.int32, device=dev)
         _all_to_all_v(dist, ret, packed, send_counts, recv_counts, P, r)
         ops.scatter(perm, ret, d_cid, d_keep)
+        mark("6_results")
         self.summary = summ
         return summ
 

@@ -256,7 +256,20 @@ int humid_stage_scatter(humid_ctx *ctx, const uint32_t *d_perm, const uint32_t *
  *     interleaved = 0: a plain ascending word array with ids id_base + index (combination 0 only).
  *   humid_stage_compact_nodes: the distinct endpoints of an edge list (ascending) and the same
  *     edges over positions in that list -- the input of humid_stage_graph_edges for a graph that
- *     leaves out the singletons (every singleton is its own cluster and its own maxLeaf). */
+ *     leaves out the singletons (every singleton is its own cluster and its own maxLeaf).
+ *   humid_stage_route_words: the words of this rank's usable reads in the owner-major order of the
+ *     preceding humid_stage_owner_perm (the all-to-all send buffer).
+ *   humid_stage_exchange_ids: cluster id + maxLeaf flag of this rank's unique words (global walk
+ *     indices id_base ..) from the compact graph's results; ids count the cluster-creating leaves
+ *     before a leaf in the WHOLE walk (src/humid.cc:177-180): singletons + compact creators.
+ * humid_stage_count_dense accepts d_filtered = NULL with the full value range: every read is owned
+ * and counted as it stands. */
+int humid_stage_route_words(humid_ctx *ctx, const uint64_t *d_words, uint64_t n_send,
+                            const uint64_t **d_routed);
+int humid_stage_exchange_ids(humid_ctx *ctx, const uint32_t *d_nodes, const uint32_t *d_compact_cluster_id,
+                             const uint8_t *d_compact_is_max, uint64_t n_nodes, uint64_t n_clusters,
+                             uint64_t id_base, uint64_t u_local, const uint32_t **d_local_cluster_id,
+                             const uint8_t **d_local_is_max);
 int humid_stage_plan_info(humid_ctx *ctx, uint32_t word_nt, uint32_t distance, uint64_t plan_unique,
                           uint32_t *n_combos, uint32_t *prefix_bits);
 int humid_stage_combo_route(humid_ctx *ctx, const uint64_t *d_word, uint64_t n_unique, uint64_t id_base,

@@ -60,6 +60,8 @@ class CpuStageOps:
 
     # ---- dense count / map ----
     def count_dense(self, g_w, g_f, word_nt, lo, hi, shard_begin):
+        if g_f is None:                       # exchange mode: every read is owned
+            g_f = torch.zeros(len(g_w), dtype=torch.uint8)
         u, usable = self.count(g_w, g_f, word_nt, lo, hi, len(g_w))
         idx = self.read_idx
         counts = [int(((idx >= shard_begin[q]) & (idx < shard_begin[q + 1])).sum())
