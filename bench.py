@@ -90,7 +90,10 @@ def main():
         sd = ShardedDedup(device=local_rank, word_nt=a.word_nt, distance=a.distance)
 
         def step():
-            return sd.run(d_w, d_f, d_cid, d_keep)
+            s = dict(sd.run(d_w, d_f, d_cid, d_keep))
+            if sd.mode_used == "exchange":          # HIP-event times of this rank's dominant kernels
+                s.update(sd.ops.kernel_ms())
+            return s
 
     def barrier():
         if dist is not None:
@@ -133,7 +136,8 @@ def main():
 
     # ---- roofline of the dominant kernel (HIP events around its single launch, live) ----
     # candidates: the two N-proportional single-launch kernels (13 B/read x N is their unit)
-    lds = int(last.get("count_mode_used", 0)) in (0, 2) and world == 1 and not a.force_sharded
+    lds = int(last.get("count_mode_used", 0)) in (0, 2) and \
+        (not world_sharded or getattr(sd, "mode_used", "") == "exchange")
     kern = {("k_dedup_lds" if lds else "k_hash_insert"): ks["ms_k_insert"],
             ("k_read_map_part" if lds else "k_read_map"): ks["ms_k_map"]}
     dom = max(kern, key=lambda k: kern[k])
@@ -179,7 +183,11 @@ def main():
                                % (n_local, world, a.word_nt, a.distance),
                    "reads_per_gpu": n_local, "word_nt": a.word_nt, "distance": a.distance,
                    "method": "directional",
-                   "sharding": "single GPU" if world == 1 else "reads sharded, RCCL all-gather of packed words"},
+                   "sharding": "single GPU" if not world_sharded else (
+                       "reads sharded by input order; RCCL all-to-all of the packed words to value-range "
+                       "owners, keyed exchange of unique words, all-gather of the neighbour pairs"
+                       if sd.mode_used == "exchange" else
+                       "reads sharded by input order; RCCL all-gather of the packed words")},
         "summary": {k: int(last[k]) for k in ("total", "usable", "unique", "clusters", "edges") if k in last},
         "device_ms": {k: round(v, 4) for k, v in ks.items()},
         "roofline": roofline,

@@ -61,6 +61,7 @@ struct humid_ctx {
   DBuf x_route, x_creator, x_base, x_mark, x_markcr, x_scan, x_lcid, x_lismax,
        x_items, x_w, x_id, x_ids, x_ends, x_ends_s, x_head, x_hpos, x_nodes, x_cedges;   // multi-GPU exchange mode
   DBuf w_sorted, w_head, w_hpos, w_start;                                         // wide-word (sorted) counts
+  bool stage_map_timed = false;                                                   // kev[37..38] bracket the last humid_stage_map_dense
   bool last_count_sorted = false;                                                 // last count was the wide-word sort
   u32 g_wpr = 1;                                                                  // uint64 per word of g_word
   bool dense_mode = false;   // last count ran on a compacted list of this rank's reads
@@ -1347,6 +1348,7 @@ int humid_stage_count_dense(humid_ctx *c, const uint64_t *d_words, const uint8_t
   if (n_unique) *n_unique = 0;
   if (n_usable) *n_usable = 0;
   c->dense_mode = true;
+  c->stage_map_timed = false;
   if (N == 0) return HUMID_OK;
   if (all_owned) {
     for (u32 q = 0; q < n_shards; q++) counts[q] = shard_begin[q + 1] - shard_begin[q];
@@ -1403,12 +1405,15 @@ int humid_stage_map_dense(humid_ctx *c, const uint32_t *d_local_cluster_id, cons
     hipLaunchKernelGGL(k_slot_results, dim3(blocks_for(U)), dim3(256), 0, st, d_local_cluster_id, d_local_is_max,
                        c->s_first.as<u32>(), c->s_slot.as<u32>(), U, c->slot_out.as<u64>());
   ENSURE(c->own_packed, ((size_t)N + 1) * 4);
+  HIPCHK(hipEventRecord(c->kev[37], st));
   if (c->last_count_lds)
     hipLaunchKernelGGL(k_read_map_part, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->pk_vals.as<u32>(),
                        c->pslot.as<u32>(), c->slot_out.as<u64>(), N, c->own_packed.as<u32>());
   else
     hipLaunchKernelGGL(k_read_map_packed, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->slot_of_read.as<u32>(),
                        c->slot_out.as<u64>(), N, c->own_packed.as<u32>());
+  HIPCHK(hipEventRecord(c->kev[38], st));
+  c->stage_map_timed = true;
   HIPCHK(hipGetLastError());
   *d_packed = c->own_packed.as<u32>();     // queued on the context's stream
   return HUMID_OK;
@@ -1680,8 +1685,7 @@ int humid_stage_pairs_keyed(humid_ctx *c, const uint64_t *d_items, uint64_t n_it
                        c->x_ids.as<u32>());
     TRY(emit_pairs(c, c->seg_ws.as<u64>(), c->x_ids.as<u32>(), n, plan, combo, distance, &E));
   }
-  HIPCHK(hipStreamSynchronize(st));
-  *n_edges = E;
+  *n_edges = E;                  // known since emit_pairs' count phase; the fill is queued on the stream
   *d_edges = E ? c->share_edges.as<u64>() : nullptr;
   return HUMID_OK;
 }
@@ -1720,10 +1724,27 @@ int humid_stage_compact_nodes(humid_ctx *c, const uint64_t *d_edges, uint64_t n_
   hipLaunchKernelGGL(k_relabel_edges, dim3(blocks_for(E)), dim3(256), 0, st, d_edges, E, c->x_nodes.as<u32>(), M,
                      c->x_cedges.as<u64>());
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(st));
-  *d_nodes = c->x_nodes.as<u32>();
+  *d_nodes = c->x_nodes.as<u32>();     // M is known; the node list and the relabelling are queued
   *n_nodes = M;
   *d_compact_edges = c->x_cedges.as<u64>();
+  return HUMID_OK;
+}
+
+// HIP-event times of the two N-proportional kernels of the last count_dense / map_dense pair on
+// this context (bench.py's roofline leg in multi-GPU runs); waits for the stream.
+int humid_stage_kernel_ms(humid_ctx *c, float *ms_k_insert, float *ms_k_map, uint32_t *count_mode_used) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (!c->dense_mode || !c->stage_map_timed) return fail(c, HUMID_E_STATE, "no completed humid_stage_count_dense + humid_stage_map_dense");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  float a = 0, b = 0;
+  if (c->N) {
+    HIPCHK(hipEventElapsedTime(&a, c->kev[0], c->kev[1]));
+    HIPCHK(hipEventElapsedTime(&b, c->kev[37], c->kev[38]));
+  }
+  if (ms_k_insert) *ms_k_insert = a;
+  if (ms_k_map) *ms_k_map = b;
+  if (count_mode_used) *count_mode_used = c->last_count_sorted ? 3u : c->last_count_lds ? (c->last_count_ordered ? 2u : 0u) : 1u;
   return HUMID_OK;
 }
 

@@ -248,6 +248,12 @@ class HipStageOps(Context):
         return (_wrap(pc.value, u_local, "<i4", torch.int32, self.device),
                 _wrap(pm.value, u_local, "|u1", torch.uint8, self.device))
 
+    def kernel_ms(self):
+        """HIP-event ms of the dominant kernels of the last count_dense / map_dense pair"""
+        a, b, m = C.c_float(), C.c_float(), C.c_uint32()
+        self._call(self._lib.humid_stage_kernel_ms, C.byref(a), C.byref(b), C.byref(m))
+        return dict(ms_k_insert=a.value, ms_k_map=b.value, count_mode_used=m.value)
+
     def map(self, l_cid, l_ismax, out_cid, out_keep):
         self._call(self._lib.humid_stage_map, self._p(l_cid), self._p(l_ismax), out_cid.numel(),
                    self._p(out_cid), self._p(out_keep))

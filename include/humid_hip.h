@@ -264,6 +264,9 @@ int humid_stage_scatter(humid_ctx *ctx, const uint32_t *d_perm, const uint32_t *
  *     before a leaf in the WHOLE walk (src/humid.cc:177-180): singletons + compact creators.
  * humid_stage_count_dense accepts d_filtered = NULL with the full value range: every read is owned
  * and counted as it stands. */
+/* HIP-event durations of the dominant kernels of the last humid_stage_count_dense /
+ * humid_stage_map_dense pair (k_dedup_lds or k_hash_insert; k_read_map_part or k_read_map_packed) */
+int humid_stage_kernel_ms(humid_ctx *ctx, float *ms_k_insert, float *ms_k_map, uint32_t *count_mode_used);
 int humid_stage_route_words(humid_ctx *ctx, const uint64_t *d_words, uint64_t n_send,
                             const uint64_t **d_routed);
 int humid_stage_exchange_ids(humid_ctx *ctx, const uint32_t *d_nodes, const uint32_t *d_compact_cluster_id,
