@@ -72,14 +72,15 @@ SYMBOLS = {
                                            C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p),
                                            C.POINTER(C.c_void_p)]),
     "humid_stage_plan_info": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, u32p, u32p]),
-    "humid_stage_combo_route": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32,
-                                          C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
+    "humid_stage_combo_route": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                          C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
                                           C.POINTER(C.c_void_p), u64p]),
     "humid_stage_pairs_keyed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64,
-                                          C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
+                                          C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
                                           C.POINTER(C.c_void_p), u64p]),
-    "humid_stage_compact_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p),
-                                            u64p, C.POINTER(C.c_void_p)]),
+    "humid_stage_compact_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                            C.POINTER(C.c_void_p), u64p, C.POINTER(C.c_void_p),
+                                            C.POINTER(C.c_void_p)]),
     "humid_stage_graph_edges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                           C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),

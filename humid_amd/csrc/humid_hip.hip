@@ -58,7 +58,7 @@ struct humid_ctx {
   DBuf pc, poff, share_edges;                                                     // multi-GPU pair-search share
   DBuf own_words;                                                                 // multi-GPU dense count
   DBuf heads;                                                                     // big-component heads
-  DBuf x_route, x_creator, x_base, x_mark, x_markcr, x_scan, x_lcid, x_lismax,
+  DBuf x_cnt, x_cnts, x_rec, x_ncnt, x_route, x_creator, x_base, x_mark, x_markcr, x_scan, x_lcid, x_lismax,
        x_items, x_w, x_id, x_ids, x_ends, x_ends_s, x_head, x_hpos, x_nodes, x_cedges;   // multi-GPU exchange mode
   DBuf w_sorted, w_head, w_hpos, w_start;                                         // wide-word (sorted) counts
   bool stage_map_timed = false;                                                   // kev[37..38] bracket the last humid_stage_map_dense
@@ -997,7 +997,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
-                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->seg_ws, &c->csize, &c->cur, &c->plan_dev, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -1561,8 +1561,8 @@ static ComboFields plan_fields(const ComboPlan &plan, u32 cb) {
   return cf;
 }
 
-int humid_stage_combo_route(humid_ctx *c, const uint64_t *d_word, uint64_t n_unique, uint64_t id_base,
-                            uint32_t word_nt, uint32_t distance, uint64_t plan_unique, uint32_t combo,
+int humid_stage_combo_route(humid_ctx *c, const uint64_t *d_word, const uint32_t *d_count, uint64_t n_unique,
+                            uint64_t id_base, uint32_t word_nt, uint32_t distance, uint64_t plan_unique, uint32_t combo,
                             uint32_t n_ranks, const uint64_t **d_items, uint64_t *counts) {
   if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
   if (!d_items || !counts || n_ranks == 0) return fail(c, HUMID_E_INVALID, "bad argument");
@@ -1598,7 +1598,7 @@ int humid_stage_combo_route(humid_ctx *c, const uint64_t *d_word, uint64_t n_uni
   ENSURE(c->small, (size_t)(n_ranks + 2) * 4);
   hipLaunchKernelGGL(k_owner_bounds, dim3(1), dim3(256), 0, st, c->owner_sorted.as<u8>(), n, n_ranks,
                      c->small.as<u32>());
-  hipLaunchKernelGGL(k_route_items, dim3(blocks_for(n)), dim3(256), 0, st, d_word, c->x_ids.as<u32>(), n,
+  hipLaunchKernelGGL(k_route_items, dim3(blocks_for(n)), dim3(256), 0, st, d_word, d_count, c->x_ids.as<u32>(), n,
                      (u64)id_base, c->x_items.as<ulonglong2>());
   std::vector<u32> b(n_ranks + 2);
   HIPCHK(hipMemcpyAsync(b.data(), c->small.p, (n_ranks + 2) * 4, hipMemcpyDeviceToHost, st));
@@ -1609,7 +1609,8 @@ int humid_stage_combo_route(humid_ctx *c, const uint64_t *d_word, uint64_t n_uni
   return HUMID_OK;
 }
 
-// pairs among W[0, n) walked in bucket order of combination cb (ids V) -> c->share_edges
+// pairs among W[0, n) walked in bucket order of combination cb -> c->share_edges, as
+// (V[i] << 32 | V[j]) ordered by value; V == null: positions themselves
 static int emit_pairs(humid_ctx *c, const u64 *W, const u32 *V, u32 n, const ComboPlan &plan, u32 cb,
                       u32 distance, u64 *E_out) {
   hipStream_t st = c->stream;
@@ -1620,9 +1621,14 @@ static int emit_pairs(humid_ctx *c, const u64 *W, const u32 *V, u32 n, const Com
   ENSURE(c->poff, ((size_t)n + 1) * 4);
   HIPCHK(hipMemsetAsync(c->pc.as<u32>() + n, 0, 4, st));
   const dim3 grid(blocks_for(n)), blk(256);
-  hipLaunchKernelGGL((k_pairs<false, PM_EMIT_COUNT, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
-                     cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
-                     (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>());
+  if (V)
+    hipLaunchKernelGGL((k_pairs<false, PM_EMIT_COUNT, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
+                       cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
+                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>());
+  else
+    hipLaunchKernelGGL((k_pairs<true, PM_EMIT_COUNT, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
+                       cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
+                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>());
   TRY(exscan_u32(c, c->pc.as<u32>(), c->poff.as<u32>(), (u64)n + 1));
   HIPCHK(hipGetLastError());
   TRY(read_counters(c, c->poff.as<u32>() + n));
@@ -1630,22 +1636,27 @@ static int emit_pairs(humid_ctx *c, const u64 *W, const u32 *V, u32 n, const Com
   *E_out = E;
   if (E == 0) return HUMID_OK;
   ENSURE(c->share_edges, (size_t)E * 8);
-  hipLaunchKernelGGL((k_pairs<false, PM_EMIT_FILL, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
-                     cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
-                     (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>());
+  if (V)
+    hipLaunchKernelGGL((k_pairs<false, PM_EMIT_FILL, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
+                       cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
+                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>());
+  else
+    hipLaunchKernelGGL((k_pairs<true, PM_EMIT_FILL, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
+                       cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
+                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>());
   HIPCHK(hipGetLastError());
   return HUMID_OK;
 }
 
 int humid_stage_pairs_keyed(humid_ctx *c, const uint64_t *d_items, uint64_t n_items, int interleaved,
-                            uint64_t id_base, uint32_t word_nt, uint32_t distance, uint64_t plan_unique,
-                            uint32_t combo, const uint64_t **d_edges, uint64_t *n_edges) {
+                            uint64_t id_base, const uint32_t *d_count, uint32_t word_nt, uint32_t distance,
+                            uint64_t plan_unique, uint32_t combo, const uint64_t **d_records, uint64_t *n_edges) {
   if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
-  if (!d_edges || !n_edges) return fail(c, HUMID_E_INVALID, "bad argument");
+  if (!d_records || !n_edges) return fail(c, HUMID_E_INVALID, "bad argument");
   TRY(check_run_args(c, n_items, word_nt, 0));
   HIPCHK(hipSetDevice(c->device));
   hipStream_t st = c->stream;
-  *d_edges = nullptr;
+  *d_records = nullptr;
   *n_edges = 0;
   const u32 n = (u32)n_items;
   if (n < 2 || distance == 0) return HUMID_OK;
@@ -1655,20 +1666,20 @@ int humid_stage_pairs_keyed(humid_ctx *c, const uint64_t *d_items, uint64_t n_it
   if (!interleaved && combo != 0) return fail(c, HUMID_E_INVALID, "a plain word array is in bucket order for combination 0 only");
   if (!interleaved && id_base + n_items > 0xffffffffull) return fail(c, HUMID_E_OVERFLOW, "global unique index exceeds 32 bits");
   u64 E = 0;
-  ENSURE(c->x_id, (size_t)n * 4);
+  const u32 *id_of = nullptr, *cnt_of = d_count;
   if (!interleaved) {
-    hipLaunchKernelGGL(k_iota_base, dim3(blocks_for(n)), dim3(256), 0, st, c->x_id.as<u32>(), n, (u32)id_base);
-    TRY(emit_pairs(c, d_items, c->x_id.as<u32>(), n, plan, 0, distance, &E));
+    TRY(emit_pairs(c, d_items, nullptr, n, plan, 0, distance, &E));     // pairs of positions
   } else {
     ENSURE(c->x_w, (size_t)n * 8);
+    ENSURE(c->x_id, (size_t)n * 4);
+    ENSURE(c->x_cnt, (size_t)n * 4);
     ENSURE(c->seg_k0, (size_t)n * 8);
     ENSURE(c->seg_v0, (size_t)n * 4);
     ENSURE(c->seg_ks, (size_t)n * 8);
     ENSURE(c->seg_vs, (size_t)n * 4);
     ENSURE(c->seg_ws, (size_t)n * 8);
-    ENSURE(c->x_ids, (size_t)n * 4);
     hipLaunchKernelGGL(k_split_items, dim3(blocks_for(n)), dim3(256), 0, st, (const ulonglong2 *)d_items, n,
-                       c->x_w.as<u64>(), c->x_id.as<u32>());
+                       c->x_w.as<u64>(), c->x_id.as<u32>(), c->x_cnt.as<u32>());
     const u32 kb = plan.key_bits ? plan.key_bits : 1;
     if (kb <= 32) {
       hipLaunchKernelGGL((k_combo_keys<u32, u64>), dim3(blocks_for(n)), dim3(256), 0, st, c->x_w.as<u64>(), n,
@@ -1681,25 +1692,36 @@ int humid_stage_pairs_keyed(humid_ctx *c, const uint64_t *d_items, uint64_t n_it
     }
     hipLaunchKernelGGL(k_gather_bucket_words<u64>, dim3(blocks_for(n)), dim3(256), 0, st, c->x_w.as<u64>(),
                        c->seg_vs.as<u32>(), n, c->seg_ws.as<u64>());
-    hipLaunchKernelGGL(k_gather_u32, dim3(blocks_for(n)), dim3(256), 0, st, c->x_id.as<u32>(), c->seg_vs.as<u32>(), n,
-                       c->x_ids.as<u32>());
-    TRY(emit_pairs(c, c->seg_ws.as<u64>(), c->x_ids.as<u32>(), n, plan, combo, distance, &E));
+    // pairs of positions in the received array (V = bucket order -> received position)
+    TRY(emit_pairs(c, c->seg_ws.as<u64>(), c->seg_vs.as<u32>(), n, plan, combo, distance, &E));
+    id_of = c->x_id.as<u32>();
+    cnt_of = c->x_cnt.as<u32>();
   }
-  *n_edges = E;                  // known since emit_pairs' count phase; the fill is queued on the stream
-  *d_edges = E ? c->share_edges.as<u64>() : nullptr;
+  *n_edges = E;                  // known since emit_pairs' count phase; the rest is queued on the stream
+  if (E == 0) return HUMID_OK;
+  ENSURE(c->x_rec, (size_t)E * 16);
+  hipLaunchKernelGGL(k_edge_records, dim3(blocks_for(E)), dim3(256), 0, st, c->share_edges.as<u64>(), (u32)E, id_of,
+                     (u32)id_base, cnt_of, c->x_rec.as<ulonglong2>());
+  HIPCHK(hipGetLastError());
+  *d_records = c->x_rec.as<u64>();
   return HUMID_OK;
 }
 
-// distinct endpoints of an edge list, ascending, and the edges relabelled to positions in that list
-int humid_stage_compact_nodes(humid_ctx *c, const uint64_t *d_edges, uint64_t n_edges, const uint32_t **d_nodes,
-                              uint64_t *n_nodes, const uint64_t **d_compact_edges) {
+// distinct endpoints of an edge list, ascending, and the edges relabelled to positions in that list.
+// record_stride 1: d_edges[k] = (a << 32 | b).  record_stride 2: the 16-byte records of
+// humid_stage_pairs_keyed; *d_node_counts then holds the count of every node.
+int humid_stage_compact_nodes(humid_ctx *c, const uint64_t *d_edges, uint64_t n_edges, uint32_t record_stride,
+                              const uint32_t **d_nodes, uint64_t *n_nodes, const uint64_t **d_compact_edges,
+                              const uint32_t **d_node_counts) {
   if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
   if (!d_nodes || !n_nodes || !d_compact_edges) return fail(c, HUMID_E_INVALID, "bad argument");
+  if (record_stride != 1 && record_stride != 2) return fail(c, HUMID_E_INVALID, "record_stride must be 1 or 2");
   if (n_edges >= 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "2*edges exceeds 32 bits");
   HIPCHK(hipSetDevice(c->device));
   hipStream_t st = c->stream;
   *d_nodes = nullptr;
   *d_compact_edges = nullptr;
+  if (d_node_counts) *d_node_counts = nullptr;
   *n_nodes = 0;
   const u32 E = (u32)n_edges;
   if (E == 0) return HUMID_OK;
@@ -1709,7 +1731,7 @@ int humid_stage_compact_nodes(humid_ctx *c, const uint64_t *d_edges, uint64_t n_
   ENSURE(c->x_ends_s, (size_t)n2 * 4);
   ENSURE(c->x_head, ((size_t)n2 + 1) * 4);
   ENSURE(c->x_hpos, ((size_t)n2 + 1) * 4);
-  hipLaunchKernelGGL(k_edge_ends, dim3(blocks_for(E)), dim3(256), 0, st, d_edges, E, c->x_ends.as<u32>());
+  hipLaunchKernelGGL(k_edge_ends, dim3(blocks_for(E)), dim3(256), 0, st, d_edges, E, record_stride, c->x_ends.as<u32>());
   TRY(sort_keys<u32>(c, c->x_ends.as<u32>(), c->x_ends_s.as<u32>(), n2, 0, 32));
   hipLaunchKernelGGL(k_heads_u32, dim3(blocks_for((u64)n2 + 1)), dim3(256), 0, st, c->x_ends_s.as<u32>(), n2,
                      c->x_head.as<u32>());
@@ -1718,15 +1740,17 @@ int humid_stage_compact_nodes(humid_ctx *c, const uint64_t *d_edges, uint64_t n_
   TRY(read_counters(c, c->x_hpos.as<u32>() + n2));
   const u32 M = (u32)(c->h_ctr[CTR_N - 1] & 0xffffffffull);
   ENSURE(c->x_nodes, ((size_t)M + 1) * 4);
+  ENSURE(c->x_ncnt, ((size_t)M + 1) * 4);
   ENSURE(c->x_cedges, (size_t)E * 8);
   hipLaunchKernelGGL(k_compact_heads_u32, dim3(blocks_for(n2)), dim3(256), 0, st, c->x_ends_s.as<u32>(),
                      c->x_head.as<u32>(), c->x_hpos.as<u32>(), n2, c->x_nodes.as<u32>());
-  hipLaunchKernelGGL(k_relabel_edges, dim3(blocks_for(E)), dim3(256), 0, st, d_edges, E, c->x_nodes.as<u32>(), M,
-                     c->x_cedges.as<u64>());
+  hipLaunchKernelGGL(k_relabel_edges, dim3(blocks_for(E)), dim3(256), 0, st, d_edges, E, record_stride,
+                     c->x_nodes.as<u32>(), M, c->x_cedges.as<u64>(), c->x_ncnt.as<u32>());
   HIPCHK(hipGetLastError());
   *d_nodes = c->x_nodes.as<u32>();     // M is known; the node list and the relabelling are queued
   *n_nodes = M;
   *d_compact_edges = c->x_cedges.as<u64>();
+  if (d_node_counts && record_stride == 2) *d_node_counts = c->x_ncnt.as<u32>();
   return HUMID_OK;
 }
 

@@ -185,22 +185,39 @@ k_combo_owner(const u64 *__restrict__ words, u32 n, ComboFields cf, u32 n_ranks,
   owner[i] = (u8)(((h >> 32) * (u64)n_ranks) >> 32);
 }
 
-// (word, id) items in routed order: id = id_base + index in the local unique array
+// (word, id | count << 32) items in routed order: id = id_base + index in the local unique array
 __global__ void __launch_bounds__(256)
-k_route_items(const u64 *__restrict__ words, const u32 *__restrict__ perm, u32 n, u64 id_base,
-              ulonglong2 *__restrict__ items) {
+k_route_items(const u64 *__restrict__ words, const u32 *__restrict__ counts, const u32 *__restrict__ perm, u32 n,
+              u64 id_base, ulonglong2 *__restrict__ items) {
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const u32 i = perm[k];
-  items[k] = make_ulonglong2(words[i], id_base + i);
+  items[k] = make_ulonglong2(words[i], (id_base + i) | ((u64)(counts ? counts[i] : 0u) << 32));
 }
 
-__global__ void k_split_items(const ulonglong2 *__restrict__ items, u32 n, u64 *__restrict__ w, u32 *__restrict__ id) {
+__global__ void k_split_items(const ulonglong2 *__restrict__ items, u32 n, u64 *__restrict__ w,
+                              u32 *__restrict__ id, u32 *__restrict__ cnt) {
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const ulonglong2 it = items[k];
   w[k] = it.x;
   id[k] = (u32)it.y;
+  cnt[k] = (u32)(it.y >> 32);
+}
+
+// pairs over item POSITIONS -> records {smaller id << 32 | larger id, count(smaller) | count(larger) << 32}
+// id_of == null: id = id_base + position (the plain ascending array of the prefix combination)
+__global__ void __launch_bounds__(256)
+k_edge_records(const u64 *__restrict__ pos_edges, u32 n_edges, const u32 *__restrict__ id_of, u32 id_base,
+               const u32 *__restrict__ cnt_of, ulonglong2 *__restrict__ rec) {
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_edges) return;
+  const u64 e = pos_edges[k];
+  const u32 pa = (u32)(e >> 32), pb = (u32)e;
+  u32 a = id_of ? id_of[pa] : id_base + pa, b = id_of ? id_of[pb] : id_base + pb;
+  u32 ca = cnt_of ? cnt_of[pa] : 0u, cb = cnt_of ? cnt_of[pb] : 0u;
+  if (a > b) { u32 t = a; a = b; b = t; t = ca; ca = cb; cb = t; }
+  rec[k] = make_ulonglong2(((u64)a << 32) | b, (u64)ca | ((u64)cb << 32));
 }
 
 __global__ void k_iota_base(u32 *p, u32 n, u32 base) {
@@ -213,11 +230,11 @@ __global__ void k_gather_u32(const u32 *__restrict__ src, const u32 *__restrict_
   if (i < n) dst[i] = src[idx[i]];
 }
 
-// both endpoints of every edge (smaller << 32 | larger)
-__global__ void k_edge_ends(const u64 *__restrict__ edges, u32 n_edges, u32 *__restrict__ ends) {
+// both endpoints of every edge (smaller << 32 | larger); stride = uint64 per edge record (1 or 2)
+__global__ void k_edge_ends(const u64 *__restrict__ edges, u32 n_edges, u32 stride, u32 *__restrict__ ends) {
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_edges) return;
-  const u64 e = edges[k];
+  const u64 e = edges[(size_t)k * stride];
   ends[2 * k] = (u32)(e >> 32);
   ends[2 * k + 1] = (u32)e;
 }
@@ -235,12 +252,13 @@ __global__ void k_compact_heads_u32(const u32 *__restrict__ sorted, const u32 *_
   if (i < n && head[i]) out[hpos[i]] = sorted[i];
 }
 
-// edges over node ids -> edges over positions in the ascending node list
-__global__ void k_relabel_edges(const u64 *__restrict__ edges, u32 n_edges, const u32 *__restrict__ nodes,
-                                u32 n_nodes, u64 *__restrict__ out) {
+// edges over node ids -> edges over positions in the ascending node list; with records (stride 2)
+// also the count of every node (all records of a node carry the same count)
+__global__ void k_relabel_edges(const u64 *__restrict__ edges, u32 n_edges, u32 stride, const u32 *__restrict__ nodes,
+                                u32 n_nodes, u64 *__restrict__ out, u32 *__restrict__ node_cnt) {
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_edges) return;
-  const u64 e = edges[k];
+  const u64 e = edges[(size_t)k * stride];
   u32 r[2];
 #pragma unroll
   for (int q = 0; q < 2; q++) {
@@ -253,6 +271,11 @@ __global__ void k_relabel_edges(const u64 *__restrict__ edges, u32 n_edges, cons
     r[q] = lo;
   }
   out[k] = ((u64)r[0] << 32) | r[1];
+  if (stride == 2 && r[0] < n_nodes && r[1] < n_nodes) {
+    const u64 cc = edges[(size_t)k * 2 + 1];
+    node_cnt[r[0]] = (u32)cc;
+    node_cnt[r[1]] = (u32)(cc >> 32);
+  }
 }
 
 // routed copy of the usable reads' words (owner-major order of humid_stage_owner_perm)

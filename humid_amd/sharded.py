@@ -14,9 +14,9 @@ per-rank work and traffic stay constant as ranks are added (weak scaling):
   4. neighbour pairs: the prefix combination is local to a range; for each other combination the
      unique words go to the rank that owns their combination key (all-to-all of (word, index),
      12..16 B per unique word) and are compared there; pairs come out in global indices;
-  5. all-gather of the pairs (~2 % of the reads) -> compact graph over the pairs' endpoints only,
-     counts of the endpoints all-gathered, clustered replicated (singletons never enter: a singleton
-     is its own cluster and its own maxLeaf); cluster ids from closed-form prefix counts;
+  5. all-gather of the pairs (~2 % of the reads; each carries the counts of its two endpoints) ->
+     compact graph over the pairs' endpoints only, clustered replicated (singletons never enter: a
+     singleton is its own cluster and its own maxLeaf); cluster ids from closed-form prefix counts;
   6. per-read results at the owner (humid_stage_map_dense), all-to-all back (4 B per read), scatter.
 
 mode "allgather" (BASELINE.json's literal wording; also the fallback for > 16 ranks and for plans
@@ -213,31 +213,35 @@ class HipStageOps(Context):
         self._call(self._lib.humid_stage_route_words, self._p(d_w), n_send, C.byref(pr))
         return _wrap(pr.value, n_send, "<i8", torch.int64, self.device)
 
-    def combo_route(self, l_word, id_base, word_nt, distance, plan_unique, combo, n_ranks):
-        """(word, id) items of the local unique array in destination-major order: int64[n, 2]"""
+    def combo_route(self, l_word, l_cnt, id_base, word_nt, distance, plan_unique, combo, n_ranks):
+        """(word, id | count << 32) items of the local unique array in destination-major order:
+        int64[n, 2]"""
         pi = C.c_void_p()
         counts = (C.c_uint64 * n_ranks)()
         n = l_word.numel()
-        self._call(self._lib.humid_stage_combo_route, self._p(l_word), n, id_base, word_nt, distance,
-                   plan_unique, combo, n_ranks, C.byref(pi), counts)
+        self._call(self._lib.humid_stage_combo_route, self._p(l_word), self._p(l_cnt), n, id_base, word_nt,
+                   distance, plan_unique, combo, n_ranks, C.byref(pi), counts)
         return _wrap(pi.value, 2 * n, "<i8", torch.int64, self.device).view(-1, 2), [int(x) for x in counts]
 
-    def pairs_keyed(self, items, interleaved, id_base, word_nt, distance, plan_unique, combo):
-        """pairs (smaller id << 32 | larger id) among the items; a VIEW of ctx memory that the next
-        call overwrites"""
+    def pairs_keyed(self, items, interleaved, id_base, l_cnt, word_nt, distance, plan_unique, combo):
+        """pair records int64[E, 2]: (smaller id << 32 | larger id, count(smaller) | count(larger) << 32);
+        a VIEW of ctx memory that the next call overwrites"""
         pe = C.c_void_p()
         ne = C.c_uint64()
         self._call(self._lib.humid_stage_pairs_keyed, self._p(items), items.shape[0], int(interleaved),
-                   id_base, word_nt, distance, plan_unique, combo, C.byref(pe), C.byref(ne))
-        return _wrap(pe.value, ne.value, "<i8", torch.int64, self.device)
+                   id_base, self._p(l_cnt), word_nt, distance, plan_unique, combo, C.byref(pe), C.byref(ne))
+        return _wrap(pe.value, 2 * ne.value, "<i8", torch.int64, self.device).view(-1, 2)
 
-    def compact_nodes(self, edges):
-        pn, pc = C.c_void_p(), C.c_void_p()
+    def compact_nodes(self, records):
+        """pair records int64[E, 2] -> (nodes int32[M] ascending, compact edges int64[E], counts int32[M])"""
+        pn, pc, pk = C.c_void_p(), C.c_void_p(), C.c_void_p()
         nn = C.c_uint64()
-        self._call(self._lib.humid_stage_compact_nodes, self._p(edges), edges.numel(), C.byref(pn),
-                   C.byref(nn), C.byref(pc))
+        e = records.shape[0]
+        self._call(self._lib.humid_stage_compact_nodes, self._p(records), e, 2, C.byref(pn), C.byref(nn),
+                   C.byref(pc), C.byref(pk))
         return (_wrap(pn.value, nn.value, "<i4", torch.int32, self.device),
-                _wrap(pc.value, edges.numel(), "<i8", torch.int64, self.device))
+                _wrap(pc.value, e, "<i8", torch.int64, self.device),
+                _wrap(pk.value, nn.value, "<i4", torch.int32, self.device))
 
     def exchange_ids(self, nodes, ccid, cismax, n_clusters, id_base, u_local):
         """cluster id (int32) + maxLeaf flag (uint8) of the local unique words; views of ctx memory"""
@@ -486,37 +490,34 @@ class ShardedDedup:
             raise HumidError(-5, "more than 2^32-2 unique words in total")
         lw, lc = ops.unique() if u_local else (torch.empty(0, **i64), torch.empty(0, dtype=torch.int32, device=dev))
         mark("3_count")
-        # ---- 4. neighbour pairs in global unique indices ----
+        # ---- 4. neighbour pairs in global unique indices, each with the counts of its endpoints ----
         e_parts = []
         if self.distance > 0 and u_total > 1:
             n_combos, _ = ops.plan_info(self.word_nt, self.distance, u_total)
             if u_local > 1:
-                e_parts.append(ops.pairs_keyed(lw, False, goff, self.word_nt, self.distance, u_total, 0).clone())
+                e_parts.append(ops.pairs_keyed(lw, False, goff, lc, self.word_nt, self.distance, u_total, 0).clone())
             for cb in range(1, n_combos):
-                items, sc = ops.combo_route(lw, goff, self.word_nt, self.distance, u_total, cb, P)
+                items, sc = ops.combo_route(lw, lc, goff, self.word_nt, self.distance, u_total, cb, P)
                 cm = torch.empty(P * P, **i64)
                 _all_gather_flat(dist, cm, torch.tensor(sc, **i64), P)
                 rc = cm.cpu().view(P, P)[:, r].tolist()
                 got = torch.empty((sum(rc), 2), **i64)
                 _all_to_all_v(dist, got, items, rc, sc, P, r)
                 if got.shape[0] > 1:
-                    e_parts.append(ops.pairs_keyed(got, True, 0, self.word_nt, self.distance, u_total, cb).clone())
-        e_loc = torch.cat(e_parts) if e_parts else torch.empty(0, **i64)
-        e_all, _ = _all_gather_var(dist, e_loc, P)
+                    e_parts.append(ops.pairs_keyed(got, True, 0, None, self.word_nt, self.distance, u_total, cb).clone())
+        e_loc = torch.cat(e_parts) if e_parts else torch.empty((0, 2), **i64)
+        e_flat, _ = _all_gather_var(dist, e_loc.view(-1), P)
+        e_all = e_flat.view(-1, 2)
         mark("4_pairs")
         # ---- 5. compact graph over the pairs' endpoints; ids by closed-form prefix counts ----
-        if e_all.numel():
-            nodes, cedges = ops.compact_nodes(e_all)                  # ascending global indices, int32
+        if e_all.shape[0]:
+            # ascending global indices of the leaves with neighbours, edges over positions in that
+            # list, endpoint counts (they travelled with the pairs): the singletons never enter
+            nodes, cedges, cnt_c = ops.compact_nodes(e_all)
             M = nodes.numel()
-            # counts of the endpoints: every rank contributes the slice it owns (ranks own
-            # contiguous index ranges, so the slices concatenate to the node order)
-            nodes64 = nodes.long() & 0xffffffff
-            s0, s1 = torch.searchsorted(nodes64, torch.tensor([goff, goff + u_local], **i64)).tolist()
-            own_cnt = lc[nodes64[s0:s1] - goff] if s1 > s0 else torch.empty(0, dtype=torch.int32, device=dev)
-            cnt_c, _ = _all_gather_var(dist, own_cnt, P)
             ccid, cismax, gs = ops.graph_edges(nodes, cnt_c, cedges, self.word_nt, self.distance, self.method)
             C_c = int(gs["clusters"])
-            summ.update(clusters=u_total - M + C_c, edges=int(e_all.numel()), nonsingle=M)
+            summ.update(clusters=u_total - M + C_c, edges=int(e_all.shape[0]), nonsingle=M)
             for k, v in gs.items():
                 if k.startswith("ms_"):
                     summ[k] = v

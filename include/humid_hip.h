@@ -248,15 +248,18 @@ int humid_stage_scatter(humid_ctx *ctx, const uint32_t *d_perm, const uint32_t *
  * counts of their endpoints are replicated, and clustered as a compact graph.
  *   humid_stage_plan_info:   combinations of the pigeonhole plan for plan_unique words in total (all
  *     ranks pass the same number) and the bits of the shortest prefix combination.
- *   humid_stage_combo_route: (word, id_base + index) items of this rank's ascending unique array in
- *     destination-major order, *d_items[2k] = word, [2k+1] = id; counts[q] = items for rank q.
+ *   humid_stage_combo_route: (word, id | count << 32) items of this rank's ascending unique array
+ *     (id = id_base + index) in destination-major order, *d_items[2k] = word, [2k+1] = id | count<<32;
+ *     counts[q] = items for rank q.
  *   humid_stage_pairs_keyed: the neighbour pairs among n_items items that share the bucket of
- *     `combo` and were not already found by an earlier combination, as
- *     (smaller id << 32 | larger id).  interleaved = 1: d_items as above (any order);
- *     interleaved = 0: a plain ascending word array with ids id_base + index (combination 0 only).
- *   humid_stage_compact_nodes: the distinct endpoints of an edge list (ascending) and the same
- *     edges over positions in that list -- the input of humid_stage_graph_edges for a graph that
- *     leaves out the singletons (every singleton is its own cluster and its own maxLeaf).
+ *     `combo` and were not already found by an earlier combination, as 16-byte records
+ *     *d_records[2k] = (smaller id << 32 | larger id), [2k+1] = count(smaller) | count(larger) << 32.
+ *     interleaved = 1: d_items as above (any order; d_count ignored); interleaved = 0: a plain
+ *     ascending word array with ids id_base + index and counts d_count (combination 0 only).
+ *   humid_stage_compact_nodes: the distinct endpoints of an edge list (ascending), the same edges
+ *     over positions in that list and (record_stride 2: the records above) the endpoints' counts --
+ *     the input of humid_stage_graph_edges for a graph that leaves out the singletons (every
+ *     singleton is its own cluster and its own maxLeaf).  record_stride 1: plain (a << 32 | b) edges.
  *   humid_stage_route_words: the words of this rank's usable reads in the owner-major order of the
  *     preceding humid_stage_owner_perm (the all-to-all send buffer).
  *   humid_stage_exchange_ids: cluster id + maxLeaf flag of this rank's unique words (global walk
@@ -275,15 +278,17 @@ int humid_stage_exchange_ids(humid_ctx *ctx, const uint32_t *d_nodes, const uint
                              const uint8_t **d_local_is_max);
 int humid_stage_plan_info(humid_ctx *ctx, uint32_t word_nt, uint32_t distance, uint64_t plan_unique,
                           uint32_t *n_combos, uint32_t *prefix_bits);
-int humid_stage_combo_route(humid_ctx *ctx, const uint64_t *d_word, uint64_t n_unique, uint64_t id_base,
-                            uint32_t word_nt, uint32_t distance, uint64_t plan_unique, uint32_t combo,
-                            uint32_t n_ranks, const uint64_t **d_items, uint64_t *counts);
+int humid_stage_combo_route(humid_ctx *ctx, const uint64_t *d_word, const uint32_t *d_count,
+                            uint64_t n_unique, uint64_t id_base, uint32_t word_nt, uint32_t distance,
+                            uint64_t plan_unique, uint32_t combo, uint32_t n_ranks,
+                            const uint64_t **d_items, uint64_t *counts);
 int humid_stage_pairs_keyed(humid_ctx *ctx, const uint64_t *d_items, uint64_t n_items, int interleaved,
-                            uint64_t id_base, uint32_t word_nt, uint32_t distance, uint64_t plan_unique,
-                            uint32_t combo, const uint64_t **d_edges, uint64_t *n_edges);
+                            uint64_t id_base, const uint32_t *d_count, uint32_t word_nt,
+                            uint32_t distance, uint64_t plan_unique, uint32_t combo,
+                            const uint64_t **d_records, uint64_t *n_edges);
 int humid_stage_compact_nodes(humid_ctx *ctx, const uint64_t *d_edges, uint64_t n_edges,
-                              const uint32_t **d_nodes, uint64_t *n_nodes,
-                              const uint64_t **d_compact_edges);
+                              uint32_t record_stride, const uint32_t **d_nodes, uint64_t *n_nodes,
+                              const uint64_t **d_compact_edges, const uint32_t **d_node_counts);
 
 /* src/cluster.cc:31-33 atLeastDouble_, evaluated on the device (parity probe). */
 int humid_at_least_double(humid_ctx *ctx, uint64_t a, uint64_t b, int *result);

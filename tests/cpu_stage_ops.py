@@ -123,27 +123,31 @@ class CpuStageOps:
         shift, width = seg
         return (w >> np.uint64(shift)) & np.uint64((1 << width) - 1)
 
-    def combo_route(self, l_word, id_base, word_nt, distance, plan_unique, combo, n_ranks):
+    def combo_route(self, l_word, l_cnt, id_base, word_nt, distance, plan_unique, combo, n_ranks):
         w = l_word.numpy().view(np.uint64)
+        cnt = l_cnt.numpy().astype(np.int64)
         key = self._seg_key(w, self._segments(word_nt, distance)[combo])
         owner = ((key * np.uint64(0x9e3779b97f4a7c15)) >> np.uint64(40)) % np.uint64(n_ranks)
         order = np.argsort(owner, kind="stable")
-        items = np.stack([w[order].view(np.int64), (id_base + order).astype(np.int64)], axis=1)
+        second = (id_base + order).astype(np.int64) | (cnt[order] << 32)
+        items = np.stack([w[order].view(np.int64), second], axis=1)
         counts = [int((owner == q).sum()) for q in range(n_ranks)]
         return torch.from_numpy(np.ascontiguousarray(items)), counts
 
-    def pairs_keyed(self, items, interleaved, id_base, word_nt, distance, plan_unique, combo):
+    def pairs_keyed(self, items, interleaved, id_base, l_cnt, word_nt, distance, plan_unique, combo):
         if interleaved:
             a = items.numpy()
-            w, ids = a[:, 0].view(np.uint64), a[:, 1].astype(np.int64)
+            w = a[:, 0].view(np.uint64)
+            ids, cnt = a[:, 1] & 0xffffffff, (a[:, 1] >> 32) & 0xffffffff
         else:
             assert combo == 0
             w = items.numpy().view(np.uint64)
             ids = id_base + np.arange(len(w), dtype=np.int64)
+            cnt = l_cnt.numpy().astype(np.int64)
         segs = self._segments(word_nt, distance)
         key = self._seg_key(w, segs[combo])
         order = np.argsort(key, kind="stable")
-        w, ids, key = w[order], ids[order], key[order]
+        w, ids, cnt, key = w[order], ids[order], cnt[order], key[order]
         out = []
         start = 0
         m55 = np.uint64(0x5555555555555555)
@@ -156,17 +160,23 @@ class CpuStageOps:
                 for q in range(combo):                                   # found by an earlier combination
                     ok &= self._seg_key(x, segs[q]) != 0
                 for j in np.nonzero(ok)[0]:
-                    a_, b_ = int(ids[i]), int(ids[i + 1 + j])
-                    out.append((min(a_, b_) << 32) | max(a_, b_))
+                    a_, b_ = (int(ids[i]), int(cnt[i])), (int(ids[i + 1 + j]), int(cnt[i + 1 + j]))
+                    lo_, hi_ = min(a_, b_), max(a_, b_)
+                    out.append(((lo_[0] << 32) | hi_[0], lo_[1] | (hi_[1] << 32)))
             start = end
-        return torch.from_numpy(np.array(out, dtype=np.int64))
+        return torch.from_numpy(np.array(out, dtype=np.int64).reshape(-1, 2))
 
-    def compact_nodes(self, edges):
-        e = edges.numpy().astype(np.int64)
+    def compact_nodes(self, records):
+        rec = records.numpy().astype(np.int64)
+        e, cc = rec[:, 0], rec[:, 1]
         a, b = e >> 32, e & 0xffffffff
         nodes = np.unique(np.concatenate([a, b]))
-        ce = (np.searchsorted(nodes, a) << 32) | np.searchsorted(nodes, b)
-        return torch.from_numpy(nodes.astype(np.uint32).view(np.int32)), torch.from_numpy(ce.astype(np.int64))
+        pa, pb = np.searchsorted(nodes, a), np.searchsorted(nodes, b)
+        cnt = np.zeros(len(nodes), dtype=np.int64)
+        cnt[pa] = cc & 0xffffffff
+        cnt[pb] = (cc >> 32) & 0xffffffff
+        return (torch.from_numpy(nodes.astype(np.uint32).view(np.int32)),
+                torch.from_numpy(((pa << 32) | pb).astype(np.int64)), torch.from_numpy(cnt.astype(np.int32)))
 
     # ---- dense result return ----
     max_ranks_dense = 16
