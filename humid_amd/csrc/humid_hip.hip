@@ -374,17 +374,44 @@ static inline u32 part_bits(u32 N) {
   return pb;
 }
 
+// Ordered partition key = (word - lo) * scale: the value range the reads lie in, stretched over the
+// whole 64-bit key space (see PartKeyOp).  shift < 64 iff scale == 2^shift.
+struct KeyMap {
+  u64 lo, scale;
+  u32 shift;
+};
+static KeyMap key_map(u32 word_nt, u64 lo, u64 hi, bool within) {
+  const u64 top = word_nt >= 32 ? ~0ull : (((u64)1 << (2 * word_nt)) - 1);
+  if (!within) { lo = 0; hi = top; }
+  if (hi > top) hi = top;
+  if (lo > hi) { lo = 0; hi = top; }
+  KeyMap m;
+  m.lo = lo;
+  const u64 span = hi - lo;
+  if (span == ~0ull) { m.scale = 1; m.shift = 0; return m; }
+  const u64 cnt = span + 1;
+  if ((cnt & (cnt - 1)) == 0 && cnt > 1) {
+    const u32 k = (u32)__builtin_ctzll(cnt);
+    m.shift = 64 - k;
+    m.scale = (u64)1 << m.shift;
+  } else {
+    m.shift = 64;
+    m.scale = ~0ull / cnt;
+  }
+  return m;
+}
+
 // Partitioned variant of stage A (see section 1b of the kernels).  Returns HUMID_OK with
 // *overflowed = true when a bucket held more unique words than its LDS table (the caller then
 // runs the global-table variant; results are never taken from an overflowed run).
 static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N, u32 word_nt,
-                           u64 range_lo, u64 range_hi, bool ordered, humid_summary &s, bool *overflowed) {
+                           u64 range_lo, u64 range_hi, const KeyMap &km, bool ordered, humid_summary &s,
+                           bool *overflowed) {
   hipStream_t st = c->stream;
   *overflowed = false;
   c->last_count_lds = true;
   c->last_count_sorted = false;
   c->last_count_ordered = ordered;
-  const u32 lshift = 64 - 2 * word_nt;
   const u32 pb = part_bits(N);
   const u32 n_parts = 1u << pb;
   ENSURE(c->pk_keys, (size_t)N * 8);
@@ -402,7 +429,7 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   HIPCHK(hipEventRecord(c->ev[0], st));
   HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_N * sizeof(ull), st));
   {
-    auto kin = rocprim::make_transform_iterator(d_words, PartKeyOp{ordered ? 1u : 0u, lshift});
+    auto kin = rocprim::make_transform_iterator(d_words, PartKeyOp{ordered ? 1u : 0u, km.lo, km.scale});
     auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<u32>(0),
                                                 ReadTagOp{d_words, d_filt, range_lo, range_hi});
     // MergeSortLimit = 0: block sort up to 1024 items, Onesweep above (never the merge path)
@@ -420,11 +447,11 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   HIPCHK(hipEventRecord(c->kev[0], st));
   if (ordered)
     hipLaunchKernelGGL(k_dedup_lds<true>, dim3(n_parts), dim3(256), 0, st, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(),
-                       c->pbeg.as<u32>(), N, pb, lshift, c->pad_word.as<u64>(), c->pad_cf.as<uint2>(),
+                       c->pbeg.as<u32>(), N, pb, km.lo, km.scale, km.shift, c->pad_word.as<u64>(), c->pad_cf.as<uint2>(),
                        c->ucount.as<u32>(), c->pusable.as<u32>(), c->pslot.as<u32>(), c->d_ctr);
   else
     hipLaunchKernelGGL(k_dedup_lds<false>, dim3(n_parts), dim3(256), 0, st, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(),
-                       c->pbeg.as<u32>(), N, pb, lshift, c->pad_word.as<u64>(), c->pad_cf.as<uint2>(),
+                       c->pbeg.as<u32>(), N, pb, km.lo, km.scale, km.shift, c->pad_word.as<u64>(), c->pad_cf.as<uint2>(),
                        c->ucount.as<u32>(), c->pusable.as<u32>(), c->pslot.as<u32>(), c->d_ctr);
   HIPCHK(hipEventRecord(c->kev[1], st));
   hipLaunchKernelGGL(k_part_totals, dim3(1), dim3(256), 0, st, c->ucount.as<u32>(), c->pusable.as<u32>(),
@@ -467,7 +494,8 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
 // bucket, with a 1.5x margin, must stay below the table's fill limit (a bucket's unique words
 // cannot exceed its reads).  UMI-first layouts pass; read-prefix-first amplicon or low-complexity
 // data does not and keeps the hashed buckets.  A wrong "yes" only costs the overflow fallback.
-static int prefix_fits_ordered(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N, u32 word_nt, bool *fits) {
+static int prefix_fits_ordered(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N, u32 word_nt,
+                               const KeyMap &km, bool *fits) {
   *fits = false;
   const u32 bits = 2 * word_nt < 12 ? 2 * word_nt : 12;
   const u32 n_bins = 1u << bits;
@@ -477,7 +505,7 @@ static int prefix_fits_ordered(humid_ctx *c, const u64 *d_words, const u8 *d_fil
   ENSURE(c->small, (size_t)n_bins * 4);
   HIPCHK(hipMemsetAsync(c->small.p, 0, (size_t)n_bins * 4, c->stream));
   hipLaunchKernelGGL(k_top_hist, dim3(64), dim3(256), n_bins * 4, c->stream, d_words, d_filt, n_sample,
-                     2 * word_nt - bits, n_bins, c->small.as<u32>());
+                     km.lo, km.scale, bits, c->small.as<u32>());
   std::vector<u32> h(n_bins);
   HIPCHK(hipMemcpyAsync(h.data(), c->small.p, (size_t)n_bins * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipGetLastError());
@@ -501,20 +529,22 @@ static int prefix_fits_ordered(humid_ctx *c, const u64 *d_words, const u8 *d_fil
   return HUMID_OK;
 }
 
-// stage A dispatcher: partitioned LDS tables when the whole value range is counted here, the
-// global table for a partial range (multi-GPU ranks) or after a bucket overflow.
+// stage A dispatcher: partitioned LDS tables when every usable read is counted here (one GPU; a
+// multi-GPU rank in exchange mode, `within`: all reads lie in [range_lo, range_hi]), the global
+// table for a partial range of a larger array or after a bucket overflow.
 static int stage_count(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N, u32 word_nt,
-                       u64 range_lo, u64 range_hi, u64 expected_reads, humid_summary &s) {
+                       u64 range_lo, u64 range_hi, u64 expected_reads, humid_summary &s, bool within = false) {
   const bool full_range = (range_lo == 0 && range_hi == ~0ull);
-  if (c->count_mode == 0 && full_range) {
+  if (c->count_mode == 0 && (full_range || within)) {
+    const KeyMap km = key_map(word_nt, range_lo, range_hi, within);
     bool overflowed = false;
     bool ordered = c->count_order == 1;
-    if (c->count_order < 0) TRY(prefix_fits_ordered(c, d_words, d_filt, N, word_nt, &ordered));
+    if (c->count_order < 0) TRY(prefix_fits_ordered(c, d_words, d_filt, N, word_nt, km, &ordered));
     if (ordered) {
-      TRY(stage_count_lds(c, d_words, d_filt, N, word_nt, range_lo, range_hi, true, s, &overflowed));
+      TRY(stage_count_lds(c, d_words, d_filt, N, word_nt, range_lo, range_hi, km, true, s, &overflowed));
       if (!overflowed) return HUMID_OK;
     }
-    TRY(stage_count_lds(c, d_words, d_filt, N, word_nt, range_lo, range_hi, false, s, &overflowed));
+    TRY(stage_count_lds(c, d_words, d_filt, N, word_nt, range_lo, range_hi, km, false, s, &overflowed));
     if (!overflowed) return HUMID_OK;
   }
   return stage_count_global(c, d_words, d_filt, N, word_nt, range_lo, range_hi, expected_reads, s);
@@ -1290,7 +1320,7 @@ int humid_stage_histogram(humid_ctx *c, const uint64_t *d_words, const uint8_t *
   HIPCHK(hipMemsetAsync(d_hist, 0, n_bins * 4, c->stream));
   if (n_reads)
     hipLaunchKernelGGL(k_top_hist, dim3(512), dim3(256), n_bins * 4, c->stream, d_words, d_filtered,
-                       (u32)n_reads, 2 * word_nt - bits, n_bins, d_hist);
+                       (u32)n_reads, (u64)0, word_nt >= 32 ? (u64)1 : ((u64)1 << (64 - 2 * word_nt)), bits, d_hist);
   HIPCHK(hipGetLastError());
   return HUMID_OK;              // queued on the context's stream; no host value is returned
 }
@@ -1330,9 +1360,10 @@ int humid_stage_count_dense(humid_ctx *c, const uint64_t *d_words, const uint8_t
   c->dense_mode = false;
   TRY(check_run_args(c, n_reads, word_nt, 0));
   if (!shard_begin || !counts || n_shards == 0 || n_shards > 4096) return fail(c, HUMID_E_INVALID, "bad argument");
-  // d_filtered == NULL with the full value range: every read is owned (exchange mode: the reads
-  // were routed here because they are); the array is counted as it stands, no compaction pass
-  const bool all_owned = d_filtered == nullptr && range_lo == 0 && range_hi == ~0ull;
+  // d_filtered == NULL: every read is usable and lies in [range_lo, range_hi] (exchange mode: the
+  // reads were routed here because they do); the array is counted as it stands, no compaction
+  // pass, and the range only shapes the word-ordered buckets
+  const bool all_owned = d_filtered == nullptr;
   if (n_reads && (!d_words || (!d_filtered && !all_owned))) return fail(c, HUMID_E_INVALID, "null buffer");
   HIPCHK(hipSetDevice(c->device));
   hipStream_t st = c->stream;
@@ -1353,8 +1384,9 @@ int humid_stage_count_dense(humid_ctx *c, const uint64_t *d_words, const uint8_t
   if (all_owned) {
     for (u32 q = 0; q < n_shards; q++) counts[q] = shard_begin[q + 1] - shard_begin[q];
     c->N = N;
-    TRY(stage_count(c, d_words, nullptr, N, word_nt, 0ull, ~0ull, 0, s));
+    TRY(stage_count(c, d_words, nullptr, N, word_nt, range_lo, range_hi, 0, s, true));
     HIPCHK(hipStreamSynchronize(st));
+    if (c->usable != N) return fail(c, HUMID_E_INVALID, "a read outside [range_lo, range_hi] in an all-owned count");
     if (n_unique) *n_unique = c->U;
     if (n_usable) *n_usable = c->usable;
     return HUMID_OK;
@@ -1758,7 +1790,8 @@ int humid_stage_compact_nodes(humid_ctx *c, const uint64_t *d_edges, uint64_t n_
 // this context (bench.py's roofline leg in multi-GPU runs); waits for the stream.
 int humid_stage_kernel_ms(humid_ctx *c, float *ms_k_insert, float *ms_k_map, uint32_t *count_mode_used) {
   if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
-  if (!c->dense_mode || !c->stage_map_timed) return fail(c, HUMID_E_STATE, "no completed humid_stage_count_dense + humid_stage_map_dense");
+  if (!c->dense_mode || (c->N && !c->stage_map_timed))
+    return fail(c, HUMID_E_STATE, "no completed humid_stage_count_dense + humid_stage_map_dense");
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
   float a = 0, b = 0;

@@ -131,12 +131,14 @@ k_compact_table(const Slot *__restrict__ tab, u32 n_slots, u64 *__restrict__ uni
 #define PART_TARGET 700u         // mean reads per bucket
 
 // keys_input transform: word -> partition key.  Hashed: mix64(word) (a bijection; robust to any
-// word distribution).  Ordered: the word itself, left-aligned, so that buckets are runs of the
-// word order -- used when the top word bits are uniform (UMI first), see stage_count.
+// word distribution).  Ordered: (word - lo) * scale, a strictly increasing map of the value range
+// [lo, hi] the reads lie in onto the whole 64-bit key space, so that buckets are runs of the word
+// order -- used when the words are uniform over the range (UMI first), see stage_count.  A single
+// GPU has lo = 0, scale = 2^(64 - 2n): the left-aligned word.
 struct PartKeyOp {
   u32 ordered;
-  u32 lshift;                    // 64 - 2n
-  __host__ __device__ u64 operator()(u64 w) const { return ordered ? (w << lshift) : mix64(w); }
+  u64 lo, scale;
+  __host__ __device__ u64 operator()(u64 w) const { return ordered ? (w - lo) * scale : mix64(w); }
 };
 struct ReadTagOp {               // values_input transform: read index | excluded << 31
   const u64 *words;
@@ -175,7 +177,8 @@ __global__ void k_part_bounds(const u64 *__restrict__ keys, u32 n, u32 pb, u32 n
 template <bool ORDERED>
 __global__ void __launch_bounds__(256)
 k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u32 *__restrict__ pbeg,
-            u32 n_reads, u32 pb, u32 lshift, u64 *__restrict__ pad_word, uint2 *__restrict__ pad_cf,
+            u32 n_reads, u32 pb, u64 klo, u64 kscale, u32 kshift, u64 *__restrict__ pad_word,
+            uint2 *__restrict__ pad_cf,
             u32 *__restrict__ ucount, u32 *__restrict__ pusable, u32 *__restrict__ pslot, ull *ctr) {
   __shared__ u64 lkey[LDS_SLOTS + 1];
   __shared__ u32 lcnt[LDS_SLOTS + 1];
@@ -267,7 +270,8 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
   }
   for (u32 li = threadIdx.x; li < n_uniq; li += 256) {
     const u32 s = lslot_of[li];
-    pad_word[beg + li] = ORDERED ? (lkey[s] >> lshift) : unmix64(lkey[s]);
+    // ordered key -> word: kshift < 64 when the scale is a power of two (always on one GPU)
+    pad_word[beg + li] = ORDERED ? klo + (kshift < 64 ? (lkey[s] >> kshift) : lkey[s] / kscale) : unmix64(lkey[s]);
     pad_cf[beg + li] = make_uint2(lcnt[s], lfirst[s]);
     lfirst[s] = li;
   }

@@ -372,18 +372,20 @@ __global__ void k_creator_sizes(const u32 *__restrict__ flag, const u32 *__restr
   if (u < n && flag[u]) out[pos[u]] = cl_size[u];
 }
 
-// reads per top-`bits` bin of the word (usable reads only): balanced range splitters for the
-// multi-GPU path.  LDS-privatised, fixed grid.
+// reads per top-`bits` bin of (word - lo) * scale (usable reads only): balanced range splitters for
+// the multi-GPU path (lo = 0, scale = 2^(64-2n): the top bits of the word itself) and the
+// uniformity check of the word-ordered buckets.  LDS-privatised, fixed grid.
 __global__ void __launch_bounds__(256)
-k_top_hist(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n_reads, u32 shift,
-           u32 n_bins, u32 *hist) {
+k_top_hist(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n_reads, u64 lo, u64 scale,
+           u32 bits, u32 *hist) {
   extern __shared__ u32 lh[];
+  const u32 n_bins = 1u << bits;
   for (u32 b = threadIdx.x; b < n_bins; b += blockDim.x) lh[b] = 0;
   __syncthreads();
   for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x)
     if (!(filtered && filtered[r])) {
-      u32 b = (u32)(words[r] >> shift);
-      atomicAdd(&lh[b < n_bins ? b : n_bins - 1], 1u);   // malformed words cannot index out of LDS
+      const u32 b = (u32)(((words[r] - lo) * scale) >> (64 - bits));   // < n_bins by construction
+      atomicAdd(&lh[b], 1u);
     }
   __syncthreads();
   for (u32 b = threadIdx.x; b < n_bins; b += blockDim.x)

@@ -462,6 +462,9 @@ class ShardedDedup:
         hist = ops.histogram(d_w, d_f, self.word_nt, bits)
         dist.all_reduce(hist)
         ranges = splitters_from_hist(hist.cpu().numpy(), P, self.word_nt, bits)
+        lo_r, hi_r = ranges[r][0], ranges[r][1]
+        if lo_r > hi_r:
+            lo_r, hi_r = 0, (1 << 64) - 1                 # empty range: nothing arrives
         mark("1_ranges")
         # ---- 2. usable words -> owner of their range ----
         perm, send_counts = ops.owner_perm(d_w, d_f, ranges)          # owner-major, filtered reads last
@@ -478,7 +481,7 @@ class ShardedDedup:
         _all_to_all_v(dist, recv_w, send_w, recv_counts, send_counts, P, r)
         mark("2_route_words")
         # ---- 3. exact counts of the received words (all usable, all in this rank's range) ----
-        u_local, usable_local, _ = ops.count_dense(recv_w, None, self.word_nt, 0, (1 << 64) - 1, [0, n_recv])
+        u_local, usable_local, _ = ops.count_dense(recv_w, None, self.word_nt, lo_r, hi_r, [0, n_recv])
         metas = torch.empty(3 * P, **i64)
         _all_gather_flat(dist, metas, torch.tensor([u_local, usable_local, n_local], **i64), P)
         metas = metas.cpu().view(P, 3)

@@ -265,8 +265,9 @@ int humid_stage_scatter(humid_ctx *ctx, const uint32_t *d_perm, const uint32_t *
  *   humid_stage_exchange_ids: cluster id + maxLeaf flag of this rank's unique words (global walk
  *     indices id_base ..) from the compact graph's results; ids count the cluster-creating leaves
  *     before a leaf in the WHOLE walk (src/humid.cc:177-180): singletons + compact creators.
- * humid_stage_count_dense accepts d_filtered = NULL with the full value range: every read is owned
- * and counted as it stands. */
+ * humid_stage_count_dense accepts d_filtered = NULL: every read is usable and lies in
+ * [range_lo, range_hi] (checked); the array is counted as it stands and the range only shapes the
+ * word-ordered LDS buckets. */
 /* HIP-event durations of the dominant kernels of the last humid_stage_count_dense /
  * humid_stage_map_dense pair (k_dedup_lds or k_hash_insert; k_read_map_part or k_read_map_packed) */
 int humid_stage_kernel_ms(humid_ctx *ctx, float *ms_k_insert, float *ms_k_map, uint32_t *count_mode_used);

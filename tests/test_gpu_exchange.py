@@ -39,6 +39,8 @@ def run_ranks(P, words, filt, n, d, method, mode, sizes=None, plan_segments=0, p
             for _ in range(passes):
                 s = sd.run(w, f, c, k)
             torch.cuda.synchronize()
+            if sd.mode_used == "exchange" and s["usable"]:
+                s = dict(s, **ops.kernel_ms())
             out[r] = (c.cpu().numpy().view(np.uint32), k.cpu().numpy(), s, sd.mode_used)
             ops.close()
         except Exception:  # pragma: no cover
@@ -79,6 +81,25 @@ def test_exchange_mode_virtual_ranks(P, cfg):
     n_reads, n, d, mode, method = cfg
     words, filt = synth_words(n_reads, 177 + P, n, p_sub=5e-3, p_n=1e-3, mode=mode, genome_bp=20000)
     check(P, words, filt, n, d, method)
+
+
+def test_exchange_ranges_use_word_ordered_buckets():
+    """inside its value range a rank still gets word-ordered LDS buckets (keys = (word - lo) * scale):
+    count_mode_used 2, no unique sort -- and an amplicon-like prefix falls back to hashed buckets"""
+    words, filt = synth_words(1_200_000, 61, 24, p_sub=2e-3, p_n=1e-3)
+    ocid, okeep, osum, _ = orc.dedup_run(words, filt, 24, 1, 0)
+    out, offs = run_ranks(4, words, filt, 24, 1, 0, "exchange")
+    for r in range(4):
+        cid, keep, s, used = out[r]
+        assert np.array_equal(cid, ocid[offs[r]:offs[r + 1]]) and np.array_equal(keep, okeep[offs[r]:offs[r + 1]])
+        assert s["count_mode_used"] == 2, s
+    skew = (words & np.uint64(0xffffff)) | (np.uint64(0x5a5a5a) << np.uint64(24))      # constant 12-nt prefix
+    ocid, okeep, osum, _ = orc.dedup_run(skew, filt, 24, 1, 0)
+    out, offs = run_ranks(3, skew, filt, 24, 1, 0, "exchange")
+    for r in range(3):
+        cid, keep, s, used = out[r]
+        assert np.array_equal(cid, ocid[offs[r]:offs[r + 1]]) and np.array_equal(keep, okeep[offs[r]:offs[r + 1]])
+        assert s["count_mode_used"] in (0, 1) or s["ms_k_insert"] == 0.0     # ranks without reads: nothing ran
 
 
 def test_exchange_uneven_shards_and_reuse():
