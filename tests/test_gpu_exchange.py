@@ -143,3 +143,48 @@ def test_exchange_forced_plans(segs):
 def test_allgather_mode_virtual_ranks():
     words, filt = synth_words(120_000, 8, 24, p_sub=5e-3, p_n=1e-3)
     check(3, words, filt, 24, 1, 0, mode="allgather")
+
+
+def test_exchange_entry_points_reject_bad_arguments():
+    """the new stage entry points fail with a code and a message, never with a fault"""
+    import torch
+    import humid_amd
+    from humid_amd.sharded import HipStageOps
+    ops = HipStageOps(0)
+    dev = torch.device("cuda:0")
+    w = torch.arange(100, dtype=torch.int64, device=dev)
+    c = torch.ones(100, dtype=torch.int32, device=dev)
+    nc, pb = ops.plan_info(24, 1, 1000)
+    assert nc == 2 and pb == 24
+    assert ops.plan_info(2, 3, 10) == (1, 0)                       # d >= n: one empty-mask combination
+    with pytest.raises(humid_amd.HumidError) as e:
+        ops.combo_route(w, c, 0, 24, 1, 1000, 5, 4)                # combination out of range
+    assert e.value.code == -1
+    with pytest.raises(humid_amd.HumidError) as e:
+        ops.combo_route(w, c, (1 << 32) - 50, 24, 1, 1000, 1, 4)   # global index beyond 32 bits
+    assert e.value.code == -5
+    with pytest.raises(humid_amd.HumidError) as e:
+        ops.pairs_keyed(w, False, 0, c, 24, 1, 1000, 1)            # plain array with a sorted combination
+    assert e.value.code == -1
+    with pytest.raises(humid_amd.HumidError) as e:
+        ops.pairs_keyed(w, False, 0, c, 33, 1, 1000, 0)            # wide words: single-GPU only
+    assert e.value.code == -2
+    with pytest.raises(humid_amd.HumidError) as e:
+        ops.kernel_ms()                                            # nothing counted yet
+    assert e.value.code == -6
+    # an all-owned count with a word outside the promised range is refused
+    with pytest.raises(humid_amd.HumidError) as e:
+        ops.count_dense(w, None, 24, 10, 50, [0, 100])
+    assert e.value.code == -1
+    # words 0..99 are pairwise neighbours in the low nucleotides: a real answer comes back
+    u, usable, _ = ops.count_dense(w, None, 24, 0, 99, [0, 100])
+    assert (u, usable) == (100, 100)
+    rec = ops.pairs_keyed(w, False, 7, c, 24, 1, 100, 0)
+    e_ids = rec[:, 0].cpu().numpy()
+    a, b = e_ids >> 32, e_ids & 0xffffffff
+    assert len(a) and (a < b).all() and a.min() >= 7 and b.max() <= 106
+    assert (rec[:, 1].cpu().numpy() == (1 | (1 << 32))).all()
+    nodes, cedges, cnt = ops.compact_nodes(rec)
+    assert nodes.numel() == 100 and (cnt.cpu().numpy() == 1).all()
+    assert (cedges.cpu().numpy() >> 32).max() < 100
+    ops.close()
