@@ -74,20 +74,50 @@ static bool ends_with(const std::string &s, const char *suf) {
   return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
 }
 
-FastqWriter::FastqWriter(const std::string &path) {
-  if (ends_with(path, ".gz")) {
+FastqWriter::FastqWriter(const std::string &path, bool members) {
+  if (ends_with(path, ".gz") && !members) {
     gz_ = gzopen(path.c_str(), "wb4");   // fastp Options default compression level 4
     if (gz_) gzbuffer(gz_, 1u << 18);
   } else {
     plain_ = fopen(path.c_str(), "wb");
+    members_ = ends_with(path, ".gz");
   }
   pending_.reserve(kBuf + 4096);
+}
+
+bool FastqWriter::compress_member(const char *data, size_t n, std::string &out, int level) {
+  out.clear();
+  z_stream zs;
+  memset(&zs, 0, sizeof zs);
+  if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+  out.resize(deflateBound(&zs, (uLong)n) + 64);
+  size_t n_in = 0, n_out = 0;
+  int rc = Z_OK;
+  while (rc != Z_STREAM_END) {
+    const size_t in_chunk = n - n_in < (1u << 30) ? n - n_in : (1u << 30);
+    const size_t out_chunk = out.size() - n_out < (1u << 30) ? out.size() - n_out : (1u << 30);
+    zs.next_in = (Bytef *)(data + n_in);
+    zs.avail_in = (uInt)in_chunk;
+    zs.next_out = (Bytef *)(&out[0] + n_out);
+    zs.avail_out = (uInt)out_chunk;
+    rc = deflate(&zs, n_in + in_chunk == n ? Z_FINISH : Z_NO_FLUSH);
+    n_in += in_chunk - zs.avail_in;
+    n_out += out_chunk - zs.avail_out;
+    if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) break;
+    if (rc == Z_BUF_ERROR && n_out == out.size()) out.resize(out.size() * 2);
+  }
+  deflateEnd(&zs);
+  out.resize(n_out);
+  return rc == Z_STREAM_END;
 }
 
 void FastqWriter::flush() {
   if (pending_.empty()) return;
   if (gz_) gzwrite(gz_, pending_.data(), (unsigned)pending_.size());
-  else if (plain_) fwrite(pending_.data(), 1, pending_.size(), plain_);
+  else if (plain_ && members_) {
+    if (compress_member(pending_.data(), pending_.size(), z_)) fwrite(z_.data(), 1, z_.size(), plain_);
+    wrote_ = true;
+  } else if (plain_) fwrite(pending_.data(), 1, pending_.size(), plain_);
   pending_.clear();
 }
 
@@ -96,8 +126,14 @@ void FastqWriter::write(const char *data, size_t n) {
   if (pending_.size() >= kBuf) flush();
 }
 
+void FastqWriter::write_member(const std::string &z) {
+  flush();
+  if (plain_ && !z.empty()) { fwrite(z.data(), 1, z.size(), plain_); wrote_ = true; }
+}
+
 FastqWriter::~FastqWriter() {
   flush();
+  if (plain_ && members_ && !wrote_ && compress_member("", 0, z_)) fwrite(z_.data(), 1, z_.size(), plain_);   // valid empty gzip
   if (gz_) gzclose(gz_);
   if (plain_) fclose(plain_);
 }

@@ -55,15 +55,24 @@ class MultiReader {
 };
 
 // Output file; gzip-compressed when the name ends in ".gz" (as fastp's Writer decides).
+// members = true: the file is written as a sequence of independent gzip members, so that the
+// caller can compress blocks on several threads (compress_member) and hand them over in order
+// (write_member).  Tools read such a file exactly like a single-member one.
 class FastqWriter {
  public:
-  explicit FastqWriter(const std::string &path);
+  explicit FastqWriter(const std::string &path, bool members = false);
   ~FastqWriter();
   bool ok() const { return plain_ != nullptr || gz_ != nullptr; }
+  bool gz_members() const { return members_; }
   void write(const char *data, size_t n);
+  void write_member(const std::string &z);          // one precompressed gzip member
   void flush();
+  // data -> one complete gzip member (fastp Options default compression level 4)
+  static bool compress_member(const char *data, size_t n, std::string &out, int level = 4);
  private:
   FILE *plain_ = nullptr;
   gzFile gz_ = nullptr;
-  std::string pending_;
+  bool members_ = false;
+  bool wrote_ = false;
+  std::string pending_, z_;
 };

@@ -4,6 +4,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +16,13 @@ unsigned host_threads() {
   if (t == 0) t = std::thread::hardware_concurrency();
   if (t == 0) t = 1;
   return t > 64 ? 64 : t;
+}
+
+size_t retain_budget_bytes() {
+  if (const char *e = getenv("HUMID_RETAIN_GB")) return (size_t)(atof(e) * 1073741824.0);
+  const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+  if (pages <= 0 || psz <= 0) return (size_t)8 << 30;
+  return (size_t)pages * (size_t)psz / 3;
 }
 
 void parallel_ranges(size_t n, unsigned threads, const std::function<void(size_t, size_t, unsigned)> &fn) {
@@ -37,8 +45,61 @@ static inline const char *next_line(const char *p, const char *end) {
   return nl ? nl + 1 : end;
 }
 
-bool MappedFastq::open(const std::string &path, unsigned threads) {
-  if (path.size() >= 3 && path.compare(path.size() - 3, 3, ".gz") == 0) return false;
+// gzip (one or more members) -> an anonymous mapping that replaces data/size; false when the
+// stream is damaged or the inflated size would exceed max_inflated
+bool MappedFastq::inflate_all(const char *z, size_t zn, size_t max_inflated) {
+  size_t cap = zn * 4 + (1u << 20);
+  if (cap > max_inflated) cap = max_inflated;
+  if (cap < (1u << 16)) cap = 1u << 16;
+  char *out = (char *)mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (out == MAP_FAILED) return false;
+  size_t n_out = 0, n_in = 0;
+  z_stream zs;
+  memset(&zs, 0, sizeof zs);
+  if (inflateInit2(&zs, 15 + 32) != Z_OK) { munmap(out, cap); return false; }
+  bool good = true;
+  while (good) {
+    if (n_out == cap) {                                   // grow by half (the mapping may move)
+      size_t want = cap + cap / 2;
+      if (want > max_inflated) want = max_inflated;
+      if (want <= cap) { good = false; break; }           // over the retention bound
+      void *m2 = mremap(out, cap, want, MREMAP_MAYMOVE);
+      if (m2 == MAP_FAILED) { good = false; break; }
+      out = (char *)m2;
+      cap = want;
+    }
+    const size_t in_chunk = zn - n_in < (1u << 30) ? zn - n_in : (1u << 30);
+    const size_t out_chunk = cap - n_out < (1u << 30) ? cap - n_out : (1u << 30);
+    zs.next_in = (Bytef *)(z + n_in);
+    zs.avail_in = (uInt)in_chunk;
+    zs.next_out = (Bytef *)(out + n_out);
+    zs.avail_out = (uInt)out_chunk;
+    const int rc = inflate(&zs, Z_NO_FLUSH);
+    n_in += in_chunk - zs.avail_in;
+    n_out += out_chunk - zs.avail_out;
+    if (rc == Z_STREAM_END) {
+      if (n_in == zn) break;                              // last member done
+      if (inflateReset(&zs) != Z_OK) good = false;        // another member follows
+    } else if (rc != Z_OK && rc != Z_BUF_ERROR) {
+      good = false;
+    } else if (n_in == zn && zs.avail_out != 0) {
+      good = false;                                       // input ended inside a member
+    }
+  }
+  inflateEnd(&zs);
+  if (!good) { munmap(out, cap); return false; }
+  if (n_out == 0) { munmap(out, cap); data = nullptr; size = 0; return true; }
+  if (n_out < cap) {                                      // give the tail back
+    const size_t page = (size_t)sysconf(_SC_PAGE_SIZE);
+    const size_t keep = (n_out + page - 1) / page * page;
+    if (keep < cap) munmap(out + keep, cap - keep);
+  }
+  data = out;
+  size = n_out;
+  return true;
+}
+
+bool MappedFastq::open(const std::string &path, unsigned threads, size_t max_inflated) {
   fd_ = ::open(path.c_str(), O_RDONLY);
   if (fd_ < 0) return false;
   struct stat st;
@@ -50,7 +111,17 @@ bool MappedFastq::open(const std::string &path, unsigned threads) {
   if (m == MAP_FAILED) { data = nullptr; return false; }
   data = (const char *)m;
   madvise(m, size, MADV_SEQUENTIAL);
-  if (data[0] != '@' || data[size - 1] != '\n') return false;    // gzip magic, missing final newline...
+  if (size >= 2 && (unsigned char)data[0] == 0x1f && (unsigned char)data[1] == 0x8b) {
+    const char *z = data;
+    const size_t zn = size;
+    data = nullptr;
+    size = 0;
+    const bool ok = inflate_all(z, zn, max_inflated);
+    munmap((void *)z, zn);
+    if (!ok) { data = nullptr; size = 0; return false; }
+    if (size == 0) { rec_off.push_back(0); canonical = true; return true; }
+  }
+  if (data[0] != '@' || data[size - 1] != '\n') return false;    // missing final newline, not FastQ...
   const char *const end = data + size;
   if (threads == 0) threads = 1;
   std::vector<std::vector<uint64_t>> part(threads);

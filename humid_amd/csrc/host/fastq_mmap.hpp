@@ -4,8 +4,13 @@
 // kept, nothing is parsed twice).  SURVEY.md section 8(f).1: the single-threaded FastQ streaming
 // of the reference (src/fastq.cc:96-114 + fastp) is what bounds end-to-end time.
 //
-// Only "canonical" files take this path: four lines per record, '\n' line ends, no blank lines.
-// Anything else (gzip, CRLF, blank lines) goes through the streaming reader of fastq_io.hpp, whose
+// gzip input (any number of members) is inflated ONCE into memory (one thread per file, zlib; the
+// image has no isa-l) and then treated like a mapping, so pass 2 does not inflate again; the
+// retained bytes are bounded (HUMID_RETAIN_GB, default a third of the physical memory over all
+// files) -- beyond that the streaming reader takes over.
+//
+// Only "canonical" contents take this path: four lines per record, '\n' line ends, no blank lines.
+// Anything else (CRLF, blank lines) goes through the streaming reader of fastq_io.hpp, whose
 // output is byte-identical by construction (tests/test_cli_host.py compares the two).
 #pragma once
 #include <cstdint>
@@ -25,8 +30,9 @@ struct MappedFastq {
   MappedFastq(const MappedFastq &) = delete;
   MappedFastq &operator=(const MappedFastq &) = delete;
 
-  // maps the file and indexes its records with `threads` workers; false = use the streaming path
-  bool open(const std::string &path, unsigned threads);
+  // maps (or inflates) the file and indexes its records with `threads` workers; false = use the
+  // streaming path.  max_inflated: bound on the bytes kept for a gzip file.
+  bool open(const std::string &path, unsigned threads, size_t max_inflated = ~(size_t)0);
   size_t records() const { return rec_off.empty() ? 0 : rec_off.size() - 1; }
 
   // the four lines of record i (no line terminators)
@@ -37,8 +43,11 @@ struct MappedFastq {
   }
 
  private:
+  bool inflate_all(const char *z, size_t zn, size_t max_inflated);
   int fd_ = -1;
 };
+
+size_t retain_budget_bytes();             // HUMID_RETAIN_GB or a third of the physical memory
 
 unsigned host_threads();                  // HUMID_THREADS or hardware concurrency, 1..64
 // runs fn(begin, end, worker) over [0, n) split into contiguous ranges, one per worker

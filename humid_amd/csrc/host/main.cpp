@@ -20,6 +20,8 @@
 #include "../../../include/humid_hip.h"
 #include "fastq_io.hpp"
 #include "fastq_mmap.hpp"
+#include <thread>
+
 #include "words.hpp"
 
 using namespace humid_host;
@@ -142,7 +144,19 @@ int main(int argc, char **argv) {
   const unsigned threads = host_threads();
   std::vector<MappedFastq> maps(a.files.size());
   bool fast = a.files.size() <= 64 && getenv("HUMID_HOST_SLOW") == nullptr;
-  for (size_t f = 0; fast && f < a.files.size(); f++) fast = maps[f].open(a.files[f], threads);
+  if (fast) {
+    // one opener per file (a gzip file is inflated by one zlib stream); the indexing inside uses
+    // the remaining workers
+    const size_t nf = a.files.size();
+    const size_t budget = retain_budget_bytes() / (nf ? nf : 1);
+    const unsigned per = threads / (unsigned)nf ? threads / (unsigned)nf : 1;
+    std::vector<char> okf(nf, 0);
+    std::vector<std::thread> openers;
+    for (size_t f = 0; f < nf; f++)
+      openers.emplace_back([&, f] { okf[f] = maps[f].open(a.files[f], per, budget) ? 1 : 0; });
+    for (auto &th : openers) th.join();
+    for (size_t f = 0; f < nf; f++) fast = fast && okf[f];
+  }
 
   // ---- pass 1: readData (src/humid.cc:89-100) ----
   t = start_message(log, "Reading data");
@@ -227,8 +241,9 @@ int main(int argc, char **argv) {
     if (a.filter) tf = start_message(log, "Writing filtered results");
     std::vector<FastqWriter *> dedup, annot;
     for (const std::string &f : a.files) {
-      if (a.filter) dedup.push_back(new FastqWriter(make_file_name(f, a.dir_name, "dedup")));
-      if (a.annotate) annot.push_back(new FastqWriter(make_file_name(f, a.dir_name, "annotated")));
+      // fast path: .gz outputs are written as gzip members compressed on all cores
+      if (a.filter) dedup.push_back(new FastqWriter(make_file_name(f, a.dir_name, "dedup"), fast));
+      if (a.annotate) annot.push_back(new FastqWriter(make_file_name(f, a.dir_name, "annotated"), fast));
     }
     bool ok = true;
     for (FastqWriter *w : dedup) ok = ok && w->ok();
@@ -239,12 +254,14 @@ int main(int argc, char **argv) {
       // in order
       const size_t nf = maps.size();
       const size_t batch = 1u << 20;
-      std::vector<std::string> bufs(threads);
+      std::vector<std::string> bufs(threads), zbufs(threads);
       for (size_t b0 = 0; b0 < N; b0 += batch) {
         const size_t b1 = b0 + batch < N ? b0 + batch : N;
         for (size_t f = 0; f < nf; f++) {
           for (int what = 0; what < 2; what++) {           // 0 = dedup, 1 = annotated
             if ((what == 0 && !a.filter) || (what == 1 && !a.annotate)) continue;
+            FastqWriter *wr = what == 0 ? dedup[f] : annot[f];
+            const bool zip = wr->gz_members();
             parallel_ranges(b1 - b0, threads, [&](size_t rb, size_t re, unsigned w) {
               std::string &o = bufs[w];
               o.clear();
@@ -263,10 +280,16 @@ int main(int argc, char **argv) {
                   o.append(ql.data(), ql.size()).push_back('\n');
                 }
               }
+              if (zip) {
+                zbufs[w].clear();
+                if (!o.empty()) FastqWriter::compress_member(o.data(), o.size(), zbufs[w]);
+              }
             });
-            FastqWriter *wr = what == 0 ? dedup[f] : annot[f];
             const unsigned used = (threads <= 1 || b1 - b0 < 4096) ? 1 : threads;
-            for (unsigned w = 0; w < used; w++) wr->write(bufs[w].data(), bufs[w].size());
+            for (unsigned w = 0; w < used; w++) {
+              if (zip) wr->write_member(zbufs[w]);
+              else wr->write(bufs[w].data(), bufs[w].size());
+            }
           }
         }
       }

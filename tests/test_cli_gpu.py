@@ -96,3 +96,41 @@ def test_fast_and_streaming_host_paths_write_identical_files(tmp_path):
     for fn in sorted(os.listdir(outs[0])):
         assert open(os.path.join(outs[0], fn), "rb").read() == open(os.path.join(outs[1], fn), "rb").read(), fn
     assert len(os.listdir(outs[0])) == 8     # 2 dedup + 2 annotated + 4 .dat
+
+
+def test_cli_gzip_fast_path_outputs(tmp_path):
+    """gzip in -> gzip out through the inflate-once / parallel-member path: decompressed outputs
+    equal the streaming path's and the oracle-derived expectation, for dedup and annotated files"""
+    files = synth_fastq(str(tmp_path / "in"), 6000, 31, n_files=2, umi_len=8, read_len=36, p_sub=4e-3, p_n=2e-3)
+    gzs = []
+    for f in files:
+        g = f + ".gz"
+        with gzip.open(g, "wb") as fh:
+            fh.write(open(f, "rb").read())
+        gzs.append(g)
+    outs = {}
+    for label, env in (("fast", {"HUMID_THREADS": "6"}), ("slow", {"HUMID_HOST_SLOW": "1"})):
+        out = str(tmp_path / ("out_" + label))
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.check_call([HUMID, "-d", out, "-l", "/dev/null", "-a"] + gzs, env=e)
+        outs[label] = out
+    words, filt, recs, _ = expected_words(files, 24)
+    _, cid, keep = run_oracle(words, filt, 24, 1, False)
+    for fi, g in enumerate(gzs):
+        base = os.path.basename(g)
+        for suffix in ("_dedup", "_annotated"):
+            name = base.replace(".fastq.gz", suffix + ".fastq.gz")
+            a = gzip.open(os.path.join(outs["fast"], name), "rb").read()
+            b = gzip.open(os.path.join(outs["slow"], name), "rb").read()
+            assert a == b, name
+        dedup = read_fastq(os.path.join(outs["fast"], base.replace(".fastq.gz", "_dedup.fastq.gz")))
+        assert dedup == [recs[fi][i] for i in range(len(words)) if keep[i]]
+    # nothing kept (every read filtered): the member-mode writer still leaves a valid, empty gzip
+    nf = str(tmp_path / "n.fastq.gz")
+    with gzip.open(nf, "wb") as fh:
+        for i in range(50):
+            fh.write(b"@r%d_NNNNNNNN\nNNNNNNNNNNNNNNNNNNNN\n+\nIIIIIIIIIIIIIIIIIIII\n" % i)
+    out = str(tmp_path / "out_n")
+    subprocess.check_call([HUMID, "-d", out, "-l", "/dev/null", nf])
+    assert gzip.open(os.path.join(out, "n_dedup.fastq.gz"), "rb").read() == b""

@@ -107,3 +107,37 @@ def test_quality_lines_starting_with_at_sign(tmp_path):
     w_fast, f_fast = dump_words([path], 24, str(tmp_path), env={"HUMID_THREADS": "7"})
     w_slow, f_slow = dump_words([path], 24, str(tmp_path), env={"HUMID_HOST_SLOW": "1"})
     assert len(w_fast) == 30000 and np.array_equal(w_fast, w_slow) and np.array_equal(f_fast, f_slow)
+
+
+def test_gzip_input_takes_the_mapped_path(tmp_path):
+    """gzip input is inflated once into memory and indexed like a mapping: same words as the plain
+    file and as the streaming reader -- single member, several members (bgzip-like), and a file
+    beyond the retention bound (falls back to streaming)"""
+    files = synth_fastq(str(tmp_path), 30000, 12, n_files=2, umi_len=8, read_len=40, p_sub=5e-3, p_n=2e-3)
+    w_ref, f_ref = dump_words(files, 24, str(tmp_path))
+    gz1, gz2 = [], []
+    for f in files:
+        raw = open(f, "rb").read()
+        g = f + ".gz"
+        with gzip.open(g, "wb") as fh:
+            fh.write(raw)
+        gz1.append(g)
+        m = f.replace(".fastq", "_members.fastq.gz")
+        with open(m, "wb") as fh:                      # members cut in the middle of records
+            for k in range(0, len(raw), 250_007):
+                fh.write(gzip.compress(raw[k:k + 250_007]))
+        gz2.append(m)
+    for inputs in (gz1, gz2):
+        for env in ({"HUMID_THREADS": "5"}, {"HUMID_HOST_SLOW": "1"}, {"HUMID_RETAIN_GB": "0.0001"}):
+            w, f = dump_words(inputs, 24, str(tmp_path), env=env)
+            assert len(w) == 30000 and np.array_equal(w, w_ref) and np.array_equal(f, f_ref), (inputs, env)
+
+
+def test_truncated_gzip_is_not_silently_accepted(tmp_path):
+    files = synth_fastq(str(tmp_path), 5000, 13, n_files=1, read_len=40)
+    raw = gzip.compress(open(files[0], "rb").read())
+    bad = str(tmp_path / "cut.fastq.gz")
+    open(bad, "wb").write(raw[:len(raw) // 2])
+    w_fast, _ = dump_words([bad], 24, str(tmp_path))
+    w_slow, _ = dump_words([bad], 24, str(tmp_path), env={"HUMID_HOST_SLOW": "1"})
+    assert len(w_fast) == len(w_slow) < 5000         # both paths stop where the stream breaks

@@ -46,12 +46,25 @@ def main():
     fq = os.path.join(tmp, "reads.fastq")
     size = write_fastq(fq, n, 7)
     exe = os.path.join(ROOT, "humid_amd", "humid")
-    for label, extra in (("dedup only", []), ("dedup + annotate + stats", ["-a", "-s"])):
+    inputs = [("plain", fq)]
+    if "--gz" in sys.argv:
+        gz = fq + ".gz"
         t0 = time.perf_counter()
-        subprocess.check_call([exe, "-d", os.path.join(tmp, "out"), "-l", os.path.join(tmp, "log.txt")] + extra + [fq])
-        dt = time.perf_counter() - t0
-        print("%s: %d reads (%.0f MB FastQ): %.2f s wall = %.2f M reads/s, %.0f MB/s of input"
-              % (label, n, size / 1e6, dt, n / dt / 1e6, size / dt / 1e6), flush=True)
+        subprocess.check_call("gzip -4 -c %s > %s" % (fq, gz), shell=True)
+        print("gzip -4 of the input took %.1f s (%.0f MB)" % (time.perf_counter() - t0, os.path.getsize(gz) / 1e6), flush=True)
+        inputs.append(("gzip in, gzip out", gz))
+    for kind, path in inputs:
+        for label, extra in (("dedup only", []), ("dedup + annotate + stats", ["-a", "-s"])):
+            for env_label, env in (("mapped/inflate-once host path", {}), ("streaming host path", {"HUMID_HOST_SLOW": "1"})):
+                if kind == "plain" and env:
+                    continue
+                e = dict(os.environ)
+                e.update(env)
+                t0 = time.perf_counter()
+                subprocess.check_call([exe, "-d", os.path.join(tmp, "out"), "-l", os.path.join(tmp, "log.txt")] + extra + [path], env=e)
+                dt = time.perf_counter() - t0
+                print("%s, %s, %s: %d reads (%.0f MB FastQ): %.2f s wall = %.2f M reads/s, %.0f MB/s of FastQ"
+                      % (kind, env_label, label, n, size / 1e6, dt, n / dt / 1e6, size / dt / 1e6), flush=True)
     print(open(os.path.join(tmp, "log.txt")).read())
 
 
