@@ -48,13 +48,13 @@ HOST_EXE = os.path.join(HERE, "humid")
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
     """The `humid` command-line host (C++17, g++): FastQ streaming + the C ABI."""
-    srcs = [os.path.join(HOST_DIR, f) for f in ("main.cpp", "fastq_io.cpp", "fastq_mmap.cpp", "words.cpp")]
-    deps = srcs + [os.path.join(HOST_DIR, f) for f in ("fastq_io.hpp", "fastq_mmap.hpp", "words.hpp")] + [HDR]
+    srcs = [os.path.join(HOST_DIR, f) for f in ("main.cpp", "fastq_io.cpp", "fastq_mmap.cpp", "fast_inflate.cpp", "words.cpp")]
+    deps = srcs + [os.path.join(HOST_DIR, f) for f in ("fastq_io.hpp", "fastq_mmap.hpp", "fast_inflate.hpp", "words.hpp")] + [HDR]
     build_hip(force=False, verbose=verbose)
     if not force and os.path.exists(HOST_EXE) and \
             all(os.path.getmtime(p) <= os.path.getmtime(HOST_EXE) for p in deps + [SO]):
         return HOST_EXE
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", HOST_EXE] + srcs + \
+    cmd = ["g++", "-O3", "-std=c++17", "-Wall", "-Wextra", "-o", HOST_EXE] + srcs + \
           ["-L" + HERE, "-lhumid_hip", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))

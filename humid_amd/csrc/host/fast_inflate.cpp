@@ -1,0 +1,481 @@
+#include "fast_inflate.hpp"
+
+#include <zlib.h>   // crc32, crc32_combine only
+
+#include <cstring>
+#include <thread>
+
+namespace humid_host {
+namespace {
+
+// Decode table entry: [31:16] literal / base value / subtable offset, [15] literal, [14] end of
+// block, [13] subtable pointer, [11:8] length of the Huffman code itself (subtable pointer: index
+// bits of the subtable), [7:0] bits to consume = code + extra bits (second level: what is left of
+// the code + extra bits).  One shift consumes code and extra bits together; the extra value is cut
+// out of a saved copy of the bit buffer, off the look-up -> shift -> look-up dependency chain.
+// 0 = no code ends here (invalid input).
+constexpr uint32_t F_LIT = 0x8000u, F_EOB = 0x4000u, F_SUB = 0x2000u;
+// [12] with F_LIT in the first level of the literal/length table: TWO literals whose codes both fit
+// the index ([23:16] the first, [31:24] the second; [7:0] = the sum of both code lengths).  Table
+// look-ups are a serial dependency chain (bits -> entry -> shift -> bits); text and sequence data
+// is mostly literals with short codes, so pairing them nearly halves the chain.
+constexpr uint32_t F_LIT2 = 0x1000u;
+constexpr unsigned LL_TB = 11, D_TB = 8, PRE_TB = 7;
+
+const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59,
+                               67, 83, 99, 115, 131, 163, 195, 227, 258};
+const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769,
+                                1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+
+enum Kind { K_LITLEN, K_DIST, K_PRE };
+
+inline uint32_t payload(Kind k, unsigned sym) {
+  switch (k) {
+    case K_LITLEN:
+      if (sym < 256) return (sym << 16) | F_LIT;
+      if (sym == 256) return F_EOB;
+      if (sym <= 285) return ((uint32_t)kLenBase[sym - 257] << 16) | ((uint32_t)kLenExtra[sym - 257] << 8);
+      return 0;
+    case K_DIST:
+      if (sym < 30) return ((uint32_t)kDistBase[sym] << 16) | ((uint32_t)kDistExtra[sym] << 8);
+      return 0;
+    default:
+      return sym << 16;
+  }
+}
+
+// payload (extra-bit count in [11:8]) + code length -> table entry
+inline uint32_t finish_entry(uint32_t pl, unsigned codelen) {
+  const unsigned extra = (pl >> 8) & 15;
+  return (pl & ~0x0f00u) | (codelen << 8) | (codelen + extra);
+}
+
+inline unsigned reverse_bits(unsigned code, unsigned len) {
+  unsigned r = 0;
+  for (unsigned i = 0; i < len; i++) { r = (r << 1) | (code & 1); code >>= 1; }
+  return r;
+}
+
+// canonical Huffman code lengths -> two-level table (first level tb bits)
+bool build_table(const uint8_t *lens, unsigned n, unsigned tb, Kind kind, std::vector<uint32_t> &t) {
+  unsigned count[16] = {0};
+  for (unsigned i = 0; i < n; i++) count[lens[i] & 15]++;
+  count[0] = 0;
+  unsigned long used = 0;
+  for (unsigned len = 1; len <= 15; len++) used += (unsigned long)count[len] << (15 - len);
+  if (used > (1ul << 15)) return false;                       // over-subscribed
+  unsigned next[16];
+  unsigned code = 0;
+  for (unsigned len = 1; len <= 15; len++) { code = (code + count[len - 1]) << 1; next[len] = code; }
+  const unsigned first = 1u << tb;
+  t.assign(first, 0);
+  uint8_t submax[1u << LL_TB];
+  memset(submax, 0, first);
+  struct Long { uint16_t sym, rev; uint8_t len; };
+  Long longs[320];
+  unsigned n_long = 0;
+  for (unsigned sym = 0; sym < n; sym++) {
+    const unsigned len = lens[sym];
+    if (!len) continue;
+    const unsigned rev = reverse_bits(next[len]++, len);
+    const uint32_t pl = payload(kind, sym);
+    if (len <= tb) {
+      if (pl || kind == K_PRE)
+        for (unsigned i = rev; i < first; i += 1u << len) t[i] = finish_entry(pl, len);
+    } else {
+      const unsigned p = rev & (first - 1);
+      if (len > submax[p]) submax[p] = (uint8_t)len;
+      longs[n_long++] = Long{(uint16_t)sym, (uint16_t)rev, (uint8_t)len};
+    }
+  }
+  for (unsigned p = 0; p < first; p++) {
+    if (!submax[p]) continue;
+    const unsigned bits = submax[p] - tb;
+    const size_t off = t.size();
+    if (off + (1u << bits) > 65535u) return false;
+    t.resize(off + (1u << bits), 0);
+    t[p] = ((uint32_t)off << 16) | F_SUB | (bits << 8) | tb;
+  }
+  for (unsigned k = 0; k < n_long; k++) {
+    const Long &l = longs[k];
+    const uint32_t pl = payload(kind, l.sym);
+    if (!pl && kind != K_PRE) continue;
+    const uint32_t main = t[l.rev & (first - 1)];
+    const unsigned off = main >> 16, bits = (main >> 8) & 15;
+    for (unsigned i = l.rev >> tb; i < (1u << bits); i += 1u << (l.len - tb)) t[off + i] = finish_entry(pl, l.len - tb);
+  }
+  return true;
+}
+
+// pair up literals in the first level of a literal/length table (see F_LIT2)
+void pair_literals(std::vector<uint32_t> &t) {
+  const unsigned first = 1u << LL_TB;
+  std::vector<uint32_t> o(t.begin(), t.begin() + first);
+  for (unsigned i = 0; i < first; i++) {
+    const uint32_t e1 = o[i];
+    if ((e1 & (F_LIT | F_SUB)) != F_LIT) continue;
+    const unsigned l1 = e1 & 0xff;
+    if (l1 >= LL_TB) continue;
+    const uint32_t e2 = o[i >> l1];
+    const unsigned l2 = e2 & 0xff;
+    if ((e2 & (F_LIT | F_SUB)) != F_LIT || l2 == 0 || l1 + l2 > LL_TB) continue;
+    t[i] = F_LIT | F_LIT2 | (e1 & 0x00ff0000u) | ((e2 & 0x00ff0000u) << 8) | (l1 + l2);
+  }
+}
+
+struct Bits {
+  const uint8_t *p, *end;
+  uint64_t buf = 0;
+  unsigned cnt = 0;
+  size_t phantom = 0;            // zero bytes supplied past the end (safe refill)
+  bool clean = true;             // no garbage above cnt
+};
+
+inline uint64_t load64(const uint8_t *p) {
+  uint64_t v;
+  memcpy(&v, p, 8);
+  return v;                      // little-endian host (x86-64)
+}
+
+inline void refill_fast(Bits &b) {   // needs b.p + 8 <= b.end; afterwards 56 <= cnt <= 63
+  b.buf |= load64(b.p) << b.cnt;
+  b.p += (63 - b.cnt) >> 3;
+  b.cnt |= 56;
+  b.clean = false;
+}
+
+inline void make_clean(Bits &b) {
+  if (!b.clean) { b.buf &= (b.cnt >= 64) ? ~0ull : ((1ull << b.cnt) - 1); b.clean = true; }
+}
+
+inline void refill_safe(Bits &b) {
+  make_clean(b);
+  while (b.cnt <= 56) {
+    uint64_t byte = 0;
+    if (b.p < b.end) byte = *b.p++; else { b.phantom++; }
+    b.buf |= byte << b.cnt;
+    b.cnt += 8;
+  }
+}
+
+inline void consume(Bits &b, unsigned n) { b.buf >>= n; b.cnt -= n; }
+
+struct Decoder {
+  std::vector<uint32_t> lt, dt, pt;
+  Bits in;
+  bool final_block = false;
+};
+
+enum { R_EOB = 0, R_NEED_OUT = 1, R_ERROR = -1, R_INPUT_TAIL = 2 };
+
+// symbols of one Huffman block.  FAST: unchecked refills and word copies, leaves with
+// R_INPUT_TAIL / R_NEED_OUT near the end of either buffer.  The bit buffer lives in locals for the
+// whole loop (byte stores to `out` may alias anything reachable through a reference).
+template <bool FAST>
+int decode_huffman(Decoder &d, uint8_t *out, size_t &out_pos, size_t out_cap, size_t member_begin) {
+  const uint32_t *const lt = d.lt.data(), *const dt = d.dt.data();
+  if (!FAST) make_clean(d.in);
+  uint64_t buf = d.in.buf;
+  unsigned cnt = d.in.cnt;
+  const uint8_t *ip = d.in.p;
+  const uint8_t *const iend = d.in.end;
+  size_t phantom = d.in.phantom;
+  uint8_t *op = out + out_pos;
+  uint8_t *const olimit = out + out_cap - 320;          // caller guarantees out_cap >= 320
+  const uint8_t *const mbegin = out + member_begin;
+  int rc = R_ERROR;
+#define HUMID_CONSUME(n) do { buf >>= (n); cnt -= (n); } while (0)
+#define HUMID_REFILL()                                                               \
+  do {                                                                               \
+    if (FAST) {                                                                      \
+      buf |= load64(ip) << cnt;          /* afterwards 56 <= cnt <= 63 */            \
+      ip += (63 - cnt) >> 3;                                                         \
+      cnt |= 56;                                                                     \
+    } else {                                                                         \
+      while (cnt <= 56) {                                                            \
+        uint64_t byte = 0;                                                           \
+        if (ip < iend) byte = *ip++; else phantom++;                                 \
+        buf |= byte << cnt;                                                          \
+        cnt += 8;                                                                    \
+      }                                                                              \
+    }                                                                                \
+  } while (0)
+  uint32_t e;
+  for (;;) {
+    if (op > olimit) { rc = R_NEED_OUT; break; }
+    if (FAST && iend - ip < 16) { rc = R_INPUT_TAIL; break; }        // two refills per turn at most
+    HUMID_REFILL();
+    if (!FAST && phantom > 8) break;                                  // decoding zeros past a truncated input
+    e = lt[buf & ((1u << LL_TB) - 1)];
+  have_entry:
+    if ((e & (F_LIT | F_SUB)) == F_LIT) {
+      // up to four look-ups of one or two literals from one refill (<= 11 bits each, 44 of >= 56)
+      unsigned k = 0;
+      do {
+        HUMID_CONSUME(e & 0xff);
+        const uint16_t two = (uint16_t)(e >> 16);        // second byte is scratch for a single literal
+        memcpy(op, &two, 2);
+        op += 1 + ((e >> 12) & 1);
+        e = lt[buf & ((1u << LL_TB) - 1)];
+      } while (++k < 4 && (e & (F_LIT | F_SUB)) == F_LIT);
+      // e was looked up with the bits that are left: go on without a refill only when a whole
+      // length / distance pair (<= 48 bits) is certainly there
+      if (!FAST || cnt < 48 || (e & (F_LIT | F_SUB)) == F_LIT) continue;
+    }
+    if (e & F_SUB) {
+      HUMID_CONSUME(LL_TB);
+      e = lt[(e >> 16) + (buf & ((1u << ((e >> 8) & 15)) - 1))];
+    }
+    const uint64_t saved = buf;
+    HUMID_CONSUME(e & 0xff);                                           // code and extra bits at once
+    if (e & F_LIT) { *op++ = (uint8_t)(e >> 16); continue; }           // second-level entries are single literals
+    if (e & F_EOB) { rc = R_EOB; break; }
+    {
+      if (!FAST) { HUMID_REFILL(); }
+      uint32_t f;
+      f = dt[buf & ((1u << D_TB) - 1)];                                // does not wait for the length's extra bits
+      if ((e >> 16) == 0 || (e & 0xff) == 0) break;                    // no such code
+      const unsigned lcode = (e >> 8) & 15, ltot = e & 0xff;
+      const unsigned len = (e >> 16) + (unsigned)((saved >> lcode) & ((1u << (ltot - lcode)) - 1));
+      if (f & F_SUB) {
+        HUMID_CONSUME(D_TB);
+        f = dt[(f >> 16) + (buf & ((1u << ((f >> 8) & 15)) - 1))];
+      }
+      const uint64_t saved2 = buf;
+      HUMID_CONSUME(f & 0xff);
+      if ((f >> 16) == 0 || (f & 0xff) == 0) break;
+      const unsigned dcode = (f >> 8) & 15, dtot = f & 0xff;
+      const size_t dist = (f >> 16) + (size_t)((saved2 >> dcode) & ((1u << (dtot - dcode)) - 1));
+      if (dist > (size_t)(op - mbegin)) break;                         // before the start of the member
+      const uint8_t *src = op - dist;
+      uint8_t *const stop = op + len;
+      // FAST: the next symbol's table entry is fetched BEFORE the copy, so that its latency hides
+      // behind the stores (same conditions as at the top of the loop)
+      const bool ahead = FAST && stop <= olimit && iend - ip >= 16;
+      if (ahead) {
+        HUMID_REFILL();
+        e = lt[buf & ((1u << LL_TB) - 1)];
+      }
+      if (FAST && dist >= 8) {
+        // word copies (each 8-byte source lies wholly before its destination), overshooting by up to
+        // 15 bytes.  Sequence data is matched in pieces of about 10 bytes: two words without a
+        // loop cover nearly every match, so the (unpredictable) trip count costs no branch miss
+        memcpy(op, src, 8);
+        memcpy(op + 8, src + 8, 8);
+        if (len > 16) {
+          uint8_t *o2 = op + 16;
+          const uint8_t *s2 = src + 16;
+          do { memcpy(o2, s2, 8); o2 += 8; s2 += 8; } while (o2 < stop);
+        }
+      } else if (dist == 1) {
+        memset(op, *src, len);
+      } else {
+        while (op < stop) *op++ = *src++;
+      }
+      op = stop;
+      if (ahead) goto have_entry;
+    }
+  }
+#undef HUMID_CONSUME
+#undef HUMID_REFILL
+  d.in.buf = buf;
+  d.in.cnt = cnt;
+  d.in.p = ip;
+  d.in.phantom = phantom;
+  d.in.clean = !FAST;
+  out_pos = (size_t)(op - out);
+  return rc;
+}
+
+// bit-level helpers of the (rare) header paths; always the safe refill
+inline unsigned take(Bits &b, unsigned n) {
+  refill_safe(b);
+  const unsigned v = (unsigned)(b.buf & ((1u << n) - 1));
+  consume(b, n);
+  return v;
+}
+
+inline size_t byte_pos(Bits &b, const uint8_t *base) {   // input position of the next unread byte (byte aligned)
+  return (size_t)(b.p - base) + b.phantom - (b.cnt >> 3);
+}
+
+inline void align_to_byte(Bits &b) {
+  make_clean(b);
+  consume(b, b.cnt & 7);
+}
+
+// drop the bit buffer and continue reading bytes at the aligned position
+inline const uint8_t *rewind_to_bytes(Bits &b) {
+  align_to_byte(b);
+  const uint8_t *q = b.p - (b.cnt >> 3);
+  b.buf = 0;
+  b.cnt = 0;
+  b.clean = true;
+  return q;
+}
+
+bool read_dynamic_tables(Decoder &d) {
+  Bits &b = d.in;
+  const unsigned hlit = take(b, 5) + 257, hdist = take(b, 5) + 1, hclen = take(b, 4) + 4;
+  if (hlit > 286 || hdist > 30) return false;
+  static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+  uint8_t pre[19] = {0};
+  for (unsigned i = 0; i < hclen; i++) pre[order[i]] = (uint8_t)take(b, 3);
+  if (!build_table(pre, 19, PRE_TB, K_PRE, d.pt)) return false;
+  uint8_t lens[286 + 30 + 16] = {0};
+  unsigned i = 0;
+  while (i < hlit + hdist) {
+    refill_safe(b);
+    if (b.phantom > 8) return false;
+    const uint32_t e = d.pt[b.buf & ((1u << PRE_TB) - 1)];
+    if ((e & 0xff) == 0) return false;
+    consume(b, e & 0xff);
+    const unsigned sym = e >> 16;
+    if (sym < 16) { lens[i++] = (uint8_t)sym; continue; }
+    unsigned rep, val = 0;
+    if (sym == 16) { if (i == 0) return false; val = lens[i - 1]; rep = 3 + take(b, 2); }
+    else if (sym == 17) rep = 3 + take(b, 3);
+    else rep = 11 + take(b, 7);
+    if (i + rep > hlit + hdist) return false;
+    while (rep--) lens[i++] = (uint8_t)val;
+  }
+  if (lens[256] == 0) return false;                                 // no end-of-block code
+  if (!build_table(lens, hlit, LL_TB, K_LITLEN, d.lt) || !build_table(lens + hlit, hdist, D_TB, K_DIST, d.dt)) return false;
+  pair_literals(d.lt);
+  return true;
+}
+
+bool fixed_tables(Decoder &d) {
+  uint8_t lens[288 + 32];
+  for (unsigned i = 0; i < 144; i++) lens[i] = 8;
+  for (unsigned i = 144; i < 256; i++) lens[i] = 9;
+  for (unsigned i = 256; i < 280; i++) lens[i] = 7;
+  for (unsigned i = 280; i < 288; i++) lens[i] = 8;
+  for (unsigned i = 0; i < 32; i++) lens[288 + i] = 5;
+  if (!build_table(lens, 288, LL_TB, K_LITLEN, d.lt) || !build_table(lens + 288, 32, D_TB, K_DIST, d.dt)) return false;
+  pair_literals(d.lt);
+  return true;
+}
+
+struct Member { size_t begin, end; uint32_t crc; };
+
+}  // namespace
+
+bool fast_gunzip(const uint8_t *in, size_t n_in, GrowFn grow, void *user, size_t *n_out, unsigned threads) {
+  *n_out = 0;
+  size_t cap = 0, pos = 0;
+  uint8_t *out = nullptr;
+  auto need = [&](size_t extra) -> bool {                 // at least `extra` free bytes behind pos
+    if (out && cap - pos >= extra) return true;
+    size_t want = pos + extra;
+    if (want < cap + cap / 2) want = cap + cap / 2;
+    if (want < n_in * 4) want = n_in * 4;
+    char *p = grow(user, want, &cap);
+    if (!p && want > pos + extra) p = grow(user, pos + extra, &cap);   // the bound may still allow the minimum
+    if (!p) return false;
+    out = (uint8_t *)p;
+    return cap - pos >= extra;
+  };
+  std::vector<Member> members;
+  Decoder d;
+  size_t ip = 0;
+  while (ip < n_in) {
+    // ---- gzip member header (RFC 1952) ----
+    if (n_in - ip < 18 || in[ip] != 0x1f || in[ip + 1] != 0x8b || in[ip + 2] != 8) return false;
+    const unsigned flg = in[ip + 3];
+    if (flg & 0xe0) return false;
+    size_t q = ip + 10;
+    if (flg & 4) { if (q + 2 > n_in) return false; q += 2 + (size_t)(in[q] | (in[q + 1] << 8)); }
+    if (flg & 8) { while (q < n_in && in[q]) q++; q++; }
+    if (flg & 16) { while (q < n_in && in[q]) q++; q++; }
+    if (flg & 2) q += 2;
+    if (q >= n_in) return false;
+    d.in = Bits();
+    d.in.p = in + q;
+    d.in.end = in + n_in;
+    const size_t member_begin = pos;
+    // ---- deflate blocks ----
+    for (;;) {
+      const unsigned bfinal = take(d.in, 1), btype = take(d.in, 2);
+      if (d.in.phantom > 8) return false;
+      if (btype == 0) {
+        const uint8_t *s = rewind_to_bytes(d.in);
+        if (d.in.phantom || d.in.end - s < 4) return false;
+        const unsigned len = s[0] | (s[1] << 8), nlen = s[2] | (s[3] << 8);
+        if ((len ^ nlen) != 0xffff || (size_t)(d.in.end - s) < 4 + (size_t)len) return false;
+        if (!need((size_t)len + 1)) return false;
+        memcpy(out + pos, s + 4, len);
+        pos += len;
+        d.in.p = s + 4 + len;
+      } else if (btype == 1 || btype == 2) {
+        if (btype == 1 ? !fixed_tables(d) : !read_dynamic_tables(d)) return false;
+        for (;;) {
+          if (!need(1u << 16)) return false;
+          int rc = (d.in.end - d.in.p >= 16) ? decode_huffman<true>(d, out, pos, cap, member_begin)
+                                             : decode_huffman<false>(d, out, pos, cap, member_begin);
+          if (rc == R_EOB) break;
+          if (rc == R_ERROR) return false;
+          if (rc == R_INPUT_TAIL) {
+            if (!need(1u << 16)) return false;
+            rc = decode_huffman<false>(d, out, pos, cap, member_begin);
+            if (rc == R_EOB) break;
+            if (rc == R_ERROR) return false;
+          }
+          // R_NEED_OUT: grow and go on
+          if (!need(1u << 20)) return false;
+        }
+      } else {
+        return false;
+      }
+      if (bfinal) break;
+    }
+    // ---- trailer: CRC-32 and ISIZE ----
+    const uint8_t *s = rewind_to_bytes(d.in);
+    if (d.in.phantom || s > d.in.end || d.in.end - s < 8) return false;   // consumed bits that were not there
+    const uint32_t crc = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
+    const uint32_t isize = (uint32_t)s[4] | ((uint32_t)s[5] << 8) | ((uint32_t)s[6] << 16) | ((uint32_t)s[7] << 24);
+    if (isize != (uint32_t)(pos - member_begin)) return false;
+    members.push_back(Member{member_begin, pos, crc});
+    ip = (size_t)(s + 8 - in);
+  }
+  // ---- CRC-32 of every member: chunks on all cores, combined in order ----
+  if (threads == 0) threads = 1;
+  const size_t chunk = 8u << 20;
+  struct Piece { size_t b, e; uLong crc; };
+  std::vector<Piece> pieces;
+  std::vector<size_t> first_piece;
+  for (const Member &m : members) {
+    first_piece.push_back(pieces.size());
+    for (size_t b0 = m.begin; b0 < m.end; b0 += chunk) pieces.push_back(Piece{b0, b0 + chunk < m.end ? b0 + chunk : m.end, 0});
+  }
+  first_piece.push_back(pieces.size());
+  if (!pieces.empty()) {
+    std::vector<std::thread> pool;
+    const unsigned nt = threads < pieces.size() ? threads : (unsigned)pieces.size();
+    for (unsigned w = 0; w < nt; w++)
+      pool.emplace_back([&, w] {
+        for (size_t k = w; k < pieces.size(); k += nt) {
+          Piece &pc = pieces[k];
+          uLong c = crc32(0L, Z_NULL, 0);
+          for (size_t o = pc.b; o < pc.e; o += (1u << 30)) {
+            const size_t n = pc.e - o < (1u << 30) ? pc.e - o : (1u << 30);
+            c = crc32(c, out + o, (uInt)n);
+          }
+          pc.crc = c;
+        }
+      });
+    for (auto &t : pool) t.join();
+  }
+  for (size_t mi = 0; mi < members.size(); mi++) {
+    uLong c = crc32(0L, Z_NULL, 0);
+    for (size_t k = first_piece[mi]; k < first_piece[mi + 1]; k++)
+      c = crc32_combine(c, pieces[k].crc, (z_off_t)(pieces[k].e - pieces[k].b));
+    if ((uint32_t)c != members[mi].crc) return false;
+  }
+  *n_out = pos;
+  return true;
+}
+
+}  // namespace humid_host

@@ -6,6 +6,8 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include "fast_inflate.hpp"
+
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -47,7 +49,42 @@ static inline const char *next_line(const char *p, const char *end) {
 
 // gzip (one or more members) -> an anonymous mapping that replaces data/size; false when the
 // stream is damaged or the inflated size would exceed max_inflated
+namespace {
+struct AnonBuf {             // growing anonymous mapping (mremap: no copy when it can extend in place)
+  char *p = nullptr;
+  size_t cap = 0, limit = 0;
+};
+char *grow_anon(void *user, size_t min_cap, size_t *capacity) {
+  AnonBuf *b = (AnonBuf *)user;
+  if (min_cap <= b->cap) { *capacity = b->cap; return b->p; }
+  if (min_cap > b->limit) return nullptr;
+  void *m = b->p ? mremap(b->p, b->cap, min_cap, MREMAP_MAYMOVE)
+                 : mmap(nullptr, min_cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (m == MAP_FAILED) return nullptr;
+  b->p = (char *)m;
+  b->cap = min_cap;
+  *capacity = min_cap;
+  return b->p;
+}
+}  // namespace
+
 bool MappedFastq::inflate_all(const char *z, size_t zn, size_t max_inflated) {
+  if (getenv("HUMID_ZLIB_INFLATE") == nullptr) {
+    // the host's own decoder first (fast_inflate.hpp); zlib below takes over if it declines
+    AnonBuf b;
+    b.limit = max_inflated;
+    size_t n = 0;
+    if (humid_host::fast_gunzip((const uint8_t *)z, zn, grow_anon, &b, &n, host_threads())) {
+      if (n == 0) { if (b.p) munmap(b.p, b.cap); data = nullptr; size = 0; return true; }
+      const size_t page = (size_t)sysconf(_SC_PAGE_SIZE);
+      const size_t keep = (n + page - 1) / page * page;
+      if (keep < b.cap) munmap(b.p + keep, b.cap - keep);
+      data = b.p;
+      size = n;
+      return true;
+    }
+    if (b.p) munmap(b.p, b.cap);
+  }
   size_t cap = zn * 4 + (1u << 20);
   if (cap > max_inflated) cap = max_inflated;
   if (cap < (1u << 16)) cap = 1u << 16;

@@ -20,8 +20,10 @@
 #include "../../../include/humid_hip.h"
 #include "fastq_io.hpp"
 #include "fastq_mmap.hpp"
+#include <iterator>
 #include <thread>
 
+#include "fast_inflate.hpp"
 #include "words.hpp"
 
 using namespace humid_host;
@@ -113,6 +115,33 @@ bool write_hist(humid_ctx *ctx, uint32_t which, const std::string &path) {
 }  // namespace
 
 int main(int argc, char **argv) {
+  // development aid (no GPU): --gunzip IN.gz OUT inflates through the host's own decoder only
+  // (fast_inflate.hpp); exit code 3 = the decoder declined the file
+  if (argc == 4 && std::string(argv[1]) == "--gunzip") {
+    std::ifstream in(argv[2], std::ios::binary);
+    if (!in) return 1;
+    std::string z((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    struct Buf { std::vector<char> v; size_t limit; } buf;
+    buf.limit = z.size() * 1100 + (1u << 20);            // DEFLATE cannot expand more than 1032 : 1
+    if (buf.limit > ((size_t)8 << 30)) buf.limit = (size_t)8 << 30;
+    auto grow = [](void *user, size_t min_cap, size_t *cap) -> char * {
+      Buf *b = (Buf *)user;
+      if (min_cap > b->limit) return nullptr;
+      if (b->v.size() < min_cap) b->v.resize(min_cap);
+      *cap = b->v.size();
+      return b->v.data();
+    };
+    size_t n = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool ok = humid_host::fast_gunzip((const uint8_t *)z.data(), z.size(), grow, &buf, &n, host_threads());
+    if (getenv("HUMID_TIMING"))
+      std::fprintf(stderr, "fast_gunzip: %zu -> %zu bytes in %.3f s\n", z.size(), n,
+                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    if (!ok) return 3;
+    std::ofstream out(argv[3], std::ios::binary);
+    out.write(buf.v.data(), (std::streamsize)n);
+    return out ? 0 : 1;
+  }
   Args a;
   if (!parse(argc, argv, a)) { usage(argv[0]); return 2; }
   if (a.edit) {
