@@ -8,6 +8,8 @@
 // instead of trie.find() (src/humid.cc:223-231,276-277).
 #include <sys/stat.h>
 
+#include <unistd.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -154,6 +156,26 @@ int main(int argc, char **argv) {
   }
   std::ofstream log(a.log_name.c_str(), std::ios::out | std::ios::binary);
 
+  // The HIP runtime and the context come up (a few hundred ms) while pass 1 parses the files.
+  humid_ctx *ctx = nullptr;
+  int ctx_rc = HUMID_OK;
+  std::string ctx_err;
+  struct Joiner {
+    std::thread th;
+    ~Joiner() { if (th.joinable()) th.join(); }
+  } ctx_init;
+  if (a.dump_words.empty())
+    ctx_init.th = std::thread([&] {
+      ctx_rc = humid_ctx_create(&ctx, -1, nullptr);
+      if (ctx_rc != HUMID_OK) ctx_err = humid_last_error(nullptr);
+    });
+  const auto t_start = std::chrono::steady_clock::now();
+  auto phase = [&](const char *what) {                 // HUMID_TIMING=1: wall time of the host phases
+    if (getenv("HUMID_TIMING"))
+      std::fprintf(stderr, "[humid] %-28s %.3f s\n", what,
+                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+  };
+
   // ---- preCompute (src/humid.cc:38-59): UMI size from the first header of the first file ----
   size_t first_umi = 0;
   {
@@ -187,6 +209,7 @@ int main(int argc, char **argv) {
     for (size_t f = 0; f < nf; f++) fast = fast && okf[f];
   }
 
+  phase("files opened / indexed");
   // ---- pass 1: readData (src/humid.cc:89-100) ----
   t = start_message(log, "Reading data");
   const size_t wpr = a.word_length > 32 ? 2 : 1;   // uint64 per word (include/humid_hip.h)
@@ -238,11 +261,13 @@ int main(int argc, char **argv) {
   }
 
   // ---- the hot path on the GPU ----
-  humid_ctx *ctx = nullptr;
-  if (humid_ctx_create(&ctx, -1, nullptr) != HUMID_OK) {
-    std::fprintf(stderr, "humid: %s\n", humid_last_error(nullptr));
+  phase("pass 1 done");
+  if (ctx_init.th.joinable()) ctx_init.th.join();
+  if (ctx_rc != HUMID_OK || !ctx) {
+    std::fprintf(stderr, "humid: %s\n", ctx_err.c_str());
     return 1;
   }
+  phase("context ready");
   std::vector<uint32_t> cluster_id(N ? N : 1);
   std::vector<uint8_t> keep(N ? N : 1);
   humid_summary sum;
@@ -258,6 +283,7 @@ int main(int argc, char **argv) {
     return 1;
   }
   end_message(log, t);
+  phase("device path done");
   t = start_message(log, a.maximum ? "Calculating maximum clusters" : "Calculating directional clusters");
   end_message(log, t);
   std::vector<uint64_t>().swap(words);
@@ -353,6 +379,7 @@ int main(int argc, char **argv) {
     if (a.annotate) { ta = start_message(log, "Writing annotated results"); end_message(log, ta); }
   }
 
+  phase("pass 2 done");
   // ---- statistics (src/humid.cc:301-357, src/cluster.cc:89-95) ----
   if (a.stats) {
     t = start_message(log, "Calculating count and neighbour stats");
@@ -367,6 +394,14 @@ int main(int argc, char **argv) {
     out << "clusters: " << sum.clusters << '\n';
   }
   log.close();
+  phase("outputs closed");
   humid_ctx_destroy(ctx);
+  phase("context destroyed");
+  // every output is closed: leave without the static destructors of the HIP runtime and without
+  // unmapping the inputs page by page (HUMID_SLOW_EXIT=1 keeps the ordinary exit)
+  if (getenv("HUMID_SLOW_EXIT") == nullptr) {
+    std::fflush(nullptr);
+    _exit(0);
+  }
   return 0;
 }

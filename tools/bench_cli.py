@@ -60,6 +60,7 @@ def main():
                     continue
                 e = dict(os.environ)
                 e.update(env)
+                e["HUMID_TIMING"] = "1"
                 t0 = time.perf_counter()
                 subprocess.check_call([exe, "-d", os.path.join(tmp, "out"), "-l", os.path.join(tmp, "log.txt")] + extra + [path], env=e)
                 dt = time.perf_counter() - t0
