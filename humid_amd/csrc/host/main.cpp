@@ -320,20 +320,32 @@ int main(int argc, char **argv) {
             parallel_ranges(b1 - b0, threads, [&](size_t rb, size_t re, unsigned w) {
               std::string &o = bufs[w];
               o.clear();
-              std::string_view nm, sq, st, ql;
-              for (size_t i = b0 + rb; i < b0 + re; i++) {
-                if (what == 0) {
+              if (what == 0) {
+                for (size_t i = b0 + rb; i < b0 + re; i++)
                   if (keep[i]) { std::string_view r = maps[f].raw(i); o.append(r.data(), r.size()); }
-                } else {
-                  maps[f].lines(i, nm, sq, st, ql);
-                  o.append(nm.data(), nm.size());
-                  o.push_back(':');
-                  o.append(std::to_string(cluster_id[i]));   // src/humid.cc:281
-                  o.push_back('\n');
-                  o.append(sq.data(), sq.size()).push_back('\n');
-                  o.append(st.data(), st.size()).push_back('\n');
-                  o.append(ql.data(), ql.size()).push_back('\n');
+              } else if (re > rb) {
+                // annotated record = header + ':' + cluster id + the rest of the record verbatim
+                // (src/humid.cc:281); written with pointer arithmetic into a buffer sized up front
+                const size_t first = b0 + rb, last = b0 + re;
+                const size_t in_bytes = (size_t)(maps[f].rec_off[last] - maps[f].rec_off[first]);
+                o.resize(in_bytes + 11 * (last - first));
+                char *q = &o[0];
+                for (size_t i = first; i < last; i++) {
+                  const std::string_view r = maps[f].raw(i);
+                  const char *nl = (const char *)memchr(r.data(), '\n', r.size());
+                  const size_t hl = nl ? (size_t)(nl - r.data()) : r.size();
+                  memcpy(q, r.data(), hl);
+                  q += hl;
+                  *q++ = ':';
+                  char dig[10];
+                  unsigned nd = 0;
+                  uint32_t v = cluster_id[i];
+                  do { dig[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
+                  while (nd) *q++ = dig[--nd];
+                  memcpy(q, r.data() + hl, r.size() - hl);
+                  q += r.size() - hl;
                 }
+                o.resize((size_t)(q - o.data()));
               }
               if (zip) {
                 zbufs[w].clear();
