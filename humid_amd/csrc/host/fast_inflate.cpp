@@ -2,6 +2,8 @@
 
 #include <zlib.h>   // crc32, crc32_combine only
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -316,13 +318,25 @@ inline const uint8_t *rewind_to_bytes(Bits &b) {
   return q;
 }
 
-bool read_dynamic_tables(Decoder &d) {
+// sum of 2^(15 - len) over the used codes == 2^15: the code is complete (every zlib-made code is,
+// except a distance code with a single symbol)
+inline bool kraft_complete(const uint8_t *lens, unsigned n) {
+  unsigned long used = 0;
+  for (unsigned i = 0; i < n; i++)
+    if (lens[i]) used += 1ul << (15 - lens[i]);
+  return used == (1ul << 15);
+}
+
+// strict: additionally insist on complete codes -- the block-start search of the parallel decoder
+// uses this to tell a real header from random bits
+bool read_dynamic_tables(Decoder &d, bool strict = false) {
   Bits &b = d.in;
   const unsigned hlit = take(b, 5) + 257, hdist = take(b, 5) + 1, hclen = take(b, 4) + 4;
   if (hlit > 286 || hdist > 30) return false;
   static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
   uint8_t pre[19] = {0};
   for (unsigned i = 0; i < hclen; i++) pre[order[i]] = (uint8_t)take(b, 3);
+  if (strict && !kraft_complete(pre, 19)) return false;
   if (!build_table(pre, 19, PRE_TB, K_PRE, d.pt)) return false;
   uint8_t lens[286 + 30 + 16] = {0};
   unsigned i = 0;
@@ -342,6 +356,11 @@ bool read_dynamic_tables(Decoder &d) {
     while (rep--) lens[i++] = (uint8_t)val;
   }
   if (lens[256] == 0) return false;                                 // no end-of-block code
+  if (strict) {
+    unsigned nd = 0;
+    for (unsigned k = 0; k < hdist; k++) nd += lens[hlit + k] != 0;
+    if (!kraft_complete(lens, hlit) || (nd > 1 && !kraft_complete(lens + hlit, hdist))) return false;
+  }
   if (!build_table(lens, hlit, LL_TB, K_LITLEN, d.lt) || !build_table(lens + hlit, hdist, D_TB, K_DIST, d.dt)) return false;
   pair_literals(d.lt);
   return true;
@@ -361,9 +380,389 @@ bool fixed_tables(Decoder &d) {
 
 struct Member { size_t begin, end; uint32_t crc; };
 
+// ------------------------------------------------------------------------------------------
+// Parallel inflate of ONE gzip member (two passes, after Kerbiriou & Chikhi's pugz idea).
+//
+// A DEFLATE stream can only be entered at a block boundary, and a block may refer to the 32 KiB
+// before it.  Pass 1: the compressed bytes are cut into chunks; for every cut a block start is
+// SEARCHED (a dynamic-block header with complete Huffman codes whose block decodes to its end and
+// is followed by another valid header) and every chunk is decoded on its own thread from its block
+// start to the next chunk's, into 16-bit symbols: 0..255 = a byte, 256 + k = "byte k of the unknown
+// 32 KiB window before this chunk" (the window is simply laid out in front of the chunk's output,
+// so copies need no special case and unknown bytes propagate through matches by themselves).
+// Pass 2: chunk after chunk (cheap: 32 KiB each) the windows become known; then all chunks are
+// translated to bytes in parallel into the final buffer.  The member's CRC-32 and size decide:
+// anything unexpected (no block start found, a chunk that does not end exactly on the next start,
+// a second member, a mismatch) makes the caller decode serially instead.
+// ------------------------------------------------------------------------------------------
+constexpr size_t WIN = 32768;
+
+inline size_t bit_position(const Bits &b, const uint8_t *base) { return 8 * (size_t)(b.p - base) - b.cnt; }
+
+void start_at_bit(Bits &b, const uint8_t *in, size_t n_in, size_t bitpos) {
+  b = Bits();
+  b.p = in + (bitpos >> 3);
+  b.end = in + n_in;
+  if (bitpos & 7) { refill_safe(b); consume(b, (unsigned)(bitpos & 7)); }
+}
+
+struct Out16 {
+  uint16_t *base = nullptr;      // WIN placeholder symbols, then the chunk's output
+  size_t cap = 0, pos = 0;
+  ~Out16() { free(base); }
+  bool reserve(size_t extra) {
+    if (cap - pos >= extra) return true;
+    size_t want = cap + cap / 2 + extra;
+    uint16_t *p = (uint16_t *)realloc(base, want * 2);
+    if (!p) return false;
+    base = p;
+    cap = want;
+    return true;
+  }
+  bool init(size_t guess) {
+    cap = WIN + guess + 1024;
+    base = (uint16_t *)malloc(cap * 2);
+    if (!base) return false;
+    for (size_t k = 0; k < WIN; k++) base[k] = (uint16_t)(256 + k);
+    pos = WIN;
+    return true;
+  }
+};
+
+// one Huffman block into 16-bit symbols (see above); R_EOB or R_ERROR
+int decode_huffman16(Decoder &d, Out16 &o) {
+  const uint32_t *const lt = d.lt.data(), *const dt = d.dt.data();
+  make_clean(d.in);
+  uint64_t buf = d.in.buf;
+  unsigned cnt = d.in.cnt;
+  const uint8_t *ip = d.in.p;
+  const uint8_t *const iend = d.in.end;
+  size_t phantom = d.in.phantom;
+  int rc = R_ERROR;
+  for (;;) {
+    if (o.cap - o.pos < 600 && !o.reserve(1u << 20)) break;
+    uint16_t *op = o.base + o.pos;
+    if (iend - ip >= 16) {
+      buf |= load64(ip) << cnt;
+      ip += (63 - cnt) >> 3;
+      cnt |= 56;
+    } else {
+      buf &= (cnt >= 64) ? ~0ull : ((1ull << cnt) - 1);
+      while (cnt <= 56) {
+        uint64_t byte = 0;
+        if (ip < iend) byte = *ip++; else phantom++;
+        buf |= byte << cnt;
+        cnt += 8;
+      }
+      if (phantom > 8) break;
+    }
+    uint32_t e = lt[buf & ((1u << LL_TB) - 1)];
+    unsigned k = 0;
+    while (k < 4 && (e & (F_LIT | F_SUB)) == F_LIT) {       // up to four look-ups of one or two literals
+      buf >>= (e & 0xff);
+      cnt -= (e & 0xff);
+      op[0] = (uint16_t)((e >> 16) & 0xff);
+      op[1] = (uint16_t)(e >> 24);
+      op += 1 + ((e >> 12) & 1);
+      e = lt[buf & ((1u << LL_TB) - 1)];
+      k++;
+    }
+    o.pos = (size_t)(op - o.base);
+    if (k) continue;
+    if (e & F_SUB) {
+      buf >>= LL_TB;
+      cnt -= LL_TB;
+      e = lt[(e >> 16) + (buf & ((1u << ((e >> 8) & 15)) - 1))];
+    }
+    const uint64_t saved = buf;
+    buf >>= (e & 0xff);
+    cnt -= (e & 0xff);
+    if (e & F_LIT) { *op++ = (uint16_t)((e >> 16) & 0xff); o.pos++; continue; }
+    if (e & F_EOB) { rc = R_EOB; break; }
+    if ((e >> 16) == 0 || (e & 0xff) == 0) break;
+    const unsigned lcode = (e >> 8) & 15, ltot = e & 0xff;
+    const unsigned len = (e >> 16) + (unsigned)((saved >> lcode) & ((1u << (ltot - lcode)) - 1));
+    uint32_t f = dt[buf & ((1u << D_TB) - 1)];
+    if (f & F_SUB) {
+      buf >>= D_TB;
+      cnt -= D_TB;
+      f = dt[(f >> 16) + (buf & ((1u << ((f >> 8) & 15)) - 1))];
+    }
+    const uint64_t saved2 = buf;
+    buf >>= (f & 0xff);
+    cnt -= (f & 0xff);
+    if ((f >> 16) == 0 || (f & 0xff) == 0) break;
+    const unsigned dcode = (f >> 8) & 15, dtot = f & 0xff;
+    const size_t dist = (f >> 16) + (size_t)((saved2 >> dcode) & ((1u << (dtot - dcode)) - 1));
+    if (dist > o.pos) break;                                 // before even the window
+    const uint16_t *src = op - dist;
+    if (dist >= 4) {                                         // four symbols per copy, overshoot < 4
+      uint16_t *const stop = op + len;
+      do { memcpy(op, src, 8); op += 4; src += 4; } while (op < stop);
+    } else {
+      for (unsigned i = 0; i < len; i++) op[i] = src[i];
+    }
+    o.pos += len;
+  }
+  d.in.buf = buf;
+  d.in.cnt = cnt;
+  d.in.p = ip;
+  d.in.phantom = phantom;
+  d.in.clean = false;
+  return rc;
+}
+
+// blocks from the decoder's position up to (exactly) stop_bit, or, stop_bit == 0, to the end of the
+// final block.  *final_seen: the final block ended here.
+bool decode_blocks16(Decoder &d, const uint8_t *in, Out16 &o, size_t stop_bit, size_t max_blocks, bool *final_seen) {
+  *final_seen = false;
+  for (size_t nb = 0; nb < max_blocks; nb++) {
+    if (stop_bit) {
+      const size_t bp = bit_position(d.in, in);
+      if (bp == stop_bit) return true;
+      if (bp > stop_bit) return false;
+    }
+    const unsigned bfinal = take(d.in, 1), btype = take(d.in, 2);
+    if (d.in.phantom) return false;
+    if (btype == 0) {
+      const uint8_t *s = rewind_to_bytes(d.in);
+      if (d.in.end - s < 4) return false;
+      const unsigned len = s[0] | (s[1] << 8), nlen = s[2] | (s[3] << 8);
+      if ((len ^ nlen) != 0xffff || (size_t)(d.in.end - s) < 4 + (size_t)len) return false;
+      if (!o.reserve((size_t)len + 8)) return false;
+      for (unsigned k = 0; k < len; k++) o.base[o.pos + k] = s[4 + k];
+      o.pos += len;
+      d.in.p = s + 4 + len;
+    } else if (btype == 1 || btype == 2) {
+      if (btype == 1 ? !fixed_tables(d) : !read_dynamic_tables(d)) return false;
+      if (decode_huffman16(d, o) != R_EOB) return false;
+    } else {
+      return false;
+    }
+    if (bfinal) { *final_seen = true; return stop_bit == 0; }
+  }
+  return false;
+}
+
+// first bit position in [from_bit, to_bit) that looks like the start of a dynamic block: strict
+// header, the block decodes to its end-of-block, and another well-formed block follows
+size_t find_block_start(const uint8_t *in, size_t n_in, size_t from_bit, size_t to_bit) {
+  Decoder d;
+  for (size_t bp = from_bit; bp < to_bit; bp++) {
+    // cheap filter: BFINAL = 0, BTYPE = 2 (bits 0, 01 in stream order -> value 4), HLIT <= 29, HDIST <= 29
+    const size_t by = bp >> 3;
+    if (by + 4 >= n_in) break;
+    const uint32_t w = ((uint32_t)in[by] | ((uint32_t)in[by + 1] << 8) | ((uint32_t)in[by + 2] << 16) |
+                        ((uint32_t)in[by + 3] << 24)) >> (bp & 7);
+    if ((w & 7) != 4 || ((w >> 3) & 31) > 29 || ((w >> 8) & 31) > 29) continue;
+    start_at_bit(d.in, in, n_in, bp + 3);
+    if (!read_dynamic_tables(d, true) || d.in.phantom) continue;
+    Out16 scratch;
+    if (!scratch.init(1u << 16)) return 0;
+    if (decode_huffman16(d, scratch) != R_EOB || d.in.phantom) continue;
+    if (scratch.pos - WIN < 256) continue;                    // real blocks of a large file are not tiny
+    // the following block header
+    const unsigned nb_final = take(d.in, 1), nb_type = take(d.in, 2);
+    (void)nb_final;
+    if (d.in.phantom || nb_type == 3) continue;
+    if (nb_type == 2 && !read_dynamic_tables(d, true)) continue;
+    if (nb_type == 0) {
+      const uint8_t *s2 = rewind_to_bytes(d.in);
+      if (d.in.end - s2 < 4 || (((unsigned)(s2[0] | (s2[1] << 8)) ^ (unsigned)(s2[2] | (s2[3] << 8))) != 0xffff)) continue;
+    }
+    return bp;
+  }
+  return 0;
+}
+
+size_t parse_gzip_header(const uint8_t *in, size_t n_in, size_t ip) {   // -> first deflate byte, 0 = bad
+  if (n_in - ip < 18 || in[ip] != 0x1f || in[ip + 1] != 0x8b || in[ip + 2] != 8) return 0;
+  const unsigned flg = in[ip + 3];
+  if (flg & 0xe0) return 0;
+  size_t q = ip + 10;
+  if (flg & 4) { if (q + 2 > n_in) return 0; q += 2 + (size_t)(in[q] | (in[q + 1] << 8)); }
+  if (flg & 8) { while (q < n_in && in[q]) q++; q++; }
+  if (flg & 16) { while (q < n_in && in[q]) q++; q++; }
+  if (flg & 2) q += 2;
+  return q < n_in ? q : 0;
+}
+
+uint32_t parallel_crc32(const uint8_t *data, size_t n, unsigned threads) {
+  const size_t chunk = 8u << 20;
+  const size_t np = (n + chunk - 1) / chunk;
+  if (np == 0) return (uint32_t)crc32(0L, Z_NULL, 0);
+  std::vector<uLong> part(np);
+  const unsigned nt = threads < np ? (threads ? threads : 1) : (unsigned)np;
+  std::vector<std::thread> pool;
+  for (unsigned w = 0; w < nt; w++)
+    pool.emplace_back([&, w] {
+      for (size_t k = w; k < np; k += nt) {
+        const size_t b = k * chunk, e = b + chunk < n ? b + chunk : n;
+        part[k] = crc32(crc32(0L, Z_NULL, 0), data + b, (uInt)(e - b));
+      }
+    });
+  for (auto &t : pool) t.join();
+  uLong c = crc32(0L, Z_NULL, 0);
+  for (size_t k = 0; k < np; k++) {
+    const size_t b = k * chunk, e = b + chunk < n ? b + chunk : n;
+    c = crc32_combine(c, part[k], (z_off_t)(e - b));
+  }
+  return (uint32_t)c;
+}
+
+struct Chunk16 {
+  size_t start_bit = 0, stop_bit = 0;     // stop_bit 0: the last chunk (runs to the final block)
+  Out16 out;
+  bool ok = false;
+  std::vector<uint8_t> window;            // the 32 KiB before this chunk, once known
+  size_t offset = 0;                      // of its bytes in the final buffer
+};
+
+bool gunzip_parallel(const uint8_t *in, size_t n_in, GrowFn grow, void *user, size_t *n_out, unsigned threads) {
+  const size_t q = parse_gzip_header(in, n_in, 0);
+  if (threads > 32) threads = 32;
+  // test hook: HUMID_PAR_INFLATE_CHUNK (bytes) forces the chunk size, so that small files take
+  // this path too
+  size_t forced = 0;
+  if (const char *e = getenv("HUMID_PAR_INFLATE_CHUNK")) forced = (size_t)atol(e);
+  if (!q || threads < 2 || n_in < q + 64 || (!forced && n_in - q < ((size_t)16 << 20))) return false;
+  size_t ch = (n_in - q) / ((size_t)threads * 4);
+  if (ch < ((size_t)2 << 20)) ch = (size_t)2 << 20;
+  if (ch > ((size_t)16 << 20)) ch = (size_t)16 << 20;
+  if (forced) ch = forced < 1024 ? 1024 : forced;
+  const size_t n_cut = (n_in - q) / ch;                 // cuts at q + k*ch, k = 1 .. n_cut (the last may be dropped)
+  std::vector<size_t> found(n_cut + 1, 0);
+  {
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < threads; w++)
+      pool.emplace_back([&, w] {
+        for (size_t k = 1 + w; k <= n_cut; k += threads) {
+          const size_t from = (q + k * ch) * 8;
+          size_t to = (q + (k + 1) * ch) * 8;
+          if (to > (n_in - 16) * 8) to = (n_in - 16) * 8;
+          if (from < to) found[k] = find_block_start(in, n_in, from, to);
+        }
+      });
+    for (auto &t : pool) t.join();
+  }
+  std::vector<size_t> starts;
+  starts.push_back(q * 8);
+  for (size_t k = 1; k <= n_cut; k++)
+    if (found[k]) starts.push_back(found[k]);
+  if (starts.size() < 2) return false;
+  const size_t n_chunks = starts.size();
+  std::vector<Chunk16> chunks(n_chunks);
+  for (size_t k = 0; k < n_chunks; k++) {
+    chunks[k].start_bit = starts[k];
+    chunks[k].stop_bit = k + 1 < n_chunks ? starts[k + 1] : 0;
+  }
+  uint32_t want_crc = 0, want_isize = 0;
+  std::vector<uint8_t> window(WIN, 0);
+  bool window_known = false;                // chunk 0 has no window at all
+  size_t total = 0, cap = 0;
+  uint8_t *out = nullptr;
+  bool fail = false;
+  for (size_t w0 = 0; w0 < n_chunks && !fail; w0 += threads) {
+    const size_t w1 = w0 + threads < n_chunks ? w0 + threads : n_chunks;
+    {   // ---- pass 1 of this wave: every chunk on its own thread ----
+      std::vector<std::thread> pool;
+      for (size_t k = w0; k < w1; k++)
+        pool.emplace_back([&, k] {
+          Chunk16 &c = chunks[k];
+          const size_t zbytes = ((c.stop_bit ? c.stop_bit : n_in * 8) - c.start_bit) / 8;
+          if (!c.out.init(zbytes * 5)) return;
+          Decoder d;
+          start_at_bit(d.in, in, n_in, c.start_bit);
+          bool final_seen = false;
+          if (!decode_blocks16(d, in, c.out, c.stop_bit, ~(size_t)0, &final_seen)) return;
+          if (c.stop_bit == 0) {
+            if (!final_seen) return;
+            const uint8_t *s = rewind_to_bytes(d.in);
+            if (d.in.phantom || (size_t)(d.in.end - s) != 8) return;   // trailer must end the file (one member)
+            want_crc = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
+            want_isize = (uint32_t)s[4] | ((uint32_t)s[5] << 8) | ((uint32_t)s[6] << 16) | ((uint32_t)s[7] << 24);
+          } else if (final_seen) {
+            return;                                                    // the member ended inside the file
+          }
+          c.ok = true;
+        });
+      for (auto &t : pool) t.join();
+    }
+    // ---- pass 2a: windows, in order ----
+    size_t wave_bytes = 0;
+    for (size_t k = w0; k < w1; k++) {
+      Chunk16 &c = chunks[k];
+      if (!c.ok) { fail = true; break; }
+      c.window = window;
+      c.offset = total + wave_bytes;
+      const size_t n = c.out.pos - WIN;
+      const uint16_t *sym = c.out.base + WIN;
+      std::vector<uint8_t> next(WIN, 0);
+      const size_t keep_old = n < WIN ? WIN - n : 0;            // a short chunk keeps part of the old window
+      for (size_t j = 0; j < keep_old; j++) next[j] = window[WIN - keep_old + j];
+      for (size_t j = n < WIN ? 0 : n - WIN; j < n; j++) {
+        const uint16_t s = sym[j];
+        if (s >= 256 && !window_known) { fail = true; break; }   // the first chunk refers to nothing
+        next[keep_old + (j - (n < WIN ? 0 : n - WIN))] = s < 256 ? (uint8_t)s : window[s - 256];
+      }
+      if (fail) break;
+      window.swap(next);
+      window_known = true;
+      wave_bytes += n;
+    }
+    if (fail) break;
+    // ---- pass 2b: symbols -> bytes in the final buffer, all chunks of the wave at once ----
+    if (total + wave_bytes > cap) {
+      size_t want = total + wave_bytes;
+      if (w1 < n_chunks) want += want / 2;
+      char *p = grow(user, want, &cap);
+      if (!p && want > total + wave_bytes) p = grow(user, total + wave_bytes, &cap);
+      if (!p) { fail = true; break; }
+      out = (uint8_t *)p;
+    }
+    {
+      std::vector<std::thread> pool;
+      std::vector<char> bad(w1 - w0, 0);
+      for (size_t k = w0; k < w1; k++)
+        pool.emplace_back([&, k] {
+          Chunk16 &c = chunks[k];
+          const size_t n = c.out.pos - WIN;
+          const uint16_t *sym = c.out.base + WIN;
+          const uint8_t *win = c.window.data();
+          uint8_t *dst = out + c.offset;
+          const bool first = k == 0;
+          unsigned seen = 0;
+          for (size_t j = 0; j < n; j++) {
+            const uint16_t s = sym[j];
+            seen |= s;
+            dst[j] = s < 256 ? (uint8_t)s : win[s - 256];
+          }
+          if (first && seen >= 256) bad[k - w0] = 1;
+          free(c.out.base);
+          c.out.base = nullptr;
+          c.out.cap = c.out.pos = 0;
+          std::vector<uint8_t>().swap(c.window);
+        });
+      for (auto &t : pool) t.join();
+      for (char b : bad) fail = fail || b;
+    }
+    total += wave_bytes;
+  }
+  if (fail) return false;
+  if ((uint32_t)total != want_isize) return false;
+  if (parallel_crc32(out, total, threads) != want_crc) return false;
+  *n_out = total;
+  return true;
+}
+
 }  // namespace
 
 bool fast_gunzip(const uint8_t *in, size_t n_in, GrowFn grow, void *user, size_t *n_out, unsigned threads) {
+  *n_out = 0;
+  if (getenv("HUMID_SERIAL_INFLATE") == nullptr && gunzip_parallel(in, n_in, grow, user, n_out, threads)) {
+    if (getenv("HUMID_TIMING")) std::fprintf(stderr, "[humid] gzip member inflated by the parallel two-pass decoder\n");
+    return true;
+  }
   *n_out = 0;
   size_t cap = 0, pos = 0;
   uint8_t *out = nullptr;

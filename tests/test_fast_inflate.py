@@ -105,3 +105,43 @@ def test_large_fastq_roundtrip(tmp_path):
     for level in (1, 4, 9):
         rc, out = gunzip(str(tmp_path), gzip.compress(raw, level), "big%d" % level)
         assert rc == 0 and out == raw
+
+
+@pytest.mark.parametrize("chunk", ["20000", "70000", "300000"])
+@pytest.mark.parametrize("level", [1, 4, 9])
+def test_parallel_two_pass_inflate(chunk, level, tmp_path):
+    """the two-pass parallel decoder (block starts searched at the chunk cuts, 16-bit symbols with an
+    unknown window, windows resolved afterwards) gives the bytes of the serial one; HUMID_TIMING shows
+    which path ran"""
+    files = synth_fastq(str(tmp_path), 40000, 5, n_files=1, read_len=150, p_sub=2e-3)
+    raw = open(files[0], "rb").read()
+    blob = gzip.compress(raw, level)
+    src, dst = str(tmp_path / "p.gz"), str(tmp_path / "p.out")
+    open(src, "wb").write(blob)
+    env = dict(os.environ, HUMID_PAR_INFLATE_CHUNK=chunk, HUMID_THREADS="6", HUMID_TIMING="1")
+    p = subprocess.run([HUMID, "--gunzip", src, dst], env=env, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and open(dst, "rb").read() == raw
+    assert b"parallel" in p.stderr, p.stderr
+
+
+def test_parallel_inflate_declines_gracefully(tmp_path):
+    """several members, stored-only data and damaged input: the parallel attempt gives up and the
+    serial decoder (or its refusal) decides"""
+    files = synth_fastq(str(tmp_path), 20000, 6, n_files=1, read_len=100)
+    raw = open(files[0], "rb").read()
+    env = dict(os.environ, HUMID_PAR_INFLATE_CHUNK="30000", HUMID_THREADS="4")
+    cases = {
+        "two_members": (gzip.compress(raw[:len(raw) // 2]) + gzip.compress(raw[len(raw) // 2:]), raw),
+        "stored": (gz_member(np.random.default_rng(1).integers(0, 256, 400_000, dtype=np.uint8).tobytes(), 0), None),
+    }
+    for name, (blob, want) in cases.items():
+        src, dst = str(tmp_path / (name + ".gz")), str(tmp_path / (name + ".out"))
+        open(src, "wb").write(blob)
+        assert subprocess.call([HUMID, "--gunzip", src, dst], env=env) == 0
+        assert open(dst, "rb").read() == (want if want is not None else gzip.decompress(blob))
+    good = gzip.compress(raw, 6)
+    bad = bytearray(good)
+    bad[len(bad) // 2] ^= 0x21
+    src = str(tmp_path / "bad.gz")
+    open(src, "wb").write(bytes(bad))
+    assert subprocess.call([HUMID, "--gunzip", src, str(tmp_path / "bad.out")], env=env) == 3
