@@ -381,7 +381,8 @@ bool fixed_tables(Decoder &d) {
 struct Member { size_t begin, end; uint32_t crc; };
 
 // ------------------------------------------------------------------------------------------
-// Parallel inflate of ONE gzip member (two passes, after Kerbiriou & Chikhi's pugz idea).
+// Parallel inflate of a gzip file -- one large member or many (bgzip, this tool's own output) --
+// in two passes, after Kerbiriou & Chikhi's pugz idea.
 //
 // A DEFLATE stream can only be entered at a block boundary, and a block may refer to the 32 KiB
 // before it.  Pass 1: the compressed bytes are cut into chunks; for every cut a block start is
@@ -391,9 +392,10 @@ struct Member { size_t begin, end; uint32_t crc; };
 // 32 KiB window before this chunk" (the window is simply laid out in front of the chunk's output,
 // so copies need no special case and unknown bytes propagate through matches by themselves).
 // Pass 2: chunk after chunk (cheap: 32 KiB each) the windows become known; then all chunks are
-// translated to bytes in parallel into the final buffer.  The member's CRC-32 and size decide:
-// anything unexpected (no block start found, a chunk that does not end exactly on the next start,
-// a second member, a mismatch) makes the caller decode serially instead.
+// translated to bytes in parallel into the final buffer.  Members may end inside a chunk (trailer
+// recorded, next header skipped).  Every member's CRC-32 and size decide: anything unexpected (no
+// block start found, a chunk that does not end exactly on the next start, a mismatch) makes the
+// caller decode serially instead.
 // ------------------------------------------------------------------------------------------
 constexpr size_t WIN = 32768;
 
@@ -512,11 +514,27 @@ int decode_huffman16(Decoder &d, Out16 &o) {
   return rc;
 }
 
+size_t parse_gzip_header(const uint8_t *in, size_t n_in, size_t ip) {   // -> first deflate byte, 0 = bad
+  if (n_in - ip < 18 || in[ip] != 0x1f || in[ip + 1] != 0x8b || in[ip + 2] != 8) return 0;
+  const unsigned flg = in[ip + 3];
+  if (flg & 0xe0) return 0;
+  size_t q = ip + 10;
+  if (flg & 4) { if (q + 2 > n_in) return 0; q += 2 + (size_t)(in[q] | (in[q + 1] << 8)); }
+  if (flg & 8) { while (q < n_in && in[q]) q++; q++; }
+  if (flg & 16) { while (q < n_in && in[q]) q++; q++; }
+  if (flg & 2) q += 2;
+  return q < n_in ? q : 0;
+}
+
+struct MemberEnd { size_t out_pos; uint32_t crc, isize; };   // out_pos: symbols of the chunk before the member's end
+
 // blocks from the decoder's position up to (exactly) stop_bit, or, stop_bit == 0, to the end of the
-// final block.  *final_seen: the final block ended here.
-bool decode_blocks16(Decoder &d, const uint8_t *in, Out16 &o, size_t stop_bit, size_t max_blocks, bool *final_seen) {
-  *final_seen = false;
-  for (size_t nb = 0; nb < max_blocks; nb++) {
+// input.  A member that ends on the way is recorded (trailer read, next header skipped) and decoding
+// goes on in the next member.  *at_end: the input ended right after a member.
+bool decode_blocks16(Decoder &d, const uint8_t *in, size_t n_in, Out16 &o, size_t stop_bit,
+                     std::vector<MemberEnd> &ends, bool *at_end) {
+  *at_end = false;
+  for (;;) {
     if (stop_bit) {
       const size_t bp = bit_position(d.in, in);
       if (bp == stop_bit) return true;
@@ -539,9 +557,22 @@ bool decode_blocks16(Decoder &d, const uint8_t *in, Out16 &o, size_t stop_bit, s
     } else {
       return false;
     }
-    if (bfinal) { *final_seen = true; return stop_bit == 0; }
+    if (bfinal) {
+      const uint8_t *s = rewind_to_bytes(d.in);
+      if (d.in.phantom || d.in.end - s < 8) return false;
+      MemberEnd me;
+      me.out_pos = o.pos - WIN;
+      me.crc = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
+      me.isize = (uint32_t)s[4] | ((uint32_t)s[5] << 8) | ((uint32_t)s[6] << 16) | ((uint32_t)s[7] << 24);
+      ends.push_back(me);
+      const size_t after = (size_t)(s + 8 - in);
+      if (after == n_in) { *at_end = true; return stop_bit == 0; }
+      const size_t q = parse_gzip_header(in, n_in, after);            // the next member
+      if (!q) return false;
+      if (stop_bit && q * 8 > stop_bit) return false;
+      d.in.p = in + q;
+    }
   }
-  return false;
 }
 
 // first bit position in [from_bit, to_bit) that looks like the start of a dynamic block: strict
@@ -549,18 +580,28 @@ bool decode_blocks16(Decoder &d, const uint8_t *in, Out16 &o, size_t stop_bit, s
 size_t find_block_start(const uint8_t *in, size_t n_in, size_t from_bit, size_t to_bit) {
   Decoder d;
   for (size_t bp = from_bit; bp < to_bit; bp++) {
-    // cheap filter: BFINAL = 0, BTYPE = 2 (bits 0, 01 in stream order -> value 4), HLIT <= 29, HDIST <= 29
+    // cheap filter: BTYPE = 2 (bits 01 in stream order after BFINAL), HLIT <= 29, HDIST <= 29
     const size_t by = bp >> 3;
     if (by + 4 >= n_in) break;
     const uint32_t w = ((uint32_t)in[by] | ((uint32_t)in[by + 1] << 8) | ((uint32_t)in[by + 2] << 16) |
                         ((uint32_t)in[by + 3] << 24)) >> (bp & 7);
-    if ((w & 7) != 4 || ((w >> 3) & 31) > 29 || ((w >> 8) & 31) > 29) continue;
+    if ((w & 6) != 4 || ((w >> 3) & 31) > 29 || ((w >> 8) & 31) > 29) continue;
+    const bool cand_final = (w & 1) != 0;
     start_at_bit(d.in, in, n_in, bp + 3);
     if (!read_dynamic_tables(d, true) || d.in.phantom) continue;
     Out16 scratch;
     if (!scratch.init(1u << 16)) return 0;
     if (decode_huffman16(d, scratch) != R_EOB || d.in.phantom) continue;
     if (scratch.pos - WIN < 256) continue;                    // real blocks of a large file are not tiny
+    if (cand_final) {
+      // a member's last block: its trailer and the next member's header (or the end) must follow
+      const uint8_t *s2 = rewind_to_bytes(d.in);
+      if (d.in.phantom || d.in.end - s2 < 8) continue;
+      const size_t after = (size_t)(s2 + 8 - in);
+      if ((uint32_t)(s2[4] | (s2[5] << 8) | (s2[6] << 16) | ((uint32_t)s2[7] << 24)) < scratch.pos - WIN) continue;
+      if (after != n_in && !parse_gzip_header(in, n_in, after)) continue;
+      return bp;
+    }
     // the following block header
     const unsigned nb_final = take(d.in, 1), nb_type = take(d.in, 2);
     (void)nb_final;
@@ -573,18 +614,6 @@ size_t find_block_start(const uint8_t *in, size_t n_in, size_t from_bit, size_t 
     return bp;
   }
   return 0;
-}
-
-size_t parse_gzip_header(const uint8_t *in, size_t n_in, size_t ip) {   // -> first deflate byte, 0 = bad
-  if (n_in - ip < 18 || in[ip] != 0x1f || in[ip + 1] != 0x8b || in[ip + 2] != 8) return 0;
-  const unsigned flg = in[ip + 3];
-  if (flg & 0xe0) return 0;
-  size_t q = ip + 10;
-  if (flg & 4) { if (q + 2 > n_in) return 0; q += 2 + (size_t)(in[q] | (in[q + 1] << 8)); }
-  if (flg & 8) { while (q < n_in && in[q]) q++; q++; }
-  if (flg & 16) { while (q < n_in && in[q]) q++; q++; }
-  if (flg & 2) q += 2;
-  return q < n_in ? q : 0;
 }
 
 uint32_t parallel_crc32(const uint8_t *data, size_t n, unsigned threads) {
@@ -616,6 +645,7 @@ struct Chunk16 {
   bool ok = false;
   std::vector<uint8_t> window;            // the 32 KiB before this chunk, once known
   size_t offset = 0;                      // of its bytes in the final buffer
+  std::vector<MemberEnd> ends;            // members that end inside this chunk
 };
 
 bool gunzip_parallel(const uint8_t *in, size_t n_in, GrowFn grow, void *user, size_t *n_out, unsigned threads) {
@@ -656,7 +686,6 @@ bool gunzip_parallel(const uint8_t *in, size_t n_in, GrowFn grow, void *user, si
     chunks[k].start_bit = starts[k];
     chunks[k].stop_bit = k + 1 < n_chunks ? starts[k + 1] : 0;
   }
-  uint32_t want_crc = 0, want_isize = 0;
   std::vector<uint8_t> window(WIN, 0);
   bool window_known = false;                // chunk 0 has no window at all
   size_t total = 0, cap = 0;
@@ -673,17 +702,9 @@ bool gunzip_parallel(const uint8_t *in, size_t n_in, GrowFn grow, void *user, si
           if (!c.out.init(zbytes * 5)) return;
           Decoder d;
           start_at_bit(d.in, in, n_in, c.start_bit);
-          bool final_seen = false;
-          if (!decode_blocks16(d, in, c.out, c.stop_bit, ~(size_t)0, &final_seen)) return;
-          if (c.stop_bit == 0) {
-            if (!final_seen) return;
-            const uint8_t *s = rewind_to_bytes(d.in);
-            if (d.in.phantom || (size_t)(d.in.end - s) != 8) return;   // trailer must end the file (one member)
-            want_crc = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
-            want_isize = (uint32_t)s[4] | ((uint32_t)s[5] << 8) | ((uint32_t)s[6] << 16) | ((uint32_t)s[7] << 24);
-          } else if (final_seen) {
-            return;                                                    // the member ended inside the file
-          }
+          bool at_end = false;
+          if (!decode_blocks16(d, in, n_in, c.out, c.stop_bit, c.ends, &at_end)) return;
+          if ((c.stop_bit == 0) != at_end) return;                     // only the last chunk reaches the end
           c.ok = true;
         });
       for (auto &t : pool) t.join();
@@ -749,8 +770,37 @@ bool gunzip_parallel(const uint8_t *in, size_t n_in, GrowFn grow, void *user, si
     total += wave_bytes;
   }
   if (fail) return false;
-  if ((uint32_t)total != want_isize) return false;
-  if (parallel_crc32(out, total, threads) != want_crc) return false;
+  // ---- every member's size and CRC-32 (members on all cores; a single member in pieces) ----
+  struct Span { size_t b, e; uint32_t crc, isize; };
+  std::vector<Span> spans;
+  size_t mb = 0;
+  for (const Chunk16 &c : chunks)
+    for (const MemberEnd &me : c.ends) {
+      spans.push_back(Span{mb, c.offset + me.out_pos, me.crc, me.isize});
+      mb = c.offset + me.out_pos;
+    }
+  if (spans.empty() || mb != total) return false;
+  for (const Span &sp : spans)
+    if (sp.e < sp.b || (uint32_t)(sp.e - sp.b) != sp.isize) return false;
+  if (spans.size() == 1) {
+    if (parallel_crc32(out, total, threads) != spans[0].crc) return false;
+  } else {
+    std::vector<char> bad(threads, 0);
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < threads; w++)
+      pool.emplace_back([&, w] {
+        for (size_t k = w; k < spans.size(); k += threads) {
+          uLong c = crc32(0L, Z_NULL, 0);
+          for (size_t o2 = spans[k].b; o2 < spans[k].e; o2 += (1u << 30)) {
+            const size_t n = spans[k].e - o2 < (1u << 30) ? spans[k].e - o2 : (1u << 30);
+            c = crc32(c, out + o2, (uInt)n);
+          }
+          if ((uint32_t)c != spans[k].crc) bad[w] = 1;
+        }
+      });
+    for (auto &t : pool) t.join();
+    for (char b : bad) if (b) return false;
+  }
   *n_out = total;
   return true;
 }

@@ -124,24 +124,33 @@ def test_parallel_two_pass_inflate(chunk, level, tmp_path):
     assert b"parallel" in p.stderr, p.stderr
 
 
-def test_parallel_inflate_declines_gracefully(tmp_path):
-    """several members, stored-only data and damaged input: the parallel attempt gives up and the
-    serial decoder (or its refusal) decides"""
+def test_parallel_inflate_members_and_fallbacks(tmp_path):
+    """several members (two large ones; bgzip-like 64 KB members whose only block is final) are
+    decoded in parallel across the member boundaries; stored-only data and damaged input make the
+    parallel attempt give up and the serial decoder (or its refusal) decides"""
     files = synth_fastq(str(tmp_path), 20000, 6, n_files=1, read_len=100)
     raw = open(files[0], "rb").read()
-    env = dict(os.environ, HUMID_PAR_INFLATE_CHUNK="30000", HUMID_THREADS="4")
+    env = dict(os.environ, HUMID_PAR_INFLATE_CHUNK="30000", HUMID_THREADS="4", HUMID_TIMING="1")
     cases = {
-        "two_members": (gzip.compress(raw[:len(raw) // 2]) + gzip.compress(raw[len(raw) // 2:]), raw),
-        "stored": (gz_member(np.random.default_rng(1).integers(0, 256, 400_000, dtype=np.uint8).tobytes(), 0), None),
+        "two_members": (gzip.compress(raw[:len(raw) // 2]) + gzip.compress(raw[len(raw) // 2:]), True),
+        "bgzip_like": (b"".join(gzip.compress(raw[k:k + 65280], 6) for k in range(0, len(raw), 65280)), True),
+        "stored": (gz_member(np.random.default_rng(1).integers(0, 256, 400_000, dtype=np.uint8).tobytes(), 0), False),
     }
-    for name, (blob, want) in cases.items():
+    for name, (blob, parallel) in cases.items():
         src, dst = str(tmp_path / (name + ".gz")), str(tmp_path / (name + ".out"))
         open(src, "wb").write(blob)
-        assert subprocess.call([HUMID, "--gunzip", src, dst], env=env) == 0
-        assert open(dst, "rb").read() == (want if want is not None else gzip.decompress(blob))
+        p = subprocess.run([HUMID, "--gunzip", src, dst], env=env, stderr=subprocess.PIPE)
+        assert p.returncode == 0 and open(dst, "rb").read() == gzip.decompress(blob), name
+        assert (b"parallel" in p.stderr) == parallel, (name, p.stderr)
     good = gzip.compress(raw, 6)
-    bad = bytearray(good)
-    bad[len(bad) // 2] ^= 0x21
-    src = str(tmp_path / "bad.gz")
-    open(src, "wb").write(bytes(bad))
-    assert subprocess.call([HUMID, "--gunzip", src, str(tmp_path / "bad.out")], env=env) == 3
+    for where in (len(good) // 2, len(good) - 6):              # the bit stream / the CRC
+        bad = bytearray(good)
+        bad[where] ^= 0x21
+        src = str(tmp_path / "bad.gz")
+        open(src, "wb").write(bytes(bad))
+        assert subprocess.call([HUMID, "--gunzip", src, str(tmp_path / "bad.out")], env=env) == 3
+    members = gzip.compress(raw[:300000]) + gzip.compress(raw[300000:])
+    bad = bytearray(members)
+    bad[len(gzip.compress(raw[:300000])) - 7] ^= 0x08            # CRC of the FIRST member
+    open(str(tmp_path / "bad2.gz"), "wb").write(bytes(bad))
+    assert subprocess.call([HUMID, "--gunzip", str(tmp_path / "bad2.gz"), str(tmp_path / "bad2.out")], env=env) == 3
