@@ -365,6 +365,22 @@ def _exchange_ids_torch(nodes, ccid, cismax, n_clusters, goff, u_local, dev):
     return l_cid.to(torch.int32), l_ismax
 
 
+def _order_hint(hist, rng, word_nt, bits):
+    """count_order for humid_stage_count_dense from the global top-bits histogram: 1 = the words of
+    this value range are spread evenly (word-ordered buckets fit their LDS tables), 0 = clearly
+    not, -1 = let the library sample"""
+    lo, hi, _ = rng
+    if lo > hi:
+        return -1
+    shift = 2 * word_nt - bits
+    b0, b1 = lo >> shift, min(hi >> shift, len(hist) - 1)
+    h = hist[b0:b1 + 1].astype(np.float64)
+    if len(h) < 4 or h.sum() < 65536:
+        return -1
+    ratio = float(h.max() / h.mean())
+    return 1 if ratio <= 1.25 else (0 if ratio > 2.5 else -1)
+
+
 def splitters_from_hist(hist: np.ndarray, world: int, word_nt: int, bits: int):
     """P ordered, disjoint, covering value ranges with balanced usable-read counts.
     Returns [(lo, hi_inclusive, expected_reads)] -- identical on every rank."""
@@ -461,10 +477,15 @@ class ShardedDedup:
         # ---- 1. global histogram -> balanced ordered value ranges (cut at prefix boundaries) ----
         hist = ops.histogram(d_w, d_f, self.word_nt, bits)
         dist.all_reduce(hist)
-        ranges = splitters_from_hist(hist.cpu().numpy(), P, self.word_nt, bits)
+        hist_host = hist.cpu().numpy()
+        ranges = splitters_from_hist(hist_host, P, self.word_nt, bits)
         lo_r, hi_r = ranges[r][0], ranges[r][1]
         if lo_r > hi_r:
             lo_r, hi_r = 0, (1 << 64) - 1                 # empty range: nothing arrives
+        if hasattr(ops, "set_option"):
+            # word-ordered LDS buckets need words that are uniform over this rank's range; the global
+            # histogram already says so (saves the library's own sampling pass and its host wait)
+            ops.set_option("count_order", _order_hint(hist_host, ranges[r], self.word_nt, bits))
         mark("1_ranges")
         # ---- 2. usable words -> owner of their range ----
         perm, send_counts = ops.owner_perm(d_w, d_f, ranges)          # owner-major, filtered reads last
@@ -545,6 +566,8 @@ class ShardedDedup:
 
     def _run_allgather(self, d_w, d_f, d_cid, d_keep):
         dist, P, r = self.dist, self.world, self.rank
+        if hasattr(self.ops, "set_option"):
+            self.ops.set_option("count_order", -1)
         dev = d_w.device
         n_local = d_w.numel()
         if self._n_max is None:                      # shard sizes are fixed per instance
