@@ -154,3 +154,40 @@ def test_parallel_inflate_members_and_fallbacks(tmp_path):
     bad[len(gzip.compress(raw[:300000])) - 7] ^= 0x08            # CRC of the FIRST member
     open(str(tmp_path / "bad2.gz"), "wb").write(bytes(bad))
     assert subprocess.call([HUMID, "--gunzip", str(tmp_path / "bad2.gz"), str(tmp_path / "bad2.out")], env=env) == 3
+
+
+def test_fuzzed_streams_never_crash_or_pass_silently(tmp_path):
+    """bit flips, truncations, insertions, deletions and overwritten ranges: the decoders (serial and
+    parallel) either decline or return exactly what zlib returns -- no crash, no hang"""
+    import random
+    files = synth_fastq(str(tmp_path), 6000, 5, n_files=1, read_len=120)
+    raw = open(files[0], "rb").read()
+    rnd = random.Random(7)
+    base = [gzip.compress(raw, 6), gzip.compress(raw[:200000], 1) + gzip.compress(raw[200000:], 9),
+            b"".join(gzip.compress(raw[k:k + 65280]) for k in range(0, len(raw), 65280))]
+    for it in range(60):
+        b = bytearray(rnd.choice(base))
+        kind = it % 5
+        if kind == 0:
+            b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+        elif kind == 1:
+            del b[rnd.randrange(len(b)):]
+        elif kind == 2:
+            p = rnd.randrange(len(b))
+            b[p:p] = bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 50)))
+        elif kind == 3:
+            p = rnd.randrange(len(b))
+            del b[p:p + rnd.randrange(1, 2000)]
+        else:
+            p = rnd.randrange(len(b))
+            q = min(len(b), p + rnd.randrange(1, 5000))
+            b[p:q] = bytes(rnd.randrange(256) for _ in range(q - p))
+        src, dst = str(tmp_path / "f.gz"), str(tmp_path / "f.out")
+        open(src, "wb").write(bytes(b))
+        env = dict(os.environ, HUMID_THREADS="4")
+        if it % 2 == 0:
+            env["HUMID_PAR_INFLATE_CHUNK"] = str(rnd.choice([5000, 20000, 100000]))
+        rc = subprocess.call([HUMID, "--gunzip", src, dst], env=env, timeout=60, stderr=subprocess.DEVNULL)
+        assert rc in (0, 3), (it, kind, rc)
+        if rc == 0:
+            assert open(dst, "rb").read() == gzip.decompress(bytes(b)), (it, kind)
