@@ -8,6 +8,7 @@
 #pragma once
 #include <zlib.h>
 
+#include <cstdint>
 #include <string>
 #include <vector>
 
@@ -62,16 +63,20 @@ class FastqWriter {
  public:
   explicit FastqWriter(const std::string &path, bool members = false);
   ~FastqWriter();
-  bool ok() const { return plain_ != nullptr || gz_ != nullptr; }
+  bool ok() const { return fd_ >= 0 || gz_ != nullptr; }
   bool gz_members() const { return members_; }
   void write(const char *data, size_t n);
   void write_member(const std::string &z);          // one precompressed gzip member
+  // parts[0 .. n_parts) back to back (plain text, or precompressed members of a members-mode file)
+  void write_parts(const std::vector<std::string> &parts, unsigned n_parts);
   void flush();
   // data -> one complete gzip member (fastp Options default compression level 4)
   static bool compress_member(const char *data, size_t n, std::string &out, int level = 4);
  private:
-  FILE *plain_ = nullptr;
-  gzFile gz_ = nullptr;
+  void put(const char *data, size_t n);             // at the current end of the file
+  int fd_ = -1;                                     // plain files and members-mode gzip files
+  uint64_t off_ = 0;
+  gzFile gz_ = nullptr;                             // streaming gzip (single thread)
   bool members_ = false;
   bool wrote_ = false;
   std::string pending_, z_;

@@ -353,10 +353,7 @@ int main(int argc, char **argv) {
               }
             });
             const unsigned used = (threads <= 1 || b1 - b0 < 4096) ? 1 : threads;
-            for (unsigned w = 0; w < used; w++) {
-              if (zip) wr->write_member(zbufs[w]);
-              else wr->write(bufs[w].data(), bufs[w].size());
-            }
+            wr->write_parts(zip ? zbufs : bufs, used);       // every part at its final offset, in parallel
           }
         }
       }
