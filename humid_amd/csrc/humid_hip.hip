@@ -454,8 +454,8 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
                        c->pbeg.as<u32>(), N, pb, km.lo, km.scale, km.shift, c->pad_word.as<u64>(), c->pad_cf.as<uint2>(),
                        c->ucount.as<u32>(), c->pusable.as<u32>(), c->pslot.as<u32>(), c->d_ctr);
   HIPCHK(hipEventRecord(c->kev[1], st));
-  hipLaunchKernelGGL(k_part_totals, dim3(1), dim3(256), 0, st, c->ucount.as<u32>(), c->pusable.as<u32>(),
-                     n_parts, c->d_ctr);
+  hipLaunchKernelGGL(k_part_totals, dim3(n_parts >= 16384 ? 64 : 4), dim3(256), 0, st, c->ucount.as<u32>(),
+                     c->pusable.as<u32>(), n_parts, c->d_ctr);
   TRY(exscan_u32(c, c->ucount.as<u32>(), c->ubase.as<u32>(), (u64)n_parts + 1));
   HIPCHK(hipGetLastError());
   TRY(read_counters(c));

@@ -298,16 +298,19 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
   }
 }
 
-// totals over the buckets: U = sum ucount, usable = sum pusable (one block)
+// totals over the buckets: U = sum ucount, usable = sum pusable (a few blocks, two atomics each;
+// the counters were zeroed at the start of the stage)
 __global__ void __launch_bounds__(256)
 k_part_totals(const u32 *__restrict__ ucount, const u32 *__restrict__ pusable, u32 n_parts, ull *ctr) {
   __shared__ u32 lds[4];
-  ull u = 0, us = 0;
-  for (u32 p = threadIdx.x; p < n_parts; p += 256) { u += ucount[p]; us += pusable[p]; }
-  // 64-bit block sums via two 32-bit halves are unnecessary: both totals are < 2^32
-  const u32 tu = block_sum((u32)u, lds);
-  const u32 ts = block_sum((u32)us, lds);
-  if (threadIdx.x == 0) { ctr[CTR_UNIQUE] = tu; ctr[CTR_USABLE] = ts; }
+  u32 u = 0, us = 0;                    // both totals are < 2^32 (reads < 2^31)
+  for (u32 p = blockIdx.x * blockDim.x + threadIdx.x; p < n_parts; p += gridDim.x * blockDim.x) { u += ucount[p]; us += pusable[p]; }
+  const u32 tu = block_sum(u, lds);
+  const u32 ts = block_sum(us, lds);
+  if (threadIdx.x == 0) {
+    if (tu) atomicAdd(&ctr[CTR_UNIQUE], (ull)tu);
+    if (ts) atomicAdd(&ctr[CTR_USABLE], (ull)ts);
+  }
 }
 
 // padded -> dense unique list (word, padded position), one wave per bucket.  Hashed buckets: the
