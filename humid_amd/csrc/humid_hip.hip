@@ -917,6 +917,7 @@ static int run_device(humid_ctx *c, const WT *d_words, const u8 *d_filt, u64 n_r
   c->dense_mode = false;
   TRY(check_run_args(c, n_reads, word_nt, method, 64));
   if (WIDE != (word_nt > 32)) return fail(c, HUMID_E_INVALID, "word layout does not match word_nt");
+  if (WIDE && ((uintptr_t)d_words & 15)) return fail(c, HUMID_E_INVALID, "wide words must be 16-byte aligned on the device");
   if (n_reads && (!d_words || !d_filt || !d_cid || !d_keep)) return fail(c, HUMID_E_INVALID, "null buffer");
   HIPCHK(hipSetDevice(c->device));
   hipStream_t st = c->stream;
