@@ -411,10 +411,12 @@ void start_at_bit(Bits &b, const uint8_t *in, size_t n_in, size_t bitpos) {
 struct Out16 {
   uint16_t *base = nullptr;      // WIN placeholder symbols, then the chunk's output
   size_t cap = 0, pos = 0;
+  size_t limit = ~(size_t)0;     // symbols a chunk may grow to (memory bound of the parallel path)
   ~Out16() { free(base); }
   bool reserve(size_t extra) {
     if (cap - pos >= extra) return true;
     size_t want = cap + cap / 2 + extra;
+    if (want > limit) return false;
     uint16_t *p = (uint16_t *)realloc(base, want * 2);
     if (!p) return false;
     base = p;
@@ -699,6 +701,9 @@ bool gunzip_parallel(const uint8_t *in, size_t n_in, GrowFn grow, void *user, si
         pool.emplace_back([&, k] {
           Chunk16 &c = chunks[k];
           const size_t zbytes = ((c.stop_bit ? c.stop_bit : n_in * 8) - c.start_bit) / 8;
+          // FastQ inflates 4-6x; a chunk that wants more than 40x (or 64 M symbols) is not worth
+          // 2 bytes of memory per symbol on every thread: the serial decoder takes the file
+          c.out.limit = WIN + (zbytes * 40 > ((size_t)64 << 20) ? zbytes * 40 : ((size_t)64 << 20));
           if (!c.out.init(zbytes * 5)) return;
           Decoder d;
           start_at_bit(d.in, in, n_in, c.start_bit);
