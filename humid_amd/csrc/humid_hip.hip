@@ -504,7 +504,7 @@ static int prefix_fits_ordered(humid_ctx *c, const u64 *d_words, const u8 *d_fil
   const u32 n_sample = N < (1u << 19) ? N : (1u << 19);
   ENSURE(c->small, (size_t)n_bins * 4);
   HIPCHK(hipMemsetAsync(c->small.p, 0, (size_t)n_bins * 4, c->stream));
-  hipLaunchKernelGGL(k_top_hist, dim3(64), dim3(256), n_bins * 4, c->stream, d_words, d_filt, n_sample,
+  hipLaunchKernelGGL(k_top_hist, dim3(512), dim3(256), n_bins * 4, c->stream, d_words, d_filt, n_sample,
                      km.lo, km.scale, bits, c->small.as<u32>());
   std::vector<u32> h(n_bins);
   HIPCHK(hipMemcpyAsync(h.data(), c->small.p, (size_t)n_bins * 4, hipMemcpyDeviceToHost, c->stream));
