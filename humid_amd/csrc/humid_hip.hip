@@ -58,7 +58,7 @@ struct humid_ctx {
   DBuf pc, poff, share_edges;                                                     // multi-GPU pair-search share
   DBuf own_words;                                                                 // multi-GPU dense count
   DBuf heads;                                                                     // big-component heads
-  DBuf x_cnt, x_cnts, x_rec, x_ncnt, x_route, x_creator, x_base, x_mark, x_markcr, x_scan, x_lcid, x_lismax,
+  DBuf x_slot, x_slot_s, x_cnt, x_cnts, x_rec, x_ncnt, x_route, x_creator, x_base, x_mark, x_markcr, x_scan, x_lcid, x_lismax,
        x_items, x_w, x_id, x_ids, x_ends, x_ends_s, x_head, x_hpos, x_nodes, x_cedges;   // multi-GPU exchange mode
   DBuf w_sorted, w_head, w_hpos, w_start;                                         // wide-word (sorted) counts
   bool stage_map_timed = false;                                                   // kev[37..38] bracket the last humid_stage_map_dense
@@ -1028,7 +1028,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
-                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->seg_ws, &c->csize, &c->cur, &c->plan_dev, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -1762,10 +1762,13 @@ int humid_stage_compact_nodes(humid_ctx *c, const uint64_t *d_edges, uint64_t n_
   const u32 n2 = 2 * E;
   ENSURE(c->x_ends, (size_t)n2 * 4);
   ENSURE(c->x_ends_s, (size_t)n2 * 4);
+  ENSURE(c->x_slot, (size_t)n2 * 4);
+  ENSURE(c->x_slot_s, (size_t)n2 * 4);
   ENSURE(c->x_head, ((size_t)n2 + 1) * 4);
   ENSURE(c->x_hpos, ((size_t)n2 + 1) * 4);
-  hipLaunchKernelGGL(k_edge_ends, dim3(blocks_for(E)), dim3(256), 0, st, d_edges, E, record_stride, c->x_ends.as<u32>());
-  TRY(sort_keys<u32>(c, c->x_ends.as<u32>(), c->x_ends_s.as<u32>(), n2, 0, 32));
+  hipLaunchKernelGGL(k_edge_ends, dim3(blocks_for(E)), dim3(256), 0, st, d_edges, E, record_stride, c->x_ends.as<u32>(),
+                     c->x_slot.as<u32>());
+  TRY(sort_pairs<u32, u32>(c, c->x_ends.as<u32>(), c->x_ends_s.as<u32>(), c->x_slot.as<u32>(), c->x_slot_s.as<u32>(), n2, 0, 32));
   hipLaunchKernelGGL(k_heads_u32, dim3(blocks_for((u64)n2 + 1)), dim3(256), 0, st, c->x_ends_s.as<u32>(), n2,
                      c->x_head.as<u32>());
   TRY(exscan_u32(c, c->x_head.as<u32>(), c->x_hpos.as<u32>(), (u64)n2 + 1));
@@ -1777,8 +1780,10 @@ int humid_stage_compact_nodes(humid_ctx *c, const uint64_t *d_edges, uint64_t n_
   ENSURE(c->x_cedges, (size_t)E * 8);
   hipLaunchKernelGGL(k_compact_heads_u32, dim3(blocks_for(n2)), dim3(256), 0, st, c->x_ends_s.as<u32>(),
                      c->x_head.as<u32>(), c->x_hpos.as<u32>(), n2, c->x_nodes.as<u32>());
-  hipLaunchKernelGGL(k_relabel_edges, dim3(blocks_for(E)), dim3(256), 0, st, d_edges, E, record_stride,
-                     c->x_nodes.as<u32>(), M, c->x_cedges.as<u64>(), c->x_ncnt.as<u32>());
+  // x_ends is free again: the positions of both ends of every edge, by slot
+  hipLaunchKernelGGL(k_relabel_ends, dim3(blocks_for(n2)), dim3(256), 0, st, c->x_slot_s.as<u32>(), c->x_head.as<u32>(),
+                     c->x_hpos.as<u32>(), n2, d_edges, record_stride, c->x_ends.as<u32>(), c->x_ncnt.as<u32>());
+  hipLaunchKernelGGL(k_pack_cedges, dim3(blocks_for(E)), dim3(256), 0, st, c->x_ends.as<u32>(), E, c->x_cedges.as<u64>());
   HIPCHK(hipGetLastError());
   *d_nodes = c->x_nodes.as<u32>();     // M is known; the node list and the relabelling are queued
   *n_nodes = M;

@@ -230,13 +230,17 @@ __global__ void k_gather_u32(const u32 *__restrict__ src, const u32 *__restrict_
   if (i < n) dst[i] = src[idx[i]];
 }
 
-// both endpoints of every edge (smaller << 32 | larger); stride = uint64 per edge record (1 or 2)
-__global__ void k_edge_ends(const u64 *__restrict__ edges, u32 n_edges, u32 stride, u32 *__restrict__ ends) {
+// both endpoints of every edge (smaller << 32 | larger) with their slot 2k / 2k+1; stride = uint64
+// per edge record (1 or 2)
+__global__ void k_edge_ends(const u64 *__restrict__ edges, u32 n_edges, u32 stride, u32 *__restrict__ ends,
+                            u32 *__restrict__ slot) {
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_edges) return;
   const u64 e = edges[(size_t)k * stride];
   ends[2 * k] = (u32)(e >> 32);
   ends[2 * k + 1] = (u32)e;
+  slot[2 * k] = 2 * k;
+  slot[2 * k + 1] = 2 * k + 1;
 }
 
 // head[i] = 1 where a new value starts in the sorted array; head[n] = 0 (scan sentinel)
@@ -252,30 +256,28 @@ __global__ void k_compact_heads_u32(const u32 *__restrict__ sorted, const u32 *_
   if (i < n && head[i]) out[hpos[i]] = sorted[i];
 }
 
-// edges over node ids -> edges over positions in the ascending node list; with records (stride 2)
-// also the count of every node (all records of a node carry the same count)
-__global__ void k_relabel_edges(const u64 *__restrict__ edges, u32 n_edges, u32 stride, const u32 *__restrict__ nodes,
-                                u32 n_nodes, u64 *__restrict__ out, u32 *__restrict__ node_cnt) {
+// sorted endpoint i (slot = which end of which edge) -> its position in the node list, written back
+// to the edge's slot: cends[slot] = hpos[i] + head[i] - 1; with records (stride 2) also the node's
+// count (all records of a node carry the same count).  One scattered 4-byte store per endpoint
+// instead of a binary search over the node list.
+__global__ void k_relabel_ends(const u32 *__restrict__ slot_s, const u32 *__restrict__ head,
+                               const u32 *__restrict__ hpos, u32 n_ends, const u64 *__restrict__ records,
+                               u32 stride, u32 *__restrict__ cends, u32 *__restrict__ node_cnt) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_ends) return;
+  const u32 node = hpos[i] + head[i] - 1u;
+  const u32 sl = slot_s[i];
+  cends[sl] = node;
+  if (stride == 2 && head[i]) {
+    const u64 cc = records[(size_t)(sl >> 1) * 2 + 1];
+    node_cnt[node] = (sl & 1) ? (u32)(cc >> 32) : (u32)cc;
+  }
+}
+
+// (position of the smaller end, position of the larger end) -> one 64-bit compact edge
+__global__ void k_pack_cedges(const u32 *__restrict__ cends, u32 n_edges, u64 *__restrict__ out) {
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_edges) return;
-  const u64 e = edges[(size_t)k * stride];
-  u32 r[2];
-#pragma unroll
-  for (int q = 0; q < 2; q++) {
-    const u32 id = q == 0 ? (u32)(e >> 32) : (u32)e;
-    u32 lo = 0, hi = n_nodes;
-    while (lo < hi) {
-      const u32 mid = lo + ((hi - lo) >> 1);
-      if (nodes[mid] < id) lo = mid + 1; else hi = mid;
-    }
-    r[q] = lo;
-  }
-  out[k] = ((u64)r[0] << 32) | r[1];
-  if (stride == 2 && r[0] < n_nodes && r[1] < n_nodes) {
-    const u64 cc = edges[(size_t)k * 2 + 1];
-    node_cnt[r[0]] = (u32)cc;
-    node_cnt[r[1]] = (u32)(cc >> 32);
-  }
+  if (k < n_edges) out[k] = ((u64)cends[2 * k] << 32) | cends[2 * k + 1];
 }
 
 // routed copy of the usable reads' words (owner-major order of humid_stage_owner_perm)

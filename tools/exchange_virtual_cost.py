@@ -24,8 +24,10 @@ def main():
     n_local = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
     dev = torch.device("cuda:0")
     shards = [synth_words(n_local, 1002 + 7919 * r, 24) for r in range(8)]
-    for mode in ("exchange", "allgather"):
-        for P in (1, 2, 4, 8):
+    modes = sys.argv[2].split(",") if len(sys.argv) > 2 else ("exchange", "allgather")
+    worlds = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else (1, 2, 4, 8)
+    for mode in modes:
+        for P in worlds:
             world = FakeWorld(P)
             times = [0.0] * P
             errs = []
