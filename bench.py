@@ -44,6 +44,12 @@ def parse():
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  Libraries print banners there (RCCL: version, host
+    # name, library path; per rank), so file descriptor 1 is pointed at stderr for the whole run
+    # and the JSON line goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     a = parse()
     import torch
     import humid_amd
@@ -193,7 +199,8 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
