@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--distance", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=4_000_000,
                     help="reads of the same workload the CPU oracle is timed on (0 = skip)")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed passes: gather every shard's results on rank 0 and compare them, "
+                         "bit for bit, with one single-GPU pass over the concatenated read set")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path even with one rank (overhead measurement)")
     ap.add_argument("--traffic-json", default=None,
@@ -57,6 +60,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("HUMID_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = 0           # rehearsal: all ranks share the one GPU of the box (collectives over gloo)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         if rank == 0 and world > 1:
@@ -71,7 +76,11 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        backend = os.environ.get("HUMID_BENCH_BACKEND", "nccl")      # "gloo": multi-process rehearsal on ONE GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n_local = a.reads
     seed = 1002                                   # metric config (1000 + config#)
@@ -122,12 +131,30 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     for k in ks:
         ks[k] /= max(a.steps, 1)
 
+    verified = None
+    if a.verify and world_sharded:
+        from humid_amd.sharded import _all_gather_flat
+        g_cid = torch.empty(world * n_local, dtype=torch.int32, device=dev)
+        g_keep = torch.empty(world * n_local, dtype=torch.int32, device=dev)
+        _all_gather_flat(dist, g_cid, d_cid, world)
+        _all_gather_flat(dist, g_keep, d_keep.to(torch.int32), world)
+        if rank == 0:
+            parts = [synth_words(n_local, seed + 7919 * q, a.word_nt) for q in range(world)]
+            dd1 = humid_amd.Dedup(device=local_rank)
+            cid1, keep1, s1 = dd1.run(np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]),
+                                      word_nt=a.word_nt, distance=a.distance)
+            dd1.close()
+            verified = bool(np.array_equal(g_cid.cpu().numpy().view(np.uint32), cid1) and
+                            np.array_equal(g_keep.cpu().numpy().astype(np.uint8), keep1) and
+                            all(int(last[k]) == int(s1[k]) for k in ("total", "usable", "unique", "clusters", "edges")))
+    elif a.verify:
+        verified = True          # the single-GPU path is the one the sharded results are compared with
     if rank == 0 and world_sharded and getattr(sd, "trace", None):
         print("shard trace (ms per timed pass): %s" %
               {k: round(v / a.steps, 3) for k, v in sorted(sd.trace.items())}, file=sys.stderr)
@@ -199,6 +226,8 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
+    if verified is not None:
+        out["verified_vs_single_gpu"] = verified
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:

@@ -266,7 +266,30 @@ class HipStageOps(Context):
 # ------------------------------------------------------------------------------------------
 # collectives with a fallback for backends (gloo, CPU tests) that lack the tensor forms
 # ------------------------------------------------------------------------------------------
+def _bounce(dist, t):
+    """gloo moves host memory only: device tensors take a round trip through the host (multi-process
+    rehearsals on a box without RCCL peers; never the case under nccl)"""
+    try:
+        return bool(t.is_cuda) and dist.get_backend() == "gloo"
+    except Exception:
+        return False
+
+
+def _all_reduce_sum(dist, t):
+    if _bounce(dist, t):
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t)
+
+
 def _all_gather_flat(dist, out, inp, world):
+    if _bounce(dist, inp):
+        parts = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(world)]
+        dist.all_gather(parts, inp.cpu())
+        out.copy_(torch.cat([p.reshape(-1) for p in parts]).view_as(out))
+        return
     try:
         dist.all_gather_into_tensor(out, inp)
     except (RuntimeError, NotImplementedError):
@@ -277,12 +300,14 @@ def _all_gather_flat(dist, out, inp, world):
 
 def _reduce_scatter_sum(dist, out, inp, world, rank):
     try:
+        if _bounce(dist, inp):
+            raise NotImplementedError
         dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM)
     except (RuntimeError, NotImplementedError):
         tmp = inp.clone()
         if tmp.dtype == torch.uint8:        # gloo has no uint8 sum
             tmp = tmp.to(torch.int32)
-        dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+        _all_reduce_sum(dist, tmp)
         n = out.numel()
         out.copy_(tmp[rank * n:(rank + 1) * n].to(out.dtype))
 
@@ -294,11 +319,12 @@ def _all_to_all_v(dist, out, inp, out_splits, in_splits, world, rank):
         k = inp.shape[1]
         return _all_to_all_v(dist, out.view(-1), inp.reshape(-1), [x * k for x in out_splits],
                              [x * k for x in in_splits], world, rank)
-    try:
-        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits)
-        return
-    except (RuntimeError, NotImplementedError, ValueError):
-        pass
+    if not _bounce(dist, inp):
+        try:
+            dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits)
+            return
+        except (RuntimeError, NotImplementedError, ValueError):
+            pass
     dev = inp.device
     meta = torch.tensor(in_splits, dtype=torch.int64, device=dev)
     metas = torch.empty(world * world, dtype=torch.int64, device=dev)
@@ -476,7 +502,7 @@ class ShardedDedup:
             t_last[0] = now
         # ---- 1. global histogram -> balanced ordered value ranges (cut at prefix boundaries) ----
         hist = ops.histogram(d_w, d_f, self.word_nt, bits)
-        dist.all_reduce(hist)
+        _all_reduce_sum(dist, hist)
         hist_host = hist.cpu().numpy()
         ranges = splitters_from_hist(hist_host, P, self.word_nt, bits)
         lo_r, hi_r = ranges[r][0], ranges[r][1]
