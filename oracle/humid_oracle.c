@@ -556,6 +556,63 @@ uint64_t orc_find_hamming_neighbours(orc_ctx *c, uint32_t distance) {
   return c->unique;
 }
 
+/* Trie::asymmetricLevenshtein (call site src/humid.cc:146-147).  lib/trie is absent (PARITY
+ * UNPINNED, see humid_oracle.h): restated as the textbook Levenshtein search of a trie -- depth
+ * first over the children in index order with one dynamic-programming row per node (edit distances
+ * between the path so far and every prefix of the query), pruned when the whole row exceeds the
+ * bound -- with hypothesis H3: "asymmetric" = every unordered pair is reported once, from its
+ * smaller word, in ascending order (the Hamming variant's H2). */
+typedef struct { orc_ctx *c; const uint64_t *word; OLeaf *from; uint64_t pairs; int distance; } LevArg;
+static void asym_lev_(LevArg *a, const ONode *node, uint32_t depth, const int *prev) {
+  const uint32_t n = a->c->n;
+  if (depth == n) {
+    OLeaf *h = node->leaf;
+    if (h && h != a->from && h->rank > a->from->rank && prev[n] <= a->distance) {   /* src/humid.cc:148 */
+      leaf_push(a->from, h);          /* :149 */
+      leaf_push(h, a->from);          /* :150 */
+      a->pairs++;
+    }
+    return;
+  }
+  for (unsigned i = 0; i < 4; i++) {
+    const ONode *ch = node->child[i];
+    if (!ch) continue;
+    int row[66];
+    int best;
+    row[0] = (int)depth + 1;
+    best = row[0];
+    for (uint32_t j = 1; j <= n; j++) {
+      const int sub = prev[j - 1] + (sym(a->word, n, j - 1) != i);
+      const int del = prev[j] + 1, ins = row[j - 1] + 1;
+      int v = sub < del ? sub : del;
+      if (ins < v) v = ins;
+      row[j] = v;
+      if (v < best) best = v;
+    }
+    if (best <= a->distance) asym_lev_(a, ch, depth + 1, row);
+  }
+}
+
+static void edit_neighbours_cb(OLeaf *l, const uint64_t *w, void *arg) {
+  NbArg *a = (NbArg *)arg;
+  LevArg h = {a->c, w, l, 0, (int)a->distance};
+  int row0[66];
+  for (uint32_t j = 0; j <= a->c->n; j++) row0[j] = (int)j;
+  asym_lev_(&h, a->c->root, 0, row0);
+  a->c->edges += h.pairs;
+}
+
+/* src/humid.cc:140-158 findEditNeighbours */
+uint64_t orc_find_edit_neighbours(orc_ctx *c, uint32_t distance) {
+  free(c->walk);
+  c->walk = (OLeaf **)xmalloc((size_t)c->unique * sizeof(OLeaf *));
+  NbArg a = {c, distance, 0};
+  walk_leaves(c, collect_cb, &a);
+  a.k = 0;
+  walk_leaves(c, edit_neighbours_cb, &a);
+  return c->unique;
+}
+
 typedef struct { orc_ctx *c; int maximum; size_t id; } ClArg;
 static void clusters_cb(OLeaf *l, const uint64_t *w, void *arg) {
   (void)w;
@@ -655,9 +712,10 @@ int orc_dedup_run(const uint64_t *words, const uint8_t *filtered, uint64_t n_rea
   double t0 = now_s();
   orc_read_data(c, words, filtered, n_reads);
   double t1 = now_s();
-  orc_find_hamming_neighbours(c, distance);
+  if (method & 2) orc_find_edit_neighbours(c, distance);       /* -e, src/humid.cc:381-382 */
+  else orc_find_hamming_neighbours(c, distance);
   double t2 = now_s();
-  orc_find_clusters(c, method != 0);
+  orc_find_clusters(c, (method & 1) != 0);
   double t3 = now_s();
   orc_map_reads(c, words, filtered, n_reads, cluster_id, keep);
   double t4 = now_s();

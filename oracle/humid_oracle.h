@@ -21,6 +21,10 @@
  *    search = words >= query in ascending order) restates the library's published
  *    algorithm (4-ary trie, children visited in index order) and is isolated in
  *    orc_walk()/orc_asym_hamming() below.
+ *  - edit distance (-e, src/humid.cc:140-158): the same un-vendored library; PARITY UNPINNED.
+ *    Membership (Levenshtein distance between equal-length words <= d) is fixed by the call
+ *    site; ORDER and MULTIPLICITY (hypothesis H3: every pair reported once, ascending) restate
+ *    the textbook trie search, see orc_find_edit_neighbours().
  *  - The reference as a whole is UNBUILDABLE here (four empty submodules, -lisal
  *    absent); no stand-in headers were written, so there is no oracle/_ref.
  *
@@ -105,6 +109,7 @@ void     orc_destroy(orc_ctx *c);
 void     orc_read_data(orc_ctx *c, const uint64_t *words, const uint8_t *filtered,
                        uint64_t n_reads);
 uint64_t orc_find_hamming_neighbours(orc_ctx *c, uint32_t distance); /* :113-130 */
+uint64_t orc_find_edit_neighbours(orc_ctx *c, uint32_t distance);    /* :140-158 (-e) */
 uint64_t orc_find_clusters(orc_ctx *c, int maximum);                 /* :167-193 */
 /* writeFiltered :220-234 (keep) + writeAnnotated :268-285 (cluster_id) */
 void     orc_map_reads(orc_ctx *c, const uint64_t *words, const uint8_t *filtered,
@@ -125,6 +130,7 @@ void     orc_export_clusters(const orc_ctx *c, uint64_t *size, uint64_t *max_cou
                              uint32_t *max_leaf_rank);
 
 /* one-call convenience: read -> neighbours -> clusters -> map; returns 0.
+ * method bit 0: maximum clustering (-x); bit 1: Levenshtein instead of Hamming neighbours (-e).
  * phase_seconds (may be NULL): [0] read+count, [1] neighbours, [2] clusters, [3] map */
 int orc_dedup_run(const uint64_t *words, const uint8_t *filtered, uint64_t n_reads,
                   uint32_t word_nt, uint32_t distance, uint32_t method,

@@ -72,6 +72,8 @@ def lib():
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_read_data.argtypes = [C.c_void_p, u64p, u8p, C.c_uint64]
         L.orc_find_hamming_neighbours.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_find_edit_neighbours.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_find_edit_neighbours.restype = C.c_uint64
         L.orc_find_hamming_neighbours.restype = C.c_uint64
         L.orc_find_clusters.argtypes = [C.c_void_p, C.c_int]
         L.orc_find_clusters.restype = C.c_uint64
@@ -179,6 +181,9 @@ class Graph:
     def assign(self, leaf, cluster_id, maximum=False):
         lib().orc_graph_assign(self.h, leaf, cluster_id, int(maximum))
 
+    def find_edit_neighbours(self, distance):
+        return int(lib().orc_find_edit_neighbours(self.h, distance))
+
     def find_clusters(self, maximum=False):
         return int(lib().orc_graph_find_clusters(self.h, int(maximum)))
 
@@ -217,6 +222,9 @@ class Pipeline:
 
     def find_hamming_neighbours(self, distance):
         return int(lib().orc_find_hamming_neighbours(self.h, distance))
+
+    def find_edit_neighbours(self, distance):
+        return int(lib().orc_find_edit_neighbours(self.h, distance))
 
     def find_clusters(self, maximum=False):
         return int(lib().orc_find_clusters(self.h, int(maximum)))
@@ -274,8 +282,10 @@ class Pipeline:
         return dict(size=size[:c], max_count=mc[:c], max_leaf=ml[:c])
 
 
-def dedup_run(words, filtered, word_nt, distance=1, method=0):
-    """One-call oracle run.  Returns (cluster_id, keep, summary dict, phase seconds)."""
+def dedup_run(words, filtered, word_nt, distance=1, method=0, edit=False):
+    """One-call oracle run.  Returns (cluster_id, keep, summary dict, phase seconds).
+    method 0 directional / 1 maximum; edit: Levenshtein instead of Hamming neighbours (-e)."""
+    method = (int(method) & 1) | (2 if edit else 0)
     w = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1, 2 if word_nt > 32 else 1)
     f = np.ascontiguousarray(filtered, dtype=np.uint8)
     n = len(w)

@@ -50,6 +50,34 @@ def adjacency(uw, distance):
     return out
 
 
+def levenshtein(a, b):
+    """plain dynamic programme over two symbol lists"""
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        row = [i]
+        for j, y in enumerate(b, 1):
+            row.append(min(prev[j - 1] + (x != y), prev[j] + 1, row[j - 1] + 1))
+        prev = row
+    return prev[-1]
+
+
+def unpack(w, n):
+    return [(int(w) >> (2 * (n - 1 - i))) & 3 for i in range(n)]
+
+
+def edit_adjacency(uw, n, distance):
+    """ascending neighbour lists under Levenshtein distance (one-word words, small U only)"""
+    syms = [unpack(w, n) for w in uw.tolist()]
+    u = len(syms)
+    out = [[] for _ in range(u)]
+    for i in range(u):
+        for j in range(i + 1, u):
+            if levenshtein(syms[i], syms[j]) <= distance:
+                out[i].append(j)
+                out[j].append(i)
+    return out
+
+
 def cluster(counts, nbrs, maximum=False, order=None):
     """findClusters (src/humid.cc:176-189) + src/cluster.cc, literal recursion."""
     sys.setrecursionlimit(max(10000, 4 * len(counts) + 100))
@@ -103,12 +131,13 @@ def cluster(counts, nbrs, maximum=False, order=None):
     return cl, info
 
 
-def dedup(words, filtered, distance=1, maximum=False):
-    """(cluster_id[N], keep[N], detail) for a small read set."""
+def dedup(words, filtered, distance=1, maximum=False, edit_nt=0):
+    """(cluster_id[N], keep[N], detail) for a small read set.  edit_nt = word length: Levenshtein
+    instead of Hamming neighbours (-e)."""
     words = np.asarray(words, dtype=np.uint64)
     filtered = np.asarray(filtered, dtype=np.uint8)
     uw, cnt = unique_counts(words, filtered)
-    nbrs = adjacency(uw, distance)
+    nbrs = edit_adjacency(uw, edit_nt, distance) if edit_nt else adjacency(uw, distance)
     cl, info = cluster(cnt, nbrs, maximum)
     key = (lambda w: tuple(int(x) for x in w)) if words.ndim == 2 else int
     rank = {key(w): i for i, w in enumerate(uw.tolist())}

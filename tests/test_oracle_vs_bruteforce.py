@@ -117,3 +117,51 @@ def test_wide_matches_one_word_embedding():
     _, c1, k1 = run_oracle(lo, filt, 32, 1, False)
     _, c2, k2 = run_oracle(wide, filt, 36, 1, False)
     assert np.array_equal(c1, c2) and np.array_equal(k1, k2)
+
+
+def indel_words(rng, n_reads, n, p_indel=0.3):
+    """families of a few base words; variants by a deletion + an insertion (one shifted stretch),
+    substitutions, or both -- the pairs edit distance finds and Hamming distance does not"""
+    bases = rng.integers(0, 4, size=(max(2, n_reads // 12), n))
+    out = np.zeros(n_reads, dtype=np.uint64)
+    for r in range(n_reads):
+        s = bases[rng.integers(0, len(bases))].tolist()
+        if rng.random() < p_indel:
+            i = int(rng.integers(0, n))
+            del s[i]
+            s.insert(int(rng.integers(0, n)), int(rng.integers(0, 4)))
+        for _ in range(int(rng.integers(0, 3))):
+            if rng.random() < 0.4:
+                s[int(rng.integers(0, n))] = int(rng.integers(0, 4))
+        w = 0
+        for x in s:
+            w = (w << 2) | x
+        out[r] = w
+    return out
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("d", [1, 2, 3])
+@pytest.mark.parametrize("maximum", [False, True])
+def test_edit_distance_neighbours(seed, d, maximum):
+    """-e: the trie Levenshtein search of the oracle against an all-pairs dynamic programme"""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(5, 17))
+    words = indel_words(rng, int(rng.integers(20, 220)), n)
+    filt = (rng.random(len(words)) < 0.03).astype(np.uint8)
+    cid, keep, summ, _ = orc.dedup_run(words, filt, n, d, int(maximum), edit=True)
+    bcid, bkeep, det = bf.dedup(words, filt, d, maximum, edit_nt=n)
+    assert np.array_equal(cid, bcid) and np.array_equal(keep, bkeep)
+    p = orc.Pipeline(n)
+    p.read_data(words, filt)
+    p.find_edit_neighbours(d)
+    off, idx = p.adjacency()
+    assert idx.tolist() == [x for row in det["nbrs"] for x in row]
+
+
+def test_edit_distance_one_is_hamming_distance_one():
+    """equal-length words: one edit can only be a substitution"""
+    words, filt = synth_words(3000, 9, 12, p_sub=0.03)
+    a = orc.dedup_run(words, filt, 12, 1, 0, edit=True)
+    b = orc.dedup_run(words, filt, 12, 1, 0, edit=False)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
