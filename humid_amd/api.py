@@ -66,8 +66,9 @@ class Context:
 class Dedup(Context):
     """The whole hot path on one GPU."""
 
-    def run(self, words, filtered, word_nt=24, distance=1, method=DIRECTIONAL):
+    def run(self, words, filtered, word_nt=24, distance=1, method=DIRECTIONAL, edit=False):
         """Host numpy buffers in, (cluster_id u32[N], keep u8[N], summary dict) out.
+        edit: neighbours under Levenshtein instead of Hamming distance (the reference's -e).
 
         word_nt <= 32: words is u64[N].  33 <= word_nt <= 64: words is u64[N, 2], [:, 0] = the
         first word_nt-32 nucleotides, [:, 1] = the last 32 (include/humid_hip.h)."""
@@ -78,6 +79,7 @@ class Dedup(Context):
             raise ValueError("words must have shape %r for word_nt=%d (filtered: %r)" % (want, word_nt, f.shape))
         n = len(f)
         self._wide = word_nt > 32
+        self.set_option("edit_distance", int(bool(edit)))
         cid = np.zeros(n, dtype=np.uint32)
         keep = np.zeros(n, dtype=np.uint8)
         s = _lib.HumidSummary()

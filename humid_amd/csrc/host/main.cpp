@@ -146,8 +146,8 @@ int main(int argc, char **argv) {
   }
   Args a;
   if (!parse(argc, argv, a)) { usage(argv[0]); return 2; }
-  if (a.edit) {
-    std::fprintf(stderr, "humid: edit distance (-e) is not supported by the HIP path (Hamming only)\n");
+  if (a.edit && (a.distance > 3 || a.word_length > 32)) {
+    std::fprintf(stderr, "humid: edit distance (-e) is supported for -m <= 3 and -n <= 32 by the HIP path\n");
     return 2;
   }
   if (a.word_length == 0 || a.word_length > 64) {
@@ -272,7 +272,9 @@ int main(int argc, char **argv) {
   std::vector<uint8_t> keep(N ? N : 1);
   humid_summary sum;
   std::memset(&sum, 0, sizeof sum);
-  t = start_message(log, "Calculating neighbours using Hamming distance");
+  if (a.edit) humid_ctx_set_option(ctx, "edit_distance", 1);
+  t = start_message(log, a.edit ? "Calculating neighbours using Levenshtein distance"     // src/humid.cc:142
+                                : "Calculating neighbours using Hamming distance");
   int rc = humid_dedup_run(ctx, words.data(), filtered.data(), N, (uint32_t)a.word_length,
                            (uint32_t)a.distance, a.maximum ? HUMID_METHOD_MAXIMUM : HUMID_METHOD_DIRECTIONAL,
                            cluster_id.data(), keep.data(), &sum);

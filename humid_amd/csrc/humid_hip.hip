@@ -58,6 +58,8 @@ struct humid_ctx {
   DBuf pc, poff, share_edges;                                                     // multi-GPU pair-search share
   DBuf own_words;                                                                 // multi-GPU dense count
   DBuf heads;                                                                     // big-component heads
+  DBuf e_kx, e_vx, e_ky0, e_vy0, e_ky, e_vy, e_raw, e_sorted, e_edges, e_head, e_hpos;   // edit-distance neighbour search
+  bool edit = false;         // option "edit_distance": Levenshtein instead of Hamming neighbours (-e)
   DBuf x_slot, x_slot_s, x_cnt, x_cnts, x_rec, x_ncnt, x_route, x_creator, x_base, x_mark, x_markcr, x_scan, x_lcid, x_lismax,
        x_items, x_w, x_id, x_ids, x_ends, x_ends_s, x_head, x_hpos, x_nodes, x_cedges;   // multi-GPU exchange mode
   DBuf w_sorted, w_head, w_hpos, w_start;                                         // wide-word (sorted) counts
@@ -761,6 +763,131 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
   return HUMID_OK;
 }
 
+static ComboFields plan_fields(const ComboPlan &plan, u32 cb);
+
+// ---- edit distance (-e): neighbour pairs under Levenshtein distance 2 or 3 --------------------------
+// (distance <= 1 is the Hamming search: equal lengths leave no room for a lone insertion.)
+// Pigeonhole with shifts.  The plan of the Hamming search cuts the word into s segments and looks at
+// every combination of k = s - d of them: d edits damage at most d segments, so some combination is
+// untouched.  Untouched does not mean unmoved: between a deletion and an insertion the text is
+// shifted by one position.  With at most one such pair (d <= 3) the untouched segments of a
+// combination are, in order, unshifted / shifted by one / unshifted again; taking as "X" the word
+// whose text reappears one position LATER in the other (the other has the insertion first), the
+// shift is +1.  So for every combination and every pattern (a, b) --
+// members [a, b) of the combination shifted, a == b: none -- the words' own segments (X) are joined
+// with the segments read at the shifted positions (Y); candidates are verified by the dynamic
+// programme (lev_band1).  Every unordered pair is found from one of its two sides;
+// duplicates go away in a final sort + unique.  Result: c->e_edges (ascending), *n_edges_out.
+static int edit_edges(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt, u32 distance, u64 *n_edges_out) {
+  hipStream_t st = c->stream;
+  *n_edges_out = 0;
+  if (U < 2) return HUMID_OK;
+  const ComboPlan plan = make_plan(word_nt, distance, U, c->force_segments);
+  const u32 kb = plan.key_bits ? plan.key_bits : 1;
+  const bool k32 = kb <= 32;
+  const size_t ksz = k32 ? 4 : 8;
+  ENSURE(c->e_kx, (size_t)U * 8);
+  ENSURE(c->e_vx, (size_t)U * 4);
+  ENSURE(c->e_ky0, (size_t)U * 8);
+  ENSURE(c->e_vy0, (size_t)U * 4);
+  ENSURE(c->e_ky, (size_t)U * 8);
+  ENSURE(c->e_vy, (size_t)U * 4);
+  ENSURE(c->seg_k0, (size_t)U * 8);
+  ENSURE(c->seg_v0, (size_t)U * 4);
+  ENSURE(c->pc, ((size_t)U + 1) * 4);
+  ENSURE(c->poff, ((size_t)U + 1) * 4);
+  (void)ksz;
+  u64 raw = 0;                                   // pairs collected so far (with duplicates)
+  auto sort_keys_of = [&](const ComboFields &cf, DBuf &kout, DBuf &vout) -> int {
+    if (k32) {
+      hipLaunchKernelGGL((k_combo_keys<u32, u64>), dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, cf,
+                         c->seg_k0.as<u32>(), c->seg_v0.as<u32>());
+      TRY(sort_pairs<u32, u32>(c, c->seg_k0.as<u32>(), kout.as<u32>(), c->seg_v0.as<u32>(), vout.as<u32>(), U, 0, kb));
+    } else {
+      hipLaunchKernelGGL((k_combo_keys<u64, u64>), dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, cf,
+                         c->seg_k0.as<u64>(), c->seg_v0.as<u32>());
+      TRY(sort_pairs<u64, u32>(c, c->seg_k0.as<u64>(), kout.as<u64>(), c->seg_v0.as<u32>(), vout.as<u32>(), U, 0, kb));
+    }
+    return HUMID_OK;
+  };
+  for (u32 cb = 0; cb < plan.ncombo; cb++) {
+    const ComboFields cfx = plan_fields(plan, cb);
+    TRY(sort_keys_of(cfx, c->e_kx, c->e_vx));
+    const u32 k = cfx.nf;
+    for (u32 a = 0; a <= k; a++) {
+      for (u32 b = a; b <= k; b++) {
+        if (a == b && a != 0) continue;                       // the unshifted pattern once
+        ComboFields cfy = cfx;
+        bool valid = true;
+        for (u32 t = a; t < b; t++) {
+          if (cfy.shift[t] < 2) { valid = false; break; }     // the last segment has nowhere to go
+          cfy.shift[t] = (u8)(cfy.shift[t] - 2);              // one nucleotide towards the end
+        }
+        if (!valid) continue;
+        const void *ky = c->e_kx.p;
+        const u32 *vy = c->e_vx.as<u32>();
+        if (a != b) {
+          TRY(sort_keys_of(cfy, c->e_ky, c->e_vy));
+          ky = c->e_ky.p;
+          vy = c->e_vy.as<u32>();
+        }
+        HIPCHK(hipMemsetAsync(c->pc.as<u32>() + U, 0, 4, st));
+        if (k32)
+          hipLaunchKernelGGL((k_edit_join<false, u32>), dim3(blocks_for(U)), dim3(256), 0, st, c->e_kx.as<u32>(),
+                             c->e_vx.as<u32>(), (const u32 *)ky, vy, U, g_word, word_nt, distance, c->pc.as<u32>(),
+                             (const u32 *)nullptr, (u64 *)nullptr);
+        else
+          hipLaunchKernelGGL((k_edit_join<false, u64>), dim3(blocks_for(U)), dim3(256), 0, st, c->e_kx.as<u64>(),
+                             c->e_vx.as<u32>(), (const u64 *)ky, vy, U, g_word, word_nt, distance, c->pc.as<u32>(),
+                             (const u32 *)nullptr, (u64 *)nullptr);
+        TRY(exscan_u32(c, c->pc.as<u32>(), c->poff.as<u32>(), (u64)U + 1));
+        HIPCHK(hipGetLastError());
+        TRY(read_counters(c, c->poff.as<u32>() + U));
+        const u64 found = c->h_ctr[CTR_N - 1] & 0xffffffffull;
+        if (found == 0) continue;
+        if (raw + found >= 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "too many candidate pairs in the edit-distance search");
+        if ((raw + found) * 8 > c->e_raw.cap) {               // grow, keeping what is there
+          DBuf bigger;
+          HIPCHK(bigger.ensure((size_t)((raw + found) * 8 * 2)));
+          if (raw) HIPCHK(hipMemcpyAsync(bigger.p, c->e_raw.p, (size_t)raw * 8, hipMemcpyDeviceToDevice, st));
+          HIPCHK(hipStreamSynchronize(st));
+          c->e_raw.release();
+          c->e_raw = bigger;
+        }
+        if (k32)
+          hipLaunchKernelGGL((k_edit_join<true, u32>), dim3(blocks_for(U)), dim3(256), 0, st, c->e_kx.as<u32>(),
+                             c->e_vx.as<u32>(), (const u32 *)ky, vy, U, g_word, word_nt, distance, (u32 *)nullptr,
+                             c->poff.as<u32>(), c->e_raw.as<u64>() + raw);
+        else
+          hipLaunchKernelGGL((k_edit_join<true, u64>), dim3(blocks_for(U)), dim3(256), 0, st, c->e_kx.as<u64>(),
+                             c->e_vx.as<u32>(), (const u64 *)ky, vy, U, g_word, word_nt, distance, (u32 *)nullptr,
+                             c->poff.as<u32>(), c->e_raw.as<u64>() + raw);
+        raw += found;
+      }
+    }
+  }
+  HIPCHK(hipGetLastError());
+  if (raw == 0) return HUMID_OK;
+  // ---- sort + unique ----
+  const u32 R = (u32)raw;
+  ENSURE(c->e_sorted, (size_t)R * 8);
+  ENSURE(c->e_head, ((size_t)R + 1) * 4);
+  ENSURE(c->e_hpos, ((size_t)R + 1) * 4);
+  TRY(sort_keys<u64>(c, c->e_raw.as<u64>(), c->e_sorted.as<u64>(), R, 0, 32 + bits_for(U)));
+  hipLaunchKernelGGL(k_heads_u64, dim3(blocks_for((u64)R + 1)), dim3(256), 0, st, c->e_sorted.as<u64>(), R,
+                     c->e_head.as<u32>());
+  TRY(exscan_u32(c, c->e_head.as<u32>(), c->e_hpos.as<u32>(), (u64)R + 1));
+  HIPCHK(hipGetLastError());
+  TRY(read_counters(c, c->e_hpos.as<u32>() + R));
+  const u64 E = c->h_ctr[CTR_N - 1] & 0xffffffffull;
+  ENSURE(c->e_edges, (size_t)(E + 1) * 8);
+  hipLaunchKernelGGL(k_compact_heads_u64, dim3(blocks_for(R)), dim3(256), 0, st, c->e_sorted.as<u64>(),
+                     c->e_head.as<u32>(), c->e_hpos.as<u32>(), R, c->e_edges.as<u64>());
+  HIPCHK(hipGetLastError());
+  *n_edges_out = E;
+  return HUMID_OK;
+}
+
 // ---- multi-GPU: this rank's share of the neighbour search ----------------------------------
 // Every rank holds the whole ascending unique array.  Rank r of P looks for the pairs whose
 // first element lies in its slice: for the prefix combo the r-th P-th of the positions, for a
@@ -941,7 +1068,20 @@ static int run_device(humid_ctx *c, const WT *d_words, const u8 *d_filt, u64 n_r
     return HUMID_OK;
   }
   u32 n_pair_segs = 0;
-  TRY(stage_graph<WT>(c, c->s_word.as<WT>(), c->s_cnt.as<u32>(), U, word_nt, distance, method, s, n_pair_segs));
+  if (c->edit && distance >= 2) {
+    // -e: Levenshtein neighbours (src/humid.cc:140-158); distance <= 1 IS the Hamming search
+    if constexpr (WIDE) {
+      return fail(c, HUMID_E_UNSUPPORTED, "edit distance with word_nt > 32 is not supported");
+    } else {
+      if (distance > 3) return fail(c, HUMID_E_UNSUPPORTED, "edit distance %u > 3 is not supported", distance);
+      u64 E = 0;
+      TRY(edit_edges(c, c->s_word.as<u64>(), U, word_nt, distance, &E));
+      static const u64 no_edges = 0;
+      TRY(stage_graph<u64>(c, c->s_word.as<u64>(), c->s_cnt.as<u32>(), U, word_nt, distance, method, s, n_pair_segs,
+                           E ? c->e_edges.as<u64>() : &no_edges, E));
+    }
+  } else
+    TRY(stage_graph<WT>(c, c->s_word.as<WT>(), c->s_cnt.as<u32>(), U, word_nt, distance, method, s, n_pair_segs));
   TRY(stage_map(c, c->cid.as<u32>(), c->ismax.as<u8>(), N, d_cid, d_keep));
   TRY(n_clusters_from_scan(c, U, &c->C));
   s.clusters = c->C;
@@ -1028,7 +1168,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
-                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->e_kx, &c->e_vx, &c->e_ky0, &c->e_vy0, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->seg_ws, &c->csize, &c->cur, &c->plan_dev, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -1053,6 +1193,10 @@ int humid_ctx_set_option(humid_ctx *c, const char *key, int64_t value) {
   if (strcmp(key, "count_order") == 0) {
     if (value < -1 || value > 1) return fail(c, HUMID_E_INVALID, "count_order must be -1 (auto), 0 or 1");
     c->count_order = (int)value;
+    return HUMID_OK;
+  }
+  if (strcmp(key, "edit_distance") == 0) {
+    c->edit = value != 0;
     return HUMID_OK;
   }
   if (strcmp(key, "coop_big") == 0) {

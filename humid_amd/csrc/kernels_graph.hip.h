@@ -214,6 +214,75 @@ k_select_keyrange(const u64 *__restrict__ s_word, u32 n, ComboFields cf, u64 klo
   }
 }
 
+// --------------------------------------------------------------------------------
+// 3b. edit distance (-e, /root/reference/src/humid.cc:140-158)
+// --------------------------------------------------------------------------------
+// Levenshtein distance between two n-nucleotide words, exact up to 3 (returns >= 4 otherwise).
+// Equal lengths: d edits hold at most d/2 insertions and as many deletions, so for d <= 3 an
+// optimal alignment never leaves the diagonals -1, 0, +1.  Row i keeps D[i][i-1], D[i][i],
+// D[i][i+1] (L, M, R).
+__device__ __forceinline__ u32 lev_band1(u64 x, u64 y, u32 n) {
+  const u32 INF = 64;
+  u32 L = INF, M = 0, R = 1;
+  for (u32 i = 0; i < n; i++) {                          // row i -> row i + 1
+    const u32 xs = (u32)(x >> (2 * (n - 1 - i))) & 3u;                        // x_{i+1}
+    const u32 y0 = i >= 1 ? ((u32)(y >> (2 * (n - i))) & 3u) : 4u;            // y_i
+    const u32 y1 = (u32)(y >> (2 * (n - 1 - i))) & 3u;                        // y_{i+1}
+    const u32 y2 = i + 2 <= n ? ((u32)(y >> (2 * (n - 2 - i))) & 3u) : 4u;    // y_{i+2}
+    const u32 nl = min(L + (xs != y0), M + 1u);
+    const u32 nm = min(min(M + (xs != y1), R + 1u), nl + 1u);
+    const u32 nr = i + 2 <= n ? min(R + (xs != y2), nm + 1u) : INF;
+    L = nl; M = nm; R = nr;
+  }
+  return M;
+}
+
+// Candidate join of one combination and one shift pattern: X = the words' own segments (sorted by
+// key), Y = the same segments read at shifted positions (sorted by key).  Thread per X entry: the
+// run of equal keys in Y is found by binary search, every candidate is verified by the dynamic
+// programme.  COUNT: pc[t] = pairs found; FILL: (smaller rank << 32 | larger rank) from poff[t].
+// A pair may come out several times (both roles, several combinations): the list is made unique
+// afterwards.
+template <bool FILL, class KeyT>
+__global__ void __launch_bounds__(256)
+k_edit_join(const KeyT *__restrict__ KX, const u32 *__restrict__ VX, const KeyT *__restrict__ KY,
+            const u32 *__restrict__ VY, u32 n, const u64 *__restrict__ words, u32 word_nt, u32 distance,
+            u32 *__restrict__ pc, const u32 *__restrict__ poff, u64 *__restrict__ edges) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const KeyT key = KX[t];
+  const u32 rx = VX[t];
+  const u64 wx = words[rx];
+  u32 lo = 0, hi = n;
+  while (lo < hi) {
+    const u32 mid = lo + ((hi - lo) >> 1);
+    if (KY[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  u32 found = 0;
+  u64 e = FILL ? (u64)poff[t] : 0;
+  for (u32 j = lo; j < n && KY[j] == key; j++) {
+    const u32 ry = VY[j];
+    if (ry == rx) continue;
+    if (lev_band1(wx, words[ry], word_nt) > distance) continue;
+    if (FILL) edges[e++] = rx < ry ? (((u64)rx << 32) | ry) : (((u64)ry << 32) | rx);
+    else found++;
+  }
+  if (!FILL) pc[t] = found;
+}
+
+// head[i] = 1 where a new value starts in the sorted 64-bit array; head[n] = 0 (scan sentinel)
+__global__ void k_heads_u64(const u64 *__restrict__ sorted, u32 n, u32 *__restrict__ head) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  head[i] = (i < n && (i == 0 || sorted[i] != sorted[i - 1])) ? 1u : 0u;
+}
+
+__global__ void k_compact_heads_u64(const u64 *__restrict__ sorted, const u32 *__restrict__ head,
+                                    const u32 *__restrict__ hpos, u32 n, u64 *__restrict__ out) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && head[i]) out[hpos[i]] = sorted[i];
+}
+
 // every CSR row ascending (the order NLeaf::neighbours has under the trie hypotheses H1+H2)
 __global__ void __launch_bounds__(256)
 k_sort_lists(const u32 *__restrict__ off, u32 n, u32 *idx) {

@@ -33,7 +33,7 @@ extern "C" {
 
 #define HUMID_OK             0
 #define HUMID_E_INVALID     -1   /* bad argument                                    */
-#define HUMID_E_UNSUPPORTED -2   /* word_nt > 64 (stages: > 32), edit distance (-e)  */
+#define HUMID_E_UNSUPPORTED -2   /* word_nt > 64 (stages: > 32), edit distance > 3   */
 #define HUMID_E_NOMEM       -3   /* device or host allocation failed                */
 #define HUMID_E_HIP         -4   /* HIP runtime error (text in humid_last_error)    */
 #define HUMID_E_OVERFLOW    -5   /* an index exceeded 32 bits (reads, 2*edges)      */
@@ -87,6 +87,10 @@ const char *humid_last_error(const humid_ctx *ctx);   /* ctx may be NULL */
  * sort unnecessary: -1 (default) = when a sampled histogram of the top word bits says the fullest
  * bucket fits its LDS table (UMI-first layouts), 0 = never, 1 = always (either way a bucket
  * overflow falls back to hashed buckets).
+ * "edit_distance": 1 = neighbours under Levenshtein instead of Hamming distance (-e,
+ *   findEditNeighbours src/humid.cc:140-158 / Trie::asymmetricLevenshtein) in humid_dedup_run*.
+ *   Between equal-length words distance <= 1 is the Hamming search itself; 2 and 3 add the pairs that
+ *   need one deletion + one insertion; distance > 3 and word_nt > 32 return HUMID_E_UNSUPPORTED.
  * "coop_big": 1 (default) = components of more than 32 leaves are clustered by one workgroup each
  * (parallel flood), 0 = by one lane each (the literal sequential loop). */
 int  humid_ctx_set_option(humid_ctx *ctx, const char *key, int64_t value);

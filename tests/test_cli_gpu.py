@@ -134,3 +134,23 @@ def test_cli_gzip_fast_path_outputs(tmp_path):
     out = str(tmp_path / "out_n")
     subprocess.check_call([HUMID, "-d", out, "-l", "/dev/null", nf])
     assert gzip.open(os.path.join(out, "n_dedup.fastq.gz"), "rb").read() == b""
+
+
+def test_cli_edit_distance(tmp_path):
+    """-e -m 2: Levenshtein neighbours end to end; the log names the distance (src/humid.cc:142)"""
+    files = synth_fastq(str(tmp_path / "in"), 3000, 77, n_files=1, umi_len=8, read_len=36, p_sub=2e-2)
+    out = str(tmp_path / "out")
+    subprocess.check_call([HUMID, "-e", "-m", "2", "-d", out, "-l", str(tmp_path / "log.txt"), "-a", "-s"] + files)
+    words, filt, recs, _ = expected_words(files, 24)
+    p = orc.Pipeline(24)
+    p.read_data(words, filt)
+    p.find_edit_neighbours(2)
+    p.find_clusters(False)
+    cid, keep = p.map_reads()
+    base = os.path.basename(files[0])
+    dedup = read_fastq(os.path.join(out, base.replace(".fastq", "_dedup.fastq")))
+    annot = read_fastq(os.path.join(out, base.replace(".fastq", "_annotated.fastq")))
+    assert dedup == [recs[0][i] for i in range(len(words)) if keep[i]]
+    assert annot == [(recs[0][i][0] + ":%d" % cid[i],) + recs[0][i][1:] for i in range(len(words))]
+    assert dat(os.path.join(out, "neigh.dat")) == orc.histograms(p)["neigh"]
+    assert "Calculating neighbours using Levenshtein distance... done." in open(tmp_path / "log.txt").read()

@@ -1,0 +1,104 @@
+"""-m gpu parity tests of the edit-distance mode (-e, src/humid.cc:140-158): the HIP path through the
+C ABI against the CPU oracle's trie Levenshtein search, bit-exact (cluster ids, keep flags, leaves,
+adjacency, clusters)."""
+import numpy as np
+import pytest
+
+import humid_amd
+from humid_amd.synth import synth_words
+from oracle import pyoracle as orc
+from test_oracle_vs_bruteforce import indel_words
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dd():
+    d = humid_amd.Dedup()
+    yield d
+    d.close()
+
+
+def check_edit(dd, words, filt, n, d, maximum, deep=True):
+    cid, keep, s = dd.run(words, filt, word_nt=n, distance=d, method=int(maximum), edit=True)
+    p = orc.Pipeline(n)
+    p.read_data(words, filt)
+    p.find_edit_neighbours(d)
+    p.find_clusters(maximum)
+    ocid, okeep = p.map_reads()
+    os_ = p.summary()
+    for k in ("total", "usable", "unique", "clusters", "edges"):
+        assert s[k] == os_[k], (k, s[k], os_[k])
+    assert np.array_equal(cid, ocid) and np.array_equal(keep, okeep)
+    if deep and s["unique"]:
+        lv, olv = dd.leaves(), p.leaves()
+        assert np.array_equal(lv["degree"], olv["degree"])
+        assert np.array_equal(lv["cluster_id"], olv["cluster_id"])
+        off, idx = dd.adjacency()
+        ooff, oidx = p.adjacency()
+        assert np.array_equal(off.astype(np.uint64), ooff) and np.array_equal(idx, oidx)
+        cl, ocl = dd.clusters(), p.clusters()
+        assert np.array_equal(cl["size"], ocl["size"]) and np.array_equal(cl["max_leaf"], ocl["max_leaf"])
+    return s
+
+
+@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("d", [2, 3])
+@pytest.mark.parametrize("maximum", [False, True])
+def test_edit_indel_families(dd, seed, d, maximum):
+    rng = np.random.default_rng(300 + seed)
+    n = int(rng.integers(6, 33))
+    words = indel_words(rng, int(rng.integers(500, 6000)), n)
+    filt = (rng.random(len(words)) < 0.02).astype(np.uint8)
+    check_edit(dd, words, filt, n, d, maximum)
+
+
+@pytest.mark.parametrize("n", [4, 9, 24, 32])
+@pytest.mark.parametrize("d", [2, 3])
+def test_edit_finds_more_than_hamming(dd, n, d):
+    """shifted variants are edit neighbours but far apart in Hamming distance"""
+    rng = np.random.default_rng(n * 7 + d)
+    words = indel_words(rng, 4000, n, p_indel=0.6)
+    filt = np.zeros(len(words), np.uint8)
+    se = check_edit(dd, words, filt, n, d, False)
+    _, _, sh = dd.run(words, filt, word_nt=n, distance=d)          # Hamming run on the same words
+    assert se["edges"] >= sh["edges"]
+    if n >= 9:
+        assert se["edges"] > sh["edges"]
+
+
+def test_edit_distance_one_and_zero_equal_hamming(dd):
+    words, filt = synth_words(50_000, 3, 24, p_sub=5e-3)
+    for d in (0, 1):
+        a = dd.run(words, filt, word_nt=24, distance=d, edit=True)
+        b = dd.run(words, filt, word_nt=24, distance=d, edit=False)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2]["edges"] == b[2]["edges"]
+
+
+def test_edit_synthetic_umi_at_size(dd):
+    """the metric's data shape (substitution errors only) at a size the oracle's trie search finishes
+    in seconds: edit distance 2 still has to agree pair for pair"""
+    words, filt = synth_words(120_000, 17, 24, p_sub=5e-3, p_n=1e-3)
+    check_edit(dd, words, filt, 24, 2, False, deep=False)
+
+
+@pytest.mark.parametrize("segs", [3, 4, 5, 6])
+def test_edit_forced_plans(segs):
+    dq = humid_amd.Dedup()
+    dq.set_option("plan_segments", segs)
+    rng = np.random.default_rng(segs)
+    words = indel_words(rng, 3000, 24, p_indel=0.5)
+    check_edit(dq, words, np.zeros(len(words), np.uint8), 24, 2, False)
+    dq.close()
+
+
+def test_edit_unsupported_cases(dd):
+    w = np.zeros(4, np.uint64)
+    f = np.zeros(4, np.uint8)
+    with pytest.raises(humid_amd.HumidError) as e:
+        dd.run(w, f, word_nt=24, distance=4, edit=True)
+    assert e.value.code == -2
+    with pytest.raises(humid_amd.HumidError) as e:
+        dd.run(np.zeros((4, 2), np.uint64), f, word_nt=40, distance=2, edit=True)
+    assert e.value.code == -2
+    dd.run(w, f, word_nt=24, distance=1, edit=False)                  # the option does not stick
