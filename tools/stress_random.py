@@ -46,7 +46,14 @@ def make_case(rng):
     else:
         w, f = synth_words(n_reads, seed, n, p_sub=p_sub, p_n=1e-3, mode=kind,
                            genome_bp=int(rng.choice([2000, 50_000, 4_000_000])))
-    return dict(n=n, d=d, method=method, kind=str(kind), wide=wide, reads=n_reads, p_sub=p_sub, seed=seed), w, f
+    edit = (not wide) and d in (2, 3) and n_reads <= 70_000 and rng.random() < 0.5
+    if edit and rng.random() < 0.5:                       # families with deletions + insertions
+        from test_oracle_vs_bruteforce import indel_words
+        w = indel_words(np.random.default_rng(seed), n_reads, n, p_indel=0.4)
+        f = (np.random.default_rng(seed + 1).random(n_reads) < 0.01).astype(np.uint8)
+        kind = "indel"
+    return dict(n=n, d=d, method=method, kind=str(kind), wide=wide, reads=n_reads, p_sub=p_sub, seed=seed,
+                edit=bool(edit)), w, f
 
 
 def main():
@@ -60,12 +67,13 @@ def main():
         n, d, method = desc["n"], desc["d"], desc["method"]
         if desc["kind"] == "dense" and d >= 2 and desc["reads"] > 70_000:
             d = desc["d"] = 1                                     # the single-thread oracle would take minutes
-        ocid, okeep, osum, _ = orc.dedup_run(w, f, n, d, method)
-        cid, keep, s = dd.run(w, f, word_nt=n, distance=d, method=method)
+        edit = desc["edit"]
+        ocid, okeep, osum, _ = orc.dedup_run(w, f, n, d, method, edit=edit)
+        cid, keep, s = dd.run(w, f, word_nt=n, distance=d, method=method, edit=edit)
         ok = np.array_equal(cid, ocid) and np.array_equal(keep, okeep) and \
             all(s[k] == osum[k] for k in ("usable", "unique", "clusters"))
         ok_x = True
-        if not desc["wide"] and desc["reads"] > 1:
+        if not desc["wide"] and desc["reads"] > 1 and not edit:
             P = int(rng.integers(2, 6))
             out, offs = run_ranks(P, w, f, n, d, method, "exchange")
             for r in range(P):
