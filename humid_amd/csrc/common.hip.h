@@ -77,6 +77,12 @@ __host__ __device__ __forceinline__ u64 w_field(W2 w, u32 shift, u32 width) {
   const unsigned __int128 v = ((unsigned __int128)w.hi << 64) | w.lo;
   return (u64)(v >> shift) & ((width >= 64) ? ~0ull : ((1ull << width) - 1ull));
 }
+// nucleotide i (0 = first) of an n-nucleotide word
+__host__ __device__ __forceinline__ u32 w_sym(u64 w, u32 n, u32 i) { return (u32)(w >> (2 * (n - 1 - i))) & 3u; }
+__host__ __device__ __forceinline__ u32 w_sym(W2 w, u32 n, u32 i) {
+  const u32 nh = n - 32;
+  return i < nh ? (u32)(w.hi >> (2 * (nh - 1 - i))) & 3u : (u32)(w.lo >> (2 * (n - 1 - i))) & 3u;
+}
 __host__ __device__ __forceinline__ bool w_less(W2 a, W2 b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
 __host__ __device__ __forceinline__ bool w_eq(W2 a, W2 b) { return a.hi == b.hi && a.lo == b.lo; }
 template <class WT> __host__ __device__ __forceinline__ WT w_from(W2 m);

@@ -146,8 +146,8 @@ int main(int argc, char **argv) {
   }
   Args a;
   if (!parse(argc, argv, a)) { usage(argv[0]); return 2; }
-  if (a.edit && (a.distance > 3 || a.word_length > 32)) {
-    std::fprintf(stderr, "humid: edit distance (-e) is supported for -m <= 3 and -n <= 32 by the HIP path\n");
+  if (a.edit && a.distance > 3) {
+    std::fprintf(stderr, "humid: edit distance (-e) is supported for -m <= 3 by the HIP path\n");
     return 2;
   }
   if (a.word_length == 0 || a.word_length > 64) {

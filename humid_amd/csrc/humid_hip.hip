@@ -778,7 +778,8 @@ static ComboFields plan_fields(const ComboPlan &plan, u32 cb);
 // with the segments read at the shifted positions (Y); candidates are verified by the dynamic
 // programme (lev_band1).  Every unordered pair is found from one of its two sides;
 // duplicates go away in a final sort + unique.  Result: c->e_edges (ascending), *n_edges_out.
-static int edit_edges(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt, u32 distance, u64 *n_edges_out) {
+template <class WT>
+static int edit_edges(humid_ctx *c, const WT *g_word, u32 U, u32 word_nt, u32 distance, u64 *n_edges_out) {
   hipStream_t st = c->stream;
   *n_edges_out = 0;
   if (U < 2) return HUMID_OK;
@@ -800,11 +801,11 @@ static int edit_edges(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt, u32 d
   u64 raw = 0;                                   // pairs collected so far (with duplicates)
   auto sort_keys_of = [&](const ComboFields &cf, DBuf &kout, DBuf &vout) -> int {
     if (k32) {
-      hipLaunchKernelGGL((k_combo_keys<u32, u64>), dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, cf,
+      hipLaunchKernelGGL((k_combo_keys<u32, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, cf,
                          c->seg_k0.as<u32>(), c->seg_v0.as<u32>());
       TRY(sort_pairs<u32, u32>(c, c->seg_k0.as<u32>(), kout.as<u32>(), c->seg_v0.as<u32>(), vout.as<u32>(), U, 0, kb));
     } else {
-      hipLaunchKernelGGL((k_combo_keys<u64, u64>), dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, cf,
+      hipLaunchKernelGGL((k_combo_keys<u64, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, cf,
                          c->seg_k0.as<u64>(), c->seg_v0.as<u32>());
       TRY(sort_pairs<u64, u32>(c, c->seg_k0.as<u64>(), kout.as<u64>(), c->seg_v0.as<u32>(), vout.as<u32>(), U, 0, kb));
     }
@@ -833,11 +834,11 @@ static int edit_edges(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt, u32 d
         }
         HIPCHK(hipMemsetAsync(c->pc.as<u32>() + U, 0, 4, st));
         if (k32)
-          hipLaunchKernelGGL((k_edit_join<false, u32>), dim3(blocks_for(U)), dim3(256), 0, st, c->e_kx.as<u32>(),
+          hipLaunchKernelGGL((k_edit_join<false, u32, WT>), dim3(blocks_for(U)), dim3(256), 0, st, c->e_kx.as<u32>(),
                              c->e_vx.as<u32>(), (const u32 *)ky, vy, U, g_word, word_nt, distance, c->pc.as<u32>(),
                              (const u32 *)nullptr, (u64 *)nullptr);
         else
-          hipLaunchKernelGGL((k_edit_join<false, u64>), dim3(blocks_for(U)), dim3(256), 0, st, c->e_kx.as<u64>(),
+          hipLaunchKernelGGL((k_edit_join<false, u64, WT>), dim3(blocks_for(U)), dim3(256), 0, st, c->e_kx.as<u64>(),
                              c->e_vx.as<u32>(), (const u64 *)ky, vy, U, g_word, word_nt, distance, c->pc.as<u32>(),
                              (const u32 *)nullptr, (u64 *)nullptr);
         TRY(exscan_u32(c, c->pc.as<u32>(), c->poff.as<u32>(), (u64)U + 1));
@@ -855,11 +856,11 @@ static int edit_edges(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt, u32 d
           c->e_raw = bigger;
         }
         if (k32)
-          hipLaunchKernelGGL((k_edit_join<true, u32>), dim3(blocks_for(U)), dim3(256), 0, st, c->e_kx.as<u32>(),
+          hipLaunchKernelGGL((k_edit_join<true, u32, WT>), dim3(blocks_for(U)), dim3(256), 0, st, c->e_kx.as<u32>(),
                              c->e_vx.as<u32>(), (const u32 *)ky, vy, U, g_word, word_nt, distance, (u32 *)nullptr,
                              c->poff.as<u32>(), c->e_raw.as<u64>() + raw);
         else
-          hipLaunchKernelGGL((k_edit_join<true, u64>), dim3(blocks_for(U)), dim3(256), 0, st, c->e_kx.as<u64>(),
+          hipLaunchKernelGGL((k_edit_join<true, u64, WT>), dim3(blocks_for(U)), dim3(256), 0, st, c->e_kx.as<u64>(),
                              c->e_vx.as<u32>(), (const u64 *)ky, vy, U, g_word, word_nt, distance, (u32 *)nullptr,
                              c->poff.as<u32>(), c->e_raw.as<u64>() + raw);
         raw += found;
@@ -1070,16 +1071,12 @@ static int run_device(humid_ctx *c, const WT *d_words, const u8 *d_filt, u64 n_r
   u32 n_pair_segs = 0;
   if (c->edit && distance >= 2) {
     // -e: Levenshtein neighbours (src/humid.cc:140-158); distance <= 1 IS the Hamming search
-    if constexpr (WIDE) {
-      return fail(c, HUMID_E_UNSUPPORTED, "edit distance with word_nt > 32 is not supported");
-    } else {
-      if (distance > 3) return fail(c, HUMID_E_UNSUPPORTED, "edit distance %u > 3 is not supported", distance);
-      u64 E = 0;
-      TRY(edit_edges(c, c->s_word.as<u64>(), U, word_nt, distance, &E));
-      static const u64 no_edges = 0;
-      TRY(stage_graph<u64>(c, c->s_word.as<u64>(), c->s_cnt.as<u32>(), U, word_nt, distance, method, s, n_pair_segs,
-                           E ? c->e_edges.as<u64>() : &no_edges, E));
-    }
+    if (distance > 3) return fail(c, HUMID_E_UNSUPPORTED, "edit distance %u > 3 is not supported", distance);
+    u64 E = 0;
+    TRY(edit_edges<WT>(c, c->s_word.as<WT>(), U, word_nt, distance, &E));
+    static const u64 no_edges = 0;
+    TRY(stage_graph<WT>(c, c->s_word.as<WT>(), c->s_cnt.as<u32>(), U, word_nt, distance, method, s, n_pair_segs,
+                        E ? c->e_edges.as<u64>() : &no_edges, E));
   } else
     TRY(stage_graph<WT>(c, c->s_word.as<WT>(), c->s_cnt.as<u32>(), U, word_nt, distance, method, s, n_pair_segs));
   TRY(stage_map(c, c->cid.as<u32>(), c->ismax.as<u8>(), N, d_cid, d_keep));

@@ -221,18 +221,20 @@ k_select_keyrange(const u64 *__restrict__ s_word, u32 n, ComboFields cf, u64 klo
 // Equal lengths: d edits hold at most d/2 insertions and as many deletions, so for d <= 3 an
 // optimal alignment never leaves the diagonals -1, 0, +1.  Row i keeps D[i][i-1], D[i][i],
 // D[i][i+1] (L, M, R).
-__device__ __forceinline__ u32 lev_band1(u64 x, u64 y, u32 n) {
+template <class WT>
+__device__ __forceinline__ u32 lev_band1(WT x, WT y, u32 n) {
   const u32 INF = 64;
   u32 L = INF, M = 0, R = 1;
+  u32 y0 = 4u, y1 = w_sym(y, n, 0), y2 = n >= 2 ? w_sym(y, n, 1) : 4u;    // y_i, y_{i+1}, y_{i+2}
   for (u32 i = 0; i < n; i++) {                          // row i -> row i + 1
-    const u32 xs = (u32)(x >> (2 * (n - 1 - i))) & 3u;                        // x_{i+1}
-    const u32 y0 = i >= 1 ? ((u32)(y >> (2 * (n - i))) & 3u) : 4u;            // y_i
-    const u32 y1 = (u32)(y >> (2 * (n - 1 - i))) & 3u;                        // y_{i+1}
-    const u32 y2 = i + 2 <= n ? ((u32)(y >> (2 * (n - 2 - i))) & 3u) : 4u;    // y_{i+2}
+    const u32 xs = w_sym(x, n, i);                       // x_{i+1}
     const u32 nl = min(L + (xs != y0), M + 1u);
     const u32 nm = min(min(M + (xs != y1), R + 1u), nl + 1u);
     const u32 nr = i + 2 <= n ? min(R + (xs != y2), nm + 1u) : INF;
     L = nl; M = nm; R = nr;
+    y0 = y1;
+    y1 = y2;
+    y2 = i + 3 <= n ? w_sym(y, n, i + 2) : 4u;           // y_{(i+1)+2}
   }
   return M;
 }
@@ -243,16 +245,16 @@ __device__ __forceinline__ u32 lev_band1(u64 x, u64 y, u32 n) {
 // programme.  COUNT: pc[t] = pairs found; FILL: (smaller rank << 32 | larger rank) from poff[t].
 // A pair may come out several times (both roles, several combinations): the list is made unique
 // afterwards.
-template <bool FILL, class KeyT>
+template <bool FILL, class KeyT, class WT>
 __global__ void __launch_bounds__(256)
 k_edit_join(const KeyT *__restrict__ KX, const u32 *__restrict__ VX, const KeyT *__restrict__ KY,
-            const u32 *__restrict__ VY, u32 n, const u64 *__restrict__ words, u32 word_nt, u32 distance,
+            const u32 *__restrict__ VY, u32 n, const WT *__restrict__ words, u32 word_nt, u32 distance,
             u32 *__restrict__ pc, const u32 *__restrict__ poff, u64 *__restrict__ edges) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const KeyT key = KX[t];
   const u32 rx = VX[t];
-  const u64 wx = words[rx];
+  const WT wx = words[rx];
   u32 lo = 0, hi = n;
   while (lo < hi) {
     const u32 mid = lo + ((hi - lo) >> 1);

@@ -90,7 +90,7 @@ const char *humid_last_error(const humid_ctx *ctx);   /* ctx may be NULL */
  * "edit_distance": 1 = neighbours under Levenshtein instead of Hamming distance (-e,
  *   findEditNeighbours src/humid.cc:140-158 / Trie::asymmetricLevenshtein) in humid_dedup_run*.
  *   Between equal-length words distance <= 1 is the Hamming search itself; 2 and 3 add the pairs that
- *   need one deletion + one insertion; distance > 3 and word_nt > 32 return HUMID_E_UNSUPPORTED.
+ *   need one deletion + one insertion; distance > 3 returns HUMID_E_UNSUPPORTED.
  * "coop_big": 1 (default) = components of more than 32 leaves are clustered by one workgroup each
  * (parallel flood), 0 = by one lane each (the literal sequential loop). */
 int  humid_ctx_set_option(humid_ctx *ctx, const char *key, int64_t value);

@@ -98,7 +98,35 @@ def test_edit_unsupported_cases(dd):
     with pytest.raises(humid_amd.HumidError) as e:
         dd.run(w, f, word_nt=24, distance=4, edit=True)
     assert e.value.code == -2
-    with pytest.raises(humid_amd.HumidError) as e:
-        dd.run(np.zeros((4, 2), np.uint64), f, word_nt=40, distance=2, edit=True)
-    assert e.value.code == -2
     dd.run(w, f, word_nt=24, distance=1, edit=False)                  # the option does not stick
+
+
+def wide_indel_words(rng, n_reads, n):
+    """indel_words for 33 <= n <= 64: u64[N, 2] ([:, 0] = first n-32 nucleotides, [:, 1] = last 32)"""
+    bases = rng.integers(0, 4, size=(max(2, n_reads // 12), n))
+    out = np.zeros((n_reads, 2), dtype=np.uint64)
+    for r in range(n_reads):
+        s = bases[rng.integers(0, len(bases))].tolist()
+        if rng.random() < 0.4:
+            del s[int(rng.integers(0, n))]
+            s.insert(int(rng.integers(0, n)), int(rng.integers(0, 4)))
+        if rng.random() < 0.4:
+            s[int(rng.integers(0, n))] = int(rng.integers(0, 4))
+        hi = lo = 0
+        for x in s[:n - 32]:
+            hi = (hi << 2) | x
+        for x in s[n - 32:]:
+            lo = (lo << 2) | x
+        out[r] = (hi, lo)
+    return out
+
+
+@pytest.mark.parametrize("n", [33, 40, 48, 64])
+@pytest.mark.parametrize("d", [2, 3])
+def test_edit_wide_words(dd, n, d):
+    """-e with two-word (wide) words: shifts across the word boundary, keys cut to 64 bits"""
+    rng = np.random.default_rng(n + d)
+    words = wide_indel_words(rng, 2500, n)
+    filt = (rng.random(len(words)) < 0.02).astype(np.uint8)
+    check_edit(dd, words, filt, n, d, False)
+    check_edit(dd, words, filt, n, d, True, deep=False)
