@@ -438,7 +438,12 @@ class ShardedDedup:
 
     def __init__(self, device: int = 0, word_nt: int = 24, distance: int = 1, method: int = 0,
                  ops=None, dist=None, dense_return: bool = True, partition_search: bool = True,
-                 mode: str = None):
+                 mode: str = None, edit: bool = False):
+        if edit and distance >= 2:
+            # distance <= 1 under edit distance IS the Hamming search (equal-length words)
+            raise NotImplementedError("edit distance >= 2 is single-GPU only (humid_amd.Dedup.run(edit=True))")
+        if word_nt > 32:
+            raise NotImplementedError("words longer than 32 nt are single-GPU only")
         import os
         import torch.distributed as tdist
         self.mode = mode or os.environ.get("HUMID_SHARD_MODE", "exchange")
