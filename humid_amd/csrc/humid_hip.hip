@@ -58,6 +58,7 @@ struct humid_ctx {
   DBuf pc, poff, share_edges;                                                     // multi-GPU pair-search share
   DBuf own_words;                                                                 // multi-GPU dense count
   DBuf heads;                                                                     // big-component heads
+  DBuf had;                 // k_pairs: first-phase "found a pair" flags, one byte per combination and position
   DBuf e_kx, e_vx, e_ky0, e_vy0, e_ky, e_vy, e_raw, e_sorted, e_edges, e_head, e_hpos;   // edit-distance neighbour search
   bool edit = false;         // option "edit_distance": Levenshtein instead of Hamming neighbours (-e)
   DBuf x_slot, x_slot_s, x_cnt, x_cnts, x_rec, x_ncnt, x_route, x_creator, x_base, x_mark, x_markcr, x_scan, x_lcid, x_lismax,
@@ -664,6 +665,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
   if (search) {
     const u32 nseg = plan.ncombo;
     n_pair_segs = nseg < 8 ? nseg : 8;
+    ENSURE(c->had, (size_t)nseg * U);                       // per combination: this position found a pair
     if (nseg > 1) {
       ENSURE(c->seg_k0, (size_t)U * 8);
       ENSURE(c->seg_v0, (size_t)U * 4);
@@ -678,7 +680,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
         hipLaunchKernelGGL((k_pairs<true, PM_COUNT, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
                            (const u32 *)nullptr, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, c->deg.as<u32>(),
                            c->parent.as<u32>(), (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
-                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr);
+                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u8>());
       } else {
         u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
         const u32 kb = plan.key_bits ? plan.key_bits : 1;
@@ -697,7 +699,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
         hipLaunchKernelGGL((k_pairs<false, PM_COUNT, WT>), dim3(blocks_for(U)), dim3(256), 0, st, ws,
                            vs, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, c->deg.as<u32>(), c->parent.as<u32>(),
                            (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
-                           (const u32 *)nullptr, (u64 *)nullptr);
+                           (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u8>() + (size_t)seg * U);
       }
       if (seg < 8) HIPCHK(hipEventRecord(c->kev[21 + 2 * seg], st));
     }
@@ -731,14 +733,14 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
         hipLaunchKernelGGL((k_pairs<true, PM_FILL, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
                            (const u32 *)nullptr, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, (u32 *)nullptr,
                            (u32 *)nullptr, c->nbr_off.as<u32>(), c->cur.as<u32>(), c->nbr_idx.as<u32>(),
-                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr);
+                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u8>());
       } else {
         const u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
         const WT *ws = c->seg_ws.as<WT>() + (size_t)(seg - 1) * U;
         hipLaunchKernelGGL((k_pairs<false, PM_FILL, WT>), dim3(blocks_for(U)), dim3(256), 0, st, ws,
                            vs, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
                            c->nbr_off.as<u32>(), c->cur.as<u32>(), c->nbr_idx.as<u32>(),
-                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr);
+                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u8>() + (size_t)seg * U);
       }
       if (seg < 8) HIPCHK(hipEventRecord(c->kev[5 + 2 * seg], st));
     }
@@ -969,19 +971,19 @@ static int stage_pairs_share(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt
       if (seg == 0 && phase == 0)
         hipLaunchKernelGGL((k_pairs<true, PM_EMIT_COUNT, u64>), grid, blk, 0, st, g_word, vs, U, p_lo, n_sel[0], plan.mask[0].lo,
                            d_masks, 0u, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr,
-                           (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed);
+                           (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u8 *)nullptr);
       else if (seg == 0)
         hipLaunchKernelGGL((k_pairs<true, PM_EMIT_FILL, u64>), grid, blk, 0, st, g_word, vs, U, p_lo, n_sel[0], plan.mask[0].lo,
                            d_masks, 0u, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr,
-                           (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed);
+                           (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u8 *)nullptr);
       else if (phase == 0)
         hipLaunchKernelGGL((k_pairs<false, PM_EMIT_COUNT, u64>), grid, blk, 0, st, ws, vs, n_sel[seg], 0u, n_sel[seg],
                            plan.mask[seg].lo, d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
-                           (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed);
+                           (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u8 *)nullptr);
       else
         hipLaunchKernelGGL((k_pairs<false, PM_EMIT_FILL, u64>), grid, blk, 0, st, ws, vs, n_sel[seg], 0u, n_sel[seg],
                            plan.mask[seg].lo, d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
-                           (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed);
+                           (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u8 *)nullptr);
     }
     if (phase == 0) {
       TRY(exscan_u32(c, c->pc.as<u32>(), c->poff.as<u32>(), T + 1));
@@ -1165,7 +1167,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
-                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->e_kx, &c->e_vx, &c->e_ky0, &c->e_vy0, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->e_kx, &c->e_vx, &c->e_ky0, &c->e_vy0, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->seg_ws, &c->csize, &c->cur, &c->plan_dev, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -1798,11 +1800,11 @@ static int emit_pairs(humid_ctx *c, const u64 *W, const u32 *V, u32 n, const Com
   if (V)
     hipLaunchKernelGGL((k_pairs<false, PM_EMIT_COUNT, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
                        cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
-                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>());
+                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr);
   else
     hipLaunchKernelGGL((k_pairs<true, PM_EMIT_COUNT, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
                        cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
-                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>());
+                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr);
   TRY(exscan_u32(c, c->pc.as<u32>(), c->poff.as<u32>(), (u64)n + 1));
   HIPCHK(hipGetLastError());
   TRY(read_counters(c, c->poff.as<u32>() + n));
@@ -1813,11 +1815,11 @@ static int emit_pairs(humid_ctx *c, const u64 *W, const u32 *V, u32 n, const Com
   if (V)
     hipLaunchKernelGGL((k_pairs<false, PM_EMIT_FILL, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
                        cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
-                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>());
+                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr);
   else
     hipLaunchKernelGGL((k_pairs<true, PM_EMIT_FILL, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
                        cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
-                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>());
+                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr);
   HIPCHK(hipGetLastError());
   return HUMID_OK;
 }

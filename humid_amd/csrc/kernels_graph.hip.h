@@ -104,12 +104,16 @@ __global__ void __launch_bounds__(256)
 k_pairs(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, u32 i0, u32 n_i, WT mask,
         EarlierMasksT<WT> em, u32 cb, u32 distance, u32 *deg, u32 *parent,
         const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, u32 *__restrict__ pc,
-        const u32 *__restrict__ poff, u64 *__restrict__ edges) {
+        const u32 *__restrict__ poff, u64 *__restrict__ edges, u8 *__restrict__ had) {
   // W: the words IN THE ORDER WALKED (the sorted unique array for the prefix combo, a gathered
   // copy in bucket order for the sorted combos), so the inner loop is one sequential, coalesced
   // stream; the ranks V[] are only loaded for the pairs that are found.
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_i) return;
+  // second phase: only the few positions that found a pair in the first walk their bucket again
+  // (had[] / pc[] were written by the matching first-phase launch: same grid, same t)
+  if (MODE == PM_FILL && had && !had[t]) return;
+  if (MODE == PM_EMIT_FILL && pc[t] == 0) return;
   const u32 i = i0 + t;
   const WT wi = W[i];
   const u32 ri = PASS0 ? i : V[i];
@@ -139,6 +143,7 @@ k_pairs(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, u32 i0, u32 
     }
   }
   if (MODE == PM_COUNT && found) atomicAdd(&deg[ri], found);
+  if (MODE == PM_COUNT && had) had[t] = found ? 1 : 0;
   if (MODE == PM_EMIT_COUNT) pc[t] = found;
 }
 
