@@ -59,7 +59,7 @@ struct humid_ctx {
   DBuf own_words;                                                                 // multi-GPU dense count
   DBuf heads;                                                                     // big-component heads
   DBuf had;                 // k_pairs: first-phase "found a pair" flags, one byte per combination and position
-  DBuf e_kx, e_vx, e_ky0, e_vy0, e_ky, e_vy, e_raw, e_sorted, e_edges, e_head, e_hpos;   // edit-distance neighbour search
+  DBuf e_kx, e_vx, e_ky, e_vy, e_raw, e_sorted, e_edges, e_head, e_hpos;   // edit-distance neighbour search
   bool edit = false;         // option "edit_distance": Levenshtein instead of Hamming neighbours (-e)
   DBuf x_slot, x_slot_s, x_cnt, x_cnts, x_rec, x_ncnt, x_route, x_creator, x_base, x_mark, x_markcr, x_scan, x_lcid, x_lismax,
        x_items, x_w, x_id, x_ids, x_ends, x_ends_s, x_head, x_hpos, x_nodes, x_cedges;   // multi-GPU exchange mode
@@ -788,18 +788,14 @@ static int edit_edges(humid_ctx *c, const WT *g_word, u32 U, u32 word_nt, u32 di
   const ComboPlan plan = make_plan(word_nt, distance, U, c->force_segments);
   const u32 kb = plan.key_bits ? plan.key_bits : 1;
   const bool k32 = kb <= 32;
-  const size_t ksz = k32 ? 4 : 8;
   ENSURE(c->e_kx, (size_t)U * 8);
   ENSURE(c->e_vx, (size_t)U * 4);
-  ENSURE(c->e_ky0, (size_t)U * 8);
-  ENSURE(c->e_vy0, (size_t)U * 4);
   ENSURE(c->e_ky, (size_t)U * 8);
   ENSURE(c->e_vy, (size_t)U * 4);
   ENSURE(c->seg_k0, (size_t)U * 8);
   ENSURE(c->seg_v0, (size_t)U * 4);
   ENSURE(c->pc, ((size_t)U + 1) * 4);
   ENSURE(c->poff, ((size_t)U + 1) * 4);
-  (void)ksz;
   u64 raw = 0;                                   // pairs collected so far (with duplicates)
   auto sort_keys_of = [&](const ComboFields &cf, DBuf &kout, DBuf &vout) -> int {
     if (k32) {
@@ -1167,7 +1163,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
-                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->e_kx, &c->e_vx, &c->e_ky0, &c->e_vy0, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->seg_ws, &c->csize, &c->cur, &c->plan_dev, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
