@@ -81,6 +81,10 @@ SYMBOLS = {
     "humid_stage_compact_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                             C.POINTER(C.c_void_p), u64p, C.POINTER(C.c_void_p),
                                             C.POINTER(C.c_void_p)]),
+    "humid_stage_pairs_edit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
+                                         C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), u64p]),
+    "humid_stage_unique_edges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                           C.POINTER(C.c_void_p), u64p]),
     "humid_stage_graph_edges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                           C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),

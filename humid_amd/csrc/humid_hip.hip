@@ -766,6 +766,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
 }
 
 static ComboFields plan_fields(const ComboPlan &plan, u32 cb);
+static int unique_edges(humid_ctx *c, const u64 *d_edges, u64 raw, u32 U, u64 *n_edges_out);
 
 // ---- edit distance (-e): neighbour pairs under Levenshtein distance 2 or 3 --------------------------
 // (distance <= 1 is the Hamming search: equal lengths leave no room for a lone insertion.)
@@ -780,8 +781,12 @@ static ComboFields plan_fields(const ComboPlan &plan, u32 cb);
 // with the segments read at the shifted positions (Y); candidates are verified by the dynamic
 // programme (lev_band1).  Every unordered pair is found from one of its two sides;
 // duplicates go away in a final sort + unique.  Result: c->e_edges (ascending), *n_edges_out.
+// part_rank / part_world: this caller's share of the joins (multi-GPU: every rank holds the whole
+// unique array and runs every part_world-th join; the shares are gathered and made unique by
+// humid_stage_unique_edges).  make_unique = false leaves the raw list in c->e_raw.
 template <class WT>
-static int edit_edges(humid_ctx *c, const WT *g_word, u32 U, u32 word_nt, u32 distance, u64 *n_edges_out) {
+static int edit_edges(humid_ctx *c, const WT *g_word, u32 U, u32 word_nt, u32 distance, u64 *n_edges_out,
+                      u32 part_rank = 0, u32 part_world = 1, bool make_unique = true) {
   hipStream_t st = c->stream;
   *n_edges_out = 0;
   if (U < 2) return HUMID_OK;
@@ -797,6 +802,7 @@ static int edit_edges(humid_ctx *c, const WT *g_word, u32 U, u32 word_nt, u32 di
   ENSURE(c->pc, ((size_t)U + 1) * 4);
   ENSURE(c->poff, ((size_t)U + 1) * 4);
   u64 raw = 0;                                   // pairs collected so far (with duplicates)
+  u32 join_no = 0;
   auto sort_keys_of = [&](const ComboFields &cf, DBuf &kout, DBuf &vout) -> int {
     if (k32) {
       hipLaunchKernelGGL((k_combo_keys<u32, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, cf,
@@ -823,6 +829,7 @@ static int edit_edges(humid_ctx *c, const WT *g_word, u32 U, u32 word_nt, u32 di
           cfy.shift[t] = (u8)(cfy.shift[t] - 2);              // one nucleotide towards the end
         }
         if (!valid) continue;
+        if (join_no++ % part_world != part_rank) continue;     // another rank's join
         const void *ky = c->e_kx.p;
         const u32 *vy = c->e_vx.as<u32>();
         if (a != b) {
@@ -867,12 +874,23 @@ static int edit_edges(humid_ctx *c, const WT *g_word, u32 U, u32 word_nt, u32 di
   }
   HIPCHK(hipGetLastError());
   if (raw == 0) return HUMID_OK;
+  if (!make_unique) { *n_edges_out = raw; return HUMID_OK; }
+  TRY(unique_edges(c, c->e_raw.as<u64>(), raw, U, n_edges_out));
+  return HUMID_OK;
+}
+
+// sorted, duplicate-free copy of an edge list (smaller << 32 | larger) -> c->e_edges
+static int unique_edges(humid_ctx *c, const u64 *d_edges, u64 raw, u32 U, u64 *n_edges_out) {
+  hipStream_t st = c->stream;
+  *n_edges_out = 0;
+  if (raw == 0) return HUMID_OK;
+  if (raw >= 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "too many edges");
   // ---- sort + unique ----
   const u32 R = (u32)raw;
   ENSURE(c->e_sorted, (size_t)R * 8);
   ENSURE(c->e_head, ((size_t)R + 1) * 4);
   ENSURE(c->e_hpos, ((size_t)R + 1) * 4);
-  TRY(sort_keys<u64>(c, c->e_raw.as<u64>(), c->e_sorted.as<u64>(), R, 0, 32 + bits_for(U)));
+  TRY(sort_keys<u64>(c, d_edges, c->e_sorted.as<u64>(), R, 0, 32 + bits_for(U)));
   hipLaunchKernelGGL(k_heads_u64, dim3(blocks_for((u64)R + 1)), dim3(256), 0, st, c->e_sorted.as<u64>(), R,
                      c->e_head.as<u32>());
   TRY(exscan_u32(c, c->e_head.as<u32>(), c->e_hpos.as<u32>(), (u64)R + 1));
@@ -1928,6 +1946,45 @@ int humid_stage_compact_nodes(humid_ctx *c, const uint64_t *d_edges, uint64_t n_
   *n_nodes = M;
   *d_compact_edges = c->x_cedges.as<u64>();
   if (d_node_counts && record_stride == 2) *d_node_counts = c->x_ncnt.as<u32>();
+  return HUMID_OK;
+}
+
+// ---- multi-GPU, edit distance: this rank's share of the Levenshtein neighbour search over the
+// whole (replicated) unique array; the shares may overlap in pairs (a pair can be found by several
+// joins): gather them and pass them through humid_stage_unique_edges before humid_stage_graph_edges.
+int humid_stage_pairs_edit(humid_ctx *c, const uint64_t *d_g_word, uint64_t n_unique, uint32_t word_nt,
+                           uint32_t distance, uint32_t part_rank, uint32_t part_world, const uint64_t **d_edges,
+                           uint64_t *n_edges) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (!d_edges || !n_edges || part_world == 0 || part_rank >= part_world) return fail(c, HUMID_E_INVALID, "bad argument");
+  TRY(check_run_args(c, n_unique, word_nt, 0));
+  if (distance > 3) return fail(c, HUMID_E_UNSUPPORTED, "edit distance %u > 3 is not supported", distance);
+  HIPCHK(hipSetDevice(c->device));
+  *d_edges = nullptr;
+  *n_edges = 0;
+  if (n_unique && !d_g_word) return fail(c, HUMID_E_INVALID, "null buffer");
+  u64 E = 0;
+  if (n_unique > 1 && distance > 0)
+    TRY(edit_edges<u64>(c, d_g_word, (u32)n_unique, word_nt, distance, &E, part_rank, part_world, false));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *n_edges = E;
+  *d_edges = E ? c->e_raw.as<u64>() : nullptr;
+  return HUMID_OK;
+}
+
+int humid_stage_unique_edges(humid_ctx *c, const uint64_t *d_edges, uint64_t n_edges, uint64_t n_unique,
+                             const uint64_t **d_unique_edges, uint64_t *n_unique_edges) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (!d_unique_edges || !n_unique_edges || n_unique > 0xffffffffull) return fail(c, HUMID_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  *d_unique_edges = nullptr;
+  *n_unique_edges = 0;
+  if (n_edges && !d_edges) return fail(c, HUMID_E_INVALID, "null buffer");
+  u64 E = 0;
+  TRY(unique_edges(c, d_edges, n_edges, (u32)n_unique, &E));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *n_unique_edges = E;
+  *d_unique_edges = E ? c->e_edges.as<u64>() : nullptr;
   return HUMID_OK;
 }
 

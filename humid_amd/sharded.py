@@ -252,6 +252,21 @@ class HipStageOps(Context):
         return (_wrap(pc.value, u_local, "<i4", torch.int32, self.device),
                 _wrap(pm.value, u_local, "|u1", torch.uint8, self.device))
 
+    def pairs_edit(self, g_word, word_nt, distance, part_rank, part_world):
+        """this rank's share of the Levenshtein neighbour pairs (may repeat pairs); a ctx view"""
+        pe = C.c_void_p()
+        ne = C.c_uint64()
+        self._call(self._lib.humid_stage_pairs_edit, self._p(g_word), g_word.numel(), word_nt, distance,
+                   part_rank, part_world, C.byref(pe), C.byref(ne))
+        return _wrap(pe.value, ne.value, "<i8", torch.int64, self.device)
+
+    def unique_edges(self, edges, n_unique):
+        pe = C.c_void_p()
+        ne = C.c_uint64()
+        self._call(self._lib.humid_stage_unique_edges, self._p(edges), edges.numel(), n_unique,
+                   C.byref(pe), C.byref(ne))
+        return _wrap(pe.value, ne.value, "<i8", torch.int64, self.device)
+
     def kernel_ms(self):
         """HIP-event ms of the dominant kernels of the last count_dense / map_dense pair"""
         a, b, m = C.c_float(), C.c_float(), C.c_uint32()
@@ -439,9 +454,9 @@ class ShardedDedup:
     def __init__(self, device: int = 0, word_nt: int = 24, distance: int = 1, method: int = 0,
                  ops=None, dist=None, dense_return: bool = True, partition_search: bool = True,
                  mode: str = None, edit: bool = False):
-        if edit and distance >= 2:
-            # distance <= 1 under edit distance IS the Hamming search (equal-length words)
-            raise NotImplementedError("edit distance >= 2 is single-GPU only (humid_amd.Dedup.run(edit=True))")
+        # -e: distance <= 1 IS the Hamming search (equal-length words); 2 and 3 run in the all-gather
+        # mode, the joins of the shifted-segment search dealt out over the ranks
+        self.edit = bool(edit) and distance >= 2
         if word_nt > 32:
             raise NotImplementedError("words longer than 32 nt are single-GPU only")
         import os
@@ -449,6 +464,8 @@ class ShardedDedup:
         self.mode = mode or os.environ.get("HUMID_SHARD_MODE", "exchange")
         if self.mode not in ("exchange", "allgather"):
             raise ValueError("mode must be 'exchange' or 'allgather'")
+        if bool(edit) and distance >= 2:
+            self.mode = "allgather"
         self.dist = dist or tdist
         self.world = self.dist.get_world_size()
         self.rank = self.dist.get_rank()
@@ -660,7 +677,15 @@ class ShardedDedup:
                 gw = torch.cat([aw[q * u_max:q * u_max + u_all[q]] for q in range(P)])
                 gc = torch.cat([ac[q * u_max:q * u_max + u_all[q]] for q in range(P)])
             # ---- 5. neighbours + clusters over the global unique array ----
-            if self.partition_search and hasattr(self.ops, "pairs"):
+            if self.edit:
+                # Levenshtein neighbours: every rank runs its share of the joins over the whole unique
+                # array; shares can repeat a pair, the gathered list is made unique
+                e_loc = self.ops.pairs_edit(gw, self.word_nt, self.distance, r, P).clone()
+                e_raw, _ = _all_gather_var(dist, e_loc, P)
+                e_all = self.ops.unique_edges(e_raw, gw.numel())
+                cid_g, ismax_g, gs = self.ops.graph_edges(gw, gc, e_all, self.word_nt, self.distance,
+                                                          self.method)
+            elif self.partition_search and hasattr(self.ops, "pairs"):
                 # every rank searches its share of the pairs; the shares are all-gathered (tiny:
                 # ~2 % of N pairs) and every rank builds the graph from the same complete list
                 e_loc = self.ops.pairs(gw, self.word_nt, self.distance, r, P)

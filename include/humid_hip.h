@@ -218,6 +218,16 @@ int humid_stage_graph_edges(humid_ctx *ctx, const uint64_t *d_g_word, const uint
                             const uint32_t **d_cluster_id, const uint8_t **d_is_max,
                             humid_summary *summary);
 
+/* Edit distance (-e) on several GPUs (all-gather mode): humid_stage_pairs_edit = this rank's share of
+ * the Levenshtein neighbour search (every part_world-th join of the shifted-segment search) over the
+ * replicated unique array; shares may repeat a pair, so the gathered list goes through
+ * humid_stage_unique_edges (sorted, duplicate-free) before humid_stage_graph_edges. */
+int humid_stage_pairs_edit(humid_ctx *ctx, const uint64_t *d_g_word, uint64_t n_unique, uint32_t word_nt,
+                           uint32_t distance, uint32_t part_rank, uint32_t part_world,
+                           const uint64_t **d_edges, uint64_t *n_edges);
+int humid_stage_unique_edges(humid_ctx *ctx, const uint64_t *d_edges, uint64_t n_edges, uint64_t n_unique,
+                             const uint64_t **d_unique_edges, uint64_t *n_unique_edges);
+
 /* Result return without N-sized collectives.  The owner of a word computes the results of its
  * reads; the reads' home ranks need them.  Both sides know the same predicate (value ranges), so
  * the streams carry no indices:

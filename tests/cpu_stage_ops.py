@@ -86,6 +86,22 @@ class CpuStageOps:
         mine = (a * 7 + b) % part_world == part_rank        # any disjoint cover of the pairs will do
         return torch.from_numpy(((a[mine] << 32) | b[mine]).astype(np.int64))
 
+    def pairs_edit(self, g_word, word_nt, distance, part_rank, part_world):
+        uw = g_word.numpy().view(np.uint64)
+        p = orc.Pipeline(word_nt)
+        p.read_data(uw, np.zeros(len(uw), np.uint8))
+        p.find_edit_neighbours(distance)
+        off, idx = p.adjacency()
+        src = np.repeat(np.arange(len(uw), dtype=np.int64), np.diff(off.astype(np.int64)))
+        dst = idx.astype(np.int64)
+        m = src < dst
+        a, b = src[m], dst[m]
+        mine = ((a * 7 + b) % part_world == part_rank) | ((a + b) % 5 == 0)   # shares may overlap
+        return torch.from_numpy(((a[mine] << 32) | b[mine]).astype(np.int64))
+
+    def unique_edges(self, edges, n_unique):
+        return torch.from_numpy(np.unique(edges.numpy().astype(np.int64)))
+
     def graph_edges(self, g_word, g_cnt, edges, word_nt, distance, method):
         cnt = g_cnt.numpy().astype(np.int64)
         e = np.sort(edges.numpy().astype(np.int64))             # (a, b) ascending: lists come out ascending

@@ -12,7 +12,7 @@ from oracle import pyoracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def run_ranks(P, words, filt, n, d, method, mode, sizes=None, plan_segments=0, passes=1):
+def run_ranks(P, words, filt, n, d, method, mode, sizes=None, plan_segments=0, passes=1, edit=False):
     import torch
     from fake_dist import FakeDist, FakeWorld
     from humid_amd.sharded import HipStageOps, ShardedDedup
@@ -31,7 +31,7 @@ def run_ranks(P, words, filt, n, d, method, mode, sizes=None, plan_segments=0, p
             if plan_segments:
                 ops.set_option("plan_segments", plan_segments)
             sd = ShardedDedup(device=0, word_nt=n, distance=d, method=method, ops=ops,
-                              dist=FakeDist(world, r), mode=mode)
+                              dist=FakeDist(world, r), mode=mode, edit=edit)
             w = torch.from_numpy(words[offs[r]:offs[r + 1]].view(np.int64).copy()).to(dev)
             f = torch.from_numpy(filt[offs[r]:offs[r + 1]].copy()).to(dev)
             c = torch.zeros(sizes[r], dtype=torch.int32, device=dev)
@@ -188,3 +188,21 @@ def test_exchange_entry_points_reject_bad_arguments():
     assert nodes.numel() == 100 and (cnt.cpu().numpy() == 1).all()
     assert (cedges.cpu().numpy() >> 32).max() < 100
     ops.close()
+
+
+@pytest.mark.parametrize("P", [2, 3, 5])
+@pytest.mark.parametrize("d", [2, 3])
+def test_edit_distance_virtual_ranks(P, d):
+    """-e on several ranks: the joins of the Levenshtein search are dealt out over the ranks (all-gather
+    mode), shares gathered and made unique; every shard bit-identical to the oracle's -e run"""
+    from test_oracle_vs_bruteforce import indel_words
+    rng = np.random.default_rng(40 + P + d)
+    words = indel_words(rng, 20_000, 20, p_indel=0.4)
+    filt = (rng.random(len(words)) < 0.01).astype(np.uint8)
+    ocid, okeep, osum, _ = orc.dedup_run(words, filt, 20, d, 0, edit=True)
+    out, offs = run_ranks(P, words, filt, 20, d, 0, "exchange", edit=True)     # falls to the all-gather mode
+    for r in range(P):
+        cid, keep, s, used = out[r]
+        assert used == "allgather"
+        assert np.array_equal(cid, ocid[offs[r]:offs[r + 1]]) and np.array_equal(keep, okeep[offs[r]:offs[r + 1]])
+        assert s["clusters"] == osum["clusters"]

@@ -35,10 +35,11 @@ def _worker(rank, world, port, case, q):
         from humid_amd.synth import synth_words
         from oracle import pyoracle as orc
         n_reads, n, d, method, sizes, mode, p_sub, dense = case
+        edit = dense == "edit"
         shard_mode = "exchange" if dense == "exchange" else "allgather"
         dense = bool(dense)
         words, filt = synth_words(n_reads, 4242, n, p_sub=p_sub, p_n=2e-3, mode=mode, genome_bp=3000)
-        ocid, okeep, osum, _ = orc.dedup_run(words, filt, n, d, method)
+        ocid, okeep, osum, _ = orc.dedup_run(words, filt, n, d, method, edit=edit)
         if sizes is None:
             base = n_reads // world
             sizes = [base] * (world - 1) + [n_reads - base * (world - 1)]
@@ -49,7 +50,7 @@ def _worker(rank, world, port, case, q):
         keep = torch.zeros(sizes[rank], dtype=torch.uint8)
         sd = ShardedDedup(word_nt=n, distance=d, method=method, ops=CpuStageOps(), dense_return=dense,
                           partition_search=dense,   # old pair: replicated search + reduce-scatter
-                          mode=shard_mode)
+                          mode=shard_mode, edit=edit)
         for _ in range(2):          # second pass re-uses the instance (cached shard sizes)
             s = sd.run(w, f, cid, keep)
         ok = (np.array_equal(cid.numpy().view(np.uint32), ocid[off:off + sizes[rank]]) and
@@ -80,12 +81,15 @@ CASES = [
 def _matrix():
     """world 2: every case in every mode; world 3: every case in exchange mode, a few in the
     all-gather mode with the dense return (keeps the CPU suite within a couple of minutes)"""
-    names = {"exchange": "exchange", True: "allgather_dense_return", False: "allgather_reduce_scatter"}
+    names = {"exchange": "exchange", True: "allgather_dense_return", False: "allgather_reduce_scatter",
+             "edit": "edit_distance"}
     out = []
     for ci, case in enumerate(CASES):
         for dense in ("exchange", True, False):
             out.append(pytest.param(2, case, dense, id="case%d-%s-2" % (ci, names[dense])))
         out.append(pytest.param(3, case, "exchange", id="case%d-exchange-3" % ci))
+        if ci in (1, 7):                                      # d = 2 and d = 3 cases: Levenshtein neighbours
+            out.append(pytest.param(2, case, "edit", id="case%d-edit_distance-2" % ci))
         if ci in (0, 1, 3, 5):
             out.append(pytest.param(3, case, True, id="case%d-allgather_dense_return-3" % ci))
     return out
