@@ -78,7 +78,7 @@ int      humid_device_count(void);
 int  humid_ctx_create(humid_ctx **out, int device, void *stream);
 void humid_ctx_destroy(humid_ctx *ctx);
 const char *humid_last_error(const humid_ctx *ctx);   /* ctx may be NULL */
-/* Tuning knobs (never change results).  "count_mode": 0 = exact counts in hash-partitioned
+/* Options.  All but "edit_distance" are tuning knobs that never change results.  "count_mode": 0 = exact counts in hash-partitioned
  * LDS-resident tables (default; falls back to 1 by itself when a bucket overflows), 1 = one
  * open-address table in HBM.  Environment HUMID_COUNT_MODE presets it.
  * "plan_segments": 0 = automatic choice of the pigeonhole plan (s segments, buckets on every
@@ -99,6 +99,8 @@ int  humid_ctx_set_option(humid_ctx *ctx, const char *key, int64_t value);
  * Replaces, between FastQ pass 1 and pass 2:
  *   trie.add(word.data)                 src/humid.cc:94-97   (exact counts)
  *   findHammingNeighbours(trie, d)      src/humid.cc:113-130 (lib/trie walk x asymmetricHamming)
+ *     or, option "edit_distance",
+ *   findEditNeighbours(trie, d)         src/humid.cc:140-158 (walk x asymmetricLevenshtein)
  *   findClusters(trie, maximum)         src/humid.cc:167-193 + src/cluster.cc:10-87
  *   trie.find(word)->leaf->cluster ...  src/humid.cc:223-231 (keep), :276-277 (cluster id)
  * words[N] (2N uint64 when word_nt > 32), filtered[N] in; cluster_id[N] (0 = filtered, ids 1.. in the order
