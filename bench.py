@@ -172,7 +172,7 @@ def main():
     lds = int(last.get("count_mode_used", 0)) in (0, 2) and \
         (not world_sharded or getattr(sd, "mode_used", "") == "exchange")
     kern = {("k_dedup_lds" if lds else "k_hash_insert"): ks["ms_k_insert"],
-            ("k_read_map_part" if lds else "k_read_map"): ks["ms_k_map"]}
+            ("k_read_map_bucket" if lds else "k_read_map"): ks["ms_k_map"]}
     dom = max(kern, key=lambda k: kern[k])
     dom_ms = kern[dom]
     achieved = (BYTES_PER_READ * n_local / (dom_ms * 1e-3)) / 1e9 if dom_ms > 0 else 0.0

@@ -64,6 +64,7 @@ struct humid_ctx {
   DBuf x_slot, x_slot_s, x_cnt, x_cnts, x_rec, x_ncnt, x_route, x_creator, x_base, x_mark, x_markcr, x_scan, x_lcid, x_lismax,
        x_items, x_w, x_id, x_ids, x_ends, x_ends_s, x_head, x_hpos, x_nodes, x_cedges;   // multi-GPU exchange mode
   DBuf w_sorted, w_head, w_hpos, w_start;                                         // wide-word (sorted) counts
+  u32 n_parts = 0;           // buckets of the last LDS-partitioned count (0: none, e.g. the sorted wide count)
   bool stage_map_timed = false;                                                   // kev[37..38] bracket the last humid_stage_map_dense
   bool last_count_sorted = false;                                                 // last count was the wide-word sort
   u32 g_wpr = 1;                                                                  // uint64 per word of g_word
@@ -417,6 +418,7 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   c->last_count_ordered = ordered;
   const u32 pb = part_bits(N);
   const u32 n_parts = 1u << pb;
+  c->n_parts = n_parts;
   ENSURE(c->pk_keys, (size_t)N * 8);
   ENSURE(c->pk_vals, (size_t)N * 4);
   ENSURE(c->pbeg, (size_t)(n_parts + 1) * 4);
@@ -561,6 +563,7 @@ static int stage_count_wide(humid_ctx *c, const W2 *d_words, const u8 *d_filt, u
   c->last_count_lds = true;          // stage C walks pk_vals/pslot (k_read_map_part)
   c->last_count_ordered = false;
   c->last_count_sorted = true;
+  c->n_parts = 0;
   const u32 hbits = 2 * (word_nt - 32);
   const u32 grid = grid_stride_blocks(N);
   ENSURE(c->pk_keys, (size_t)N * 8);
@@ -1028,8 +1031,14 @@ static int stage_map(humid_ctx *c, const u32 *l_cid, const u8 *l_ismax, u32 N, u
   if (c->last_count_lds) {
     // pk_keys (the partitioned keys) is dead by now: reuse it for the packed per-read results
     u32 *packed = c->pk_keys.as<u32>();
-    hipLaunchKernelGGL(k_read_map_part, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->pk_vals.as<u32>(),
-                       c->pslot.as<u32>(), c->slot_out.as<u64>(), N, packed);
+    // (measured and rejected: a streaming fill of `packed` right before, to have the lines resident
+    // when the scattered stores arrive -- 0.26 vs 0.24 ms, tools/scatter_roofline.py has the rates)
+    if (c->n_parts && !c->last_count_sorted)
+      hipLaunchKernelGGL(k_read_map_bucket, dim3(c->n_parts), dim3(256), 0, st, c->pk_vals.as<u32>(),
+                         c->pslot.as<u32>(), c->slot_out.as<u64>(), c->pbeg.as<u32>(), c->ucount.as<u32>(), N, packed);
+    else
+      hipLaunchKernelGGL(k_read_map_part, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->pk_vals.as<u32>(),
+                         c->pslot.as<u32>(), c->slot_out.as<u64>(), N, packed);
     HIPCHK(hipEventRecord(c->kev[36], st));
     hipLaunchKernelGGL(k_split_out, dim3(grid_stride_blocks(N)), dim3(256), 0, st, packed, N, d_cid, d_keep);
   } else
@@ -1596,7 +1605,11 @@ int humid_stage_map_dense(humid_ctx *c, const uint32_t *d_local_cluster_id, cons
                        c->s_first.as<u32>(), c->s_slot.as<u32>(), U, c->slot_out.as<u64>());
   ENSURE(c->own_packed, ((size_t)N + 1) * 4);
   HIPCHK(hipEventRecord(c->kev[37], st));
-  if (c->last_count_lds)
+  if (c->last_count_lds && c->n_parts && !c->last_count_sorted)
+    hipLaunchKernelGGL(k_read_map_bucket, dim3(c->n_parts), dim3(256), 0, st, c->pk_vals.as<u32>(),
+                       c->pslot.as<u32>(), c->slot_out.as<u64>(), c->pbeg.as<u32>(), c->ucount.as<u32>(), N,
+                       c->own_packed.as<u32>());
+  else if (c->last_count_lds)
     hipLaunchKernelGGL(k_read_map_part, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->pk_vals.as<u32>(),
                        c->pslot.as<u32>(), c->slot_out.as<u64>(), N, c->own_packed.as<u32>());
   else

@@ -49,6 +49,36 @@ k_read_map_part(const u32 *__restrict__ vals, const u32 *__restrict__ pslot, con
   }
 }
 
+// The same per BUCKET of the LDS-partitioned counts (one workgroup per bucket, like k_dedup_lds): a
+// bucket's positions refer to its own unique words only -- padded slots [beg, beg + ucount) -- so
+// their result words are first copied into LDS with one coalesced read and the per-position look-up
+// never leaves the CU.  What remains is the scattered store itself (a bare random scatter of 10 M
+// 4-byte values takes 0.13 ms on this GPU, tools/scatter_roofline.py).
+__global__ void __launch_bounds__(256)
+k_read_map_bucket(const u32 *__restrict__ vals, const u32 *__restrict__ pslot, const u64 *__restrict__ slot_out,
+                  const u32 *__restrict__ pbeg, const u32 *__restrict__ ucount, u32 n_reads,
+                  u32 *__restrict__ packed) {
+  __shared__ u64 lres[LDS_SLOTS + 1];
+  const u32 b = blockIdx.x;
+  const u32 beg = pbeg[b], end = pbeg[b + 1];
+  if (beg >= end || end > n_reads) return;
+  u32 uc = ucount[b];
+  if (uc > LDS_SLOTS + 1) uc = LDS_SLOTS + 1;               // never more than the table held
+  for (u32 li = threadIdx.x; li < uc; li += 256) lres[li] = slot_out[beg + li];
+  __syncthreads();
+  for (u32 i = beg + threadIdx.x; i < end; i += 256) {
+    const u32 r = vals[i] & 0x7fffffffu;
+    if (r >= n_reads) continue;
+    const u32 s = pslot[i];
+    u32 c = 0;
+    if (s != NOSLOT && s - beg < uc) {
+      const u64 o = lres[s - beg];
+      c = (u32)o | (((u32)(o >> 32) == r) ? 0x80000000u : 0u);
+    }
+    packed[r] = c;
+  }
+}
+
 // global-table variant with the packed result word as output (every read is owned and usable)
 __global__ void __launch_bounds__(256)
 k_read_map_packed(const u32 *__restrict__ slot_of_read, const u64 *__restrict__ slot_out, u32 n_reads,
