@@ -65,7 +65,7 @@ typedef struct humid_summary {
   float ms_k_insert;    /* k_dedup_lds or k_hash_insert (one launch)                */
   float ms_k_pairs;     /* sum over the 2(d+1) k_pairs launches (count + fill)      */
   float ms_k_cluster;   /* k_cluster_pairs + _small (+ _components): 2-3 launches   */
-  float ms_k_map;       /* k_read_map_part or k_read_map (one launch)               */
+  float ms_k_map;       /* k_read_map_bucket, _part or k_read_map (1 launch)               */
   uint32_t count_mode_used;  /* 0 = LDS tables, hashed buckets; 2 = LDS tables, word-ordered buckets;
                               * 1 = global HBM table (option or fallback); 3 = sorted (wide words) */
 } humid_summary;
@@ -285,7 +285,7 @@ int humid_stage_scatter(humid_ctx *ctx, const uint32_t *d_perm, const uint32_t *
  * [range_lo, range_hi] (checked); the array is counted as it stands and the range only shapes the
  * word-ordered LDS buckets. */
 /* HIP-event durations of the dominant kernels of the last humid_stage_count_dense /
- * humid_stage_map_dense pair (k_dedup_lds or k_hash_insert; k_read_map_part or k_read_map_packed) */
+ * humid_stage_map_dense pair (k_dedup_lds or k_hash_insert; k_read_map_bucket, k_read_map_part or k_read_map_packed) */
 int humid_stage_kernel_ms(humid_ctx *ctx, float *ms_k_insert, float *ms_k_map, uint32_t *count_mode_used);
 int humid_stage_route_words(humid_ctx *ctx, const uint64_t *d_words, uint64_t n_send,
                             const uint64_t **d_routed);
