@@ -1031,8 +1031,10 @@ static int stage_map(humid_ctx *c, const u32 *l_cid, const u8 *l_ismax, u32 N, u
   if (c->last_count_lds) {
     // pk_keys (the partitioned keys) is dead by now: reuse it for the packed per-read results
     u32 *packed = c->pk_keys.as<u32>();
-    // (measured and rejected: a streaming fill of `packed` right before, to have the lines resident
-    // when the scattered stores arrive -- 0.26 vs 0.24 ms, tools/scatter_roofline.py has the rates)
+    // (measured and rejected: a streaming fill or a streaming read of `packed` right before, to have
+    // its lines resident when the scattered stores arrive -- 0.26 vs 0.24 ms either way; the 0.13 ms
+    // of a REPEATED identical scatter in tools/scatter_roofline.py comes from every XCD finding its
+    // own dirty lines of the previous repetition in its L2, which a pipeline cannot arrange)
     if (c->n_parts && !c->last_count_sorted)
       hipLaunchKernelGGL(k_read_map_bucket, dim3(c->n_parts), dim3(256), 0, st, c->pk_vals.as<u32>(),
                          c->pslot.as<u32>(), c->slot_out.as<u64>(), c->pbeg.as<u32>(), c->ucount.as<u32>(), N, packed);
