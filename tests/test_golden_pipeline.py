@@ -22,13 +22,14 @@ def load(path):
 
 
 def test_goldens_exist():
-    assert len(GOLD) >= 5
+    assert len(GOLD) >= 9
 
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
 def test_oracle_matches_golden(path):
     g = load(path)
-    cid, keep, s, _ = orc.dedup_run(g["words"], g["filtered"], g["word_nt"], g["distance"], g["method"])
+    cid, keep, s, _ = orc.dedup_run(g["words"], g["filtered"], g["word_nt"], g["distance"], g["method"],
+                                    edit=bool(g.get("edit", 0)))
     assert cid.tolist() == g["cluster_id"] and keep.tolist() == g["keep"]
     for k in ("total", "usable", "unique", "clusters"):
         assert s[k] == g["summary"][k]
@@ -40,7 +41,8 @@ def test_hip_matches_golden(path):
     import humid_amd
     g = load(path)
     dd = humid_amd.Dedup()
-    cid, keep, s = dd.run(g["words"], g["filtered"], g["word_nt"], g["distance"], g["method"])
+    cid, keep, s = dd.run(g["words"], g["filtered"], g["word_nt"], g["distance"], g["method"],
+                          edit=bool(g.get("edit", 0)))
     assert cid.tolist() == g["cluster_id"] and keep.tolist() == g["keep"]
     for k in ("total", "usable", "unique", "clusters", "edges"):
         assert s[k] == g["summary"][k]
