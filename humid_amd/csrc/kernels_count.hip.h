@@ -200,12 +200,11 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
   const u32 hshift = 64 - pb - 11;      // table index = the 11 key bits below the bucket bits
   u32 usable = 0;
   bool overflow = false;
-  for (u32 i = beg + threadIdx.x; i < end; i += 256) {
-    const u32 v = vals[i];
-    if ((v & 0x7fffffffu) >= n_reads) { overflow = true; break; }   // a malformed index is never used
-    if (v & 0x80000000u) { pslot[i] = NOSLOT; continue; }
+  // one read into the table; false = the table is full / the index is malformed
+  auto insert = [&](u32 i, u32 v, u64 k) -> bool {
+    if ((v & 0x7fffffffu) >= n_reads) return false;                   // a malformed index is never used
+    if (v & 0x80000000u) { pslot[i] = NOSLOT; return true; }
     usable++;
-    const u64 k = keys[i];
     u32 s;
     if (k == EMPTY_KEY) {
       s = LDS_SLOTS;
@@ -217,14 +216,32 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
         if (cur == EMPTY_KEY) cur = atomicCAS((ull *)&lkey[s], EMPTY_KEY, (ull)k);
         if (cur == EMPTY_KEY || cur == k) break;
         s = (s + 1) & (LDS_SLOTS - 1);
-        if (++probes >= LDS_SLOTS) { overflow = true; break; }
+        if (++probes >= LDS_SLOTS) return false;
       }
-      if (overflow) break;
     }
     // the first add to an entry (old count 0) registers it: its index is the claim order, so no
     // compaction scan over the table is needed afterwards
     if (atomicAdd(&lcnt[s], 1u) == 0u) lslot_of[atomicAdd(&lcount, 1u)] = (unsigned short)s;
     atomicMin(&lfirst[s], v);
+    return true;
+  };
+  {
+    // a thread's first four positions are loaded together (one round trip to memory instead of
+    // four: buckets hold ~700 reads, i.e. 3 positions per thread), the rest one by one
+    u64 kq[4];
+    u32 vq[4];
+#pragma unroll
+    for (u32 q = 0; q < 4; q++) {
+      const u32 i = beg + threadIdx.x + 256u * q;
+      if (i < end) { vq[q] = vals[i]; kq[q] = keys[i]; }
+    }
+#pragma unroll
+    for (u32 q = 0; q < 4; q++) {
+      const u32 i = beg + threadIdx.x + 256u * q;
+      if (i < end && !overflow && !insert(i, vq[q], kq[q])) overflow = true;
+    }
+    for (u32 i = beg + threadIdx.x + 1024u; i < end && !overflow; i += 256)
+      if (!insert(i, vals[i], keys[i])) overflow = true;
   }
   if (overflow) ctr[CTR_OVERFULL] = 1;
   __syncthreads();
@@ -280,11 +297,9 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
   if (threadIdx.x == 0) pusable[b] = tu;
   __syncthreads();
   // second pass: every position learns the padded slot of its word (coalesced store; the
-  // per-read outputs are produced later in this same partition order, see k_read_map_part)
-  for (u32 i = beg + threadIdx.x; i < end; i += 256) {
-    const u32 v = vals[i];
-    if (v >= n_reads) continue;          // excluded read (bit 31) or malformed index
-    const u64 k = keys[i];
+  // per-read outputs are produced later in this same partition order, see k_read_map_bucket)
+  auto locate = [&](u32 i, u32 v, u64 k) {
+    if (v >= n_reads) return;            // excluded read (bit 31) or malformed index
     u32 s;
     if (k == EMPTY_KEY) {
       s = LDS_SLOTS;
@@ -295,6 +310,21 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
     }
     const u32 li = lfirst[s];
     pslot[i] = (li < end - beg) ? beg + li : NOSLOT;
+  };
+  {
+    u64 kq[4];
+    u32 vq[4];
+#pragma unroll
+    for (u32 q = 0; q < 4; q++) {
+      const u32 i = beg + threadIdx.x + 256u * q;
+      if (i < end) { vq[q] = vals[i]; kq[q] = keys[i]; }
+    }
+#pragma unroll
+    for (u32 q = 0; q < 4; q++) {
+      const u32 i = beg + threadIdx.x + 256u * q;
+      if (i < end) locate(i, vq[q], kq[q]);
+    }
+    for (u32 i = beg + threadIdx.x + 1024u; i < end; i += 256) locate(i, vals[i], keys[i]);
   }
 }
 
