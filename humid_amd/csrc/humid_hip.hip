@@ -436,7 +436,8 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   {
     auto kin = rocprim::make_transform_iterator(d_words, PartKeyOp{ordered ? 1u : 0u, km.lo, km.scale});
     auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<u32>(0),
-                                                ReadTagOp{d_words, d_filt, range_lo, range_hi});
+                                                ReadTagOp{(range_lo == 0 && range_hi == ~0ull) ? nullptr : d_words,
+                                                          d_filt, range_lo, range_hi});
     // MergeSortLimit = 0: block sort up to 1024 items, Onesweep above (never the merge path)
     using part_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                                 rocprim::default_config, 0>;

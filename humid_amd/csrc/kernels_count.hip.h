@@ -141,12 +141,12 @@ struct PartKeyOp {
   __host__ __device__ u64 operator()(u64 w) const { return ordered ? (w - lo) * scale : mix64(w); }
 };
 struct ReadTagOp {               // values_input transform: read index | excluded << 31
-  const u64 *words;
+  const u64 *words;              // null: no value range to check (one GPU), the word is not loaded
   const u8 *filtered;
   u64 lo, hi;
   __device__ u32 operator()(u32 r) const {
-    const u64 w = words[r];
-    const bool excl = (filtered && filtered[r] != 0) || w < lo || w > hi;   // filtered == null: none
+    bool excl = filtered && filtered[r] != 0;                                // filtered == null: none
+    if (words) { const u64 w = words[r]; excl = excl || w < lo || w > hi; }
     return r | (excl ? 0x80000000u : 0u);
   }
 };
