@@ -37,11 +37,18 @@ def parse():
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
     ap.add_argument("--word-nt", type=int, default=24)
     ap.add_argument("--distance", type=int, default=1)
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000,
-                    help="reads of the same workload the CPU oracle is timed on (0 = skip)")
-    ap.add_argument("--verify", action="store_true",
-                    help="after the timed passes: gather every shard's results on rank 0 and compare them, "
-                         "bit for bit, with one single-GPU pass over the concatenated read set")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="reads of the same workload the CPU oracle is run on, outside the timed region "
+                         "(-1 = the whole workload: the GPU result is then compared with it bit for bit "
+                         "-> verified_vs_oracle; 0 = skip).  One rank only.")
+    ap.add_argument("--verify", action="store_true", default=None,
+                    help="several ranks: after the timed passes gather every shard's results on rank 0 and "
+                         "compare them, bit for bit, with one single-GPU pass over the whole read set "
+                         "(default: on)")
+    ap.add_argument("--no-verify", dest="verify", action="store_false")
+    ap.add_argument("--shard-mode", default=None, choices=["exchange", "allgather", "both"],
+                    help="multi-GPU orchestration to time (default: HUMID_SHARD_MODE or exchange; 'both' "
+                         "times the second one as well and reports it under other_mode)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path even with one rank (overhead measurement)")
     ap.add_argument("--traffic-json", default=None,
@@ -87,9 +94,17 @@ def main():
 
     n_local = a.reads
     seed = 1002                                   # metric config (1000 + config#)
-    # weak scaling: every rank holds its own n_local-read shard of ONE read set of world*n_local
-    # reads (shards differ by seed but share the molecule model); deduplication is global.
-    words, filt = synth_words(n_local, seed + 7919 * rank, a.word_nt)
+    # weak scaling: ONE shuffled read set of world*n_local reads, sliced by input order (rank r holds
+    # reads [r*n_local, (r+1)*n_local)): families span the ranks, as a real sharded FastQ does.
+    # Every rank draws the same set from the same seed and keeps its slice.
+    if world == 1:
+        words, filt = synth_words(n_local, seed, a.word_nt)
+    else:
+        all_w, all_f = synth_words(n_local * world, seed, a.word_nt)
+        words = np.ascontiguousarray(all_w[rank * n_local:(rank + 1) * n_local])
+        filt = np.ascontiguousarray(all_f[rank * n_local:(rank + 1) * n_local])
+        if rank != 0:
+            del all_w, all_f
     d_w = torch.from_numpy(words.view(np.int64)).to(dev)
     d_f = torch.from_numpy(filt).to(dev)
     d_cid = torch.zeros(n_local, dtype=torch.int32, device=dev)
@@ -97,70 +112,90 @@ def main():
     torch.cuda.synchronize()
 
     world_sharded = not (world == 1 and not a.force_sharded)
-    if not world_sharded:
-        dd = humid_amd.Dedup(device=local_rank)
-
-        def step():
-            return dd.run_device(d_w.data_ptr(), d_f.data_ptr(), d_cid.data_ptr(), d_keep.data_ptr(),
-                                 n_local, a.word_nt, a.distance, humid_amd.DIRECTIONAL)
-    else:
-        from humid_amd.sharded import ShardedDedup
-        sd = ShardedDedup(device=local_rank, word_nt=a.word_nt, distance=a.distance)
-
-        def step():
-            s = dict(sd.run(d_w, d_f, d_cid, d_keep))
-            if sd.mode_used == "exchange":          # HIP-event times of this rank's dominant kernels
-                s.update(sd.ops.kernel_ms())
-            return s
+    KS = ("ms_k_insert", "ms_k_pairs", "ms_k_cluster", "ms_k_map", "ms_k_part", "ms_k_unperm",
+          "ms_count", "ms_neighbours", "ms_cluster", "ms_map", "ms_total")
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    if world_sharded and getattr(sd, "trace", None) is not None:
-        sd.trace.clear()
-    barrier()
-    t0 = time.perf_counter()
-    ks = {"ms_k_insert": 0.0, "ms_k_pairs": 0.0, "ms_k_cluster": 0.0, "ms_k_map": 0.0,
-          "ms_count": 0.0, "ms_neighbours": 0.0, "ms_cluster": 0.0, "ms_map": 0.0, "ms_total": 0.0}
-    last = None
-    for _ in range(a.steps):
-        last = step()
+    def timed(step, trace=None):
+        """W untimed passes, then exactly K passes between barrier + synchronize; max over ranks"""
+        for _ in range(a.warmup):
+            step()
+        if trace is not None:
+            trace.clear()
+        barrier()
+        t0 = time.perf_counter()
+        ks = dict.fromkeys(KS, 0.0)
+        last = None
+        for _ in range(a.steps):
+            last = step()
+            for k in ks:
+                ks[k] += float(last.get(k, 0.0))
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
         for k in ks:
-            ks[k] += float(last.get(k, 0.0))
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    for k in ks:
-        ks[k] /= max(a.steps, 1)
+            ks[k] /= max(a.steps, 1)
+        return dt, ks, last
 
-    verified = None
-    if a.verify and world_sharded:
+    other = None
+    sd = None
+    if not world_sharded:
+        dd = humid_amd.Dedup(device=local_rank)
+
+        def step():
+            return dd.run_device(d_w.data_ptr(), d_f.data_ptr(), d_cid.data_ptr(), d_keep.data_ptr(),
+                                 n_local, a.word_nt, a.distance, humid_amd.DIRECTIONAL)
+        dt, ks, last = timed(step)
+    else:
+        from humid_amd.sharded import ShardedDedup
+        first = a.shard_mode if a.shard_mode in ("exchange", "allgather") else None
+
+        def run_mode(mode):
+            m = ShardedDedup(device=local_rank, word_nt=a.word_nt, distance=a.distance, mode=mode)
+
+            def step():
+                s = dict(m.run(d_w, d_f, d_cid, d_keep))
+                if m.mode_used == "exchange":          # HIP-event times of this rank's dominant kernels
+                    s.update(m.ops.kernel_ms())
+                return s
+            r = timed(step, getattr(m, "trace", None))
+            if rank == 0 and getattr(m, "trace", None):
+                print("shard trace %s (ms per timed pass): %s" %
+                      (m.mode_used, {k: round(v / a.steps, 3) for k, v in sorted(m.trace.items())}), file=sys.stderr)
+            return m, r
+        if a.shard_mode == "both":               # the second orchestration first: the verified results
+            m2, (dt2, _, _) = run_mode("allgather")   # below are then those of the main one
+            other = {"mode": m2.mode_used, "ms_per_step": round(1e3 * dt2 / a.steps, 4),
+                     "value": round(n_local * world * a.steps / dt2, 1)}
+            m2.ops.close()
+            first = "exchange"
+        sd, (dt, ks, last) = run_mode(first)
+
+    # ---- parity of what was just timed (outside the timed region) ----
+    verified_gpu1 = None
+    if world_sharded and (a.verify is None or a.verify):
+        # every shard's results, gathered on rank 0, against ONE single-GPU pass over the whole set
         from humid_amd.sharded import _all_gather_flat
         g_cid = torch.empty(world * n_local, dtype=torch.int32, device=dev)
         g_keep = torch.empty(world * n_local, dtype=torch.int32, device=dev)
         _all_gather_flat(dist, g_cid, d_cid, world)
         _all_gather_flat(dist, g_keep, d_keep.to(torch.int32), world)
         if rank == 0:
-            parts = [synth_words(n_local, seed + 7919 * q, a.word_nt) for q in range(world)]
+            aw, af = (words, filt) if world == 1 else (all_w, all_f)
             dd1 = humid_amd.Dedup(device=local_rank)
-            cid1, keep1, s1 = dd1.run(np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]),
-                                      word_nt=a.word_nt, distance=a.distance)
+            cid1, keep1, s1 = dd1.run(aw, af, word_nt=a.word_nt, distance=a.distance)
             dd1.close()
-            verified = bool(np.array_equal(g_cid.cpu().numpy().view(np.uint32), cid1) and
-                            np.array_equal(g_keep.cpu().numpy().astype(np.uint8), keep1) and
-                            all(int(last[k]) == int(s1[k]) for k in ("total", "usable", "unique", "clusters", "edges")))
-    elif a.verify:
-        verified = True          # the single-GPU path is the one the sharded results are compared with
-    if rank == 0 and world_sharded and getattr(sd, "trace", None):
-        print("shard trace (ms per timed pass): %s" %
-              {k: round(v / a.steps, 3) for k, v in sorted(sd.trace.items())}, file=sys.stderr)
+            verified_gpu1 = bool(np.array_equal(g_cid.cpu().numpy().view(np.uint32), cid1) and
+                                 np.array_equal(g_keep.cpu().numpy().astype(np.uint8), keep1) and
+                                 all(int(last[k]) == int(s1[k]) for k in ("total", "usable", "unique", "clusters", "edges")))
+        del g_cid, g_keep
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -171,11 +206,15 @@ def main():
     value = total_reads * a.steps / dt
 
     # ---- roofline of the dominant kernel (HIP events around its single launch, live) ----
-    # candidates: the two N-proportional single-launch kernels (13 B/read x N is their unit)
-    lds = int(last.get("count_mode_used", 0)) in (0, 2) and \
-        (not world_sharded or getattr(sd, "mode_used", "") == "exchange")
+    # candidates: the N-proportional single-launch kernels (13 B/read x N is their unit)
+    mode_used = int(last.get("count_mode_used", 0))
+    lds = mode_used in (0, 2) and (not world_sharded or getattr(sd, "mode_used", "") == "exchange")
     kern = {("k_dedup_lds" if lds else "k_hash_insert"): ks["ms_k_insert"],
-            ("k_read_map_bucket" if lds else "k_read_map"): ks["ms_k_map"]}
+            ("k_unpermute_bins" if ks["ms_k_unperm"] > 0 else ("k_read_map_bucket" if lds else "k_read_map")): ks["ms_k_map"]}
+    if ks["ms_k_part"] > 0:
+        kern["k_partition_fine"] = ks["ms_k_part"]
+    if ks["ms_k_unperm"] > 0:
+        kern["k_unpermute_window"] = ks["ms_k_unperm"]
     dom = max(kern, key=lambda k: kern[k])
     dom_ms = kern[dom]
     achieved = (BYTES_PER_READ * n_local / (dom_ms * 1e-3)) / 1e9 if dom_ms > 0 else 0.0
@@ -191,32 +230,47 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                 "traffic_source": "profiles/traffic.json (separate rocprofv3 --pmc passes of this command; 2*FETCH_SIZE+WRITE_SIZE)" if traffic else None,
                 "alg_bytes_per_read": BYTES_PER_READ, "reads_per_launch": n_local,
-                "other_kernels_ms": {k: round(v, 4) for k, v in kern.items() if k != dom}}
+                "other_kernels_ms": {k: round(v, 4) for k, v in kern.items() if k != dom},
+                "whole_path": {"achieved": round(BYTES_PER_READ * n_local / (ms_per_step * 1e-3) / 1e9, 2),
+                               "frac": round(BYTES_PER_READ * n_local / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}}
 
-    # ---- CPU baseline: the oracle, 1 thread, bounded sample of the same workload ----
+    # ---- CPU baseline + parity: the oracle (1 thread) on the SAME reads, outside the timed region ----
     cpu = None
-    if a.cpu_sample > 0:
+    verified_oracle = None
+    if a.cpu_sample != 0 and world == 1:
         from oracle import pyoracle as orc
-        ns = min(a.cpu_sample, n_local)
+        ns = n_local if a.cpu_sample < 0 else min(a.cpu_sample, n_local)
         t1 = time.perf_counter()
-        _, _, osum, phases = orc.dedup_run(words[:ns], filt[:ns], a.word_nt, a.distance, 0)
+        ocid, okeep, osum, phases = orc.dedup_run(words[:ns], filt[:ns], a.word_nt, a.distance, 0)
         cdt = time.perf_counter() - t1
         cpu = {"value": round(ns / cdt, 1), "unit": "reads/s", "cores": 1, "kind": "port",
-               "sample": "first %d reads of the same synthetic workload, oracle/humid_oracle.c "
-                         "(trie restatement), 1 thread, %.1f s" % (ns, cdt),
+               "sample": "%s %d reads of the same synthetic workload, oracle/humid_oracle.c "
+                         "(trie restatement), 1 thread, %.1f s" % ("all" if ns == n_local else "first", ns, cdt),
                "host_cores_available": os.cpu_count(),
                "phase_seconds": {"read+count": round(phases[0], 3), "neighbours": round(phases[1], 3),
                                  "clusters": round(phases[2], 3), "map": round(phases[3], 3)}}
+        if ns == n_local:
+            # the results of the LAST timed pass, bit for bit against the oracle's
+            cid = d_cid.cpu().numpy().view(np.uint32)
+            keep = d_keep.cpu().numpy()
+            verified_oracle = bool(np.array_equal(cid, ocid) and np.array_equal(keep, okeep) and
+                                   all(int(last[k]) == int(osum[k]) for k in ("total", "usable", "unique", "clusters", "edges")))
+            if not verified_oracle:
+                print("PARITY FAILURE vs oracle: cid mismatches %d, keep mismatches %d, summary gpu %s oracle %s" %
+                      (int((cid != ocid).sum()), int((keep != okeep).sum()),
+                       {k: int(last[k]) for k in ("usable", "unique", "clusters", "edges")},
+                       {k: int(osum[k]) for k in ("usable", "unique", "clusters", "edges")}), file=sys.stderr)
 
     out = {
         "metric": "reads/sec deduplicated, 10M PE150 UMI=8 d=1",
         "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "%d reads/GPU x %d GPU, PE150 UMI=8 in header -> %d-nt packed words "
+        "config": {"workload": "%d reads/GPU x %d GPU (one shuffled read set of %d reads, sliced by input "
+                               "order), PE150 UMI=8 in header -> %d-nt packed words "
                                "(8+8+8), d=%d, directional clustering; synthetic molecules=N/4, "
-                               "family 1+Geom(3), p_sub=1e-3, p_N=1e-4, shuffled"
-                               % (n_local, world, a.word_nt, a.distance),
+                               "family 1+Geom(3), p_sub=1e-3, p_N=1e-4"
+                               % (n_local, world, total_reads, a.word_nt, a.distance),
                    "reads_per_gpu": n_local, "word_nt": a.word_nt, "distance": a.distance,
                    "method": "directional",
                    "sharding": "single GPU" if not world_sharded else (
@@ -229,12 +283,20 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
-    if verified is not None:
-        out["verified_vs_single_gpu"] = verified
+    if world_sharded:
+        out["shard_mode"] = sd.mode_used
+    if other is not None:
+        out["other_mode"] = other
+    if verified_oracle is not None:
+        out["verified_vs_oracle"] = verified_oracle
+    if verified_gpu1 is not None:
+        out["verified_vs_single_gpu"] = verified_gpu1
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
+    if verified_oracle is False or verified_gpu1 is False:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

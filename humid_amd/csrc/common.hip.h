@@ -37,6 +37,16 @@ enum { CTR_UNIQUE = 0, CTR_USABLE, CTR_EDGES, CTR_NONSINGLE, CTR_MEMBERS, CTR_SP
 // --------------------------------------------------------------------------------
 // device helpers
 // --------------------------------------------------------------------------------
+// Every kernel of this library starts with HUMID_GUARD_LAST_VGPR().  Found in round 2 while chasing
+// the edge loss recorded in round 1 (tools/uniform_load_probe.hip reproduces it
+// in 40 lines of inline assembly): on this MI355X / ROCm 7.2 stack the LAST register of a wave's
+// vector-register allocation is occasionally (about one wave in 10^5) overwritten from outside the
+// wave with the lane number 0..63 while the wave waits for memory -- whatever the kernel keeps
+// there is silently replaced.  The register file is unified: naming a0 as clobbered makes the
+// kernel allocate one granule of accumulation registers it never uses BEHIND its last VGPR, so the
+// register that can be hit holds nothing (1000 launches x 45 k waves: 0 hits with the guard, 34
+// launches hit without, profiles/r02_edge_loss/).  No instruction is emitted.
+#define HUMID_GUARD_LAST_VGPR() asm volatile("" ::: "a0")
 __device__ __forceinline__ u64 mix64(u64 x) {
   x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
   x ^= x >> 27; x *= 0x94d049bb133111ebull;

@@ -3,6 +3,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -116,28 +117,44 @@ bool FastqWriter::compress_member(const char *data, size_t n, std::string &out, 
   return rc == Z_STREAM_END;
 }
 
-static void pwrite_all(int fd, const char *data, size_t n, uint64_t off) {
+// false: the bytes are not all in the file (ENOSPC, EIO, ...); an interrupted call is retried
+static bool pwrite_all(int fd, const char *data, size_t n, uint64_t off) {
   while (n) {
     const ssize_t w = ::pwrite(fd, data, n, (off_t)off);
-    if (w <= 0) return;                             // disk full etc.: the short file shows it
+    if (w < 0 && errno == EINTR) continue;
+    if (w <= 0) return false;
     data += w;
     n -= (size_t)w;
     off += (uint64_t)w;
   }
+  return true;
 }
 
 void FastqWriter::put(const char *data, size_t n) {
-  if (fd_ < 0 || n == 0) return;
-  pwrite_all(fd_, data, n, off_);
+  if (n == 0) return;
+  if (fd_ < 0) { failed_ = true; return; }
+  if (!pwrite_all(fd_, data, n, off_)) failed_ = true;
   off_ += n;
   wrote_ = true;
 }
 
+void FastqWriter::gz_put(const char *data, size_t n) {
+  if (!gz_) { failed_ = true; return; }
+  while (n) {                                       // gzwrite takes an unsigned length
+    const unsigned chunk = n < (1u << 30) ? (unsigned)n : (1u << 30);
+    if (gzwrite(gz_, data, chunk) != (int)chunk) { failed_ = true; return; }
+    data += chunk;
+    n -= chunk;
+  }
+}
+
 void FastqWriter::flush() {
   if (pending_.empty()) return;
-  if (gz_) gzwrite(gz_, pending_.data(), (unsigned)pending_.size());
-  else if (members_) { if (compress_member(pending_.data(), pending_.size(), z_)) put(z_.data(), z_.size()); }
-  else put(pending_.data(), pending_.size());
+  if (gz_) gz_put(pending_.data(), pending_.size());
+  else if (members_) {
+    if (compress_member(pending_.data(), pending_.size(), z_)) put(z_.data(), z_.size());
+    else failed_ = true;
+  } else put(pending_.data(), pending_.size());
   pending_.clear();
 }
 
@@ -155,7 +172,7 @@ void FastqWriter::write_parts(const std::vector<std::string> &parts, unsigned n_
   flush();
   if (fd_ < 0) {                                    // streaming gzip: in order, one thread
     for (unsigned k = 0; k < n_parts; k++)
-      if (gz_ && !parts[k].empty()) gzwrite(gz_, parts[k].data(), (unsigned)parts[k].size());
+      if (!parts[k].empty()) gz_put(parts[k].data(), parts[k].size());
     return;
   }
   std::vector<uint64_t> at(n_parts + 1, off_);
@@ -163,14 +180,29 @@ void FastqWriter::write_parts(const std::vector<std::string> &parts, unsigned n_
   if (at[n_parts] == off_) return;
   // one writer: concurrent pwrite()s into ONE file serialise on the inode lock and measured
   // 15-30 % slower than this loop (tools/ab_write.sh, round 1)
-  for (unsigned k = 0; k < n_parts; k++) pwrite_all(fd_, parts[k].data(), parts[k].size(), at[k]);
+  for (unsigned k = 0; k < n_parts; k++)
+    if (!pwrite_all(fd_, parts[k].data(), parts[k].size(), at[k])) failed_ = true;
   off_ = at[n_parts];
   wrote_ = true;
 }
 
-FastqWriter::~FastqWriter() {
+bool FastqWriter::close() {
+  if (closed_) return ok();
+  if (fd_ < 0 && !gz_) { failed_ = true; closed_ = true; return false; }   // never opened
   flush();
-  if (fd_ >= 0 && members_ && !wrote_ && compress_member("", 0, z_)) put(z_.data(), z_.size());   // valid empty gzip
-  if (gz_) gzclose(gz_);
-  if (fd_ >= 0) ::close(fd_);
+  if (fd_ >= 0 && members_ && !wrote_) {            // valid empty gzip
+    if (compress_member("", 0, z_)) put(z_.data(), z_.size());
+    else failed_ = true;
+  }
+  if (gz_) { if (gzclose(gz_) != Z_OK) failed_ = true; gz_ = nullptr; }
+  if (fd_ >= 0) {
+    // deferred write errors (NFS, quota) surface here; close() is never retried (POSIX: the
+    // descriptor is gone either way)
+    if (::close(fd_) != 0 && errno != EINTR) failed_ = true;
+    fd_ = -1;
+  }
+  closed_ = true;
+  return ok();
 }
+
+FastqWriter::~FastqWriter() { close(); }

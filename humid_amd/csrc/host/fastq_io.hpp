@@ -63,8 +63,12 @@ class FastqWriter {
  public:
   explicit FastqWriter(const std::string &path, bool members = false);
   ~FastqWriter();
-  bool ok() const { return fd_ >= 0 || gz_ != nullptr; }
+  // false once the file could not be created or ANY write / compression / close failed (disk
+  // full, I/O error): the caller must report it -- a truncated output with exit code 0 is silent
+  // data loss in a deduplication tool
+  bool ok() const { return !failed_ && (closed_ || fd_ >= 0 || gz_ != nullptr); }
   bool gz_members() const { return members_; }
+  bool close();                                     // flushes, closes; returns ok()
   void write(const char *data, size_t n);
   void write_member(const std::string &z);          // one precompressed gzip member
   // parts[0 .. n_parts) back to back (plain text, or precompressed members of a members-mode file)
@@ -79,5 +83,8 @@ class FastqWriter {
   gzFile gz_ = nullptr;                             // streaming gzip (single thread)
   bool members_ = false;
   bool wrote_ = false;
+  bool failed_ = false;
+  bool closed_ = false;
+  void gz_put(const char *data, size_t n);          // streaming gzip, any size
   std::string pending_, z_;
 };

@@ -52,7 +52,7 @@ void usage(const char *argv0) {
                "Deduplicate a dataset.\n"
                "  -n  word length\n  -m  allowed mismatches\n  -l  log file name\n  -d  output directory\n"
                "  -s  calculate statistics\n  -q  write deduplicated FastQ files (flag turns it OFF)\n"
-               "  -a  write annotated FastQ files\n  -e  use edit distance (not supported on the GPU path)\n"
+               "  -a  write annotated FastQ files\n  -e  use edit distance (Levenshtein neighbours; -m <= 3)\n"
                "  -x  use maximum clustering method\n",
                argv0);
 }
@@ -104,14 +104,16 @@ void make_dirs(const std::string &path) {   // std::filesystem::create_directori
   }
 }
 
-bool write_hist(humid_ctx *ctx, uint32_t which, const std::string &path) {
+// 1 = written, 0 = the library failed (humid_last_error says why), -1 = the file could not be written
+int write_hist(humid_ctx *ctx, uint32_t which, const std::string &path) {
   uint64_t n = 0;
-  if (humid_get_histogram(ctx, which, nullptr, nullptr, 0, &n) != HUMID_OK) return false;
+  if (humid_get_histogram(ctx, which, nullptr, nullptr, 0, &n) != HUMID_OK) return 0;
   std::vector<uint64_t> k(n ? n : 1), v(n ? n : 1);
-  if (n && humid_get_histogram(ctx, which, k.data(), v.data(), n, &n) != HUMID_OK) return false;
+  if (n && humid_get_histogram(ctx, which, k.data(), v.data(), n, &n) != HUMID_OK) return 0;
   std::ofstream out(path, std::ios::out | std::ios::binary);
   for (uint64_t i = 0; i < n; i++) out << k[i] << ' ' << v[i] << '\n';   // src/humid.cc:333-349
-  return true;
+  out.close();
+  return out.fail() ? -1 : 1;
 }
 
 }  // namespace
@@ -384,8 +386,17 @@ int main(int argc, char **argv) {
       i++;
     }
     }
-    for (FastqWriter *w : dedup) delete w;
-    for (FastqWriter *w : annot) delete w;
+    // a short or failed write (disk full, I/O error) must not end in exit code 0
+    bool wrote_ok = true;
+    for (FastqWriter *w : dedup) { wrote_ok = w->close() && wrote_ok; delete w; }
+    for (FastqWriter *w : annot) { wrote_ok = w->close() && wrote_ok; delete w; }
+    if (!wrote_ok) {
+      log << "failed.\n";
+      std::fprintf(stderr, "humid: writing the output FastQ files in %s failed (disk full or I/O error): "
+                           "the outputs are incomplete\n", a.dir_name.c_str());
+      humid_ctx_destroy(ctx);
+      return 1;
+    }
     if (a.filter) end_message(log, tf);
     if (a.annotate) { ta = start_message(log, "Writing annotated results"); end_message(log, ta); }
   }
@@ -394,17 +405,25 @@ int main(int argc, char **argv) {
   // ---- statistics (src/humid.cc:301-357, src/cluster.cc:89-95) ----
   if (a.stats) {
     t = start_message(log, "Calculating count and neighbour stats");
-    bool ok = write_hist(ctx, 0, a.dir_name + "/counts.dat") && write_hist(ctx, 1, a.dir_name + "/neigh.dat") &&
-              write_hist(ctx, 2, a.dir_name + "/clusters.dat");
+    const char *names[3] = {"/counts.dat", "/neigh.dat", "/clusters.dat"};
+    int ok = 1;
+    for (uint32_t which = 0; which < 3 && ok == 1; which++) ok = write_hist(ctx, which, a.dir_name + names[which]);
     end_message(log, t);
-    if (!ok) { std::fprintf(stderr, "humid: %s\n", humid_last_error(ctx)); humid_ctx_destroy(ctx); return 1; }
+    if (ok == 0) { std::fprintf(stderr, "humid: %s\n", humid_last_error(ctx)); humid_ctx_destroy(ctx); return 1; }
     std::ofstream out(a.dir_name + "/stats.dat", std::ios::out | std::ios::binary);
     out << "total: " << sum.total << '\n';
     out << "usable: " << sum.usable << '\n';
     out << "unique: " << sum.unique << '\n';
     out << "clusters: " << sum.clusters << '\n';
+    out.close();
+    if (ok < 0 || out.fail()) {
+      std::fprintf(stderr, "humid: writing the statistics files in %s failed\n", a.dir_name.c_str());
+      humid_ctx_destroy(ctx);
+      return 1;
+    }
   }
   log.close();
+  if (log.fail()) std::fprintf(stderr, "humid: writing the log %s failed\n", a.log_name.c_str());
   phase("outputs closed");
   humid_ctx_destroy(ctx);
   phase("context destroyed");

@@ -77,8 +77,7 @@ struct humid_ctx {
   bool last_count_ordered = false;
   int count_order = -1;      // LDS buckets by word prefix: -1 automatic (uniform prefix), 0 never, 1 always
   DBuf uniq_word, s_word, s_slot, s_cnt, s_first;            // unique words (walk order)
-  DBuf deg, nbr_off, nbr_idx, seg_k0, seg_v0, seg_ks, seg_vs, seg_ws, csize, cur, plan_dev;
-  ComboPlan h_plan;          // host copy of the plan in flight (source of the async upload)
+  DBuf deg, nbr_off, nbr_idx, seg_k0, seg_v0, seg_ks, seg_vs, seg_ws, csize, cur;
   DBuf parent, mk0, mk1, cl_of, maxleaf, cl_size, flag, pos, cid, ismax, stk, tmp, scratch;
   hipEvent_t ev[6] = {};
   hipEvent_t kev[40] = {};   // per-kernel timing: [0,1] insert, [2,3] cluster, [4..19] pairs fill, [20..35] pairs count
@@ -178,7 +177,11 @@ static u64 n_choose_k(u32 n, u32 k) {
 static ComboPlan make_plan(u32 n, u32 d, u64 U, u32 force_segments) {
   ComboPlan p;
   memset(&p, 0, sizeof p);
-  if (d >= n) { p.ncombo = 1; p.key_bits = 0; p.mask[0] = W2{0, 0}; p.nfield[0] = 0; return p; }
+  // d >= n: every pair is a neighbour pair.  d >= MAX_COMBOS: even the smallest plan, s = d + 1,
+  // has d + 1 > MAX_COMBOS combinations (of ONE segment of at most n / (d + 1) <= 3 nucleotides at
+  // n <= 64: buckets of a quarter of all words and more), so the search degenerates to the same
+  // single combination with an empty mask: one bucket, every pair compared.
+  if (d >= n || n_choose_k(d + 1, 1) > MAX_COMBOS) { p.ncombo = 1; p.key_bits = 0; p.mask[0] = W2{0, 0}; p.nfield[0] = 0; return p; }
   u32 want = 1;                                  // nucleotides of key wanted: 4^want >= U
   while (want < n && ((u64)1 << (2 * want)) < U) want++;
   u32 best_s = d + 1, best_len = 0;
@@ -235,6 +238,11 @@ static ComboPlan make_plan(u32 n, u32 d, u64 U, u32 force_segments) {
     if (t < 0) break;
     idx[t]++;
     for (u32 q = (u32)t + 1; q < k; q++) idx[q] = idx[q - 1] + 1;
+    if (c >= MAX_COMBOS) {           // unreachable (C(best_s, k) <= MAX_COMBOS was checked above); never overrun
+      memset(&p, 0, sizeof p);
+      p.ncombo = 1;
+      return p;
+    }
   }
   p.ncombo = c;
   p.key_bits = maxbits;
@@ -640,13 +648,12 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
   ENSURE(c->parent, (size_t)U * 4);
   ENSURE(c->csize, (size_t)U * 4);
   ENSURE(c->cur, (size_t)U * 4);
-  HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_NONSINGLE], 0, (CTR_OVERFULL - CTR_NONSINGLE + 1) * sizeof(ull), st));
+  HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_EDGES], 0, (CTR_OVERFULL - CTR_EDGES + 1) * sizeof(ull), st));
   hipLaunchKernelGGL(k_graph_init, dim3(blocks_for((u64)U + 1)), dim3(256), 0, st, c->parent.as<u32>(),
                      c->deg.as<u32>(), c->csize.as<u32>(), c->cur.as<u32>(), U);
   u64 E = 0, M = 0, Mbig = 0;
   u32 n_pair_segs = 0;
-  c->h_plan = make_plan(word_nt, distance, U, c->force_segments);
-  const ComboPlan &plan = c->h_plan;
+  const ComboPlan plan = make_plan(word_nt, distance, U, c->force_segments);
   EarlierMasksT<WT> d_masks;                         // masks of all combos, for the first-combo rule
   for (u32 t = 0; t < MAX_COMBOS; t++) d_masks.m[t] = w_from<WT>(plan.mask[t]);
   auto fields_of = [&](u32 cb) {
@@ -657,6 +664,12 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
   };
   const bool given = ext_edges != nullptr;
   const bool search = !given && distance > 0 && U > 1;
+  // one bucket holding every word (d >= n, or d too large for any pigeonhole plan): U^2 / 2
+  // comparisons and, at such distances, nearly as many pairs -- beyond a few 10^5 words the pair
+  // list cannot fit 32-bit CSR offsets anyway; refuse before spending minutes to find that out
+  if (search && plan.ncombo == 1 && plan.key_bits == 0 && U > (1u << 18))
+    return fail(c, HUMID_E_OVERFLOW, "distance %u over %u-nt words compares all pairs of %u unique words: too many neighbour pairs",
+                distance, word_nt, U);
   if (given && n_ext_edges) {
     hipLaunchKernelGGL(k_edges_apply<false>, dim3(grid_stride_blocks(n_ext_edges)), dim3(256), 0, st, ext_edges,
                        n_ext_edges, U, c->deg.as<u32>(), c->parent.as<u32>(), (const u32 *)nullptr,
@@ -717,6 +730,9 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
     HIPCHK(hipGetLastError());
     TRY(read_counters(c, c->nbr_off.as<u32>() + U));   // h_ctr[CTR_N-1] = 2E
     if (c->h_ctr[CTR_OVERFULL]) return fail(c, HUMID_E_INVALID, "malformed edge list (node index out of range)");
+    // the degrees summed in 64 bits (k_comp_count): the 32-bit scan below it may have wrapped
+    if (c->h_ctr[CTR_EDGES] > 0xffffffffull)
+      return fail(c, HUMID_E_OVERFLOW, "%llu neighbour pairs exceed the 32-bit adjacency offsets", (ull)(c->h_ctr[CTR_EDGES] / 2));
     const u64 twoE = c->h_ctr[CTR_N - 1] & 0xffffffffull;
     E = twoE / 2;
     M = c->h_ctr[CTR_NONSINGLE];
@@ -920,8 +936,7 @@ static int stage_pairs_share(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt
   hipStream_t st = c->stream;
   *n_edges_out = 0;
   if (distance == 0 || U < 2) return HUMID_OK;
-  c->h_plan = make_plan(word_nt, distance, U, c->force_segments);
-  const ComboPlan &plan = c->h_plan;
+  const ComboPlan plan = make_plan(word_nt, distance, U, c->force_segments);
   EarlierMasksT<u64> d_masks;
   for (u32 t = 0; t < MAX_COMBOS; t++) d_masks.m[t] = plan.mask[t].lo;
   auto fields_of = [&](u32 cb) {
@@ -1196,7 +1211,7 @@ void humid_ctx_destroy(humid_ctx *c) {
                   &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
-                  &c->seg_v0, &c->seg_vs, &c->seg_ws, &c->csize, &c->cur, &c->plan_dev, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
+                  &c->seg_v0, &c->seg_vs, &c->seg_ws, &c->csize, &c->cur, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
                   &c->maxleaf, &c->cl_size, &c->flag, &c->pos, &c->cid, &c->ismax, &c->stk, &c->tmp,
                   &c->scratch};
   for (DBuf *b : bufs) b->release();
@@ -1445,7 +1460,7 @@ int humid_cluster_graph(humid_ctx *c, const uint32_t *count, const uint32_t *nbr
   if (twoE) HIPCHK(hipMemcpyAsync(c->nbr_idx.p, nbr_idx, (size_t)twoE * 4, hipMemcpyHostToDevice, st));
   ENSURE(c->csize, (size_t)U * 4);
   HIPCHK(hipMemsetAsync(c->csize.p, 0, (size_t)U * 4, st));
-  HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_NONSINGLE], 0, 2 * sizeof(ull), st));
+  HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_EDGES], 0, 3 * sizeof(ull), st));
   hipLaunchKernelGGL(k_iota, dim3(blocks_for(U)), dim3(256), 0, st, c->parent.as<u32>(), U);
   hipLaunchKernelGGL(k_union_csr, dim3(blocks_for(U)), dim3(256), 0, st, c->nbr_off.as<u32>(),
                      c->nbr_idx.as<u32>(), U, c->parent.as<u32>());
@@ -1749,12 +1764,14 @@ static u32 min_prefix_bits(u32 n, u32 d, u32 force_segments) {
 
 int humid_stage_plan_info(humid_ctx *c, uint32_t word_nt, uint32_t distance, uint64_t plan_unique,
                           uint32_t *n_combos, uint32_t *prefix_bits) {
-  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
-  TRY(check_run_args(c, 0, word_nt, 0));
-  const ComboPlan plan = make_plan(word_nt, distance, plan_unique, c->force_segments);
+  // pure host arithmetic: ctx may be NULL (no GPU needed; the automatic plan is reported)
+  TRY(check_run_args(c, 0, word_nt, 0, 64));
+  const u32 force = c ? c->force_segments : 0u;
+  const ComboPlan plan = make_plan(word_nt, distance, plan_unique, force);
+  if (plan.ncombo == 0 || plan.ncombo > MAX_COMBOS) return fail(c, HUMID_E_INVALID, "internal: bad pigeonhole plan");
   if (n_combos) *n_combos = plan.ncombo;
   if (prefix_bits) {
-    const u32 mp = min_prefix_bits(word_nt, distance, c->force_segments);
+    const u32 mp = min_prefix_bits(word_nt, distance, force);
     *prefix_bits = mp < (u32)__builtin_popcountll(plan.mask[0].lo) ? mp : (u32)__builtin_popcountll(plan.mask[0].lo);
   }
   return HUMID_OK;

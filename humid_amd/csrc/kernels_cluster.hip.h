@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(64)
 k_cluster_components(const u64 *__restrict__ mkeys, u32 n_members, const u32 *__restrict__ cnt,
                      const u32 *__restrict__ off, const u32 *__restrict__ idx, u32 *cl_of,
                      u32 *maxleaf, u64 *cl_size, u32 *stk) {
+  HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_members) return;
   const u32 root = (u32)(mkeys[i] >> 32);
@@ -115,6 +116,7 @@ __global__ void __launch_bounds__(256)
 k_cluster_big_coop(const u64 *__restrict__ mkeys, u32 n_members, const u32 *__restrict__ heads,
                    const ull *__restrict__ ctr, const u32 *__restrict__ cnt, const u32 *__restrict__ off,
                    const u32 *__restrict__ idx, u32 *cl_of, u32 *maxleaf, u64 *cl_size, u32 *fr) {
+  HUMID_GUARD_LAST_VGPR();
   __shared__ u32 s_min;         // block-wide minimum (next unassigned member / first qualifying neighbour)
   __shared__ u32 s_next;        // size of the next BFS frontier
   __shared__ ull s_size;        // reads in the cluster being flooded
@@ -211,6 +213,7 @@ k_cluster_big_coop(const u64 *__restrict__ mkeys, u32 n_members, const u32 *__re
 // heads of the runs of equal root in the sorted member keys (fixed grid, one atomic per block)
 __global__ void __launch_bounds__(256)
 k_comp_heads(const u64 *__restrict__ mkeys, u32 n_members, u32 *__restrict__ heads, ull *ctr) {
+  HUMID_GUARD_LAST_VGPR();
   __shared__ u32 lds[8];
   const u32 chunk = (n_members + gridDim.x - 1) / gridDim.x;
   const u32 lo = blockIdx.x * chunk;
@@ -245,6 +248,7 @@ __global__ void __launch_bounds__(256)
 k_cluster_trivial(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *__restrict__ csize, u32 n,
                   const u32 *__restrict__ cnt, const u32 *__restrict__ off, const u32 *__restrict__ idx,
                   u32 *cl_of, u32 *maxleaf, u64 *cl_size) {
+  HUMID_GUARD_LAST_VGPR();
   u32 a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n) return;
   if (deg[a] == 0) { cl_of[a] = a + 1; maxleaf[a] = a; cl_size[a] = cnt[a]; return; }
@@ -281,6 +285,7 @@ __global__ void __launch_bounds__(128)
 k_cluster_small(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *__restrict__ csize,
                 u32 n, const u32 *__restrict__ cnt, const u32 *__restrict__ off,
                 const u32 *__restrict__ idx, u32 *cl_of, u32 *maxleaf, u64 *cl_size) {
+  HUMID_GUARD_LAST_VGPR();
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n || deg[u] == 0 || P[u] != u) return;
   const u32 target = csize[u];
@@ -308,6 +313,7 @@ k_cluster_small(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u3
 }
 
 __global__ void k_creator_flags(const u32 *__restrict__ cl_of, u32 n, u32 *flag) {
+  HUMID_GUARD_LAST_VGPR();
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u < n) flag[u] = (cl_of[u] == u + 1) ? 1u : 0u;
 }
@@ -318,6 +324,7 @@ __global__ void k_finalize_nodes(const u32 *__restrict__ cl_of, const u32 *__res
                                  const u32 *__restrict__ maxleaf, u32 n, u32 *__restrict__ cid,
                                  u8 *__restrict__ ismax, const u32 *__restrict__ s_first,
                                  const u32 *__restrict__ s_slot, u64 *__restrict__ slot_out) {
+  HUMID_GUARD_LAST_VGPR();
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n) return;
   const u32 creator = cl_of[u] - 1;
@@ -332,6 +339,7 @@ __global__ void k_finalize_nodes(const u32 *__restrict__ cl_of, const u32 *__res
 __global__ void k_slot_results(const u32 *__restrict__ l_cid, const u8 *__restrict__ l_ismax,
                                const u32 *__restrict__ s_first, const u32 *__restrict__ s_slot, u32 n,
                                u64 *__restrict__ slot_out) {
+  HUMID_GUARD_LAST_VGPR();
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n) return;
   slot_out[s_slot[u]] = ((u64)(l_ismax[u] ? s_first[u] : NONE32) << 32) | l_cid[u];
@@ -341,6 +349,7 @@ __global__ void k_export_clusters(const u32 *__restrict__ flag, const u32 *__res
                                   const u32 *__restrict__ maxleaf, const u64 *__restrict__ cl_size,
                                   const u32 *__restrict__ cnt, u32 n, u64 *o_size, u32 *o_maxcount,
                                   u32 *o_maxleaf) {
+  HUMID_GUARD_LAST_VGPR();
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n || !flag[u]) return;
   const u32 c = pos[u];

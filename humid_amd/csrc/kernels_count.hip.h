@@ -23,6 +23,7 @@ __global__ void __launch_bounds__(256)
 k_hash_insert(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n_reads,
               Slot *tab, u32 cap_log2, u32 *__restrict__ slot_of_read, u64 range_lo, u64 range_hi,
               u32 max_probe, ull *ctr) {
+  HUMID_GUARD_LAST_VGPR();
   const u32 mask = (1u << cap_log2) - 1u;
   const u32 cap = 1u << cap_log2;
   for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
@@ -84,6 +85,7 @@ __device__ __forceinline__ u32 block_rank(bool flag, u32 *lds /* >= 4 u32 */, u3
 __global__ void __launch_bounds__(256)
 k_compact_table(const Slot *__restrict__ tab, u32 n_slots, u64 *__restrict__ uniq_word,
                 u32 *__restrict__ uniq_slot, u32 uniq_cap, ull *ctr) {
+  HUMID_GUARD_LAST_VGPR();
   __shared__ u32 lds[8];
   const u32 chunk = (n_slots + gridDim.x - 1) / gridDim.x;
   const u32 lo = blockIdx.x * chunk;
@@ -154,6 +156,7 @@ struct ReadTagOp {               // values_input transform: read index | exclude
 // first position of every bucket in the partitioned key array (binary search)
 __global__ void k_part_bounds(const u64 *__restrict__ keys, u32 n, u32 pb, u32 n_parts, u32 *__restrict__ pbeg,
                               u32 *__restrict__ ucount) {
+  HUMID_GUARD_LAST_VGPR();
   u32 p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > n_parts) return;
   if (p == n_parts) { pbeg[p] = n; ucount[p] = 0; return; }   // ucount tail: scan sentinel
@@ -180,6 +183,7 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
             u32 n_reads, u32 pb, u64 klo, u64 kscale, u32 kshift, u64 *__restrict__ pad_word,
             uint2 *__restrict__ pad_cf,
             u32 *__restrict__ ucount, u32 *__restrict__ pusable, u32 *__restrict__ pslot, ull *ctr) {
+  HUMID_GUARD_LAST_VGPR();
   __shared__ u64 lkey[LDS_SLOTS + 1];
   __shared__ u32 lcnt[LDS_SLOTS + 1];
   __shared__ u32 lfirst[LDS_SLOTS + 1];
@@ -332,6 +336,7 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
 // the counters were zeroed at the start of the stage)
 __global__ void __launch_bounds__(256)
 k_part_totals(const u32 *__restrict__ ucount, const u32 *__restrict__ pusable, u32 n_parts, ull *ctr) {
+  HUMID_GUARD_LAST_VGPR();
   __shared__ u32 lds[4];
   u32 u = 0, us = 0;                    // both totals are < 2^32 (reads < 2^31)
   for (u32 p = blockIdx.x * blockDim.x + threadIdx.x; p < n_parts; p += gridDim.x * blockDim.x) { u += ucount[p]; us += pusable[p]; }
@@ -352,6 +357,7 @@ k_compact_padded(const u64 *__restrict__ pad_word, const uint2 *__restrict__ pad
                  const u32 *__restrict__ pbeg, const u32 *__restrict__ ucount,
                  const u32 *__restrict__ ubase, u32 n_parts, u64 *__restrict__ uniq_word,
                  u32 *__restrict__ uniq_slot, u32 *__restrict__ s_cnt, u32 *__restrict__ s_first) {
+  HUMID_GUARD_LAST_VGPR();
   const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const u32 lane = threadIdx.x & 63;
   if (wave >= n_parts) return;
@@ -370,6 +376,7 @@ k_compact_padded(const u64 *__restrict__ pad_word, const uint2 *__restrict__ pad
 // after the sort, padded variant: gather count / first read of rank i (one 8-byte gather)
 __global__ void k_post_sort_padded(const u32 *__restrict__ s_slot, const uint2 *__restrict__ pad_cf, u32 n,
                                    u32 *__restrict__ s_cnt, u32 *__restrict__ s_first) {
+  HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const uint2 cf = pad_cf[s_slot[i]];
@@ -381,6 +388,7 @@ __global__ void k_post_sort_padded(const u32 *__restrict__ s_slot, const uint2 *
 // after the sort: per rank i gather count / first read from the table
 __global__ void k_post_sort(const u32 *__restrict__ s_slot, const Slot *__restrict__ tab, u32 n,
                             u32 *__restrict__ s_cnt, u32 *__restrict__ s_first) {
+  HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const Slot sl = tab[s_slot[i]];

@@ -29,10 +29,13 @@ struct ComboPlan {
 
 // bucket key of combo `cb` for every unique word (fields concatenated, most significant first)
 // Kernel arguments derived from the plan are passed BY VALUE in small structs and indexed
-// STATICALLY (unrolled loops with a predicate).  A 1 KB plan struct indexed dynamically in the
-// kernarg segment -- and equally a plan freshly uploaded to device memory and read through
-// wave-uniform (scalar) loads -- returned stale fields for single waves on gfx950 / ROCm 7.2
-// (5-25 of 219 k edges lost at 10 M reads, tools/det_check.py), so neither form is used.
+// STATICALLY (unrolled loops with a predicate): they then live in scalar registers.  History
+// (DESIGN.md section 3a): with the whole plan passed as one struct and its u8 field tables indexed
+// dynamically, hipcc emitted vector byte loads and kept the loaded shift in the LAST allocated VGPR
+// (v7 of 8) of k_combo_keys -- the one register that this platform occasionally overwrites with the
+// lane number (see HUMID_GUARD_LAST_VGPR in common.hip.h): single waves computed wrong bucket keys
+// and 5-60 of 219 k neighbour pairs were lost per 10 M-read run.  Both defences are kept: no plan
+// value sits in a vector register, and no kernel's last register holds anything.
 template <class WT>
 struct EarlierMasksT {
   WT m[MAX_COMBOS];
@@ -48,6 +51,7 @@ struct ComboFields {
 template <class KeyT, class WT>
 __global__ void k_combo_keys(const WT *__restrict__ s_word, u32 n, ComboFields cf,
                              KeyT *__restrict__ key, u32 *__restrict__ val) {
+  HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const WT w = s_word[i];
@@ -105,6 +109,7 @@ k_pairs(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, u32 i0, u32 
         EarlierMasksT<WT> em, u32 cb, u32 distance, u32 *deg, u32 *parent,
         const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, u32 *__restrict__ pc,
         const u32 *__restrict__ poff, u64 *__restrict__ edges, u8 *__restrict__ had) {
+  HUMID_GUARD_LAST_VGPR();
   // W: the words IN THE ORDER WALKED (the sorted unique array for the prefix combo, a gathered
   // copy in bucket order for the sorted combos), so the inner loop is one sequential, coalesced
   // stream; the ranks V[] are only loaded for the pairs that are found.
@@ -151,6 +156,7 @@ k_pairs(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, u32 i0, u32 
 template <class WT>
 __global__ void k_gather_bucket_words(const WT *__restrict__ s_word, const u32 *__restrict__ V, u32 n,
                                       WT *__restrict__ wv) {
+  HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) wv[i] = s_word[V[i]];
 }
@@ -160,6 +166,7 @@ template <bool FILL>
 __global__ void __launch_bounds__(256)
 k_edges_apply(const u64 *__restrict__ edges, u64 n_edges, u32 n_nodes, u32 *deg, u32 *parent,
               const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, ull *ctr) {
+  HUMID_GUARD_LAST_VGPR();
   for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n_edges; k += (u64)gridDim.x * blockDim.x) {
     const u64 ed = edges[k];
     const u32 a = (u32)(ed >> 32), b = (u32)ed;
@@ -181,6 +188,7 @@ template <class KeyT>
 __global__ void __launch_bounds__(256)
 k_select_keyrange(const u64 *__restrict__ s_word, u32 n, ComboFields cf, u64 klo, u64 khi,
                   KeyT *__restrict__ key_out, u32 *__restrict__ val_out, ull *ctr) {
+  HUMID_GUARD_LAST_VGPR();
   __shared__ u32 lds[8];
   const u32 chunk = (n + gridDim.x - 1) / gridDim.x;
   const u32 lo = blockIdx.x * chunk;
@@ -255,6 +263,7 @@ __global__ void __launch_bounds__(256)
 k_edit_join(const KeyT *__restrict__ KX, const u32 *__restrict__ VX, const KeyT *__restrict__ KY,
             const u32 *__restrict__ VY, u32 n, const WT *__restrict__ words, u32 word_nt, u32 distance,
             u32 *__restrict__ pc, const u32 *__restrict__ poff, u64 *__restrict__ edges) {
+  HUMID_GUARD_LAST_VGPR();
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const KeyT key = KX[t];
@@ -279,6 +288,7 @@ k_edit_join(const KeyT *__restrict__ KX, const u32 *__restrict__ VX, const KeyT 
 
 // head[i] = 1 where a new value starts in the sorted 64-bit array; head[n] = 0 (scan sentinel)
 __global__ void k_heads_u64(const u64 *__restrict__ sorted, u32 n, u32 *__restrict__ head) {
+  HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n) return;
   head[i] = (i < n && (i == 0 || sorted[i] != sorted[i - 1])) ? 1u : 0u;
@@ -286,6 +296,7 @@ __global__ void k_heads_u64(const u64 *__restrict__ sorted, u32 n, u32 *__restri
 
 __global__ void k_compact_heads_u64(const u64 *__restrict__ sorted, const u32 *__restrict__ head,
                                     const u32 *__restrict__ hpos, u32 n, u64 *__restrict__ out) {
+  HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && head[i]) out[hpos[i]] = sorted[i];
 }
@@ -293,6 +304,7 @@ __global__ void k_compact_heads_u64(const u64 *__restrict__ sorted, const u32 *_
 // every CSR row ascending (the order NLeaf::neighbours has under the trie hypotheses H1+H2)
 __global__ void __launch_bounds__(256)
 k_sort_lists(const u32 *__restrict__ off, u32 n, u32 *idx) {
+  HUMID_GUARD_LAST_VGPR();
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n) return;
   const u32 b = off[u], d = off[u + 1] - b;
@@ -342,6 +354,7 @@ k_sort_lists(const u32 *__restrict__ off, u32 n, u32 *idx) {
 
 // flatten the forest and count the leaves of every component at its root
 __global__ void k_comp_stats(const u32 *__restrict__ deg, u32 *P, u32 n, u32 *csize) {
+  HUMID_GUARD_LAST_VGPR();
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n || deg[u] == 0) return;
   const u32 root = uf_find(P, u);
@@ -349,23 +362,36 @@ __global__ void k_comp_stats(const u32 *__restrict__ deg, u32 *P, u32 n, u32 *cs
   atomicAdd(&csize[root], 1u);
 }
 
-// M = leaves with >= 1 neighbour, Mbig = those in components larger than SMALL_COMP
+// M = leaves with >= 1 neighbour, Mbig = those in components larger than SMALL_COMP, and the sum of
+// the degrees (= 2E) in 64 bits: the CSR offsets are 32-bit, so the host must see an overflow
+// BEFORE it sizes nbr_idx from a wrapped scan
 __global__ void __launch_bounds__(256)
 k_comp_count(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *__restrict__ csize, u32 n,
              ull *ctr) {
+  HUMID_GUARD_LAST_VGPR();
   __shared__ u32 lds[4];
+  __shared__ ull ldeg;
+  if (threadIdx.x == 0) ldeg = 0;
   u32 m = 0, mb = 0;
+  ull ds = 0;
   for (u32 u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
-    if (deg[u]) {
+    const u32 dg = deg[u];
+    if (dg) {
       m++;
+      ds += dg;
       if (csize[P[u]] > SMALL_COMP) mb++;              // P was flattened by k_comp_stats
     }
   }
-  const u32 tm = block_sum(m, lds);
+  const u32 tm = block_sum(m, lds);                    // (its barriers also publish ldeg = 0)
   const u32 tb = block_sum(mb, lds);
+#pragma unroll
+  for (u32 d = 32; d >= 1; d >>= 1) ds += __shfl_xor(ds, d);
+  if ((threadIdx.x & 63) == 0 && ds) atomicAdd(&ldeg, ds);
+  __syncthreads();
   if (threadIdx.x == 0) {
     if (tm) atomicAdd(&ctr[CTR_NONSINGLE], (ull)tm);
     if (tb) atomicAdd(&ctr[CTR_MEMBERS], (ull)tb);
+    if (ldeg) atomicAdd(&ctr[CTR_EDGES], ldeg);
   }
 }
 
@@ -373,18 +399,21 @@ k_comp_count(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *
 // n + 1 entries: the extra one is the sentinel of the exclusive scan)
 __global__ void k_graph_init(u32 *__restrict__ parent, u32 *__restrict__ deg, u32 *__restrict__ csize,
                              u32 *__restrict__ cur, u32 n) {
+  HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { parent[i] = i; deg[i] = 0; csize[i] = 0; cur[i] = 0; }
   if (i == n) deg[i] = 0;
 }
 
 __global__ void k_iota(u32 *p, u32 n) {
+  HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
 }
 
 // explicit-graph entry point: union every CSR entry (u, nbr)
 __global__ void k_union_csr(const u32 *__restrict__ off, const u32 *__restrict__ idx, u32 n, u32 *P) {
+  HUMID_GUARD_LAST_VGPR();
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n) return;
   for (u32 k = off[u]; k < off[u + 1]; k++)
@@ -395,6 +424,7 @@ __global__ void k_union_csr(const u32 *__restrict__ off, const u32 *__restrict__
 __global__ void __launch_bounds__(256)
 k_member_keys(const u32 *__restrict__ deg, u32 *P, const u32 *__restrict__ csize, u32 n, u64 *mkeys,
               ull *ctr) {
+  HUMID_GUARD_LAST_VGPR();
   __shared__ u32 lds[8];
   const u32 chunk = (n + gridDim.x - 1) / gridDim.x;
   const u32 lo = blockIdx.x * chunk;

@@ -15,6 +15,7 @@
 __global__ void __launch_bounds__(256)
 k_read_map(const u32 *__restrict__ slot_of_read, const u64 *__restrict__ slot_out, u32 n_reads,
            u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
+  HUMID_GUARD_LAST_VGPR();
   for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
     const u32 s = slot_of_read[r];
     u32 c = 0;
@@ -36,6 +37,7 @@ k_read_map(const u32 *__restrict__ slot_of_read, const u64 *__restrict__ slot_ou
 __global__ void __launch_bounds__(256)
 k_read_map_part(const u32 *__restrict__ vals, const u32 *__restrict__ pslot, const u64 *__restrict__ slot_out,
                 u32 n_reads, u32 *__restrict__ packed) {
+  HUMID_GUARD_LAST_VGPR();
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_reads; i += gridDim.x * blockDim.x) {
     const u32 r = vals[i] & 0x7fffffffu;
     if (r >= n_reads) continue;
@@ -58,6 +60,7 @@ __global__ void __launch_bounds__(256)
 k_read_map_bucket(const u32 *__restrict__ vals, const u32 *__restrict__ pslot, const u64 *__restrict__ slot_out,
                   const u32 *__restrict__ pbeg, const u32 *__restrict__ ucount, u32 n_reads,
                   u32 *__restrict__ packed) {
+  HUMID_GUARD_LAST_VGPR();
   __shared__ u64 lres[LDS_SLOTS + 1];
   const u32 b = blockIdx.x;
   const u32 beg = pbeg[b], end = pbeg[b + 1];
@@ -83,6 +86,7 @@ k_read_map_bucket(const u32 *__restrict__ vals, const u32 *__restrict__ pslot, c
 __global__ void __launch_bounds__(256)
 k_read_map_packed(const u32 *__restrict__ slot_of_read, const u64 *__restrict__ slot_out, u32 n_reads,
                   u32 *__restrict__ packed) {
+  HUMID_GUARD_LAST_VGPR();
   for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
     const u32 s = slot_of_read[r];
     u32 c = 0;
@@ -96,6 +100,7 @@ k_read_map_packed(const u32 *__restrict__ slot_of_read, const u64 *__restrict__ 
 
 __global__ void __launch_bounds__(256)
 k_split_out(const u32 *__restrict__ packed, u32 n_reads, u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
+  HUMID_GUARD_LAST_VGPR();
   for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
     const u32 t = packed[r];
     cluster_id[r] = t & 0x7fffffffu;
@@ -128,6 +133,7 @@ struct OwnedRangeFlagOp {       // 1 for the usable reads whose word lies in [lo
 __global__ void __launch_bounds__(256)
 k_gather_owned(const u64 *__restrict__ words, const u8 *__restrict__ filtered, const u32 *__restrict__ opos,
                u64 lo, u64 hi, u32 n_reads, u64 *__restrict__ own_words) {
+  HUMID_GUARD_LAST_VGPR();
   for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
     if (filtered[r]) continue;
     const u64 w = words[r];
@@ -145,6 +151,7 @@ struct OwnedFlagOp {            // 1 for the reads this rank counted (global-tab
 __global__ void __launch_bounds__(256)
 k_owned_results(const u32 *__restrict__ slot_of_read, const u32 *__restrict__ opos,
                 const u64 *__restrict__ slot_out, u32 n_reads, u32 *__restrict__ packed) {
+  HUMID_GUARD_LAST_VGPR();
   for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
     const u32 s = slot_of_read[r];
     if (s == NOSLOT) continue;
@@ -157,6 +164,7 @@ k_owned_results(const u32 *__restrict__ slot_of_read, const u32 *__restrict__ op
 __global__ void __launch_bounds__(256)
 k_owner_of(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n, OwnerRanges rg,
            u32 n_ranks, u8 *__restrict__ owner) {
+  HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 o = n_ranks;
@@ -171,6 +179,7 @@ k_owner_of(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n
 
 // first position of every owner in the owner-sorted order (n_ranks + 2 boundaries)
 __global__ void k_owner_bounds(const u8 *__restrict__ sorted_owner, u32 n, u32 n_ranks, u32 *__restrict__ bounds) {
+  HUMID_GUARD_LAST_VGPR();
   u32 q = threadIdx.x;
   if (q > n_ranks + 1) return;
   u32 lo = 0, hi = n;
@@ -185,6 +194,7 @@ __global__ void k_owner_bounds(const u8 *__restrict__ sorted_owner, u32 n, u32 n
 __global__ void __launch_bounds__(256)
 k_scatter_results(const u32 *__restrict__ perm, const u32 *__restrict__ packed, u32 n_recv,
                   u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
+  HUMID_GUARD_LAST_VGPR();
   for (u32 k = blockIdx.x * blockDim.x + threadIdx.x; k < n_recv; k += gridDim.x * blockDim.x) {
     const u32 r = perm[k];
     const u32 t = packed[k];
@@ -200,6 +210,7 @@ k_scatter_results(const u32 *__restrict__ perm, const u32 *__restrict__ packed, 
 // bucket meet on one rank whatever the key distribution is
 __global__ void __launch_bounds__(256)
 k_combo_owner(const u64 *__restrict__ words, u32 n, ComboFields cf, u32 n_ranks, u8 *__restrict__ owner) {
+  HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64 w = words[i];
@@ -219,6 +230,7 @@ k_combo_owner(const u64 *__restrict__ words, u32 n, ComboFields cf, u32 n_ranks,
 __global__ void __launch_bounds__(256)
 k_route_items(const u64 *__restrict__ words, const u32 *__restrict__ counts, const u32 *__restrict__ perm, u32 n,
               u64 id_base, ulonglong2 *__restrict__ items) {
+  HUMID_GUARD_LAST_VGPR();
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const u32 i = perm[k];
@@ -227,6 +239,7 @@ k_route_items(const u64 *__restrict__ words, const u32 *__restrict__ counts, con
 
 __global__ void k_split_items(const ulonglong2 *__restrict__ items, u32 n, u64 *__restrict__ w,
                               u32 *__restrict__ id, u32 *__restrict__ cnt) {
+  HUMID_GUARD_LAST_VGPR();
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const ulonglong2 it = items[k];
@@ -240,6 +253,7 @@ __global__ void k_split_items(const ulonglong2 *__restrict__ items, u32 n, u64 *
 __global__ void __launch_bounds__(256)
 k_edge_records(const u64 *__restrict__ pos_edges, u32 n_edges, const u32 *__restrict__ id_of, u32 id_base,
                const u32 *__restrict__ cnt_of, ulonglong2 *__restrict__ rec) {
+  HUMID_GUARD_LAST_VGPR();
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_edges) return;
   const u64 e = pos_edges[k];
@@ -251,11 +265,13 @@ k_edge_records(const u64 *__restrict__ pos_edges, u32 n_edges, const u32 *__rest
 }
 
 __global__ void k_iota_base(u32 *p, u32 n, u32 base) {
+  HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = base + i;
 }
 
 __global__ void k_gather_u32(const u32 *__restrict__ src, const u32 *__restrict__ idx, u32 n, u32 *__restrict__ dst) {
+  HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[idx[i]];
 }
@@ -264,6 +280,7 @@ __global__ void k_gather_u32(const u32 *__restrict__ src, const u32 *__restrict_
 // per edge record (1 or 2)
 __global__ void k_edge_ends(const u64 *__restrict__ edges, u32 n_edges, u32 stride, u32 *__restrict__ ends,
                             u32 *__restrict__ slot) {
+  HUMID_GUARD_LAST_VGPR();
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_edges) return;
   const u64 e = edges[(size_t)k * stride];
@@ -275,6 +292,7 @@ __global__ void k_edge_ends(const u64 *__restrict__ edges, u32 n_edges, u32 stri
 
 // head[i] = 1 where a new value starts in the sorted array; head[n] = 0 (scan sentinel)
 __global__ void k_heads_u32(const u32 *__restrict__ sorted, u32 n, u32 *__restrict__ head) {
+  HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n) return;
   head[i] = (i < n && (i == 0 || sorted[i] != sorted[i - 1])) ? 1u : 0u;
@@ -282,6 +300,7 @@ __global__ void k_heads_u32(const u32 *__restrict__ sorted, u32 n, u32 *__restri
 
 __global__ void k_compact_heads_u32(const u32 *__restrict__ sorted, const u32 *__restrict__ head,
                                     const u32 *__restrict__ hpos, u32 n, u32 *__restrict__ out) {
+  HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && head[i]) out[hpos[i]] = sorted[i];
 }
@@ -293,6 +312,7 @@ __global__ void k_compact_heads_u32(const u32 *__restrict__ sorted, const u32 *_
 __global__ void k_relabel_ends(const u32 *__restrict__ slot_s, const u32 *__restrict__ head,
                                const u32 *__restrict__ hpos, u32 n_ends, const u64 *__restrict__ records,
                                u32 stride, u32 *__restrict__ cends, u32 *__restrict__ node_cnt) {
+  HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_ends) return;
   const u32 node = hpos[i] + head[i] - 1u;
@@ -306,6 +326,7 @@ __global__ void k_relabel_ends(const u32 *__restrict__ slot_s, const u32 *__rest
 
 // (position of the smaller end, position of the larger end) -> one 64-bit compact edge
 __global__ void k_pack_cedges(const u32 *__restrict__ cends, u32 n_edges, u64 *__restrict__ out) {
+  HUMID_GUARD_LAST_VGPR();
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < n_edges) out[k] = ((u64)cends[2 * k] << 32) | cends[2 * k + 1];
 }
@@ -313,12 +334,14 @@ __global__ void k_pack_cedges(const u32 *__restrict__ cends, u32 n_edges, u64 *_
 // routed copy of the usable reads' words (owner-major order of humid_stage_owner_perm)
 __global__ void __launch_bounds__(256)
 k_route_words(const u64 *__restrict__ words, const u32 *__restrict__ perm, u32 n, u64 *__restrict__ out) {
+  HUMID_GUARD_LAST_VGPR();
   for (u32 k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) out[k] = words[perm[k]];
 }
 
 // ---- cluster ids of one rank's unique words from the replicated compact graph ----
 // creator (smallest member = the leaf whose walk step created the cluster) of every compact cluster
 __global__ void k_xid_creators(const u32 *__restrict__ ccid, u32 n_nodes, u32 n_clusters, u32 *creator) {
+  HUMID_GUARD_LAST_VGPR();
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_nodes) return;
   const u32 c = ccid[k];
@@ -330,6 +353,7 @@ __global__ void k_xid_creators(const u32 *__restrict__ ccid, u32 n_nodes, u32 n_
 __global__ void k_xid_base(const u32 *__restrict__ nodes, const u32 *__restrict__ creator, u32 n_nodes,
                            u32 n_clusters, u32 goff, u32 u_local, u32 *__restrict__ base_id,
                            u32 *__restrict__ mark_cr) {
+  HUMID_GUARD_LAST_VGPR();
   u32 c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_clusters) return;
   const u32 k = creator[c];
@@ -341,6 +365,7 @@ __global__ void k_xid_base(const u32 *__restrict__ nodes, const u32 *__restrict_
 
 // mark[i] = compact position + 1 of local unique word i (0 = singleton)
 __global__ void k_xid_mark(const u32 *__restrict__ nodes, u32 n_nodes, u32 goff, u32 u_local, u32 *__restrict__ mark) {
+  HUMID_GUARD_LAST_VGPR();
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_nodes) return;
   const u32 g = nodes[k];
@@ -350,6 +375,7 @@ __global__ void k_xid_mark(const u32 *__restrict__ nodes, u32 n_nodes, u32 goff,
 // first[0] = compact nodes below goff, first[1] = compact creators below goff (binary searches)
 __global__ void k_xid_first(const u32 *__restrict__ nodes, const u32 *__restrict__ creator, u32 n_nodes,
                             u32 n_clusters, u32 goff, u32 *__restrict__ first) {
+  HUMID_GUARD_LAST_VGPR();
   if (threadIdx.x == 0) {
     u32 lo = 0, hi = n_nodes;
     while (lo < hi) { const u32 mid = lo + ((hi - lo) >> 1); if (nodes[mid] < goff) lo = mid + 1; else hi = mid; }
@@ -378,6 +404,7 @@ __global__ void __launch_bounds__(256)
 k_xid_assign(const u32 *__restrict__ mark, const u64 *__restrict__ scan, const u32 *__restrict__ first,
              const u32 *__restrict__ ccid, const u8 *__restrict__ cismax, const u32 *__restrict__ base_id,
              u32 n_clusters, u32 goff, u32 u_local, u32 *__restrict__ l_cid, u8 *__restrict__ l_ismax) {
+  HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= u_local) return;
   const u32 m = mark[i];
@@ -394,12 +421,14 @@ k_xid_assign(const u32 *__restrict__ mark, const u64 *__restrict__ scan, const u
 }
 
 __global__ void k_widen32(const u32 *__restrict__ in, u32 n, u64 *__restrict__ out) {
+  HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i];
 }
 
 __global__ void k_creator_sizes(const u32 *__restrict__ flag, const u32 *__restrict__ pos,
                                 const u64 *__restrict__ cl_size, u32 n, u64 *__restrict__ out) {
+  HUMID_GUARD_LAST_VGPR();
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u < n && flag[u]) out[pos[u]] = cl_size[u];
 }
@@ -410,6 +439,7 @@ __global__ void k_creator_sizes(const u32 *__restrict__ flag, const u32 *__restr
 __global__ void __launch_bounds__(256)
 k_top_hist(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n_reads, u64 lo, u64 scale,
            u32 bits, u32 *hist) {
+  HUMID_GUARD_LAST_VGPR();
   extern __shared__ u32 lh[];
   const u32 n_bins = 1u << bits;
   for (u32 b = threadIdx.x; b < n_bins; b += blockDim.x) lh[b] = 0;
@@ -424,7 +454,8 @@ k_top_hist(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n
     if (lh[b]) atomicAdd(&hist[b], lh[b]);
 }
 
-__global__ void k_at_least_double(u64 a, u64 b, int *out) { *out = at_least_double(a, b) ? 1 : 0; }
+__global__ void k_at_least_double(u64 a, u64 b, int *out) {
+  HUMID_GUARD_LAST_VGPR(); *out = at_least_double(a, b) ? 1 : 0; }
 
 
 #endif  // HUMID_KERNELS_MAP_HIP_H

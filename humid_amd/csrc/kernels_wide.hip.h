@@ -19,6 +19,7 @@
 __global__ void __launch_bounds__(256)
 k_wide_keys_lo(const W2 *__restrict__ words, const u8 *__restrict__ filtered, u32 n, u64 *__restrict__ key,
                u32 *__restrict__ val, ull *ctr) {
+  HUMID_GUARD_LAST_VGPR();
   __shared__ u32 lds[8];
   u32 usable = 0;
   for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
@@ -35,6 +36,7 @@ k_wide_keys_lo(const W2 *__restrict__ words, const u8 *__restrict__ filtered, u3
 __global__ void __launch_bounds__(256)
 k_wide_keys_hi(const W2 *__restrict__ words, const u8 *__restrict__ filtered, const u32 *__restrict__ v1, u32 n,
                u32 hbits, u64 *__restrict__ key) {
+  HUMID_GUARD_LAST_VGPR();
   const u64 hmask = hbits >= 64 ? ~0ull : ((1ull << hbits) - 1ull);
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const u32 r = v1[i];
@@ -47,6 +49,7 @@ k_wide_keys_hi(const W2 *__restrict__ words, const u8 *__restrict__ filtered, co
 // pass 3 input (n = 64 only): key = filtered flag
 __global__ void __launch_bounds__(256)
 k_wide_keys_flag(const u8 *__restrict__ filtered, const u32 *__restrict__ v2, u32 n, u32 *__restrict__ key) {
+  HUMID_GUARD_LAST_VGPR();
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     key[i] = (filtered && filtered[v2[i]]) ? 1u : 0u;
 }
@@ -54,6 +57,7 @@ k_wide_keys_flag(const u8 *__restrict__ filtered, const u32 *__restrict__ v2, u3
 // words in sorted order (one 16-byte gather per read)
 __global__ void __launch_bounds__(256)
 k_wide_gather(const W2 *__restrict__ words, const u32 *__restrict__ v, u32 n, u32 hbits, W2 *__restrict__ sw) {
+  HUMID_GUARD_LAST_VGPR();
   const u64 hmask = hbits >= 64 ? ~0ull : ((1ull << hbits) - 1ull);
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     W2 w = words[v[i]];
@@ -66,6 +70,7 @@ k_wide_gather(const W2 *__restrict__ words, const u32 *__restrict__ v, u32 n, u3
 // positions); head[n] = 0 is the sentinel of the exclusive scan
 __global__ void __launch_bounds__(256)
 k_wide_heads(const W2 *__restrict__ sw, u32 n, const ull *__restrict__ ctr, u32 *__restrict__ head) {
+  HUMID_GUARD_LAST_VGPR();
   const u32 usable = (u32)ctr[CTR_USABLE];
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x)
     head[i] = (i < usable && i < n && (i == 0 || !w_eq(sw[i], sw[i - 1]))) ? 1u : 0u;
@@ -77,6 +82,7 @@ __global__ void __launch_bounds__(256)
 k_wide_unique(const W2 *__restrict__ sw, const u32 *v, const u32 *__restrict__ head,
               const u32 *__restrict__ hpos, u32 n, const ull *__restrict__ ctr, W2 *__restrict__ s_word,
               u32 *__restrict__ s_first, u32 *__restrict__ start, u32 *__restrict__ pslot, u32 *vals) {
+  HUMID_GUARD_LAST_VGPR();
   const u32 usable = (u32)ctr[CTR_USABLE];
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const u32 r = v[i];
@@ -97,6 +103,7 @@ k_wide_unique(const W2 *__restrict__ sw, const u32 *v, const u32 *__restrict__ h
 // count = run length; the slot of leaf u is u itself
 __global__ void k_wide_counts(const u32 *__restrict__ start, u32 n_unique, u32 *__restrict__ s_cnt,
                               u32 *__restrict__ s_slot) {
+  HUMID_GUARD_LAST_VGPR();
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u < n_unique) { s_cnt[u] = start[u + 1] - start[u]; s_slot[u] = u; }
 }

@@ -263,7 +263,8 @@ int humid_stage_scatter(humid_ctx *ctx, const uint32_t *d_perm, const uint32_t *
  * indices (rank offset + local walk index); only the pairs -- about 2 % of the reads -- and the
  * counts of their endpoints are replicated, and clustered as a compact graph.
  *   humid_stage_plan_info:   combinations of the pigeonhole plan for plan_unique words in total (all
- *     ranks pass the same number) and the bits of the shortest prefix combination.
+ *     ranks pass the same number) and the bits of the shortest prefix combination.  Host arithmetic
+ *     only: ctx may be NULL (then the automatic plan is reported and no GPU is needed).
  *   humid_stage_combo_route: (word, id | count << 32) items of this rank's ascending unique array
  *     (id = id_base + index) in destination-major order, *d_items[2k] = word, [2k+1] = id | count<<32;
  *     counts[q] = items for rank q.

@@ -705,7 +705,7 @@ void orc_export_clusters(const orc_ctx *c, uint64_t *size, uint64_t *max_count,
 
 int orc_dedup_run(const uint64_t *words, const uint8_t *filtered, uint64_t n_reads,
                   uint32_t word_nt, uint32_t distance, uint32_t method,
-                  uint32_t *cluster_id, uint8_t *keep, uint64_t *summary4,
+                  uint32_t *cluster_id, uint8_t *keep, uint64_t *summary5,
                   double *phase_seconds) {
   orc_ctx *c = orc_create(word_nt);
   if (!c) return -1;
@@ -719,11 +719,12 @@ int orc_dedup_run(const uint64_t *words, const uint8_t *filtered, uint64_t n_rea
   double t3 = now_s();
   orc_map_reads(c, words, filtered, n_reads, cluster_id, keep);
   double t4 = now_s();
-  if (summary4) {
-    summary4[0] = c->total;
-    summary4[1] = c->usable;
-    summary4[2] = c->unique;
-    summary4[3] = c->n_clusters;
+  if (summary5) {
+    summary5[0] = c->total;
+    summary5[1] = c->usable;
+    summary5[2] = c->unique;
+    summary5[3] = c->n_clusters;
+    summary5[4] = orc_n_edges(c);
   }
   if (phase_seconds) {
     phase_seconds[0] = t1 - t0;

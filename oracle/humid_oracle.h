@@ -131,10 +131,11 @@ void     orc_export_clusters(const orc_ctx *c, uint64_t *size, uint64_t *max_cou
 
 /* one-call convenience: read -> neighbours -> clusters -> map; returns 0.
  * method bit 0: maximum clustering (-x); bit 1: Levenshtein instead of Hamming neighbours (-e).
+ * summary5 (may be NULL): total, usable, unique, clusters, neighbour pairs.
  * phase_seconds (may be NULL): [0] read+count, [1] neighbours, [2] clusters, [3] map */
 int orc_dedup_run(const uint64_t *words, const uint8_t *filtered, uint64_t n_reads,
                   uint32_t word_nt, uint32_t distance, uint32_t method,
-                  uint32_t *cluster_id, uint8_t *keep, uint64_t *summary4,
+                  uint32_t *cluster_id, uint8_t *keep, uint64_t *summary5,
                   double *phase_seconds);
 
 #ifdef __cplusplus

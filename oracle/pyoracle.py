@@ -292,13 +292,13 @@ def dedup_run(words, filtered, word_nt, distance=1, method=0, edit=False):
     assert len(f) == n
     cid = np.zeros(n, dtype=np.uint32)
     keep = np.zeros(n, dtype=np.uint8)
-    s = np.zeros(4, dtype=np.uint64)
+    s = np.zeros(5, dtype=np.uint64)
     ph = np.zeros(4, dtype=np.float64)
     rc = lib().orc_dedup_run(_p(w, u64p), _p(f, u8p), n, word_nt, distance, method,
                              _p(cid, u32p), _p(keep, u8p), _p(s, u64p), _p(ph, f64p))
     if rc != 0:
         raise RuntimeError("orc_dedup_run failed: %d" % rc)
-    summary = dict(total=int(s[0]), usable=int(s[1]), unique=int(s[2]), clusters=int(s[3]))
+    summary = dict(total=int(s[0]), usable=int(s[1]), unique=int(s[2]), clusters=int(s[3]), edges=int(s[4]))
     return cid, keep, summary, ph.tolist()
 
 

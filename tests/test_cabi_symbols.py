@@ -65,3 +65,44 @@ def test_header_is_plain_c_and_links(tmp_path):
     subprocess.check_call(cmd)
     out = subprocess.check_output([str(exe)]).decode()
     assert out.split()[0] == "1"
+
+
+def test_pigeonhole_plan_never_exceeds_its_tables():
+    """make_plan through humid_stage_plan_info with a NULL context (host arithmetic only).  The plan
+    tables hold 20 combinations; d >= 20 has no plan with so few (C(d+1, 1) = d+1) and must fall back
+    to the single all-pairs combination instead of writing past the tables (ADVICE round 1:
+    make_plan(24, 20) returned 21 combinations)."""
+    import ctypes as C
+    lib = _lib.load()
+    nc, pb = C.c_uint32(), C.c_uint32()
+    for n in (24,):
+        for m in (19, 20, 23, 24, 30):
+            assert lib.humid_stage_plan_info(None, n, m, 3_000_000, C.byref(nc), C.byref(pb)) == 0
+            assert (nc.value, pb.value) == ((20, 4) if m == 19 else (1, 0)), (n, m, nc.value, pb.value)
+    for n in range(1, 65):
+        for d in range(0, n + 3):
+            for u in (10, 3_000_000, 1 << 40):
+                assert lib.humid_stage_plan_info(None, n, d, u, C.byref(nc), C.byref(pb)) == 0
+                assert 1 <= nc.value <= 20 and pb.value <= min(64, 2 * n), (n, d, u, nc.value, pb.value)
+    # the metric configuration: two combinations of 12 nt
+    assert lib.humid_stage_plan_info(None, 24, 1, 2_700_000, C.byref(nc), C.byref(pb)) == 0
+    assert (nc.value, pb.value) == (2, 24)
+    assert lib.humid_stage_plan_info(None, 65, 1, 10, C.byref(nc), C.byref(pb)) == -2     # unsupported
+
+
+def test_every_kernel_guards_its_last_vector_register():
+    """common.hip.h: HUMID_GUARD_LAST_VGPR() is the first statement of every __global__ function of
+    the library (the platform defect of DESIGN.md section 3a overwrites a wave's last register)"""
+    import glob
+    n = 0
+    for p in glob.glob(os.path.join(ROOT, "humid_amd", "csrc", "*.hip*")):
+        src = open(p).read()
+        for m in re.finditer(r"__global__", src):
+            line_start = src.rfind("\n", 0, m.start()) + 1
+            if src[line_start:m.start()].lstrip().startswith("//"):
+                continue                                   # the word in a comment
+            body = src.index("{", m.end())
+            assert src[body + 1:body + 60].split(";")[0].strip() == "HUMID_GUARD_LAST_VGPR()", \
+                (os.path.basename(p), src[m.start():m.start() + 80])
+            n += 1
+    assert n >= 60

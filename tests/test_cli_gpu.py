@@ -154,3 +154,28 @@ def test_cli_edit_distance(tmp_path):
     assert annot == [(recs[0][i][0] + ":%d" % cid[i],) + recs[0][i][1:] for i in range(len(words))]
     assert dat(os.path.join(out, "neigh.dat")) == orc.histograms(p)["neigh"]
     assert "Calculating neighbours using Levenshtein distance... done." in open(tmp_path / "log.txt").read()
+
+
+def test_cli_output_write_errors_are_not_silent(tmp_path):
+    """a full disk (here: outputs that resolve to /dev/full) must end in a non-zero exit code, for
+    plain and for gzip outputs (short writes were swallowed, exit code 0)"""
+    if not os.path.exists("/dev/full"):
+        pytest.skip("no /dev/full")
+    files = synth_fastq(str(tmp_path / "in"), 3000, 5, n_files=1, read_len=36)
+    for gz in (False, True):
+        src = files[0]
+        if gz:
+            src = files[0] + ".gz"
+            with gzip.open(src, "wb") as fh:
+                fh.write(open(files[0], "rb").read())
+        out = tmp_path / ("out_gz" if gz else "out")
+        out.mkdir()
+        name = os.path.basename(src).replace(".fastq", "_dedup.fastq")
+        os.symlink("/dev/full", str(out / name))
+        p = subprocess.run([HUMID, "-d", str(out), "-l", str(tmp_path / "log.txt"), src],
+                           stderr=subprocess.PIPE)
+        assert p.returncode == 1, p.stderr
+        assert b"failed" in p.stderr
+        # the same command with a writable output succeeds
+        os.unlink(str(out / name))
+        assert subprocess.call([HUMID, "-d", str(out), "-l", str(tmp_path / "log.txt"), src]) == 0

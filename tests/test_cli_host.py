@@ -141,3 +141,94 @@ def test_truncated_gzip_is_not_silently_accepted(tmp_path):
     w_fast, _ = dump_words([bad], 24, str(tmp_path))
     w_slow, _ = dump_words([bad], 24, str(tmp_path), env={"HUMID_HOST_SLOW": "1"})
     assert len(w_fast) == len(w_slow) < 5000         # both paths stop where the stream breaks
+
+
+# ------------------------------------------------------------------------------------------
+# words.cpp against the reference's own known answers (tests/golden/ref_test_fastq.json =
+# /root/reference/tests/test_fastq.cc:9-166): FastQ files built from the golden cases, packed words
+# read back through --dump-words.  The oracle is not involved.
+# ------------------------------------------------------------------------------------------
+CODE = {"A": 0, "C": 1, "G": 2, "T": 3}
+
+
+def pack_expected(s):
+    """src/fastq.cc:146-161: A0 C1 G2 T3, anything else -> code of 'G' and filtered"""
+    w, filt = 0, 0
+    for ch in s:
+        if ch not in CODE:
+            filt = 1
+        w = (w << 2) | CODE.get(ch, 2)
+    return w, filt
+
+
+def write_fq(path, records):
+    with open(path, "w") as fh:
+        for name, seq in records:
+            fh.write("@%s\n%s\n+\n%s\n" % (name, seq, "I" * len(seq)))
+
+
+@pytest.mark.parametrize("slow", [False, True])
+def test_words_cpp_against_reference_vectors(slow, tmp_path, golden_dir):
+    import json
+    g = json.load(open(os.path.join(golden_dir, "ref_test_fastq.json")))
+    env = {"HUMID_HOST_SLOW": "1"} if slow else {}
+    checked = 0
+    # extractUMI (test_fastq.cc:9-46): the header UMI leads the word, 4 read bases follow
+    for k, c in enumerate(g["extract_umi"]):
+        d = tmp_path / ("u%d" % k)
+        d.mkdir()
+        f = str(d / "a.fastq")
+        seq = "CGTACGTA"
+        write_fq(f, [(c["header"], seq)] * 3)
+        n = len(c["expect"]) + 4
+        w, fl = dump_words([f], n, str(d), env=env)
+        ew, ef = pack_expected(c["expect"] + seq[:4])
+        assert w.tolist() == [ew] * 3 and fl.tolist() == [ef] * 3, c
+        checked += 1
+    # makeWord + getNucleotides (test_fastq.cc:48-110,157-166).  header_umi_size comes from the FIRST
+    # record of the first file (src/humid.cc:24-33), so a leading record with a UMI of that size sets
+    # it; nt_to_take follows from -n by ntFromFile (cases that split differently cannot be produced
+    # by a command line and are left to the nt_from_file vectors below)
+    for k, c in enumerate(g["get_nucleotides"] + g["make_word"]):
+        hdr, take, nf = c["header_umi_size"], c["nt_to_take"], len(c["seqs"])
+        n = hdr + sum(take)
+        from_file = sum(take)
+        rule = [from_file // nf] * nf
+        rule[-1] += from_file % nf                       # src/fastq.cc:220-230
+        if rule != take or n == 0:
+            continue
+        d = tmp_path / ("g%d" % k)
+        d.mkdir()
+        files = []
+        first_umi = "A" * hdr
+        # when the leading header's UMI is longer than the word it is clamped (src/humid.cc:54-56)
+        lead_umi = first_umi if "expect" not in c or c["ref"] != "test_fastq.cc:157-166" else "AAAAAA"
+        for fi in range(nf):
+            f = str(d / ("f%d.fastq" % fi))
+            lead = ("lead_" + lead_umi) if (fi == 0 and hdr) else "lead"
+            write_fq(f, [(lead, "ACGTACGTAC"), (c["headers"][fi], c["seqs"][fi])])
+            files.append(f)
+        w, fl = dump_words(files, n, str(d), env=env)
+        exp = c["expect"] if "expect" in c else "".join("ACGT"[x] for x in c["expect_data"])
+        ew, ef = pack_expected(exp)
+        assert len(w) == 2 and int(w[1]) == ew and int(fl[1]) == ef, (c, hex(int(w[1])), hex(ew))
+        if "expect_filtered" in c:
+            assert bool(fl[1]) == c["expect_filtered"]
+        checked += 1
+    assert checked >= len(g["extract_umi"]) + 6
+    # ntFromFile (test_fastq.cc:112-155) through the log of the plan
+    for k, c in enumerate(g["nt_from_file"]):
+        if c["length"] == 0 or c["length"] > 64:
+            continue
+        d = tmp_path / ("n%d" % k)
+        d.mkdir()
+        files = []
+        for fi in range(c["files"]):
+            f = str(d / ("f%d.fastq" % fi))
+            write_fq(f, [("r0", "ACGTACGTACGTACGTACGT")])
+            files.append(f)
+        dump_words(files, c["length"], str(d), env=env)
+        log = open(d / "log.txt").read()
+        assert "  header: 0" in log
+        for f, t in zip(files, c["expect"]):
+            assert "%s: %d\n" % (f, t) in log, (c, log)

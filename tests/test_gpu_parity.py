@@ -281,8 +281,8 @@ def test_ordered_buckets_are_chosen_for_uniform_prefixes_only():
 
 
 def test_repeatable_at_scale(dd):
-    """same input, same answer, run after run (guards the stale-kernel-argument bug recorded in
-    humid_hip.hip: single waves lost their edges 5-25 times per 219 k)"""
+    """same input, same answer, run after run (the edge loss of round 1, DESIGN.md section 3a, showed
+    as run-to-run differences: single waves computed wrong bucket keys)"""
     words, filt = synth_words(3_000_000, 1002, 24)
     ref = None
     for _ in range(4):
@@ -290,6 +290,50 @@ def test_repeatable_at_scale(dd):
         cur = (s["edges"], s["clusters"], s["unique"], int(cid.astype(np.uint64).sum()), int(keep.sum()))
         ref = ref or cur
         assert cur == ref
+
+
+def test_oracle_parity_at_scale(dd):
+    """3 M reads of the metric workload, every array bit for bit against the oracle, for each
+    exact-count variant: a loss of a few edges in 10^5 (the rate once seen at 10 M reads, DESIGN.md
+    section 3a) cannot hide at this size.  bench.py repeats the comparison on the full 10 M reads."""
+    words, filt = synth_words(3_000_000, 1002, 24)
+    check_against_oracle(dd, words, filt, 24, 1, False, deep=True)
+
+
+@pytest.fixture(scope="module")
+def dd1():
+    """one context with the default settings, for tests that do not depend on the count variant"""
+    d = humid_amd.Dedup()
+    yield d
+    d.close()
+
+
+@pytest.mark.parametrize("d", [19, 20, 23, 24, 40])
+def test_distances_beyond_every_pigeonhole_plan(dd1, d):
+    """-m 20 and above at n = 24 have no plan within the 20-combination tables: all pairs are
+    compared (the tables were overrun and neighbours silently wrong)"""
+    dd = dd1
+    words, filt = synth_words(1500, 40 + d, 24, p_sub=5e-2)
+    check_against_oracle(dd, words, filt, 24, d, False)
+    check_against_oracle(dd, words[:300], filt[:300], 24, d, True)
+
+
+def test_all_pairs_plan_refuses_huge_inputs(dd1):
+    dd = dd1
+    rng = np.random.default_rng(1)
+    w = rng.integers(0, 4 ** 24, size=400_000, dtype=np.uint64)
+    with pytest.raises(humid_amd.HumidError) as e:
+        dd.run(w, np.zeros(len(w), np.uint8), word_nt=24, distance=22)
+    assert e.value.code == -5
+
+
+def test_pair_count_overflow_is_reported(dd1):
+    """2E >= 2^32: the 32-bit adjacency offsets would wrap; the 64-bit degree sum sees it"""
+    dd = dd1
+    w = np.arange(70_000, dtype=np.uint64)          # 9-nt words, d = 9: all 2.4e9 pairs are neighbours
+    with pytest.raises(humid_amd.HumidError) as e:
+        dd.run(w, np.zeros(len(w), np.uint8), word_nt=9, distance=9)
+    assert e.value.code == -5
 
 
 def test_unsupported_and_invalid(dd):
