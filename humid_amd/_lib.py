@@ -22,7 +22,8 @@ class HumidSummary(C.Structure):
                 ("ms_count", C.c_float), ("ms_neighbours", C.c_float), ("ms_cluster", C.c_float),
                 ("ms_map", C.c_float), ("ms_total", C.c_float), ("ms_h2d", C.c_float),
                 ("ms_d2h", C.c_float), ("ms_k_insert", C.c_float), ("ms_k_pairs", C.c_float),
-                ("ms_k_cluster", C.c_float), ("ms_k_map", C.c_float), ("count_mode_used", C.c_uint32)]
+                ("ms_k_cluster", C.c_float), ("ms_k_map", C.c_float), ("ms_k_part", C.c_float),
+                ("ms_k_unperm", C.c_float), ("count_mode_used", C.c_uint32)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -130,7 +131,7 @@ def load(import_torch: bool = True):
             raise HumidLibraryError("%s does not export %s" % (SO_PATH, name)) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.humid_abi_version() != 1:
+    if lib.humid_abi_version() != 2:
         raise HumidLibraryError("ABI version mismatch")
     _LIB = lib
     return lib

@@ -20,6 +20,7 @@
 // entry point either runs on the GPU or fails.
 #include "common.hip.h"
 #include "kernels_count.hip.h"
+#include "kernels_part.hip.h"
 #include "kernels_graph.hip.h"
 #include "kernels_cluster.hip.h"
 #include "kernels_map.hip.h"
@@ -64,6 +65,15 @@ struct humid_ctx {
   DBuf x_slot, x_slot_s, x_cnt, x_cnts, x_rec, x_ncnt, x_route, x_creator, x_base, x_mark, x_markcr, x_scan, x_lcid, x_lismax,
        x_items, x_w, x_id, x_ids, x_ends, x_ends_s, x_head, x_hpos, x_nodes, x_cedges;   // multi-GPU exchange mode
   DBuf w_sorted, w_head, w_hpos, w_start;                                         // wide-word (sorted) counts
+  DBuf pt_work, unperm_rec;                                                       // LDS-staged partition / un-permute (kernels_part.hip.h)
+  bool use_tile_partition = true;   // option "tile_partition": 0 = library radix passes + one-kernel un-permute (round 1)
+  bool last_part_tiled = false;     // kev[39]..kev[40] bracket the second-level scatter of the last count
+  bool last_unperm_tiled = false;   // kev[36]..kev[41] bracket k_unperm_window of the last map
+  // cached answer of prefix_fits_ordered for (reads, word length, key map): the sampled histogram and
+  // its host wait run once per shape, not once per pass; an overflowing ordered run resets it
+  bool oc_valid = false, oc_fits = false;
+  u32 oc_n = 0, oc_nt = 0;
+  u64 oc_lo = 0, oc_scale = 0;
   u32 n_parts = 0;           // buckets of the last LDS-partitioned count (0: none, e.g. the sorted wide count)
   bool stage_map_timed = false;                                                   // kev[37..38] bracket the last humid_stage_map_dense
   bool last_count_sorted = false;                                                 // last count was the wide-word sort
@@ -80,7 +90,7 @@ struct humid_ctx {
   DBuf deg, nbr_off, nbr_idx, seg_k0, seg_v0, seg_ks, seg_vs, seg_ws, csize, cur;
   DBuf parent, mk0, mk1, cl_of, maxleaf, cl_size, flag, pos, cid, ismax, stk, tmp, scratch;
   hipEvent_t ev[6] = {};
-  hipEvent_t kev[40] = {};   // per-kernel timing: [0,1] insert, [2,3] cluster, [4..19] pairs fill, [20..35] pairs count
+  hipEvent_t kev[44] = {};   // per-kernel timing: [0,1] insert, [2,3] cluster, [4..19] pairs fill, [20..35] pairs count
   bool have_run = false;     // a full dedup run completed (all accessors valid)
   bool have_graph = false;   // stage B completed (leaf/adjacency/cluster accessors valid)
   bool graph_mode = false;   // last call was humid_cluster_graph
@@ -441,11 +451,50 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   ENSURE(c->uniq_word, (size_t)N * 8 + 8);
   HIPCHK(hipEventRecord(c->ev[0], st));
   HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_N * sizeof(ull), st));
-  {
+  const bool check_range = !(range_lo == 0 && range_hi == ~0ull);
+  c->last_part_tiled = c->use_tile_partition && pb <= 2 * 9;
+  if (c->last_part_tiled) {
+    // hand-written partition (kernels_part.hip.h): two levels of LDS-staged scatter; excluded reads
+    // (filtered, or outside this rank's value range) never enter it
+    const u32 d1 = (pb + 1) / 2, d2 = pb - d1;
+    const u32 nb1 = 1u << d1;
+    // pt_work, in u32: [hist1 512 | cursor1 512 | hist_fine n_parts + 1 | cursor2 n_parts] zeroed, then
+    // [cbase 513 | tprefix 513]
+    const size_t zero_words = 1024 + (size_t)n_parts + 1 + n_parts;
+    ENSURE(c->pt_work, (zero_words + 1026) * 4);
+    u32 *hist1 = c->pt_work.as<u32>(), *cursor1 = hist1 + 512, *hist_fine = cursor1 + 512,
+        *cursor2 = hist_fine + n_parts + 1, *cbase = cursor2 + n_parts, *tprefix = cbase + 513;
+    HIPCHK(hipMemsetAsync(c->pt_work.p, 0, zero_words * 4, st));
+    PtInput in;
+    in.words = d_words; in.filtered = d_filt; in.rlo = range_lo; in.rhi = range_hi;
+    in.check_range = check_range ? 1u : 0u;
+    in.key = PartKeyOp{ordered ? 1u : 0u, km.lo, km.scale};
+    const u32 tiles1 = (N + PT_TILE - 1) / PT_TILE, tiles2 = tiles1 + nb1;
+    hipLaunchKernelGGL(k_pt_hist1, dim3(tiles1 < 256 ? tiles1 : 256), dim3(1024), 0, st, in, N, d1, hist1);
+    hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, hist1, d1, cbase, tprefix,
+                       d2 ? (u32 *)nullptr : c->pbeg.as<u32>(), d2 ? (u32 *)nullptr : c->ucount.as<u32>() + n_parts);
+    // level-1 output: the final arrays when there is no second level, else scratch that is dead until
+    // k_dedup_lds writes it (pad_word, pslot)
+    u64 *k1 = d2 ? c->pad_word.as<u64>() : c->pk_keys.as<u64>();
+    u32 *v1 = d2 ? c->pslot.as<u32>() : c->pk_vals.as<u32>();
+    hipLaunchKernelGGL(k_pt_scatter<1>, dim3(tiles1), dim3(1024), 0, st, in, N, (const u64 *)nullptr,
+                       (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr, d1, d2, cbase, cursor1, k1, v1);
+    if (d2) {
+      hipLaunchKernelGGL(k_pt_hist2, dim3(tiles2), dim3(1024), 0, st, k1, tprefix, cbase, d1, d2, hist_fine);
+      hipLaunchKernelGGL(k_pt_scan2, dim3(1), dim3(1024), 0, st, hist_fine, n_parts, c->pbeg.as<u32>(),
+                         c->ucount.as<u32>() + n_parts);
+      HIPCHK(hipEventRecord(c->kev[39], st));
+      hipLaunchKernelGGL(k_pt_scatter<2>, dim3(tiles2), dim3(1024), 0, st, in, N, k1, v1, tprefix, cbase, d1, d2,
+                         c->pbeg.as<u32>(), cursor2, c->pk_keys.as<u64>(), c->pk_vals.as<u32>());
+      HIPCHK(hipEventRecord(c->kev[40], st));
+    } else {
+      HIPCHK(hipEventRecord(c->kev[39], st));
+      HIPCHK(hipEventRecord(c->kev[40], st));
+    }
+  } else {
     auto kin = rocprim::make_transform_iterator(d_words, PartKeyOp{ordered ? 1u : 0u, km.lo, km.scale});
     auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<u32>(0),
-                                                ReadTagOp{(range_lo == 0 && range_hi == ~0ull) ? nullptr : d_words,
-                                                          d_filt, range_lo, range_hi});
+                                                ReadTagOp{check_range ? d_words : nullptr, d_filt, range_lo, range_hi});
     // MergeSortLimit = 0: block sort up to 1024 items, Onesweep above (never the merge path)
     using part_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                                 rocprim::default_config, 0>;
@@ -455,9 +504,9 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
     ENSURE(c->tmp, bytes);
     HIPCHK(rocprim::radix_sort_pairs<part_cfg>(c->tmp.p, bytes, kin, c->pk_keys.as<u64>(), vin,
                                                c->pk_vals.as<u32>(), (size_t)N, 64 - pb, 64, st));
+    hipLaunchKernelGGL(k_part_bounds, dim3(blocks_for(n_parts + 1)), dim3(256), 0, st, c->pk_keys.as<u64>(), N,
+                       pb, n_parts, c->pbeg.as<u32>(), c->ucount.as<u32>());
   }
-  hipLaunchKernelGGL(k_part_bounds, dim3(blocks_for(n_parts + 1)), dim3(256), 0, st, c->pk_keys.as<u64>(), N,
-                     pb, n_parts, c->pbeg.as<u32>(), c->ucount.as<u32>());
   HIPCHK(hipEventRecord(c->kev[0], st));
   if (ordered)
     hipLaunchKernelGGL(k_dedup_lds<true>, dim3(n_parts), dim3(256), 0, st, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(),
@@ -511,6 +560,12 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
 static int prefix_fits_ordered(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N, u32 word_nt,
                                const KeyMap &km, bool *fits) {
   *fits = false;
+  // the answer for this shape is remembered: the sample and its host wait are paid once, not per
+  // pass (a wrong "yes" on other data of the same shape costs the overflow fallback and resets it)
+  if (c->oc_valid && c->oc_n == N && c->oc_nt == word_nt && c->oc_lo == km.lo && c->oc_scale == km.scale) {
+    *fits = c->oc_fits;
+    return HUMID_OK;
+  }
   const u32 bits = 2 * word_nt < 12 ? 2 * word_nt : 12;
   const u32 n_bins = 1u << bits;
   if (N < 65536) return HUMID_OK;                              // small inputs: not worth a decision
@@ -540,6 +595,8 @@ static int prefix_fits_ordered(humid_ctx *c, const u64 *d_words, const u8 *d_fil
   }
   worst *= (double)N / (double)n_sample;
   *fits = worst * 1.5 <= (double)LDS_FILL_LIMIT;
+  c->oc_valid = true; c->oc_fits = *fits;
+  c->oc_n = N; c->oc_nt = word_nt; c->oc_lo = km.lo; c->oc_scale = km.scale;
   return HUMID_OK;
 }
 
@@ -557,6 +614,9 @@ static int stage_count(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N
     if (ordered) {
       TRY(stage_count_lds(c, d_words, d_filt, N, word_nt, range_lo, range_hi, km, true, s, &overflowed));
       if (!overflowed) return HUMID_OK;
+      // these words do not fit word-ordered buckets after all: remember that for this shape
+      c->oc_valid = true; c->oc_fits = false;
+      c->oc_n = N; c->oc_nt = word_nt; c->oc_lo = km.lo; c->oc_scale = km.scale;
     }
     TRY(stage_count_lds(c, d_words, d_filt, N, word_nt, range_lo, range_hi, km, false, s, &overflowed));
     if (!overflowed) return HUMID_OK;
@@ -1032,6 +1092,41 @@ static int stage_pairs_share(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt
   return HUMID_OK;
 }
 
+// The un-permute in two coalesced passes (kernels_part.hip.h): position i of the partition order
+// (pk_vals = read, pslot = padded slot of its word) -> cluster_id / keep in read order, or, packed,
+// cluster id | keep << 31 per read.  *done = false: the read set is too large for the bin table
+// (more than 2048 windows of 32 K reads) or the option is off; the caller takes the one-kernel form.
+// ev_mid is recorded between the two kernels.
+static int unpermute_tiled(humid_ctx *c, u32 N, bool packed, u32 *d_cid, u8 *d_keep, hipEvent_t ev_mid, bool *done) {
+  hipStream_t st = c->stream;
+  *done = false;
+  if (!c->use_tile_partition || N == 0) return HUMID_OK;
+  u32 wshift = 14;
+  if (((u64)N + (1u << wshift) - 1) >> wshift > UW_MAXBINS) wshift = UW_MAXSHIFT;
+  const u32 n_bins = (u32)(((u64)N + (1u << wshift) - 1) >> wshift);
+  if (n_bins > UW_MAXBINS) return HUMID_OK;
+  ENSURE(c->unperm_rec, ((size_t)n_bins << wshift) * 8 + (size_t)UW_MAXBINS * 4);
+  u64 *rec = c->unperm_rec.as<u64>();
+  u32 *ucur = (u32 *)(rec + ((size_t)n_bins << wshift));
+  HIPCHK(hipMemsetAsync(ucur, 0, (size_t)n_bins * 4, st));
+  // positions in use: all N for the sorted (wide-word) count, else up to pbeg[n_parts] (on the device)
+  const bool bucketed = c->n_parts && !c->last_count_sorted;
+  const u32 *n_pos_dev = bucketed ? c->pbeg.as<u32>() + c->n_parts : (const u32 *)nullptr;
+  hipLaunchKernelGGL(k_unperm_bins, dim3((N + PT_TILE - 1) / PT_TILE), dim3(1024), 0, st, c->pk_vals.as<u32>(),
+                     c->pslot.as<u32>(), c->slot_out.as<u64>(), n_pos_dev, N, N, wshift, n_bins, ucur, rec);
+  HIPCHK(hipEventRecord(ev_mid, st));
+  if (packed) {
+    if (wshift == 14) hipLaunchKernelGGL((k_unperm_window<true, 14>), dim3(n_bins), dim3(512), 0, st, rec, ucur, N, d_cid, d_keep);
+    else hipLaunchKernelGGL((k_unperm_window<true, 15>), dim3(n_bins), dim3(512), 0, st, rec, ucur, N, d_cid, d_keep);
+  } else {
+    if (wshift == 14) hipLaunchKernelGGL((k_unperm_window<false, 14>), dim3(n_bins), dim3(512), 0, st, rec, ucur, N, d_cid, d_keep);
+    else hipLaunchKernelGGL((k_unperm_window<false, 15>), dim3(n_bins), dim3(512), 0, st, rec, ucur, N, d_cid, d_keep);
+  }
+  HIPCHK(hipEventRecord(c->kev[41], st));
+  *done = true;
+  return HUMID_OK;
+}
+
 // ---- stage C: per-read outputs -------------------------------------------------------------
 // l_cid/l_ismax: cluster id and maxLeaf flag of THIS context's unique words in local walk order
 // (on one GPU the arrays stage B left behind; on several, this rank's slice of them).
@@ -1045,20 +1140,24 @@ static int stage_map(humid_ctx *c, const u32 *l_cid, const u8 *l_ismax, u32 N, u
                        c->s_first.as<u32>(), c->s_slot.as<u32>(), U, c->slot_out.as<u64>());
   HIPCHK(hipEventRecord(c->ev[3], st));
   if (c->last_count_lds) {
-    // pk_keys (the partitioned keys) is dead by now: reuse it for the packed per-read results
-    u32 *packed = c->pk_keys.as<u32>();
-    // (measured and rejected: a streaming fill or a streaming read of `packed` right before, to have
-    // its lines resident when the scattered stores arrive -- 0.26 vs 0.24 ms either way; the 0.13 ms
-    // of a REPEATED identical scatter in tools/scatter_roofline.py comes from every XCD finding its
-    // own dirty lines of the previous repetition in its L2, which a pipeline cannot arrange)
-    if (c->n_parts && !c->last_count_sorted)
-      hipLaunchKernelGGL(k_read_map_bucket, dim3(c->n_parts), dim3(256), 0, st, c->pk_vals.as<u32>(),
-                         c->pslot.as<u32>(), c->slot_out.as<u64>(), c->pbeg.as<u32>(), c->ucount.as<u32>(), N, packed);
-    else
-      hipLaunchKernelGGL(k_read_map_part, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->pk_vals.as<u32>(),
-                         c->pslot.as<u32>(), c->slot_out.as<u64>(), N, packed);
-    HIPCHK(hipEventRecord(c->kev[36], st));
-    hipLaunchKernelGGL(k_split_out, dim3(grid_stride_blocks(N)), dim3(256), 0, st, packed, N, d_cid, d_keep);
+    bool tiled = false;
+    TRY(unpermute_tiled(c, N, false, d_cid, d_keep, c->kev[36], &tiled));
+    c->last_unperm_tiled = tiled;
+    if (!tiled) {
+      // round-1 form: one scattered 4-byte store per read, then a coalesced split.  pk_keys (the
+      // partitioned keys) is dead by now: reuse it for the packed per-read results; reads that were
+      // excluded from the partition are not in it, so the array starts as zeros
+      u32 *packed = c->pk_keys.as<u32>();
+      HIPCHK(hipMemsetAsync(packed, 0, (size_t)N * 4, st));
+      if (c->n_parts && !c->last_count_sorted)
+        hipLaunchKernelGGL(k_read_map_bucket, dim3(c->n_parts), dim3(256), 0, st, c->pk_vals.as<u32>(),
+                           c->pslot.as<u32>(), c->slot_out.as<u64>(), c->pbeg.as<u32>(), c->ucount.as<u32>(), N, packed);
+      else
+        hipLaunchKernelGGL(k_read_map_part, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->pk_vals.as<u32>(),
+                           c->pslot.as<u32>(), c->slot_out.as<u64>(), N, packed);
+      HIPCHK(hipEventRecord(c->kev[36], st));
+      hipLaunchKernelGGL(k_split_out, dim3(grid_stride_blocks(N)), dim3(256), 0, st, packed, N, d_cid, d_keep);
+    }
   } else
     hipLaunchKernelGGL(k_read_map, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->slot_of_read.as<u32>(),
                        c->slot_out.as<u64>(), N, d_cid, d_keep);
@@ -1096,6 +1195,7 @@ static int run_device(humid_ctx *c, const WT *d_words, const u8 *d_filt, u64 n_r
   humid_summary s;
   memset(&s, 0, sizeof s);
   s.total = n_reads;
+  c->last_unperm_tiled = false;
   c->N = n_reads; c->U = c->E = c->M = c->C = c->usable = 0;
   c->word_nt = word_nt; c->distance = distance; c->method = method;
   c->gU = 0;
@@ -1132,8 +1232,10 @@ static int run_device(humid_ctx *c, const WT *d_words, const u8 *d_filt, u64 n_r
   HIPCHK(hipEventElapsedTime(&s.ms_map, c->ev[3], c->ev[4]));
   HIPCHK(hipEventElapsedTime(&s.ms_total, c->ev[0], c->ev[4]));
   HIPCHK(hipEventElapsedTime(&s.ms_k_insert, c->kev[0], c->kev[1]));
-  if (c->last_count_lds) HIPCHK(hipEventElapsedTime(&s.ms_k_map, c->ev[3], c->kev[36]));   // k_read_map_part alone
+  if (c->last_count_lds) HIPCHK(hipEventElapsedTime(&s.ms_k_map, c->ev[3], c->kev[36]));   // first map kernel alone
   else s.ms_k_map = s.ms_map;   // ev[3]..ev[4] bracket exactly the k_read_map launch
+  if (c->last_count_lds && c->last_unperm_tiled) HIPCHK(hipEventElapsedTime(&s.ms_k_unperm, c->kev[36], c->kev[41]));
+  if (c->last_count_lds && c->last_part_tiled && !c->last_count_sorted) HIPCHK(hipEventElapsedTime(&s.ms_k_part, c->kev[39], c->kev[40]));
   s.count_mode_used = c->last_count_sorted ? 3u : c->last_count_lds ? (c->last_count_ordered ? 2u : 0u) : 1u;
   HIPCHK(hipEventElapsedTime(&s.ms_k_cluster, c->kev[2], c->kev[3]));
   for (u32 g = 0; g < n_pair_segs; g++) {
@@ -1208,7 +1310,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
-                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->seg_ws, &c->csize, &c->cur, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -1237,6 +1339,10 @@ int humid_ctx_set_option(humid_ctx *c, const char *key, int64_t value) {
   }
   if (strcmp(key, "edit_distance") == 0) {
     c->edit = value != 0;
+    return HUMID_OK;
+  }
+  if (strcmp(key, "tile_partition") == 0) {
+    c->use_tile_partition = value != 0;
     return HUMID_OK;
   }
   if (strcmp(key, "coop_big") == 0) {
@@ -1623,14 +1729,20 @@ int humid_stage_map_dense(humid_ctx *c, const uint32_t *d_local_cluster_id, cons
                        c->s_first.as<u32>(), c->s_slot.as<u32>(), U, c->slot_out.as<u64>());
   ENSURE(c->own_packed, ((size_t)N + 1) * 4);
   HIPCHK(hipEventRecord(c->kev[37], st));
-  if (c->last_count_lds && c->n_parts && !c->last_count_sorted)
+  bool tiled = false;
+  if (c->last_count_lds) TRY(unpermute_tiled(c, N, true, c->own_packed.as<u32>(), (u8 *)nullptr, c->kev[42], &tiled));
+  if (tiled) {
+    // both kernels of the un-permute are inside kev[37]..kev[38]
+  } else if (c->last_count_lds && c->n_parts && !c->last_count_sorted) {
+    HIPCHK(hipMemsetAsync(c->own_packed.p, 0, (size_t)N * 4, st));
     hipLaunchKernelGGL(k_read_map_bucket, dim3(c->n_parts), dim3(256), 0, st, c->pk_vals.as<u32>(),
                        c->pslot.as<u32>(), c->slot_out.as<u64>(), c->pbeg.as<u32>(), c->ucount.as<u32>(), N,
                        c->own_packed.as<u32>());
-  else if (c->last_count_lds)
+  } else if (c->last_count_lds) {
+    HIPCHK(hipMemsetAsync(c->own_packed.p, 0, (size_t)N * 4, st));
     hipLaunchKernelGGL(k_read_map_part, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->pk_vals.as<u32>(),
                        c->pslot.as<u32>(), c->slot_out.as<u64>(), N, c->own_packed.as<u32>());
-  else
+  } else
     hipLaunchKernelGGL(k_read_map_packed, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->slot_of_read.as<u32>(),
                        c->slot_out.as<u64>(), N, c->own_packed.as<u32>());
   HIPCHK(hipEventRecord(c->kev[38], st));

@@ -1,0 +1,379 @@
+// kernels_part.hip.h -- LDS-staged multi-way partition: reads -> buckets (front of the exact counts)
+// and per-read results -> read order (the un-permute at the end of the path)
+// Part of libhumid_hip.so (see humid_hip.hip for the pipeline and the C ABI).  Device code for
+// gfx950 only; included once, in this order, by humid_hip.hip.
+//
+// Both ends of the path move one small record per read to a place that depends on its value: the
+// (key, read) pair into the bucket of its key, the (read, result) pair back to the position of the
+// read.  Done as a plain scatter that is one random 4-12 byte store per read -- 32-byte write
+// granules for 4 bytes of payload and half-filled requests (round 1: 0.22 ms and 3.4x the
+// algorithmic bytes for the un-permute, 0.31 ms in library radix passes for the partition).  Here a
+// workgroup takes a TILE of 8192 records, sorts it by destination bin inside LDS (counting sort:
+// LDS atomics give every record its rank), reserves room in every bin with ONE global atomic per
+// non-empty bin, and writes each bin's records as one contiguous run: hundreds of bytes per run at a
+// fan-out of 128-512 bins.  Order inside a bin is not kept (nothing downstream needs it: the exact
+// counts take the minimum read index of a word, the un-permute writes disjoint positions).
+#ifndef HUMID_KERNELS_PART_HIP_H
+#define HUMID_KERNELS_PART_HIP_H
+
+#include "common.hip.h"
+#include "kernels_count.hip.h"
+
+#define PT_THREADS 1024u
+#define PT_TILE 8192u            // records per tile: 8 per thread
+#define PT_IPT (PT_TILE / PT_THREADS)
+#define PT_MAXBINS 512u          // fan-out of one level (<= 9 key bits)
+
+// where the records of the front partition come from: the caller's reads (level 1) ...
+struct PtInput {
+  const u64 *words;
+  const u8 *filtered;            // null: none filtered
+  u64 rlo, rhi;                  // value range this rank counts (multi-GPU); check_range = 0: everything
+  u32 check_range;
+  PartKeyOp key;
+};
+__device__ __forceinline__ bool pt_load(const PtInput &in, u32 r, u64 &key) {
+  if (in.filtered && in.filtered[r]) return false;
+  const u64 w = in.words[r];
+  if (in.check_range && (w < in.rlo || w > in.rhi)) return false;
+  key = in.key(w);
+  return true;
+}
+
+// exclusive scan of cnt[0, nb) (nb <= 512) by the first 512 threads of the block -> off[0, nb],
+// off[nb] = total.  All threads of the block must call it.
+__device__ __forceinline__ void block_exscan_512(const u32 *cnt, u32 *off, u32 nb, u32 *wsum /* >= 8 */) {
+  const u32 t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  u32 x = (t < nb) ? cnt[t] : 0u, incl = x;
+  if (t < 512) {
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+      const u32 y = __shfl_up(incl, d);
+      if (lane >= d) incl += y;
+    }
+    if (lane == 63) wsum[wv] = incl;
+  }
+  __syncthreads();
+  if (t < 512) {
+    u32 before = 0;
+    for (u32 k = 0; k < wv; k++) before += wsum[k];
+    if (t < nb) off[t] = before + incl - x;
+    if (t == nb - 1) off[nb] = before + incl;
+  }
+  __syncthreads();
+}
+
+// tile -> (coarse bin, first record, record count): tiles never cross a coarse bin
+__device__ __forceinline__ void pt_tile_of(const u32 *__restrict__ tprefix, const u32 *__restrict__ cbase, u32 nb1,
+                                           u32 tile, u32 &c, u32 &beg, u32 &cnt) {
+  u32 lo = 0, hi = nb1;                    // largest c with tprefix[c] <= tile
+  while (hi - lo > 1) {
+    const u32 mid = (lo + hi) >> 1;
+    if (tprefix[mid] <= tile) lo = mid; else hi = mid;
+  }
+  c = lo;
+  const u32 k = tile - tprefix[c];
+  const u32 b0 = cbase[c], b1 = cbase[c + 1];
+  beg = b0 + k * PT_TILE;
+  cnt = (beg >= b1) ? 0u : ((b1 - beg < PT_TILE) ? b1 - beg : PT_TILE);
+}
+
+// ---- level 1 histogram: usable reads per coarse bin (the top d1 key bits) ----
+__global__ void __launch_bounds__(1024)
+k_pt_hist1(PtInput in, u32 n_reads, u32 d1, u32 *__restrict__ hist1) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ u32 h[PT_MAXBINS];
+  const u32 nb = 1u << d1;
+  for (u32 b = threadIdx.x; b < nb; b += blockDim.x) h[b] = 0;
+  __syncthreads();
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
+    u64 key;
+    if (pt_load(in, r, key)) atomicAdd(&h[(u32)(key >> (64 - d1))], 1u);
+  }
+  __syncthreads();
+  for (u32 b = threadIdx.x; b < nb; b += blockDim.x)
+    if (h[b]) atomicAdd(&hist1[b], h[b]);
+}
+
+// ---- one block: coarse bin bases, tile table of level 2; pb == d1 (no level 2): also the bucket
+// boundaries themselves ----
+__global__ void __launch_bounds__(1024)
+k_pt_scan1(const u32 *__restrict__ hist1, u32 d1, u32 *__restrict__ cbase, u32 *__restrict__ tprefix,
+           u32 *__restrict__ pbeg_if_single, u32 *__restrict__ ucount_tail) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ u32 cnt[PT_MAXBINS], off[PT_MAXBINS + 1], wsum[8];
+  const u32 nb = 1u << d1;
+  if (threadIdx.x < nb) cnt[threadIdx.x] = hist1[threadIdx.x];
+  __syncthreads();
+  block_exscan_512(cnt, off, nb, wsum);
+  if (threadIdx.x <= nb) {
+    cbase[threadIdx.x] = off[threadIdx.x];
+    if (pbeg_if_single) pbeg_if_single[threadIdx.x] = off[threadIdx.x];
+  }
+  if (threadIdx.x == 0 && ucount_tail) *ucount_tail = 0;
+  __syncthreads();
+  if (threadIdx.x < nb) cnt[threadIdx.x] = (hist1[threadIdx.x] + PT_TILE - 1) / PT_TILE;
+  __syncthreads();
+  block_exscan_512(cnt, off, nb, wsum);
+  if (threadIdx.x <= nb) tprefix[threadIdx.x] = off[threadIdx.x];
+}
+
+// ---- the scatter of one level ----
+// LEVEL 1: tile = 8192 consecutive reads of the input; bin = top d1 key bits; bin b's region starts at
+//          base[b] (cbase).  LEVEL 2: tile = up to 8192 records of ONE coarse bin c; bin = the d2 key bits
+//          below; region of (c, f) starts at base[c << d2 | f] (pbeg).  cursor[]: records already placed
+//          in each region (zeroed before the launch).
+template <int LEVEL>
+__global__ void __launch_bounds__(1024)
+k_pt_scatter(PtInput in, u32 n_reads, const u64 *__restrict__ k_in, const u32 *__restrict__ v_in,
+             const u32 *__restrict__ tprefix, const u32 *__restrict__ cbase, u32 d1, u32 d2,
+             const u32 *__restrict__ base, u32 *cursor, u64 *__restrict__ k_out, u32 *__restrict__ v_out) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ u64 skey[PT_TILE];
+  __shared__ u32 sval[PT_TILE];
+  __shared__ unsigned short sbin[PT_TILE];
+  __shared__ u32 cnt[PT_MAXBINS], loff[PT_MAXBINS + 1], goff[PT_MAXBINS], wsum[8];
+  __shared__ u32 s_c, s_beg, s_cnt;
+  const u32 nb = 1u << (LEVEL == 1 ? d1 : d2);
+  u32 t_beg, t_cnt, coarse = 0;
+  if (LEVEL == 1) {
+    t_beg = blockIdx.x * PT_TILE;
+    t_cnt = (t_beg >= n_reads) ? 0u : ((n_reads - t_beg < PT_TILE) ? n_reads - t_beg : PT_TILE);
+  } else {
+    if (blockIdx.x >= tprefix[1u << d1]) return;             // beyond the last tile (uniform exit)
+    if (threadIdx.x == 0) {
+      u32 c, b, n;
+      pt_tile_of(tprefix, cbase, 1u << d1, blockIdx.x, c, b, n);
+      s_c = c; s_beg = b; s_cnt = n;
+    }
+  }
+  for (u32 b = threadIdx.x; b < nb; b += PT_THREADS) cnt[b] = 0;
+  __syncthreads();
+  if (LEVEL == 2) { coarse = s_c; t_beg = s_beg; t_cnt = s_cnt; }
+  u64 key[PT_IPT];
+  u32 val[PT_IPT], binrank[PT_IPT];                           // bin << 16 | rank inside (tile, bin); ~0: none
+#pragma unroll
+  for (u32 q = 0; q < PT_IPT; q++) {
+    const u32 j = threadIdx.x + q * PT_THREADS;
+    binrank[q] = NONE32;
+    if (j < t_cnt) {
+      bool ok = true;
+      if (LEVEL == 1) { ok = pt_load(in, t_beg + j, key[q]); val[q] = t_beg + j; }
+      else { key[q] = k_in[t_beg + j]; val[q] = v_in[t_beg + j]; }
+      if (ok) {
+        const u32 bin = (LEVEL == 1) ? (u32)(key[q] >> (64 - d1))
+                                     : (u32)(key[q] >> (64 - d1 - d2)) & (nb - 1);
+        binrank[q] = bin << 16 | atomicAdd(&cnt[bin], 1u);   // rank < 8192 < 2^16
+      }
+    }
+  }
+  __syncthreads();
+  block_exscan_512(cnt, loff, nb, wsum);
+  if (threadIdx.x < nb) {
+    const u32 c = cnt[threadIdx.x];
+    const u32 g = (LEVEL == 1) ? threadIdx.x : ((coarse << d2) | threadIdx.x);
+    goff[threadIdx.x] = base[g] + (c ? atomicAdd(&cursor[g], c) : 0u);
+  }
+#pragma unroll
+  for (u32 q = 0; q < PT_IPT; q++)
+    if (binrank[q] != NONE32) {
+      const u32 bin = binrank[q] >> 16, p = loff[bin] + (binrank[q] & 0xffffu);
+      skey[p] = key[q];
+      sval[p] = val[q];
+      sbin[p] = (unsigned short)bin;
+    }
+  __syncthreads();
+  const u32 total = loff[nb];
+  for (u32 s = threadIdx.x; s < total; s += PT_THREADS) {
+    const u32 bin = sbin[s];
+    const u32 d = goff[bin] + (s - loff[bin]);
+    k_out[d] = skey[s];
+    v_out[d] = sval[s];
+  }
+}
+
+// ---- level 2 histogram: records per fine bucket, one tile of one coarse bin per block ----
+__global__ void __launch_bounds__(1024)
+k_pt_hist2(const u64 *__restrict__ k_in, const u32 *__restrict__ tprefix, const u32 *__restrict__ cbase, u32 d1,
+           u32 d2, u32 *__restrict__ hist_fine) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ u32 h[PT_MAXBINS];
+  __shared__ u32 s_c, s_beg, s_cnt;
+  if (blockIdx.x >= tprefix[1u << d1]) return;
+  const u32 nb = 1u << d2;
+  if (threadIdx.x == 0) {
+    u32 c, b, n;
+    pt_tile_of(tprefix, cbase, 1u << d1, blockIdx.x, c, b, n);
+    s_c = c; s_beg = b; s_cnt = n;
+  }
+  for (u32 b = threadIdx.x; b < nb; b += PT_THREADS) h[b] = 0;
+  __syncthreads();
+  const u32 beg = s_beg, n = s_cnt;
+  for (u32 j = threadIdx.x; j < n; j += PT_THREADS)
+    atomicAdd(&h[(u32)(k_in[beg + j] >> (64 - d1 - d2)) & (nb - 1)], 1u);
+  __syncthreads();
+  for (u32 b = threadIdx.x; b < nb; b += PT_THREADS)
+    if (h[b]) atomicAdd(&hist_fine[(s_c << d2) | b], h[b]);
+}
+
+// ---- one block: exclusive scan of up to 2^18 counts (hist[n]) -> out[0, n], out[n] = total ----
+__global__ void __launch_bounds__(1024)
+k_pt_scan2(const u32 *__restrict__ hist, u32 n, u32 *__restrict__ out, u32 *__restrict__ ucount_tail) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ u32 part[1024], wsum[16];
+  const u32 per = (n + 1023) / 1024;
+  const u32 lo = threadIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+  u32 s = 0;
+  for (u32 i = lo; i < hi; i++) s += hist[i];
+  // block exclusive scan of the 1024 partial sums
+  const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  u32 incl = s;
+#pragma unroll
+  for (u32 d = 1; d < 64; d <<= 1) {
+    const u32 y = __shfl_up(incl, d);
+    if (lane >= d) incl += y;
+  }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  u32 before = 0;
+  for (u32 k = 0; k < wv; k++) before += wsum[k];
+  part[threadIdx.x] = before + incl - s;
+  __syncthreads();
+  u32 run = part[threadIdx.x];
+  for (u32 i = lo; i < hi; i++) { out[i] = run; run += hist[i]; }
+  if (threadIdx.x == 1023) { out[n] = before + incl; if (ucount_tail) *ucount_tail = 0; }
+}
+
+// --------------------------------------------------------------------------------
+// the un-permute: results from partition order back to read order, in two coalesced passes
+// --------------------------------------------------------------------------------
+// Pass 1 (k_unperm_bins): position i of the partition order holds read vals[i] and the padded slot of
+// its word; its packed result (cluster id | keep << 31) travels as the record (result << 32 | read)
+// into bin read >> wshift.  A bin covers 2^wshift consecutive reads, every read occurs at most once,
+// so bin b owns the fixed room [b << wshift, (b + 1) << wshift) of the record array: no histogram.
+// Pass 2 (k_unperm_window): one workgroup per bin scatters the bin's records into an LDS window of
+// 2^wshift results (excluded reads keep 0: cluster 0, never kept) and writes cluster_id / keep -- or
+// the packed word for the multi-GPU return stream -- with coalesced stores.
+#define UW_MAXBINS 2048u
+#define UW_MAXSHIFT 15u
+
+__global__ void __launch_bounds__(1024)
+k_unperm_bins(const u32 *__restrict__ vals, const u32 *__restrict__ pslot, const u64 *__restrict__ slot_out,
+              const u32 *__restrict__ n_pos_dev, u32 n_pos_max, u32 n_reads, u32 wshift, u32 n_bins, u32 *ucur,
+              u64 *__restrict__ rec) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ u64 srec[PT_TILE];
+  __shared__ unsigned short sbin[PT_TILE];
+  __shared__ u32 cnt[UW_MAXBINS], loff[UW_MAXBINS + 1], goff[UW_MAXBINS], wsum[16];
+  u32 n_pos = n_pos_dev ? *n_pos_dev : n_pos_max;
+  if (n_pos > n_pos_max) n_pos = n_pos_max;
+  const u32 t_beg = blockIdx.x * PT_TILE;
+  if (t_beg >= n_pos) return;
+  const u32 t_cnt = (n_pos - t_beg < PT_TILE) ? n_pos - t_beg : PT_TILE;
+  for (u32 b = threadIdx.x; b < n_bins; b += PT_THREADS) cnt[b] = 0;
+  __syncthreads();
+  u64 r64[PT_IPT];
+  u32 binrank[PT_IPT];
+  u32 vq[PT_IPT], sq[PT_IPT];
+#pragma unroll
+  for (u32 q = 0; q < PT_IPT; q++) {                          // all loads of the thread in flight together
+    const u32 j = threadIdx.x + q * PT_THREADS;
+    if (j < t_cnt) { vq[q] = vals[t_beg + j]; sq[q] = pslot[t_beg + j]; }
+  }
+#pragma unroll
+  for (u32 q = 0; q < PT_IPT; q++) {
+    const u32 j = threadIdx.x + q * PT_THREADS;
+    binrank[q] = NONE32;
+    if (j < t_cnt) {
+      const u32 r = vq[q] & 0x7fffffffu;
+      if (r < n_reads && !(vq[q] & 0x80000000u) && sq[q] != NOSLOT) {
+        const u64 o = slot_out[sq[q]];
+        const u32 c = (u32)o | (((u32)(o >> 32) == r) ? 0x80000000u : 0u);
+        r64[q] = ((u64)c << 32) | r;
+        const u32 bin = r >> wshift;
+        binrank[q] = atomicAdd(&cnt[bin], 1u);
+        vq[q] = bin;
+      }
+    }
+  }
+  __syncthreads();
+  // exclusive scan of up to 2048 counters: two per thread
+  {
+    const u32 a = 2 * threadIdx.x, b = a + 1;
+    const u32 ca = a < n_bins ? cnt[a] : 0u, cb = b < n_bins ? cnt[b] : 0u;
+    const u32 s = ca + cb;
+    const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    u32 incl = s;
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+      const u32 y = __shfl_up(incl, d);
+      if (lane >= d) incl += y;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    u32 before = 0;
+    for (u32 k = 0; k < wv; k++) before += wsum[k];
+    const u32 ex = before + incl - s;
+    if (a < n_bins) loff[a] = ex;
+    if (b < n_bins) loff[b] = ex + ca;
+    if (threadIdx.x == 1023) loff[n_bins] = before + incl;
+  }
+  __syncthreads();
+  for (u32 b = threadIdx.x; b < n_bins; b += PT_THREADS) {
+    const u32 c = cnt[b];
+    goff[b] = (b << wshift) + (c ? atomicAdd(&ucur[b], c) : 0u);
+  }
+#pragma unroll
+  for (u32 q = 0; q < PT_IPT; q++)
+    if (binrank[q] != NONE32) {
+      const u32 p = loff[vq[q]] + binrank[q];
+      srec[p] = r64[q];
+      sbin[p] = (unsigned short)vq[q];
+    }
+  __syncthreads();
+  const u32 total = loff[n_bins];
+  for (u32 s = threadIdx.x; s < total; s += PT_THREADS) {
+    const u32 bin = sbin[s];
+    rec[goff[bin] + (s - loff[bin])] = srec[s];
+  }
+}
+
+// PACKED: one u32 per read (multi-GPU return stream); else cluster_id u32 + keep u8.  WSHIFT: 14
+// (64 KiB window, two workgroups per CU) or 15 (read sets beyond 32 M reads)
+template <bool PACKED, u32 WSHIFT>
+__global__ void __launch_bounds__(512)
+k_unperm_window(const u64 *__restrict__ rec, const u32 *__restrict__ ucur, u32 n_reads,
+                u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ u32 win[1u << WSHIFT];
+  constexpr u32 wshift = WSHIFT;
+  const u32 W = 1u << wshift;
+  const u32 bin = blockIdx.x;
+  const u32 r0 = bin << wshift;
+  if (r0 >= n_reads) return;
+  for (u32 j = threadIdx.x; j < W; j += 512) win[j] = 0;
+  __syncthreads();
+  u32 n = ucur[bin];
+  if (n > W) n = W;                                           // never beyond the bin's room
+  const u64 *rb = rec + r0;
+  for (u32 j = threadIdx.x; j < n; j += 512) {
+    const u64 x = rb[j];
+    win[(u32)x & (W - 1)] = (u32)(x >> 32);
+  }
+  __syncthreads();
+  const u32 cntw = (n_reads - r0 < W) ? n_reads - r0 : W;
+  if (PACKED) {
+    for (u32 j = threadIdx.x; j < cntw; j += 512) cluster_id[r0 + j] = win[j];
+  } else {
+    for (u32 j = threadIdx.x; j < cntw; j += 512) cluster_id[r0 + j] = win[j] & 0x7fffffffu;
+    // keep flags: four per thread, one 4-byte store (r0 and W are multiples of 4)
+    u32 *k4 = (u32 *)(keep + r0);
+    const u32 n4 = (((uintptr_t)keep & 3) == 0) ? cntw >> 2 : 0u;
+    for (u32 j = threadIdx.x; j < n4; j += 512)
+      k4[j] = (win[4 * j] >> 31) | ((win[4 * j + 1] >> 31) << 8) | ((win[4 * j + 2] >> 31) << 16) |
+              ((win[4 * j + 3] >> 31) << 24);
+    for (u32 j = (n4 << 2) + threadIdx.x; j < cntw; j += 512) keep[r0 + j] = (u8)(win[j] >> 31);
+  }
+}
+
+#endif  // HUMID_KERNELS_PART_HIP_H

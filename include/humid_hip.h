@@ -42,7 +42,7 @@ extern "C" {
 #define HUMID_METHOD_DIRECTIONAL 0u  /* default; src/cluster.cc:82-87               */
 #define HUMID_METHOD_MAXIMUM     1u  /* -x;      src/cluster.cc:72-80               */
 
-#define HUMID_ABI_VERSION 1u
+#define HUMID_ABI_VERSION 2u
 
 typedef struct humid_ctx humid_ctx;   /* device workspace + stream; not thread-safe */
 
@@ -65,7 +65,9 @@ typedef struct humid_summary {
   float ms_k_insert;    /* k_dedup_lds or k_hash_insert (one launch)                */
   float ms_k_pairs;     /* sum over the 2(d+1) k_pairs launches (count + fill)      */
   float ms_k_cluster;   /* k_cluster_pairs + _small (+ _components): 2-3 launches   */
-  float ms_k_map;       /* k_read_map_bucket, _part or k_read_map (1 launch)               */
+  float ms_k_map;       /* first kernel of the un-permute: k_unperm_bins (or k_read_map_bucket, _part, k_read_map) */
+  float ms_k_part;      /* front partition: the second-level scatter k_pt_scatter<2> (0: library radix passes) */
+  float ms_k_unperm;    /* second kernel of the un-permute: k_unperm_window (0: one-kernel forms)   */
   uint32_t count_mode_used;  /* 0 = LDS tables, hashed buckets; 2 = LDS tables, word-ordered buckets;
                               * 1 = global HBM table (option or fallback); 3 = sorted (wide words) */
 } humid_summary;
@@ -92,7 +94,11 @@ const char *humid_last_error(const humid_ctx *ctx);   /* ctx may be NULL */
  *   Between equal-length words distance <= 1 is the Hamming search itself; 2 and 3 add the pairs that
  *   need one deletion + one insertion; distance > 3 returns HUMID_E_UNSUPPORTED.
  * "coop_big": 1 (default) = components of more than 32 leaves are clustered by one workgroup each
- * (parallel flood), 0 = by one lane each (the literal sequential loop). */
+ * (parallel flood), 0 = by one lane each (the literal sequential loop).
+ * "tile_partition": 1 (default) = reads reach their count buckets, and results their reads, through
+ * the hand-written LDS-staged partition (two coalesced passes each way); 0 = library radix passes
+ * in front and one scattered store per read at the end (the round-1 form, also taken by itself for
+ * read sets beyond ~180 M / ~67 M reads). */
 int  humid_ctx_set_option(humid_ctx *ctx, const char *key, int64_t value);
 
 /* ---- the whole hot path ----------------------------------------------------

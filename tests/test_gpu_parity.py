@@ -12,14 +12,16 @@ from oracle import pyoracle as orc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[(0, 0), (0, 1), (1, 0)],
-                ids=["lds_hashed_buckets", "lds_ordered_buckets", "global_table"])
+@pytest.fixture(scope="module", params=[(0, 0, 1), (0, 1, 1), (1, 0, 1), (0, 1, 0)],
+                ids=["lds_hashed_buckets", "lds_ordered_buckets", "global_table", "lds_ordered_library_radix"])
 def dd(request):
     """every parity test runs with all exact-count variants (humid_ctx_set_option count_mode /
-    count_order; the ordered variant falls back to hashed buckets by itself on skewed words)"""
+    count_order; the ordered variant falls back to hashed buckets by itself on skewed words) and with
+    both partition forms (tile_partition: hand-written LDS-staged passes / library radix passes)"""
     d = humid_amd.Dedup()
     d.set_option("count_mode", request.param[0])
     d.set_option("count_order", request.param[1])
+    d.set_option("tile_partition", request.param[2])
     d.count_mode = request.param[0]
     d.count_order = request.param[1]
     yield d
