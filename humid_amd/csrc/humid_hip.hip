@@ -470,27 +470,23 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
     in.check_range = check_range ? 1u : 0u;
     in.key = PartKeyOp{ordered ? 1u : 0u, km.lo, km.scale};
     const u32 tiles1 = (N + PT_TILE - 1) / PT_TILE, tiles2 = tiles1 + nb1;
-    hipLaunchKernelGGL(k_pt_hist1, dim3(tiles1 < 256 ? tiles1 : 256), dim3(1024), 0, st, in, N, d1, hist1);
-    hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, hist1, d1, cbase, tprefix,
-                       d2 ? (u32 *)nullptr : c->pbeg.as<u32>(), d2 ? (u32 *)nullptr : c->ucount.as<u32>() + n_parts);
+    hipLaunchKernelGGL(k_pt_hist1, dim3(tiles1 < 512 ? tiles1 : 512), dim3(1024), 0, st, in, N, d1, hist1);
+    hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, hist1, d1, d2, cbase, tprefix, c->pbeg.as<u32>(),
+                       c->ucount.as<u32>() + n_parts);
     // level-1 output: the final arrays when there is no second level, else scratch that is dead until
     // k_dedup_lds writes it (pad_word, pslot)
     u64 *k1 = d2 ? c->pad_word.as<u64>() : c->pk_keys.as<u64>();
     u32 *v1 = d2 ? c->pslot.as<u32>() : c->pk_vals.as<u32>();
     hipLaunchKernelGGL(k_pt_scatter<1>, dim3(tiles1), dim3(1024), 0, st, in, N, (const u64 *)nullptr,
-                       (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr, d1, d2, cbase, cursor1, k1, v1);
+                       (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr, d1, d2, cbase, cursor1, k1, v1,
+                       (u32 *)nullptr);
+    HIPCHK(hipEventRecord(c->kev[39], st));
     if (d2) {
       hipLaunchKernelGGL(k_pt_hist2, dim3(tiles2), dim3(1024), 0, st, k1, tprefix, cbase, d1, d2, hist_fine);
-      hipLaunchKernelGGL(k_pt_scan2, dim3(1), dim3(1024), 0, st, hist_fine, n_parts, c->pbeg.as<u32>(),
-                         c->ucount.as<u32>() + n_parts);
-      HIPCHK(hipEventRecord(c->kev[39], st));
       hipLaunchKernelGGL(k_pt_scatter<2>, dim3(tiles2), dim3(1024), 0, st, in, N, k1, v1, tprefix, cbase, d1, d2,
-                         c->pbeg.as<u32>(), cursor2, c->pk_keys.as<u64>(), c->pk_vals.as<u32>());
-      HIPCHK(hipEventRecord(c->kev[40], st));
-    } else {
-      HIPCHK(hipEventRecord(c->kev[39], st));
-      HIPCHK(hipEventRecord(c->kev[40], st));
+                         hist_fine, cursor2, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(), c->pbeg.as<u32>());
     }
+    HIPCHK(hipEventRecord(c->kev[40], st));
   } else {
     auto kin = rocprim::make_transform_iterator(d_words, PartKeyOp{ordered ? 1u : 0u, km.lo, km.scale});
     auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<u32>(0),

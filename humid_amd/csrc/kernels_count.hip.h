@@ -128,9 +128,10 @@ k_compact_table(const Slot *__restrict__ tab, u32 n_slots, u64 *__restrict__ uni
 // counted by one workgroup in an LDS-resident open-address table.  No random HBM line traffic:
 // the only scattered access left is the 4-byte slot_of_read[r] store.
 // --------------------------------------------------------------------------------
-#define LDS_SLOTS 2048u          // 16-byte entries: 32 KiB of LDS per workgroup, 5 workgroups per CU
-#define LDS_FILL_LIMIT 1536u     // unique words a bucket may hold (75 % load)
-#define PART_TARGET 700u         // mean reads per bucket
+#define LDS_SLOT_BITS 10u
+#define LDS_SLOTS (1u << LDS_SLOT_BITS)   // 16-byte entries: 16 KiB of LDS per workgroup
+#define LDS_FILL_LIMIT (3u * LDS_SLOTS / 4u)   // unique words a bucket may hold (75 % load)
+#define PART_TARGET 350u         // mean reads per bucket
 
 // keys_input transform: word -> partition key.  Hashed: mix64(word) (a bijection; robust to any
 // word distribution).  Ordered: (word - lo) * scale, a strictly increasing map of the value range
@@ -188,7 +189,7 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
   __shared__ u32 lcnt[LDS_SLOTS + 1];
   __shared__ u32 lfirst[LDS_SLOTS + 1];
   __shared__ unsigned short lslot_of[LDS_SLOTS + 1];   // unique index (claim order) -> table entry
-  __shared__ unsigned short lorder[ORDERED ? 512 : 1]; // ORDERED, small buckets: entries by rank
+  __shared__ unsigned short lorder[ORDERED ? (LDS_SLOTS < 512 ? LDS_SLOTS : 512) : 1];   // ORDERED, small buckets: entries by rank
   __shared__ u32 lcount;                               // unique words claimed so far
   __shared__ u32 lds[8];
   const u32 b = blockIdx.x;
@@ -201,7 +202,7 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
   for (u32 s = threadIdx.x; s <= LDS_SLOTS; s += 256) { lkey[s] = EMPTY_KEY; lcnt[s] = 0; lfirst[s] = NONE32; }
   if (threadIdx.x == 0) lcount = 0;
   __syncthreads();
-  const u32 hshift = 64 - pb - 11;      // table index = the 11 key bits below the bucket bits
+  const u32 hshift = 64 - pb - LDS_SLOT_BITS;   // table index = the key bits just below the bucket bits
   u32 usable = 0;
   bool overflow = false;
   // one read into the table; false = the table is full / the index is malformed

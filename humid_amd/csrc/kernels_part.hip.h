@@ -86,7 +86,18 @@ k_pt_hist1(PtInput in, u32 n_reads, u32 d1, u32 *__restrict__ hist1) {
   const u32 nb = 1u << d1;
   for (u32 b = threadIdx.x; b < nb; b += blockDim.x) h[b] = 0;
   __syncthreads();
-  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
+  const u32 stride = gridDim.x * blockDim.x;
+  u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+  for (; r + 3 * stride < n_reads; r += 4 * stride) {         // four independent loads in flight
+    u64 key[4];
+    bool ok[4];
+#pragma unroll
+    for (u32 q = 0; q < 4; q++) ok[q] = pt_load(in, r + q * stride, key[q]);
+#pragma unroll
+    for (u32 q = 0; q < 4; q++)
+      if (ok[q]) atomicAdd(&h[(u32)(key[q] >> (64 - d1))], 1u);
+  }
+  for (; r < n_reads; r += stride) {
     u64 key;
     if (pt_load(in, r, key)) atomicAdd(&h[(u32)(key >> (64 - d1))], 1u);
   }
@@ -95,22 +106,22 @@ k_pt_hist1(PtInput in, u32 n_reads, u32 d1, u32 *__restrict__ hist1) {
     if (h[b]) atomicAdd(&hist1[b], h[b]);
 }
 
-// ---- one block: coarse bin bases, tile table of level 2; pb == d1 (no level 2): also the bucket
-// boundaries themselves ----
+// ---- one block: coarse bin bases, tile table of level 2, and the bucket boundaries pbeg[] that no
+// level-2 tile will write: all of them when there is no second level (d2 = 0), else those of the
+// EMPTY coarse bins (no tile) and the final pbeg[2^(d1+d2)] = number of records ----
 __global__ void __launch_bounds__(1024)
-k_pt_scan1(const u32 *__restrict__ hist1, u32 d1, u32 *__restrict__ cbase, u32 *__restrict__ tprefix,
-           u32 *__restrict__ pbeg_if_single, u32 *__restrict__ ucount_tail) {
+k_pt_scan1(const u32 *__restrict__ hist1, u32 d1, u32 d2, u32 *__restrict__ cbase, u32 *__restrict__ tprefix,
+           u32 *__restrict__ pbeg, u32 *__restrict__ ucount_tail) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u32 cnt[PT_MAXBINS], off[PT_MAXBINS + 1], wsum[8];
   const u32 nb = 1u << d1;
   if (threadIdx.x < nb) cnt[threadIdx.x] = hist1[threadIdx.x];
   __syncthreads();
   block_exscan_512(cnt, off, nb, wsum);
-  if (threadIdx.x <= nb) {
-    cbase[threadIdx.x] = off[threadIdx.x];
-    if (pbeg_if_single) pbeg_if_single[threadIdx.x] = off[threadIdx.x];
-  }
-  if (threadIdx.x == 0 && ucount_tail) *ucount_tail = 0;
+  if (threadIdx.x <= nb) cbase[threadIdx.x] = off[threadIdx.x];
+  if (threadIdx.x == 0) { pbeg[nb << d2] = off[nb]; *ucount_tail = 0; }
+  for (u32 g = threadIdx.x; g < (nb << d2); g += blockDim.x)
+    if (d2 == 0 || cnt[g >> d2] == 0) pbeg[g] = off[g >> d2];
   __syncthreads();
   if (threadIdx.x < nb) cnt[threadIdx.x] = (hist1[threadIdx.x] + PT_TILE - 1) / PT_TILE;
   __syncthreads();
@@ -121,19 +132,21 @@ k_pt_scan1(const u32 *__restrict__ hist1, u32 d1, u32 *__restrict__ cbase, u32 *
 // ---- the scatter of one level ----
 // LEVEL 1: tile = 8192 consecutive reads of the input; bin = top d1 key bits; bin b's region starts at
 //          base[b] (cbase).  LEVEL 2: tile = up to 8192 records of ONE coarse bin c; bin = the d2 key bits
-//          below; region of (c, f) starts at base[c << d2 | f] (pbeg).  cursor[]: records already placed
-//          in each region (zeroed before the launch).
+//          below; base = the level-2 histogram: the region of (c, f) starts at cbase[c] + the fine
+//          counts of c before f, which the first tile of c also writes to pbeg_out[c << d2 | f].
+//          cursor[]: records already placed in each region (zeroed before the launch).
 template <int LEVEL>
 __global__ void __launch_bounds__(1024)
 k_pt_scatter(PtInput in, u32 n_reads, const u64 *__restrict__ k_in, const u32 *__restrict__ v_in,
              const u32 *__restrict__ tprefix, const u32 *__restrict__ cbase, u32 d1, u32 d2,
-             const u32 *__restrict__ base, u32 *cursor, u64 *__restrict__ k_out, u32 *__restrict__ v_out) {
+             const u32 *__restrict__ base, u32 *cursor, u64 *__restrict__ k_out, u32 *__restrict__ v_out,
+             u32 *__restrict__ pbeg_out) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u64 skey[PT_TILE];
   __shared__ u32 sval[PT_TILE];
   __shared__ unsigned short sbin[PT_TILE];
-  __shared__ u32 cnt[PT_MAXBINS], loff[PT_MAXBINS + 1], goff[PT_MAXBINS], wsum[8];
-  __shared__ u32 s_c, s_beg, s_cnt;
+  __shared__ u32 cnt[PT_MAXBINS], loff[PT_MAXBINS + 1], goff[PT_MAXBINS], fbase[PT_MAXBINS + 1], wsum[8];
+  __shared__ u32 s_c, s_beg, s_cnt, s_first;
   const u32 nb = 1u << (LEVEL == 1 ? d1 : d2);
   u32 t_beg, t_cnt, coarse = 0;
   if (LEVEL == 1) {
@@ -145,11 +158,20 @@ k_pt_scatter(PtInput in, u32 n_reads, const u64 *__restrict__ k_in, const u32 *_
       u32 c, b, n;
       pt_tile_of(tprefix, cbase, 1u << d1, blockIdx.x, c, b, n);
       s_c = c; s_beg = b; s_cnt = n;
+      s_first = (blockIdx.x == tprefix[c]) ? 1u : 0u;          // first tile of its coarse bin
     }
+    __syncthreads();
+    // where the fine buckets of this coarse bin start: the coarse base + a scan of the bin's fine
+    // counts (base = the level-2 histogram); its first tile also publishes them as pbeg[]
+    coarse = s_c;
+    if (threadIdx.x < nb) cnt[threadIdx.x] = base[(coarse << d2) | threadIdx.x];
+    __syncthreads();
+    block_exscan_512(cnt, fbase, nb, wsum);
+    if (s_first && threadIdx.x < nb) pbeg_out[(coarse << d2) | threadIdx.x] = cbase[coarse] + fbase[threadIdx.x];
   }
   for (u32 b = threadIdx.x; b < nb; b += PT_THREADS) cnt[b] = 0;
   __syncthreads();
-  if (LEVEL == 2) { coarse = s_c; t_beg = s_beg; t_cnt = s_cnt; }
+  if (LEVEL == 2) { t_beg = s_beg; t_cnt = s_cnt; }
   u64 key[PT_IPT];
   u32 val[PT_IPT], binrank[PT_IPT];                           // bin << 16 | rank inside (tile, bin); ~0: none
 #pragma unroll
@@ -172,7 +194,8 @@ k_pt_scatter(PtInput in, u32 n_reads, const u64 *__restrict__ k_in, const u32 *_
   if (threadIdx.x < nb) {
     const u32 c = cnt[threadIdx.x];
     const u32 g = (LEVEL == 1) ? threadIdx.x : ((coarse << d2) | threadIdx.x);
-    goff[threadIdx.x] = base[g] + (c ? atomicAdd(&cursor[g], c) : 0u);
+    const u32 b0 = (LEVEL == 1) ? base[g] : cbase[coarse] + fbase[threadIdx.x];
+    goff[threadIdx.x] = b0 + (c ? atomicAdd(&cursor[g], c) : 0u);
   }
 #pragma unroll
   for (u32 q = 0; q < PT_IPT; q++)
@@ -214,34 +237,6 @@ k_pt_hist2(const u64 *__restrict__ k_in, const u32 *__restrict__ tprefix, const 
   __syncthreads();
   for (u32 b = threadIdx.x; b < nb; b += PT_THREADS)
     if (h[b]) atomicAdd(&hist_fine[(s_c << d2) | b], h[b]);
-}
-
-// ---- one block: exclusive scan of up to 2^18 counts (hist[n]) -> out[0, n], out[n] = total ----
-__global__ void __launch_bounds__(1024)
-k_pt_scan2(const u32 *__restrict__ hist, u32 n, u32 *__restrict__ out, u32 *__restrict__ ucount_tail) {
-  HUMID_GUARD_LAST_VGPR();
-  __shared__ u32 part[1024], wsum[16];
-  const u32 per = (n + 1023) / 1024;
-  const u32 lo = threadIdx.x * per, hi = (lo + per < n) ? lo + per : n;
-  u32 s = 0;
-  for (u32 i = lo; i < hi; i++) s += hist[i];
-  // block exclusive scan of the 1024 partial sums
-  const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  u32 incl = s;
-#pragma unroll
-  for (u32 d = 1; d < 64; d <<= 1) {
-    const u32 y = __shfl_up(incl, d);
-    if (lane >= d) incl += y;
-  }
-  if (lane == 63) wsum[wv] = incl;
-  __syncthreads();
-  u32 before = 0;
-  for (u32 k = 0; k < wv; k++) before += wsum[k];
-  part[threadIdx.x] = before + incl - s;
-  __syncthreads();
-  u32 run = part[threadIdx.x];
-  for (u32 i = lo; i < hi; i++) { out[i] = run; run += hist[i]; }
-  if (threadIdx.x == 1023) { out[n] = before + incl; if (ucount_tail) *ucount_tail = 0; }
 }
 
 // --------------------------------------------------------------------------------
