@@ -65,7 +65,7 @@ struct humid_ctx {
   DBuf x_slot, x_slot_s, x_cnt, x_cnts, x_rec, x_ncnt, x_route, x_creator, x_base, x_mark, x_markcr, x_scan, x_lcid, x_lismax,
        x_items, x_w, x_id, x_ids, x_ends, x_ends_s, x_head, x_hpos, x_nodes, x_cedges;   // multi-GPU exchange mode
   DBuf w_sorted, w_head, w_hpos, w_start;                                         // wide-word (sorted) counts
-  DBuf pt_work, unperm_rec;                                                       // LDS-staged partition / un-permute (kernels_part.hip.h)
+  DBuf pt_work, unperm_rec;                                                     // LDS-staged partition / un-permute (kernels_part.hip.h)
   bool use_tile_partition = true;   // option "tile_partition": 0 = library radix passes + one-kernel un-permute (round 1)
   bool last_part_tiled = false;     // kev[39]..kev[40] bracket the second-level scatter of the last count
   bool last_unperm_tiled = false;   // kev[36]..kev[41] bracket k_unperm_window of the last map
@@ -470,20 +470,21 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
     in.check_range = check_range ? 1u : 0u;
     in.key = PartKeyOp{ordered ? 1u : 0u, km.lo, km.scale};
     const u32 tiles1 = (N + PT_TILE - 1) / PT_TILE, tiles2 = tiles1 + nb1;
-    hipLaunchKernelGGL(k_pt_hist1, dim3(tiles1 < 512 ? tiles1 : 512), dim3(1024), 0, st, in, N, d1, hist1);
+    const ReadsSrc src{in};
+    hipLaunchKernelGGL(k_pt_hist1<ReadsSrc>, dim3(tiles1 < 512 ? tiles1 : 512), dim3(1024), 0, st, src, N, d1, hist1);
     hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, hist1, d1, d2, cbase, tprefix, c->pbeg.as<u32>(),
                        c->ucount.as<u32>() + n_parts);
     // level-1 output: the final arrays when there is no second level, else scratch that is dead until
     // k_dedup_lds writes it (pad_word, pslot)
     u64 *k1 = d2 ? c->pad_word.as<u64>() : c->pk_keys.as<u64>();
     u32 *v1 = d2 ? c->pslot.as<u32>() : c->pk_vals.as<u32>();
-    hipLaunchKernelGGL(k_pt_scatter<1>, dim3(tiles1), dim3(1024), 0, st, in, N, (const u64 *)nullptr,
+    hipLaunchKernelGGL((k_pt_scatter<1, ReadsSrc>), dim3(tiles1), dim3(1024), 0, st, src, N, (const u64 *)nullptr,
                        (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr, d1, d2, cbase, cursor1, k1, v1,
                        (u32 *)nullptr);
     HIPCHK(hipEventRecord(c->kev[39], st));
     if (d2) {
-      hipLaunchKernelGGL(k_pt_hist2, dim3(tiles2), dim3(1024), 0, st, k1, tprefix, cbase, d1, d2, hist_fine);
-      hipLaunchKernelGGL(k_pt_scatter<2>, dim3(tiles2), dim3(1024), 0, st, in, N, k1, v1, tprefix, cbase, d1, d2,
+      hipLaunchKernelGGL(k_pt_hist2<ReadsSrc>, dim3(tiles2), dim3(1024), 0, st, src, k1, tprefix, cbase, d1, d2, hist_fine);
+      hipLaunchKernelGGL((k_pt_scatter<2, ReadsSrc>), dim3(tiles2), dim3(1024), 0, st, src, N, k1, v1, tprefix, cbase, d1, d2,
                          hist_fine, cursor2, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(), c->pbeg.as<u32>());
     }
     HIPCHK(hipEventRecord(c->kev[40], st));

@@ -24,7 +24,7 @@
 #define PT_IPT (PT_TILE / PT_THREADS)
 #define PT_MAXBINS 512u          // fan-out of one level (<= 9 key bits)
 
-// where the records of the front partition come from: the caller's reads (level 1) ...
+// the reads of the count stage
 struct PtInput {
   const u64 *words;
   const u8 *filtered;            // null: none filtered
@@ -39,6 +39,14 @@ __device__ __forceinline__ bool pt_load(const PtInput &in, u32 r, u64 &key) {
   key = in.key(w);
   return true;
 }
+// A SOURCE of the partition says what item j of the input is (load: false = not partitioned; the 64-bit
+// payload that travels with the item's index) and what 64-bit key, bins read from its top bits, a
+// payload has.  ReadsSrc: the reads of the count stage, payload = the partition key itself.
+struct ReadsSrc {
+  PtInput in;
+  __device__ __forceinline__ bool load(u32 j, u64 &payload) const { return pt_load(in, j, payload); }
+  __device__ __forceinline__ u64 key(u64 payload) const { return payload; }
+};
 
 // exclusive scan of cnt[0, nb) (nb <= 512) by the first 512 threads of the block -> off[0, nb],
 // off[nb] = total.  All threads of the block must call it.
@@ -79,8 +87,9 @@ __device__ __forceinline__ void pt_tile_of(const u32 *__restrict__ tprefix, cons
 }
 
 // ---- level 1 histogram: usable reads per coarse bin (the top d1 key bits) ----
+template <class SRC>
 __global__ void __launch_bounds__(1024)
-k_pt_hist1(PtInput in, u32 n_reads, u32 d1, u32 *__restrict__ hist1) {
+k_pt_hist1(SRC src, u32 n_reads, u32 d1, u32 *__restrict__ hist1) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u32 h[PT_MAXBINS];
   const u32 nb = 1u << d1;
@@ -92,14 +101,14 @@ k_pt_hist1(PtInput in, u32 n_reads, u32 d1, u32 *__restrict__ hist1) {
     u64 key[4];
     bool ok[4];
 #pragma unroll
-    for (u32 q = 0; q < 4; q++) ok[q] = pt_load(in, r + q * stride, key[q]);
+    for (u32 q = 0; q < 4; q++) ok[q] = src.load(r + q * stride, key[q]);
 #pragma unroll
     for (u32 q = 0; q < 4; q++)
-      if (ok[q]) atomicAdd(&h[(u32)(key[q] >> (64 - d1))], 1u);
+      if (ok[q]) atomicAdd(&h[(u32)(src.key(key[q]) >> (64 - d1))], 1u);
   }
   for (; r < n_reads; r += stride) {
     u64 key;
-    if (pt_load(in, r, key)) atomicAdd(&h[(u32)(key >> (64 - d1))], 1u);
+    if (src.load(r, key)) atomicAdd(&h[(u32)(src.key(key) >> (64 - d1))], 1u);
   }
   __syncthreads();
   for (u32 b = threadIdx.x; b < nb; b += blockDim.x)
@@ -120,8 +129,12 @@ k_pt_scan1(const u32 *__restrict__ hist1, u32 d1, u32 d2, u32 *__restrict__ cbas
   block_exscan_512(cnt, off, nb, wsum);
   if (threadIdx.x <= nb) cbase[threadIdx.x] = off[threadIdx.x];
   if (threadIdx.x == 0) { pbeg[nb << d2] = off[nb]; *ucount_tail = 0; }
-  for (u32 g = threadIdx.x; g < (nb << d2); g += blockDim.x)
-    if (d2 == 0 || cnt[g >> d2] == 0) pbeg[g] = off[g >> d2];
+  if (d2 == 0) {
+    if (threadIdx.x < nb) pbeg[threadIdx.x] = off[threadIdx.x];
+  } else {
+    if (threadIdx.x < nb && cnt[threadIdx.x] == 0)               // empty coarse bins are rare
+      for (u32 f = 0; f < (1u << d2); f++) pbeg[(threadIdx.x << d2) | f] = off[threadIdx.x];
+  }
   __syncthreads();
   if (threadIdx.x < nb) cnt[threadIdx.x] = (hist1[threadIdx.x] + PT_TILE - 1) / PT_TILE;
   __syncthreads();
@@ -135,9 +148,9 @@ k_pt_scan1(const u32 *__restrict__ hist1, u32 d1, u32 d2, u32 *__restrict__ cbas
 //          below; base = the level-2 histogram: the region of (c, f) starts at cbase[c] + the fine
 //          counts of c before f, which the first tile of c also writes to pbeg_out[c << d2 | f].
 //          cursor[]: records already placed in each region (zeroed before the launch).
-template <int LEVEL>
+template <int LEVEL, class SRC>
 __global__ void __launch_bounds__(1024)
-k_pt_scatter(PtInput in, u32 n_reads, const u64 *__restrict__ k_in, const u32 *__restrict__ v_in,
+k_pt_scatter(SRC src, u32 n_reads, const u64 *__restrict__ k_in, const u32 *__restrict__ v_in,
              const u32 *__restrict__ tprefix, const u32 *__restrict__ cbase, u32 d1, u32 d2,
              const u32 *__restrict__ base, u32 *cursor, u64 *__restrict__ k_out, u32 *__restrict__ v_out,
              u32 *__restrict__ pbeg_out) {
@@ -180,11 +193,11 @@ k_pt_scatter(PtInput in, u32 n_reads, const u64 *__restrict__ k_in, const u32 *_
     binrank[q] = NONE32;
     if (j < t_cnt) {
       bool ok = true;
-      if (LEVEL == 1) { ok = pt_load(in, t_beg + j, key[q]); val[q] = t_beg + j; }
+      if (LEVEL == 1) { ok = src.load(t_beg + j, key[q]); val[q] = t_beg + j; }
       else { key[q] = k_in[t_beg + j]; val[q] = v_in[t_beg + j]; }
       if (ok) {
-        const u32 bin = (LEVEL == 1) ? (u32)(key[q] >> (64 - d1))
-                                     : (u32)(key[q] >> (64 - d1 - d2)) & (nb - 1);
+        const u64 kk = src.key(key[q]);
+        const u32 bin = (LEVEL == 1) ? (u32)(kk >> (64 - d1)) : (u32)(kk >> (64 - d1 - d2)) & (nb - 1);
         binrank[q] = bin << 16 | atomicAdd(&cnt[bin], 1u);   // rank < 8192 < 2^16
       }
     }
@@ -216,8 +229,9 @@ k_pt_scatter(PtInput in, u32 n_reads, const u64 *__restrict__ k_in, const u32 *_
 }
 
 // ---- level 2 histogram: records per fine bucket, one tile of one coarse bin per block ----
+template <class SRC>
 __global__ void __launch_bounds__(1024)
-k_pt_hist2(const u64 *__restrict__ k_in, const u32 *__restrict__ tprefix, const u32 *__restrict__ cbase, u32 d1,
+k_pt_hist2(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ tprefix, const u32 *__restrict__ cbase, u32 d1,
            u32 d2, u32 *__restrict__ hist_fine) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u32 h[PT_MAXBINS];
@@ -233,7 +247,7 @@ k_pt_hist2(const u64 *__restrict__ k_in, const u32 *__restrict__ tprefix, const 
   __syncthreads();
   const u32 beg = s_beg, n = s_cnt;
   for (u32 j = threadIdx.x; j < n; j += PT_THREADS)
-    atomicAdd(&h[(u32)(k_in[beg + j] >> (64 - d1 - d2)) & (nb - 1)], 1u);
+    atomicAdd(&h[(u32)(src.key(k_in[beg + j]) >> (64 - d1 - d2)) & (nb - 1)], 1u);
   __syncthreads();
   for (u32 b = threadIdx.x; b < nb; b += PT_THREADS)
     if (h[b]) atomicAdd(&hist_fine[(s_c << d2) | b], h[b]);
