@@ -69,6 +69,9 @@ SYMBOLS = {
                                     C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), u64p]),
     "humid_stage_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), u32p]),
     "humid_stage_route_words": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "humid_stage_route": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, u64p, u64p, C.c_uint32, u64p,
+                                    C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "humid_stage_route_check": (C.c_int, [C.c_void_p]),
     "humid_stage_exchange_ids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                            C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p),
                                            C.POINTER(C.c_void_p)]),

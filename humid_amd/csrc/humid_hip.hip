@@ -65,9 +65,11 @@ struct humid_ctx {
   DBuf x_slot, x_slot_s, x_cnt, x_cnts, x_rec, x_ncnt, x_route, x_creator, x_base, x_mark, x_markcr, x_scan, x_lcid, x_lismax,
        x_items, x_w, x_id, x_ids, x_ends, x_ends_s, x_head, x_hpos, x_nodes, x_cedges;   // multi-GPU exchange mode
   DBuf w_sorted, w_head, w_hpos, w_start;                                         // wide-word (sorted) counts
-  DBuf pt_work, unperm_rec;                                                     // LDS-staged partition / un-permute (kernels_part.hip.h)
+  DBuf pt_work, unperm_rec, route_tiles;                                                     // LDS-staged partition / un-permute (kernels_part.hip.h)
   bool use_tile_partition = true;   // option "tile_partition": 0 = library radix passes + one-kernel un-permute (round 1)
   bool last_part_tiled = false;     // kev[39]..kev[40] bracket the second-level scatter of the last count
+  bool route_checked = true;        // no humid_stage_route since the last humid_stage_route_check
+  const u32 *route_bad = nullptr;   // device flag of the last humid_stage_route
   bool last_unperm_tiled = false;   // kev[36]..kev[41] bracket k_unperm_window of the last map
   // cached answer of prefix_fits_ordered for (reads, word length, key map): the sampled histogram and
   // its host wait run once per shape, not once per pass; an overflowing ordered run resets it
@@ -138,20 +140,25 @@ static inline u32 bits_for(u64 n) {  // bits needed to represent values < n
 }
 
 // ---- rocPRIM wrappers (temp storage grown on demand) ---------------------------------
+// MergeSortLimit = 0: block sort up to 1024 items, Onesweep above.  The library's default takes a
+// merge sort for sub-million inputs: ~20 launches of 6 us each where Onesweep needs 4 (measured on the
+// 440 k endpoint sort of the multi-GPU path, profiles/r02c_exchange_world1.md)
+using onesweep_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                rocprim::default_config, 0>;
 template <class K, class V>
 static int sort_pairs(humid_ctx *c, const K *kin, K *kout, const V *vin, V *vout, u64 n, u32 b0, u32 b1) {
   size_t bytes = 0;
-  HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (size_t)n, b0, b1, c->stream));
+  HIPCHK(rocprim::radix_sort_pairs<onesweep_cfg>(nullptr, bytes, kin, kout, vin, vout, (size_t)n, b0, b1, c->stream));
   ENSURE(c->tmp, bytes);
-  HIPCHK(rocprim::radix_sort_pairs(c->tmp.p, bytes, kin, kout, vin, vout, (size_t)n, b0, b1, c->stream));
+  HIPCHK(rocprim::radix_sort_pairs<onesweep_cfg>(c->tmp.p, bytes, kin, kout, vin, vout, (size_t)n, b0, b1, c->stream));
   return HUMID_OK;
 }
 template <class K>
 static int sort_keys(humid_ctx *c, const K *kin, K *kout, u64 n, u32 b0, u32 b1) {
   size_t bytes = 0;
-  HIPCHK(rocprim::radix_sort_keys(nullptr, bytes, kin, kout, (size_t)n, b0, b1, c->stream));
+  HIPCHK(rocprim::radix_sort_keys<onesweep_cfg>(nullptr, bytes, kin, kout, (size_t)n, b0, b1, c->stream));
   ENSURE(c->tmp, bytes);
-  HIPCHK(rocprim::radix_sort_keys(c->tmp.p, bytes, kin, kout, (size_t)n, b0, b1, c->stream));
+  HIPCHK(rocprim::radix_sort_keys<onesweep_cfg>(c->tmp.p, bytes, kin, kout, (size_t)n, b0, b1, c->stream));
   return HUMID_OK;
 }
 static int exscan_u32(humid_ctx *c, const u32 *in, u32 *out, u64 n) {
@@ -570,7 +577,7 @@ static int prefix_fits_ordered(humid_ctx *c, const u64 *d_words, const u8 *d_fil
   const u32 n_sample = N < (1u << 19) ? N : (1u << 19);
   ENSURE(c->small, (size_t)n_bins * 4);
   HIPCHK(hipMemsetAsync(c->small.p, 0, (size_t)n_bins * 4, c->stream));
-  hipLaunchKernelGGL(k_top_hist, dim3(512), dim3(256), n_bins * 4, c->stream, d_words, d_filt, n_sample,
+  hipLaunchKernelGGL(k_top_hist, dim3(128), dim3(1024), n_bins * 4, c->stream, d_words, d_filt, n_sample,
                      km.lo, km.scale, bits, c->small.as<u32>());
   std::vector<u32> h(n_bins);
   HIPCHK(hipMemcpyAsync(h.data(), c->small.p, (size_t)n_bins * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1307,7 +1314,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
-                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->seg_ws, &c->csize, &c->cur, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -1607,7 +1614,7 @@ int humid_stage_histogram(humid_ctx *c, const uint64_t *d_words, const uint8_t *
   const u32 n_bins = 1u << bits;
   HIPCHK(hipMemsetAsync(d_hist, 0, n_bins * 4, c->stream));
   if (n_reads)
-    hipLaunchKernelGGL(k_top_hist, dim3(512), dim3(256), n_bins * 4, c->stream, d_words, d_filtered,
+    hipLaunchKernelGGL(k_top_hist, dim3(256), dim3(1024), n_bins * 4, c->stream, d_words, d_filtered,
                        (u32)n_reads, (u64)0, word_nt >= 32 ? (u64)1 : ((u64)1 << (64 - 2 * word_nt)), bits, d_hist);
   HIPCHK(hipGetLastError());
   return HUMID_OK;              // queued on the context's stream; no host value is returned
@@ -2067,7 +2074,7 @@ int humid_stage_compact_nodes(humid_ctx *c, const uint64_t *d_edges, uint64_t n_
   ENSURE(c->x_hpos, ((size_t)n2 + 1) * 4);
   hipLaunchKernelGGL(k_edge_ends, dim3(blocks_for(E)), dim3(256), 0, st, d_edges, E, record_stride, c->x_ends.as<u32>(),
                      c->x_slot.as<u32>());
-  TRY(sort_pairs<u32, u32>(c, c->x_ends.as<u32>(), c->x_ends_s.as<u32>(), c->x_slot.as<u32>(), c->x_slot_s.as<u32>(), n2, 0, 32));
+  TRY(sort_pairs<u32, u32>(c, c->x_ends.as<u32>(), c->x_ends_s.as<u32>(), c->x_slot.as<u32>(), c->x_slot_s.as<u32>(), n2, 0, 32));   // (global indices: all 32 bits may be in use)
   hipLaunchKernelGGL(k_heads_u32, dim3(blocks_for((u64)n2 + 1)), dim3(256), 0, st, c->x_ends_s.as<u32>(), n2,
                      c->x_head.as<u32>());
   TRY(exscan_u32(c, c->x_head.as<u32>(), c->x_hpos.as<u32>(), (u64)n2 + 1));
@@ -2166,6 +2173,66 @@ int humid_stage_route_words(humid_ctx *c, const uint64_t *d_words, uint64_t n_se
   return HUMID_OK;
 }
 
+// Stable routing of this rank's usable reads to the owners of their value ranges, without a host
+// wait: send_counts[q] (reads of owner q; the caller knows them from the all-gathered histograms)
+// fix the block bases.  *d_routed: the words, owner-major, input order inside every block;
+// *d_perm: routed position -> read index (humid_stage_scatter takes it).  A count that does not match
+// the data raises the flag humid_stage_route_check reports.
+int humid_stage_route(humid_ctx *c, const uint64_t *d_words, const uint8_t *d_filtered, uint64_t n_reads,
+                      const uint64_t *range_lo, const uint64_t *range_hi, uint32_t n_ranks,
+                      const uint64_t *send_counts, const uint64_t **d_routed, const uint32_t **d_perm) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (!range_lo || !range_hi || !send_counts || !d_routed || !d_perm || n_ranks == 0) return fail(c, HUMID_E_INVALID, "bad argument");
+  if (n_ranks > MAX_RANKS) return fail(c, HUMID_E_UNSUPPORTED, "more than %d ranks", MAX_RANKS);
+  if (n_reads > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "n_reads exceeds 2^31-1");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  *d_routed = nullptr;
+  *d_perm = nullptr;
+  const u32 n = (u32)n_reads;
+  if (n == 0) return HUMID_OK;
+  if (!d_words || !d_filtered) return fail(c, HUMID_E_INVALID, "null buffer");
+  OwnerRanges rg;
+  OwnerBases ob;
+  u64 tot = 0;
+  for (u32 q = 0; q < MAX_RANKS; q++) {
+    rg.lo[q] = q < n_ranks ? range_lo[q] : 1;
+    rg.hi[q] = q < n_ranks ? range_hi[q] : 0;
+    ob.b[q] = (u32)tot;
+    if (q < n_ranks) tot += send_counts[q];
+  }
+  ob.b[MAX_RANKS] = (u32)tot;
+  if (tot > n) return fail(c, HUMID_E_INVALID, "send_counts exceed n_reads");
+  const u32 n_tiles = (n + ROUTE_TILE - 1) / ROUTE_TILE;
+  ENSURE(c->route_tiles, ((size_t)n_tiles * MAX_RANKS + 16) * 4);
+  ENSURE(c->perm, (size_t)n * 4);
+  ENSURE(c->x_route, (size_t)(tot ? tot : 1) * 8);
+  u32 *tile_cnt = c->route_tiles.as<u32>(), *bad = tile_cnt + (size_t)n_tiles * MAX_RANKS;
+  hipLaunchKernelGGL(k_route_tile_hist, dim3(n_tiles), dim3(1024), 0, st, d_words, d_filtered, n, rg, n_ranks, tile_cnt, bad);
+  hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(1024), 0, st, tile_cnt, n_tiles, ob, bad);
+  hipLaunchKernelGGL(k_route_scatter, dim3(n_tiles), dim3(1024), 0, st, d_words, d_filtered, n, rg, n_ranks,
+                     (const u32 *)tile_cnt, c->x_route.as<u64>(), c->perm.as<u32>());
+  HIPCHK(hipGetLastError());
+  c->route_checked = false;
+  c->route_bad = bad;
+  *d_routed = c->x_route.as<u64>();
+  *d_perm = c->perm.as<u32>();
+  return HUMID_OK;
+}
+
+// waits for the stream; HUMID_E_INVALID if the send_counts of the last humid_stage_route did not match
+int humid_stage_route_check(humid_ctx *c) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (c->route_checked || !c->route_bad) return HUMID_OK;
+  HIPCHK(hipSetDevice(c->device));
+  u32 flag = 0;
+  HIPCHK(hipMemcpyAsync(&flag, c->route_bad, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->route_checked = true;
+  if (flag) return fail(c, HUMID_E_INVALID, "humid_stage_route: send_counts do not match the reads");
+  return HUMID_OK;
+}
+
 // Cluster id and maxLeaf flag of this rank's u_local unique words (global walk indices
 // id_base .. id_base + u_local - 1) from the replicated compact graph: d_nodes[n_nodes] ascending
 // global indices of the leaves that have neighbours, d_ccid / d_cismax their results from
@@ -2188,35 +2255,33 @@ int humid_stage_exchange_ids(humid_ctx *c, const uint32_t *d_nodes, const uint32
   const u32 M = (u32)n_nodes, Cc = (u32)n_clusters, goff = (u32)id_base, U = (u32)u_local;
   ENSURE(c->x_creator, ((size_t)Cc + 1) * 4);
   ENSURE(c->x_base, ((size_t)Cc + 1) * 4);
-  ENSURE(c->x_mark, (size_t)U * 4);
-  ENSURE(c->x_markcr, (size_t)U * 4);
+  // x_mark | x_markcr | the two counters of k_xid_first: one allocation, one memset
+  ENSURE(c->x_mark, ((size_t)U * 2 + 4) * 4);
   ENSURE(c->x_scan, ((size_t)U + 1) * 8);
   ENSURE(c->x_lcid, (size_t)U * 4);
   ENSURE(c->x_lismax, (size_t)U);
-  ENSURE(c->small, 64);
-  HIPCHK(hipMemsetAsync(c->x_mark.p, 0, (size_t)U * 4, st));
-  HIPCHK(hipMemsetAsync(c->x_markcr.p, 0, (size_t)U * 4, st));
-  HIPCHK(hipMemsetAsync(c->small.p, 0, 8, st));
+  u32 *x_mark = c->x_mark.as<u32>(), *x_markcr = x_mark + U, *x_first = x_markcr + U;
+  HIPCHK(hipMemsetAsync(x_mark, 0, ((size_t)U * 2 + 2) * 4, st));
   if (M) {
     HIPCHK(hipMemsetAsync(c->x_creator.p, 0xff, ((size_t)Cc + 1) * 4, st));
     hipLaunchKernelGGL(k_xid_creators, dim3(blocks_for(M)), dim3(256), 0, st, d_ccid, M, Cc, c->x_creator.as<u32>());
     if (Cc)
       hipLaunchKernelGGL(k_xid_base, dim3(blocks_for(Cc)), dim3(256), 0, st, d_nodes, c->x_creator.as<u32>(), M, Cc,
-                         goff, U, c->x_base.as<u32>(), c->x_markcr.as<u32>());
-    hipLaunchKernelGGL(k_xid_mark, dim3(blocks_for(M)), dim3(256), 0, st, d_nodes, M, goff, U, c->x_mark.as<u32>());
+                         goff, U, c->x_base.as<u32>(), x_markcr);
+    hipLaunchKernelGGL(k_xid_mark, dim3(blocks_for(M)), dim3(256), 0, st, d_nodes, M, goff, U, x_mark);
     hipLaunchKernelGGL(k_xid_first, dim3(1), dim3(64), 0, st, d_nodes, c->x_creator.as<u32>(), M, Cc, goff,
-                       c->small.as<u32>());
+                       x_first);
   }
   {
     auto fin = rocprim::make_transform_iterator(rocprim::counting_iterator<u32>(0),
-                                                XidFlagOp{c->x_mark.as<u32>(), c->x_markcr.as<u32>(), U});
+                                                XidFlagOp{x_mark, x_markcr, U});
     size_t bytes = 0;
     HIPCHK(rocprim::exclusive_scan(nullptr, bytes, fin, c->x_scan.as<u64>(), (u64)0, (size_t)U, rocprim::plus<u64>(), st));
     ENSURE(c->tmp, bytes);
     HIPCHK(rocprim::exclusive_scan(c->tmp.p, bytes, fin, c->x_scan.as<u64>(), (u64)0, (size_t)U, rocprim::plus<u64>(), st));
   }
-  hipLaunchKernelGGL(k_xid_assign, dim3(blocks_for(U)), dim3(256), 0, st, c->x_mark.as<u32>(), c->x_scan.as<u64>(),
-                     c->small.as<u32>(), d_ccid, d_cismax, c->x_base.as<u32>(), Cc, goff, U, c->x_lcid.as<u32>(),
+  hipLaunchKernelGGL(k_xid_assign, dim3(blocks_for(U)), dim3(256), 0, st, x_mark, c->x_scan.as<u64>(),
+                     x_first, d_ccid, d_cismax, c->x_base.as<u32>(), Cc, goff, U, c->x_lcid.as<u32>(),
                      c->x_lismax.as<u8>());
   HIPCHK(hipGetLastError());
   *d_l_cid = c->x_lcid.as<u32>();

@@ -338,6 +338,118 @@ k_route_words(const u64 *__restrict__ words, const u32 *__restrict__ perm, u32 n
   for (u32 k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) out[k] = words[perm[k]];
 }
 
+// ---- routing of a rank's usable reads to the owners of their value ranges, STABLE ----
+// (humid_stage_route.)  The routed array must keep the input order inside every owner's block: the
+// owner takes "position in what it received" for "input order" when it decides which read of a word
+// came first (the keep rule, src/humid.cc:224-231).  Three kernels over tiles of ROUTE_TILE reads:
+// per-tile owner counts, one block that turns them into per-tile offsets inside every owner's block
+// (the owners' block bases come from the host: it knows the totals from the all-gathered histograms),
+// and the scatter, whose in-tile ranks come from wave ballots (at most 16 owners).
+#define ROUTE_TILE 8192u
+__device__ __forceinline__ u32 owner_of_word(const OwnerRanges &rg, u32 n_ranks, u64 w) {
+  u32 o = n_ranks;
+#pragma unroll
+  for (u32 q = 0; q < MAX_RANKS; q++)
+    if (q < n_ranks && rg.lo[q] <= rg.hi[q] && w >= rg.lo[q] && w <= rg.hi[q]) o = q;
+  return o;
+}
+
+__global__ void __launch_bounds__(1024)
+k_route_tile_hist(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n, OwnerRanges rg,
+                  u32 n_ranks, u32 *__restrict__ tile_cnt, u32 *__restrict__ bad) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ u32 cnt[MAX_RANKS];
+  if (blockIdx.x == 0 && threadIdx.x == 0) bad[0] = 0;       // k_route_scan (next launch) may raise it
+  if (threadIdx.x < MAX_RANKS) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 beg = blockIdx.x * ROUTE_TILE;
+  u32 mine[MAX_RANKS];
+#pragma unroll
+  for (u32 q = 0; q < MAX_RANKS; q++) mine[q] = 0;
+#pragma unroll
+  for (u32 k = 0; k < ROUTE_TILE / 1024; k++) {
+    const u32 j = beg + k * 1024 + threadIdx.x;
+    if (j < n && !filtered[j]) {
+      const u32 o = owner_of_word(rg, n_ranks, words[j]);
+#pragma unroll
+      for (u32 q = 0; q < MAX_RANKS; q++) mine[q] += (o == q) ? 1u : 0u;
+    }
+  }
+#pragma unroll
+  for (u32 q = 0; q < MAX_RANKS; q++) {
+    u32 x = mine[q];
+#pragma unroll
+    for (u32 d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+    if ((threadIdx.x & 63) == 0 && x) atomicAdd(&cnt[q], x);
+  }
+  __syncthreads();
+  if (threadIdx.x < MAX_RANKS) tile_cnt[blockIdx.x * MAX_RANKS + threadIdx.x] = cnt[threadIdx.x];
+}
+
+struct OwnerBases { u32 b[MAX_RANKS + 1]; };       // first routed position of every owner's block
+
+// one block, one wave per owner: tile_cnt[t][q] -> exclusive offset of tile t inside owner q's block
+// (in place), + the block's base; bad[0] = 1 if an owner's total differs from the host's count
+__global__ void __launch_bounds__(1024)
+k_route_scan(u32 *tile_cnt, u32 n_tiles, OwnerBases ob, u32 *bad) {
+  HUMID_GUARD_LAST_VGPR();
+  const u32 q = threadIdx.x >> 6, lane = threadIdx.x & 63;       // 16 waves = MAX_RANKS owners
+  u32 run = ob.b[q];
+  for (u32 t0 = 0; t0 < n_tiles; t0 += 64) {
+    const u32 t = t0 + lane;
+    const u32 x = t < n_tiles ? tile_cnt[t * MAX_RANKS + q] : 0u;
+    u32 incl = x;
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+      const u32 y = __shfl_up(incl, d);
+      if (lane >= d) incl += y;
+    }
+    if (t < n_tiles) tile_cnt[t * MAX_RANKS + q] = run + incl - x;
+    run += __shfl(incl, 63);
+  }
+  if (lane == 0 && run != ob.b[q + 1]) bad[0] = 1;
+}
+
+__global__ void __launch_bounds__(1024)
+k_route_scatter(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n, OwnerRanges rg,
+                u32 n_ranks, const u32 *__restrict__ tile_off, u64 *__restrict__ routed, u32 *__restrict__ perm) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ u32 wcnt[16][MAX_RANKS];      // this batch: reads of every owner per wave
+  __shared__ u32 run[MAX_RANKS];           // reads of every owner in the batches before
+  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const u64 lt = (1ull << lane) - 1ull;
+  if (threadIdx.x < MAX_RANKS) run[threadIdx.x] = tile_off[blockIdx.x * MAX_RANKS + threadIdx.x];
+  const u32 beg = blockIdx.x * ROUTE_TILE;
+  for (u32 k = 0; k < ROUTE_TILE / 1024; k++) {
+    const u32 j = beg + k * 1024 + threadIdx.x;
+    u32 o = MAX_RANKS + 1;
+    u64 w = 0;
+    if (j < n && !filtered[j]) { w = words[j]; o = owner_of_word(rg, n_ranks, w); }
+    u32 rank_in_wave = 0;
+#pragma unroll
+    for (u32 q = 0; q < MAX_RANKS; q++) {
+      const u64 m = __ballot(o == q);
+      if (o == q) rank_in_wave = (u32)__popcll(m & lt);
+      if (lane == 0) wcnt[wave][q] = (u32)__popcll(m);
+    }
+    __syncthreads();
+    if (o < n_ranks) {
+      u32 before = run[o];
+      for (u32 w2 = 0; w2 < wave; w2++) before += wcnt[w2][o];
+      const u32 pos = before + rank_in_wave;
+      routed[pos] = w;
+      perm[pos] = j;
+    }
+    __syncthreads();
+    if (threadIdx.x < MAX_RANKS) {
+      u32 t = 0;
+      for (u32 w2 = 0; w2 < 16; w2++) t += wcnt[w2][threadIdx.x];
+      run[threadIdx.x] += t;
+    }
+    __syncthreads();
+  }
+}
+
 // ---- cluster ids of one rank's unique words from the replicated compact graph ----
 // creator (smallest member = the leaf whose walk step created the cluster) of every compact cluster
 __global__ void k_xid_creators(const u32 *__restrict__ ccid, u32 n_nodes, u32 n_clusters, u32 *creator) {
@@ -436,7 +548,7 @@ __global__ void k_creator_sizes(const u32 *__restrict__ flag, const u32 *__restr
 // reads per top-`bits` bin of (word - lo) * scale (usable reads only): balanced range splitters for
 // the multi-GPU path (lo = 0, scale = 2^(64-2n): the top bits of the word itself) and the
 // uniformity check of the word-ordered buckets.  LDS-privatised, fixed grid.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_top_hist(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n_reads, u64 lo, u64 scale,
            u32 bits, u32 *hist) {
   HUMID_GUARD_LAST_VGPR();
@@ -444,11 +556,22 @@ k_top_hist(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n
   const u32 n_bins = 1u << bits;
   for (u32 b = threadIdx.x; b < n_bins; b += blockDim.x) lh[b] = 0;
   __syncthreads();
-  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x)
-    if (!(filtered && filtered[r])) {
-      const u32 b = (u32)(((words[r] - lo) * scale) >> (64 - bits));   // < n_bins by construction
-      atomicAdd(&lh[b], 1u);
+  const u32 stride = gridDim.x * blockDim.x;
+  u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+  for (; r + 3 * stride < n_reads; r += 4 * stride) {         // four independent loads in flight
+    u64 w[4];
+    bool ok[4];
+#pragma unroll
+    for (u32 q = 0; q < 4; q++) {
+      ok[q] = !(filtered && filtered[r + q * stride]);
+      w[q] = words[r + q * stride];
     }
+#pragma unroll
+    for (u32 q = 0; q < 4; q++)
+      if (ok[q]) atomicAdd(&lh[(u32)(((w[q] - lo) * scale) >> (64 - bits))], 1u);   // < n_bins by construction
+  }
+  for (; r < n_reads; r += stride)
+    if (!(filtered && filtered[r])) atomicAdd(&lh[(u32)(((words[r] - lo) * scale) >> (64 - bits))], 1u);
   __syncthreads();
   for (u32 b = threadIdx.x; b < n_bins; b += blockDim.x)
     if (lh[b]) atomicAdd(&hist[b], lh[b]);

@@ -213,6 +213,23 @@ class HipStageOps(Context):
         self._call(self._lib.humid_stage_route_words, self._p(d_w), n_send, C.byref(pr))
         return _wrap(pr.value, n_send, "<i8", torch.int64, self.device)
 
+    def route(self, d_w, d_f, ranges, send_counts):
+        """stable owner-major routing without a host wait: (routed words int64[sum(send_counts)],
+        perm int32[n]: routed position -> read index); views of ctx memory"""
+        P = len(ranges)
+        lo = (C.c_uint64 * P)(*[r[0] for r in ranges])
+        hi = (C.c_uint64 * P)(*[r[1] for r in ranges])
+        sc = (C.c_uint64 * P)(*send_counts)
+        pr, pp = C.c_void_p(), C.c_void_p()
+        self._call(self._lib.humid_stage_route, self._p(d_w), self._p(d_f), d_w.numel(), lo, hi, P, sc,
+                   C.byref(pr), C.byref(pp))
+        n_send = sum(send_counts)
+        return (_wrap(pr.value, n_send, "<i8", torch.int64, self.device),
+                _wrap(pp.value, d_w.numel(), "<i4", torch.int32, self.device))
+
+    def route_check(self):
+        self._call(self._lib.humid_stage_route_check)
+
     def combo_route(self, l_word, l_cnt, id_base, word_nt, distance, plan_unique, combo, n_ranks):
         """(word, id | count << 32) items of the local unique array in destination-major order:
         int64[n, 2]"""
@@ -522,11 +539,28 @@ class ShardedDedup:
             now = time.perf_counter()
             trace[name] = trace.get(name, 0.0) + 1e3 * (now - t_last[0])
             t_last[0] = now
-        # ---- 1. global histogram -> balanced ordered value ranges (cut at prefix boundaries) ----
+        # ---- 1. per-rank histograms of the top word bits, all-gathered (P x 16 KB): their sum gives
+        #         balanced ordered value ranges (cut at prefix boundaries), and since the ranges are
+        #         cut at bin boundaries the histograms also say how many reads every rank sends to
+        #         every owner -- no second exchange of counts, no host wait in the routing ----
         hist = ops.histogram(d_w, d_f, self.word_nt, bits)
-        _all_reduce_sum(dist, hist)
-        hist_host = hist.cpu().numpy()
+        n_bins = hist.numel()
+        all_h = torch.empty(P * n_bins, dtype=hist.dtype, device=dev)
+        _all_gather_flat(dist, all_h, hist, P)
+        all_host = all_h.cpu().numpy().reshape(P, n_bins).astype(np.int64)
+        hist_host = all_host.sum(axis=0)
         ranges = splitters_from_hist(hist_host, P, self.word_nt, bits)
+        shift = 2 * self.word_nt - bits
+        cum = np.concatenate([np.zeros((P, 1), np.int64), np.cumsum(all_host, axis=1)], axis=1)   # [P, n_bins + 1]
+
+        def in_range(src, q):                             # usable reads of rank src in the range of owner q
+            lo, hi, _ = ranges[q]
+            if lo > hi:
+                return 0
+            b0, b1 = lo >> shift, min(hi >> shift, n_bins - 1) + 1
+            return int(cum[src, b1] - cum[src, b0])
+        send_counts = [in_range(r, q) for q in range(P)]
+        recv_counts = [in_range(q, r) for q in range(P)]
         lo_r, hi_r = ranges[r][0], ranges[r][1]
         if lo_r > hi_r:
             lo_r, hi_r = 0, (1 << 64) - 1                 # empty range: nothing arrives
@@ -535,16 +569,14 @@ class ShardedDedup:
             # histogram already says so (saves the library's own sampling pass and its host wait)
             ops.set_option("count_order", _order_hint(hist_host, ranges[r], self.word_nt, bits))
         mark("1_ranges")
-        # ---- 2. usable words -> owner of their range ----
-        perm, send_counts = ops.owner_perm(d_w, d_f, ranges)          # owner-major, filtered reads last
+        # ---- 2. usable words -> owner of their range (stable: input order inside every block) ----
         n_send = sum(send_counts)
-        if hasattr(ops, "route_words"):
-            send_w = ops.route_words(d_w, n_send)
+        if hasattr(ops, "route"):
+            send_w, perm = ops.route(d_w, d_f, ranges, send_counts)
         else:
+            perm, sc2 = ops.owner_perm(d_w, d_f, ranges)              # owner-major, filtered reads last
+            assert sc2 == send_counts
             send_w = d_w[perm[:n_send].long()] if n_send else torch.empty(0, **i64)
-        cm = torch.empty(P * P, **i64)
-        _all_gather_flat(dist, cm, torch.tensor(send_counts, **i64), P)
-        recv_counts = cm.cpu().view(P, P)[:, r].tolist()
         n_recv = sum(recv_counts)
         recv_w = torch.empty(n_recv, **i64)
         _all_to_all_v(dist, recv_w, send_w, recv_counts, send_counts, P, r)

@@ -296,6 +296,16 @@ int humid_stage_scatter(humid_ctx *ctx, const uint32_t *d_perm, const uint32_t *
 int humid_stage_kernel_ms(humid_ctx *ctx, float *ms_k_insert, float *ms_k_map, uint32_t *count_mode_used);
 int humid_stage_route_words(humid_ctx *ctx, const uint64_t *d_words, uint64_t n_send,
                             const uint64_t **d_routed);
+/* The same routing without a host wait and without a sort: the caller already knows how many reads go
+ * to every owner (send_counts[q]: from the all-gathered per-rank histograms, whose bins the value
+ * ranges are cut at).  *d_routed = the usable words in owner-major order, INPUT ORDER inside every
+ * owner's block (the owner derives "first read of a word" from it); *d_perm = routed position -> read
+ * index, for humid_stage_scatter.  Queued on the context's stream.  humid_stage_route_check waits
+ * for the stream and returns HUMID_E_INVALID if the counts did not match the reads. */
+int humid_stage_route(humid_ctx *ctx, const uint64_t *d_words, const uint8_t *d_filtered, uint64_t n_reads,
+                      const uint64_t *range_lo, const uint64_t *range_hi, uint32_t n_ranks,
+                      const uint64_t *send_counts, const uint64_t **d_routed, const uint32_t **d_perm);
+int humid_stage_route_check(humid_ctx *ctx);
 int humid_stage_exchange_ids(humid_ctx *ctx, const uint32_t *d_nodes, const uint32_t *d_compact_cluster_id,
                              const uint8_t *d_compact_is_max, uint64_t n_nodes, uint64_t n_clusters,
                              uint64_t id_base, uint64_t u_local, const uint32_t **d_local_cluster_id,

@@ -221,6 +221,12 @@ class CpuStageOps:
         counts = [int((owner == q).sum()) for q in range(P)]
         return torch.from_numpy(perm), counts
 
+    def route(self, d_w, d_f, ranges, send_counts):
+        perm, counts = self.owner_perm(d_w, d_f, ranges)
+        assert counts == list(send_counts), (counts, send_counts)
+        n = sum(counts)
+        return d_w[perm[:n].long()], perm
+
     def scatter(self, perm, recv, out_cid, out_keep):
         out_cid.zero_()
         out_keep.zero_()
