@@ -49,11 +49,80 @@ def parse():
     ap.add_argument("--shard-mode", default=None, choices=["exchange", "allgather", "both"],
                     help="multi-GPU orchestration to time (default: HUMID_SHARD_MODE or exchange; 'both' "
                          "times the second one as well and reports it under other_mode)")
+    ap.add_argument("--e2e-reads", type=int, default=10_000_000,
+                    help="one rank only: read PAIRS of the end-to-end leg -- the `humid` command line timed on "
+                         "synthetic PE150 FastQ files with the UMI in the header (FastQ in -> _dedup FastQ out), "
+                         "reported as t_e2e_s / e2e_reads_per_s next to the core value (0 = skip)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path even with one rank (overhead measurement)")
     ap.add_argument("--traffic-json", default=None,
                     help="optional JSON with PMC-derived HBM bytes per launch of the dominant kernel")
     return ap.parse_args()
+
+
+def e2e_leg(n_reads, word_nt, distance):
+    """T_e2e: wall time of the `humid` command line, FastQ in -> _dedup FastQ out, on
+    the metric's own shape (PE150, UMI = 8 in the header of R1), page cache hot, best of two runs.
+    A separate leg like cpu_baseline: never part of `value`."""
+    import shutil
+    import subprocess
+    import tempfile
+    from humid_amd.synth import fast_fastq
+    exe = os.path.join(ROOT, "humid_amd", "humid")
+    if not os.path.exists(exe):
+        return {"error": "humid_amd/humid is not built"}
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="humid_e2e_", dir=base)
+    try:
+        r1, r2 = os.path.join(d, "R1.fastq"), os.path.join(d, "R2.fastq")
+        t0 = time.perf_counter()
+        size = fast_fastq(r1, n_reads, 1002, mate=0) + fast_fastq(r2, n_reads, 1002, mate=1)
+        gen_s = time.perf_counter() - t0
+        best = None
+        for rep in range(2):
+            out = os.path.join(d, "out%d" % rep)
+            env = dict(os.environ)
+            env["HUMID_TIMING"] = "1"
+            # timed from a small helper process: forking this one (torch, the read set: several GB of
+            # page tables) would add its own ~0.2 s to the child's wall time
+            helper = ("import subprocess, sys, time\n"
+                      "t0 = time.perf_counter()\n"
+                      "p = subprocess.run(sys.argv[1:], stderr=subprocess.PIPE)\n"
+                      "dt = time.perf_counter() - t0\n"
+                      "sys.stderr.buffer.write(p.stderr)\n"
+                      "print(dt)\n"
+                      "sys.exit(p.returncode)\n")
+            p = subprocess.run([sys.executable, "-c", helper, exe, "-n", str(word_nt), "-m", str(distance), "-d", out,
+                                "-l", os.path.join(d, "log.txt"), r1, r2], env=env, stderr=subprocess.PIPE,
+                               stdout=subprocess.PIPE)
+            try:
+                dt = float(p.stdout.decode().strip().splitlines()[-1])
+            except (ValueError, IndexError):
+                return {"error": "e2e helper failed: %s" % p.stderr.decode()[-300:]}
+            if p.returncode != 0:
+                return {"error": "humid exited with %d: %s" % (p.returncode, p.stderr.decode()[-300:])}
+            phases = {}
+            for line in p.stderr.decode().splitlines():
+                if line.startswith("[humid]   of which"):
+                    phases["device detail"] = line[7:].strip()
+                elif line.startswith("[humid]   init thread"):
+                    phases["init thread"] = line[7:].strip()
+                elif line.startswith("[humid]"):
+                    name, val = line[7:].rsplit(None, 2)[0].strip(), line.split()[-2]
+                    phases[name] = float(val)
+            kept = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out))
+            if best is None or dt < best["t_e2e_s"]:
+                best = {"t_e2e_s": round(dt, 4), "e2e_reads_per_s": round(n_reads / dt, 1),
+                        "phases_s": phases, "output_bytes": kept}
+            shutil.rmtree(out, ignore_errors=True)
+        best.update({"shape": "%d read pairs, PE150, UMI=8 in the R1 header, plain FastQ in (%.2f GB) -> "
+                              "R1/R2 _dedup FastQ out; -n %d -m %d; files in %s, page cache hot, best of 2"
+                              % (n_reads, size / 1e9, word_nt, distance, base or "the temp dir"),
+                     "fastq_bytes": size, "generate_s": round(gen_s, 1),
+                     "host_cores_available": os.cpu_count()})
+        return best
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
@@ -261,6 +330,13 @@ def main():
                        {k: int(last[k]) for k in ("usable", "unique", "clusters", "edges")},
                        {k: int(osum[k]) for k in ("usable", "unique", "clusters", "edges")}), file=sys.stderr)
 
+    e2e = None
+    if a.e2e_reads > 0 and world == 1 and not a.force_sharded:
+        try:
+            e2e = e2e_leg(a.e2e_reads, a.word_nt, a.distance)
+        except Exception as ex:                      # the leg is extra information: never lose the line
+            e2e = {"error": repr(ex)[:300]}
+
     out = {
         "metric": "reads/sec deduplicated, 10M PE150 UMI=8 d=1",
         "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": a.steps,
@@ -283,6 +359,11 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
+    if e2e is not None:
+        out["e2e"] = e2e
+        if "t_e2e_s" in e2e:
+            out["t_e2e_s"] = e2e["t_e2e_s"]
+            out["e2e_reads_per_s"] = e2e["e2e_reads_per_s"]
     if world_sharded:
         out["shard_mode"] = sd.mode_used
     if other is not None:

@@ -37,12 +37,18 @@ SYMBOLS = {
     "humid_ctx_destroy": (None, [C.c_void_p]),
     "humid_last_error": (C.c_char_p, [C.c_void_p]),
     "humid_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "humid_ctx_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32]),
+    "humid_host_alloc": (C.c_void_p, [C.c_uint64]),
+    "humid_host_free": (None, [C.c_void_p]),
     "humid_dedup_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                   C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                   C.POINTER(HumidSummary)]),
     "humid_dedup_run_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                          C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                          C.c_void_p, C.POINTER(HumidSummary)]),
+    "humid_dedup_run_bases": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.c_void_p, C.c_void_p, C.POINTER(HumidSummary)]),
+    "humid_get_packed_words": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "humid_get_leaves": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6),
     "humid_get_adjacency": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "humid_get_clusters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -88,6 +88,32 @@ class Dedup(Context):
         self.summary = s.asdict()
         return cid, keep, self.summary
 
+    def run_bases(self, bases, word_nt=24, distance=1, method=DIRECTIONAL, edit=False):
+        """bases: uint8[N, word_nt] -- the symbols of every record as the ASCII of the FastQ (what
+        getNucleotides, src/fastq.cc:116-144, assembles); the words are packed on the device.
+        Returns (cluster_id, keep, summary) like run()."""
+        b = np.ascontiguousarray(bases, dtype=np.uint8)
+        if b.ndim != 2 or b.shape[1] != word_nt:
+            raise ValueError("bases must have shape (N, %d)" % word_nt)
+        n = b.shape[0]
+        self._wide = word_nt > 32
+        self.set_option("edit_distance", int(bool(edit)))
+        cid = np.zeros(n, dtype=np.uint32)
+        keep = np.zeros(n, dtype=np.uint8)
+        s = _lib.HumidSummary()
+        self._check(self._lib.humid_dedup_run_bases(self._h, _vp(b), n, word_nt, distance, method, _vp(cid),
+                                                    _vp(keep), C.byref(s)))
+        self.summary = s.asdict()
+        return cid, keep, self.summary
+
+    def packed_words(self):
+        """words and filtered flags the device packed in the last run_bases()"""
+        n = int(self.summary["total"])
+        w = np.zeros((n, 2) if getattr(self, "_wide", False) else n, np.uint64)
+        f = np.zeros(n, np.uint8)
+        self._check(self._lib.humid_get_packed_words(self._h, _vp(w), _vp(f)))
+        return w, f
+
     def run_device(self, d_words, d_filtered, d_cluster_id, d_keep, n_reads, word_nt=24,
                    distance=1, method=DIRECTIONAL):
         """Device pointers (ints, e.g. tensor.data_ptr()); results stay in HBM."""

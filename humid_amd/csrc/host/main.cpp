@@ -6,15 +6,20 @@
 // pass 1 builds the packed words, libhumid_hip.so (include/humid_hip.h) does counts ->
 // neighbours -> clusters on the GPU, pass 2 writes with the per-read (cluster_id, keep) arrays
 // instead of trie.find() (src/humid.cc:223-231,276-277).
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 
 #include <unistd.h>
+
+#include <atomic>
 
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <iostream>
 #include <string>
 #include <vector>
@@ -116,6 +121,42 @@ int write_hist(humid_ctx *ctx, uint32_t which, const std::string &path) {
   return out.fail() ? -1 : 1;
 }
 
+// Plain (uncompressed) output of the fast path, written through a shared mapping of the output file:
+// every worker copies its share of the records straight to their final place, so the page cache is
+// filled by all cores at once (one writer through pwrite() is bound by a single core's copy rate,
+// parallel pwrite()s into one file serialise on the inode lock).  size_of(i) = bytes record i
+// contributes (0: not written), emit(i, q) writes them at q and returns the end.
+// Returns 1 = written, 0 = not possible on this file (the caller takes the buffered writer), -1 = failed.
+int write_mapped(const std::string &path, size_t n, unsigned threads, const std::function<size_t(size_t)> &size_of,
+                 const std::function<char *(size_t, char *)> &emit) {
+  if (threads == 0) threads = 1;
+  std::vector<uint64_t> part(threads + 1, 0);
+  parallel_ranges(n, threads, [&](size_t b, size_t e, unsigned w) {
+    uint64_t t = 0;
+    for (size_t i = b; i < e; i++) t += size_of(i);
+    part[w + 1] = t;
+  });
+  const bool one = threads <= 1 || n < 4096;            // parallel_ranges ran everything as worker 0
+  for (unsigned w = 0; w < threads; w++) part[w + 1] += part[w];
+  const uint64_t total = part[threads];
+  const int fd = ::open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0666);
+  if (fd < 0) return -1;
+  if (total == 0) return ::close(fd) == 0 ? 1 : -1;
+  // the blocks are reserved first, so a full disk is an error code here and not a SIGBUS later.
+  // (Measured and rejected: extending the file sparsely and letting the workers' page faults
+  // allocate it -- on tmpfs parallel faults into one file contend so badly that pass 2 takes 3x
+  // longer than with the single-threaded allocation of posix_fallocate.)
+  if (posix_fallocate(fd, 0, (off_t)total) != 0) { ::close(fd); return 0; }      // e.g. a device: buffered writer
+  char *m = (char *)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  if (m == (char *)MAP_FAILED) { ::close(fd); return 0; }
+  parallel_ranges(n, threads, [&](size_t b, size_t e, unsigned w) {
+    char *q = m + (one ? 0 : part[w]);
+    for (size_t i = b; i < e; i++) q = emit(i, q);
+  });
+  const bool ok = munmap(m, total) == 0;
+  return (::close(fd) == 0 && ok) ? 1 : -1;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -166,11 +207,41 @@ int main(int argc, char **argv) {
     std::thread th;
     ~Joiner() { if (th.joinable()) th.join(); }
   } ctx_init;
+  // ... and as soon as the number of reads is known (files indexed) it takes ONE slab of device
+  // memory for the whole run (humid_ctx_reserve) while pass 1 is still gathering words.
+  std::atomic<long long> n_known{-1};                   // -1: not yet; 0: no slab wanted
+  uint8_t *pinned = nullptr;                            // written by the init thread, read after its join
+  uint64_t pin_bytes = 0;
   if (a.dump_words.empty())
     ctx_init.th = std::thread([&] {
+      const auto ti = std::chrono::steady_clock::now();
+      auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - ti).count(); };
       ctx_rc = humid_ctx_create(&ctx, -1, nullptr);
-      if (ctx_rc != HUMID_OK) ctx_err = humid_last_error(nullptr);
+      if (ctx_rc != HUMID_OK) { ctx_err = humid_last_error(nullptr); return; }
+      const double t_ctx = since();
+      long long n;
+      while ((n = n_known.load(std::memory_order_acquire)) < 0) std::this_thread::yield();
+      const double t_wait = since();
+      double t_pin = t_wait, t_slab = t_wait;
+      if (n > 0) {
+        // page-locked staging for what crosses PCIe: packed words + flags in, cluster ids + keep flags out
+        const uint64_t wb = (uint64_t)n * (a.word_length > 32 ? 16 : 8);
+        pin_bytes = wb + (uint64_t)n + (uint64_t)n * 4 + (uint64_t)n + 64;
+        std::thread pin_thread;                            // the two take ~30 ms and ~40 ms: side by side
+        if (getenv("HUMID_NO_PINNED") == nullptr)
+          pin_thread = std::thread([&] { pinned = (uint8_t *)humid_host_alloc(pin_bytes); t_pin = since(); });
+        humid_ctx_reserve(ctx, (uint64_t)n, (uint32_t)a.word_length);   // one slab + the code object loaded
+        t_slab = since();
+        if (pin_thread.joinable()) pin_thread.join();
+      }
+      if (getenv("HUMID_TIMING"))
+        std::fprintf(stderr, "[humid]   init thread: context %.3f s, read count known %.3f s, page-locked staging %.3f s, slab + code object %.3f s\n",
+                     t_ctx, t_wait, t_pin, t_slab);
     });
+  struct Release {                                      // every early return lets the thread go on
+    std::atomic<long long> &n;
+    ~Release() { long long e = -1; n.compare_exchange_strong(e, 0); }
+  } release_init{n_known};
   const auto t_start = std::chrono::steady_clock::now();
   auto phase = [&](const char *what) {                 // HUMID_TIMING=1: wall time of the host phases
     if (getenv("HUMID_TIMING"))
@@ -217,12 +288,33 @@ int main(int argc, char **argv) {
   const size_t wpr = a.word_length > 32 ? 2 : 1;   // uint64 per word (include/humid_hip.h)
   std::vector<uint64_t> words;
   std::vector<uint8_t> filtered;
+  std::vector<uint8_t> bases;                      // device-side packing: word_length raw symbols per record
+  // HUMID_DEVICE_PACK=1: the host only gathers the raw symbols and the GPU packs them
+  // (humid_dedup_run_bases).  Not the default: 24 raw bytes per read instead of 9 packed ones cross
+  // PCIe, which costs more than the host's packing saves (profiles/r02d_cli_e2e.txt).
+  const bool device_pack = fast && a.dump_words.empty() && getenv("HUMID_DEVICE_PACK") != nullptr;
+  uint64_t n_records = 0;
   if (fast) {
     size_t n = maps[0].records();
     for (auto &m : maps) n = m.records() < n ? m.records() : n;     // stop at the shortest file
+    n_records = n;
+    n_known.store((long long)n, std::memory_order_release);
+    const size_t nf = maps.size();
+    if (device_pack) {
+      bases.resize(n * a.word_length);
+      parallel_ranges(n, threads, [&](size_t b, size_t e, unsigned) {
+        std::string_view seqs[64], name0, nm, st, ql;
+        for (size_t i = b; i < e; i++) {
+          for (size_t f = 0; f < nf; f++) {
+            maps[f].lines(i, nm, seqs[f], st, ql);
+            if (f == 0) name0 = nm;
+          }
+          gather_bases(name0, seqs, nf, plan, &bases[i * a.word_length]);
+        }
+      });
+    } else {
     words.resize(n * wpr);
     filtered.resize(n);
-    const size_t nf = maps.size();
     parallel_ranges(n, threads, [&](size_t b, size_t e, unsigned) {
       std::string_view seqs[64], name0, nm, st, ql;
       for (size_t i = b; i < e; i++) {
@@ -239,7 +331,9 @@ int main(int argc, char **argv) {
         }
       }
     });
+    }
   } else {
+    n_known.store(0, std::memory_order_release);
     MultiReader in(a.files);
     if (!in.ok()) { std::fprintf(stderr, "humid: cannot open %s\n", in.bad_file().c_str()); return 1; }
     std::vector<FastqRecord> recs;
@@ -252,7 +346,7 @@ int main(int argc, char **argv) {
     }
   }
   end_message(log, t);
-  const uint64_t N = filtered.size();
+  const uint64_t N = device_pack ? n_records : filtered.size();
 
   if (!a.dump_words.empty()) {   // development aid: host-side parsing can be checked without a GPU
     std::ofstream out(a.dump_words, std::ios::out | std::ios::binary);
@@ -270,16 +364,43 @@ int main(int argc, char **argv) {
     return 1;
   }
   phase("context ready");
-  std::vector<uint32_t> cluster_id(N ? N : 1);
-  std::vector<uint8_t> keep(N ? N : 1);
+  // results: in the page-locked staging when there is one (pass 2 reads them there), else in vectors
+  std::vector<uint32_t> cid_vec;
+  std::vector<uint8_t> keep_vec;
+  uint32_t *cluster_id = nullptr;
+  uint8_t *keep = nullptr;
+  const uint64_t *run_words = words.data();
+  const uint8_t *run_filt = filtered.data();
+  const bool staged = pinned != nullptr && N > 0 && !device_pack && (uint64_t)n_known.load() == N;
+  if (staged) {
+    const uint64_t wb = N * 8 * wpr;
+    uint8_t *p_words = pinned, *p_filt = pinned + wb;
+    cluster_id = (uint32_t *)(pinned + ((wb + N + 15) & ~(uint64_t)15));
+    keep = (uint8_t *)(cluster_id + N);
+    parallel_ranges(N, threads, [&](size_t b, size_t e, unsigned) {
+      memcpy(p_words + b * 8 * wpr, (const uint8_t *)words.data() + b * 8 * wpr, (e - b) * 8 * wpr);
+      memcpy(p_filt + b, filtered.data() + b, e - b);
+    });
+    run_words = (const uint64_t *)p_words;
+    run_filt = p_filt;
+    phase("words in page-locked staging");
+  } else {
+    cid_vec.resize(N ? N : 1);
+    keep_vec.resize(N ? N : 1);
+    cluster_id = cid_vec.data();
+    keep = keep_vec.data();
+  }
   humid_summary sum;
   std::memset(&sum, 0, sizeof sum);
   if (a.edit) humid_ctx_set_option(ctx, "edit_distance", 1);
   t = start_message(log, a.edit ? "Calculating neighbours using Levenshtein distance"     // src/humid.cc:142
                                 : "Calculating neighbours using Hamming distance");
-  int rc = humid_dedup_run(ctx, words.data(), filtered.data(), N, (uint32_t)a.word_length,
-                           (uint32_t)a.distance, a.maximum ? HUMID_METHOD_MAXIMUM : HUMID_METHOD_DIRECTIONAL,
-                           cluster_id.data(), keep.data(), &sum);
+  const uint32_t method = a.maximum ? HUMID_METHOD_MAXIMUM : HUMID_METHOD_DIRECTIONAL;
+  int rc = device_pack
+               ? humid_dedup_run_bases(ctx, bases.data(), N, (uint32_t)a.word_length, (uint32_t)a.distance, method,
+                                       cluster_id, keep, &sum)
+               : humid_dedup_run(ctx, run_words, run_filt, N, (uint32_t)a.word_length,
+                                 (uint32_t)a.distance, method, cluster_id, keep, &sum);
   if (rc != HUMID_OK) {
     log << "failed.\n";
     std::fprintf(stderr, "humid: %s\n", humid_last_error(ctx));
@@ -288,9 +409,13 @@ int main(int argc, char **argv) {
   }
   end_message(log, t);
   phase("device path done");
+  if (getenv("HUMID_TIMING"))
+    std::fprintf(stderr, "[humid]   of which on the device: upload%s %.1f ms, hot path %.2f ms, download %.1f ms\n",
+                 device_pack ? " + packing" : "", sum.ms_h2d, sum.ms_total, sum.ms_d2h);
   t = start_message(log, a.maximum ? "Calculating maximum clusters" : "Calculating directional clusters");
   end_message(log, t);
   std::vector<uint64_t>().swap(words);
+  std::vector<uint8_t>().swap(bases);
 
   make_dirs(a.dir_name);
 
@@ -308,6 +433,61 @@ int main(int argc, char **argv) {
     for (FastqWriter *w : dedup) ok = ok && w->ok();
     for (FastqWriter *w : annot) ok = ok && w->ok();
     if (!ok) { std::fprintf(stderr, "humid: cannot create output files in %s\n", a.dir_name.c_str()); return 1; }
+    // plain outputs of the fast path go through a shared mapping (write_mapped); what it cannot take
+    // (gzip outputs, files that cannot be preallocated) goes through the batch loop below
+    std::vector<char> done_dedup(a.files.size(), 0), done_annot(a.files.size(), 0);
+    bool mapped_failed = false;
+    if (fast && getenv("HUMID_NO_MAPPED_WRITE") == nullptr) {
+      auto digits = [](uint32_t v) { size_t d = 1; while (v >= 10) { v /= 10; d++; } return d; };
+      // the files of a pair are written side by side (page-cache filling scales per file), each with
+      // its share of the workers
+      const unsigned per_file = threads / (unsigned)maps.size() ? threads / (unsigned)maps.size() : 1;
+      std::vector<char> failed_f(maps.size(), 0);
+      std::vector<std::thread> file_workers;
+      for (size_t f = 0; f < maps.size(); f++) file_workers.emplace_back([&, f] {
+        const unsigned threads = per_file;               // (shadows: this file's share)
+        bool mapped_failed = false;
+        if (a.filter && !dedup[f]->gz_members()) {
+          const std::string path = make_file_name(a.files[f], a.dir_name, "dedup");
+          const int r = write_mapped(path, N, threads,
+              [&](size_t i) { return keep[i] ? maps[f].raw(i).size() : (size_t)0; },
+              [&](size_t i, char *q) {
+                if (!keep[i]) return q;
+                const std::string_view rr = maps[f].raw(i);
+                memcpy(q, rr.data(), rr.size());
+                return q + rr.size();
+              });
+          if (r > 0) done_dedup[f] = 1;
+          if (r < 0) mapped_failed = true;
+        }
+        if (a.annotate && !annot[f]->gz_members()) {
+          // annotated record = header + ':' + cluster id + the rest of the record verbatim (src/humid.cc:281)
+          const std::string path = make_file_name(a.files[f], a.dir_name, "annotated");
+          const int r = write_mapped(path, N, threads,
+              [&](size_t i) { return maps[f].raw(i).size() + 1 + digits(cluster_id[i]); },
+              [&](size_t i, char *q) {
+                const std::string_view rr = maps[f].raw(i);
+                const char *nl = (const char *)memchr(rr.data(), '\n', rr.size());
+                const size_t hl = nl ? (size_t)(nl - rr.data()) : rr.size();
+                memcpy(q, rr.data(), hl);
+                q += hl;
+                *q++ = ':';
+                char dig[10];
+                unsigned nd = 0;
+                uint32_t v = cluster_id[i];
+                do { dig[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
+                while (nd) *q++ = dig[--nd];
+                memcpy(q, rr.data() + hl, rr.size() - hl);
+                return q + (rr.size() - hl);
+              });
+          if (r > 0) done_annot[f] = 1;
+          if (r < 0) mapped_failed = true;
+        }
+        failed_f[f] = mapped_failed ? 1 : 0;
+      });
+      for (auto &th : file_workers) th.join();
+      for (char x : failed_f) mapped_failed = mapped_failed || x;
+    }
     if (fast) {
       // records come straight from the mappings; batches are formatted on all cores and written
       // in order
@@ -319,6 +499,7 @@ int main(int argc, char **argv) {
         for (size_t f = 0; f < nf; f++) {
           for (int what = 0; what < 2; what++) {           // 0 = dedup, 1 = annotated
             if ((what == 0 && !a.filter) || (what == 1 && !a.annotate)) continue;
+            if ((what == 0 && done_dedup[f]) || (what == 1 && done_annot[f])) continue;   // written through the mapping
             FastqWriter *wr = what == 0 ? dedup[f] : annot[f];
             const bool zip = wr->gz_members();
             parallel_ranges(b1 - b0, threads, [&](size_t rb, size_t re, unsigned w) {
@@ -387,9 +568,10 @@ int main(int argc, char **argv) {
     }
     }
     // a short or failed write (disk full, I/O error) must not end in exit code 0
-    bool wrote_ok = true;
-    for (FastqWriter *w : dedup) { wrote_ok = w->close() && wrote_ok; delete w; }
-    for (FastqWriter *w : annot) { wrote_ok = w->close() && wrote_ok; delete w; }
+    bool wrote_ok = !mapped_failed;
+    // (a FastqWriter whose file went through the mapping wrote nothing: it must not truncate the file)
+    for (size_t f = 0; f < dedup.size(); f++) { if (!done_dedup[f]) wrote_ok = dedup[f]->close() && wrote_ok; delete dedup[f]; }
+    for (size_t f = 0; f < annot.size(); f++) { if (!done_annot[f]) wrote_ok = annot[f]->close() && wrote_ok; delete annot[f]; }
     if (!wrote_ok) {
       log << "failed.\n";
       std::fprintf(stderr, "humid: writing the output FastQ files in %s failed (disk full or I/O error): "
@@ -425,6 +607,7 @@ int main(int argc, char **argv) {
   log.close();
   if (log.fail()) std::fprintf(stderr, "humid: writing the log %s failed\n", a.log_name.c_str());
   phase("outputs closed");
+  if (getenv("HUMID_SLOW_EXIT")) humid_host_free(pinned);     // (the quick exit below leaves it to the kernel)
   humid_ctx_destroy(ctx);
   phase("context destroyed");
   // every output is closed: leave without the static destructors of the HIP runtime and without

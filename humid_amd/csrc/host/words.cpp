@@ -1,5 +1,7 @@
 #include "words.hpp"
 
+#include <cstring>
+
 namespace humid_host {
 
 static inline int code_of(char c) {
@@ -72,6 +74,19 @@ bool make_word(std::string_view first_header, const std::string_view *seqs, size
   for (size_t f = 0; f < n_files; f++) push_symbols(seqs[f], plan.take[f], w, filtered);
   word = w;
   return filtered;
+}
+
+static inline uint8_t *copy_padded(std::string_view s, size_t want, uint8_t *out) {
+  const size_t have = s.size() < want ? s.size() : want;
+  memcpy(out, s.data(), have);
+  if (have < want) memset(out + have, 'N', want - have);
+  return out + want;
+}
+
+void gather_bases(std::string_view first_header, const std::string_view *seqs, size_t n_files,
+                  const WordPlan &plan, uint8_t *out) {
+  if (plan.header_umi > 0) out = copy_padded(header_umi(first_header), plan.header_umi, out);
+  for (size_t f = 0; f < n_files; f++) out = copy_padded(seqs[f], plan.take[f], out);
 }
 
 bool make_word_wide(std::string_view first_header, const std::string_view *seqs, size_t n_files,

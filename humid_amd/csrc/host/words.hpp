@@ -43,6 +43,13 @@ bool make_word_wide(const std::vector<FastqRecord> &recs, const WordPlan &plan, 
 bool make_word_wide(std::string_view first_header, const std::string_view *seqs, size_t n_files,
                     const WordPlan &plan, uint64_t word[2]);
 
+// getNucleotides (src/fastq.cc:116-144) as raw bytes, for the device-side packing of
+// humid_dedup_run_bases: out[plan.word_nt] = the header UMI cut or padded with 'N' to plan.header_umi
+// symbols, then the first plan.take[f] bytes of every file's read, 'N' where a read is short.  The
+// bytes are copied as they stand in the FastQ; the device maps and validates them.
+void gather_bases(std::string_view first_header, const std::string_view *seqs, size_t n_files,
+                  const WordPlan &plan, uint8_t *out);
+
 // <dir>/<basename with _suffix inserted before the first '.'>
 std::string make_file_name(const std::string &path, const std::string &dir, const std::string &suffix);
 

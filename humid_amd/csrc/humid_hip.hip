@@ -29,30 +29,52 @@
 // --------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------
+// One slab of device memory a context may hold (humid_ctx_reserve): buffers are carved out of it
+// with a bump pointer instead of one hipMalloc each -- a first run needs ~35 buffers and every
+// hipMalloc costs about a millisecond, which is most of what the `humid` command line spends between
+// "pass 1 done" and "device path done" on 10 M reads.  Nothing is returned to the slab; a buffer
+// that outgrows its carving gets a new one (slab or hipMalloc).
+struct Arena {
+  char *base = nullptr;
+  size_t size = 0, used = 0;
+  void *take(size_t bytes) {
+    const size_t at = (used + 255) & ~(size_t)255;
+    if (!base || at + bytes > size) return nullptr;
+    used = at + bytes;
+    return base + at;
+  }
+};
+
 struct DBuf {
   void *p = nullptr;
   size_t cap = 0;
-  hipError_t ensure(size_t bytes) {
+  bool in_arena = false;
+  hipError_t ensure(size_t bytes, Arena *arena = nullptr) {
     if (bytes <= cap) return hipSuccess;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    if (p && !in_arena) (void)hipFree(p);
+    p = nullptr; cap = 0; in_arena = false;
     size_t want = bytes + bytes / 8 + 256;
+    if (arena) {
+      if (void *q = arena->take(bytes + 256)) { p = q; cap = bytes + 256; in_arena = true; return hipSuccess; }
+    }
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) { p = nullptr; return e; }
     cap = want;
     return hipSuccess;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  void release() { if (p && !in_arena) (void)hipFree(p); p = nullptr; cap = 0; in_arena = false; }
   template <class T> T *as() const { return (T *)p; }
 };
 
 struct humid_ctx {
   int device = 0;
+  Arena arena;               // humid_ctx_reserve
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
   ull *d_ctr = nullptr;
   ull *h_ctr = nullptr;   // pinned mirror
-  DBuf in_words, in_filt, out_cid, out_keep;                 // host entry point staging
+  DBuf in_words, in_filt, in_bases, out_cid, out_keep;       // host entry point staging
   DBuf table, slot_out, slot_of_read, uniq_slot;             // table (cap+1) and per-read
   DBuf pk_keys, pk_vals, pbeg, ucount, pusable, ubase, pad_word, pad_cf, pslot;   // partitioned counts
   DBuf opos, own_packed, owner, owner_sorted, perm, small;                        // multi-GPU result return
@@ -124,7 +146,7 @@ static int fail(humid_ctx *c, int code, const char *fmt, ...) {
                   #expr, hipGetErrorString(_e), __FILE__, __LINE__);                        \
   } while (0)
 
-#define ENSURE(buf, bytes) HIPCHK((buf).ensure(bytes))
+#define ENSURE(buf, bytes) HIPCHK((buf).ensure((bytes), &c->arena))
 
 static inline u32 blocks_for(u64 n, u32 bs = 256) { return (u32)((n + bs - 1) / bs); }
 static inline u32 grid_stride_blocks(u64 n, u32 bs = 256) {
@@ -1312,7 +1334,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
+  DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->in_bases, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
                   &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
@@ -1321,12 +1343,46 @@ void humid_ctx_destroy(humid_ctx *c) {
                   &c->maxleaf, &c->cl_size, &c->flag, &c->pos, &c->cid, &c->ismax, &c->stk, &c->tmp,
                   &c->scratch};
   for (DBuf *b : bufs) b->release();
+  if (c->arena.base) (void)hipFree(c->arena.base);
   if (c->d_ctr) (void)hipFree(c->d_ctr);
   if (c->h_ctr) (void)hipHostFree(c->h_ctr);
   for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto &ev : c->kev) if (ev) (void)hipEventDestroy(ev);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+}
+
+void *humid_host_alloc(uint64_t bytes) {
+  void *p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+
+void humid_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
+int humid_ctx_reserve(humid_ctx *c, uint64_t n_reads, uint32_t word_nt) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (c->arena.base) return HUMID_OK;                       // one slab per context
+  if (n_reads == 0) return HUMID_OK;
+  HIPCHK(hipSetDevice(c->device));
+  // what one run over n_reads reads carves (measured: 112 B per read at 24 nt, unique/reads <= 1
+  // assumed worst; wide words: +24 B) plus the host entry point's staging (14 or 22 B per read)
+  const size_t per_read = (word_nt > 32 ? 200 : 168) + (word_nt > 32 ? 22 : 14);
+  size_t want = (size_t)n_reads * per_read + ((size_t)64 << 20);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b / 2) want = free_b / 2;
+  void *p = nullptr;
+  if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return HUMID_OK; }   // no slab: buffers are allocated one by one
+  c->arena.base = (char *)p;
+  c->arena.size = want;
+  c->arena.used = 0;
+  // the first launch of a process loads the library's code object (~1500 kernels with the sort /
+  // scan instantiations: tens of milliseconds): pay that here, off the caller's critical path
+  hipLaunchKernelGGL(k_iota, dim3(1), dim3(64), 0, c->stream, (u32 *)p, 64u);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return HUMID_OK;
 }
 
 int humid_ctx_set_option(humid_ctx *c, const char *key, int64_t value) {
@@ -1370,12 +1426,14 @@ int humid_dedup_run_device(humid_ctx *c, const uint64_t *d_words, const uint8_t 
   return run_device<u64>(c, d_words, d_filtered, n_reads, word_nt, distance, method, d_cluster_id, d_keep, summary);
 }
 
-int humid_dedup_run(humid_ctx *c, const uint64_t *words, const uint8_t *filtered, uint64_t n_reads,
-                    uint32_t word_nt, uint32_t distance, uint32_t method, uint32_t *cluster_id,
+// host buffers in, host buffers out: words + flags, or (bases != null) the raw symbols, packed on the device
+static int run_host(humid_ctx *c, const uint64_t *words, const uint8_t *filtered, const uint8_t *bases,
+                    uint64_t n_reads, uint32_t word_nt, uint32_t distance, uint32_t method, uint32_t *cluster_id,
                     uint8_t *keep, humid_summary *summary) {
   if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
-  if (n_reads && (!words || !filtered || !cluster_id || !keep)) return fail(c, HUMID_E_INVALID, "null buffer");
+  if (n_reads && (!(bases || (words && filtered)) || !cluster_id || !keep)) return fail(c, HUMID_E_INVALID, "null buffer");
   if (n_reads > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "n_reads %llu exceeds 2^31-1", (ull)n_reads);
+  if (bases) TRY(check_run_args(c, n_reads, word_nt, method, 64));
   HIPCHK(hipSetDevice(c->device));
   hipStream_t st = c->stream;
   humid_summary s;
@@ -1389,8 +1447,18 @@ int humid_dedup_run(humid_ctx *c, const uint64_t *words, const uint8_t *filtered
   ENSURE(c->in_filt, n + 8);
   ENSURE(c->out_cid, n * 4 + 8);
   ENSURE(c->out_keep, n + 8);
+  if (bases) ENSURE(c->in_bases, n * word_nt + 16);
   HIPCHK(hipEventRecord(e0, st));
-  if (n) {
+  if (n && bases) {
+    // device-side packing (makeWord, src/fastq.cc:146-161): the host only gathered the symbols
+    HIPCHK(hipMemcpyAsync(c->in_bases.p, bases, n * word_nt, hipMemcpyHostToDevice, st));
+    if (word_nt > 32)
+      hipLaunchKernelGGL(k_pack_bases<true>, dim3(blocks_for(n)), dim3(256), 0, st, c->in_bases.as<u8>(), (u32)n, word_nt,
+                         c->in_words.as<u64>(), c->in_filt.as<u8>());
+    else
+      hipLaunchKernelGGL(k_pack_bases<false>, dim3(blocks_for(n)), dim3(256), 0, st, c->in_bases.as<u8>(), (u32)n, word_nt,
+                         c->in_words.as<u64>(), c->in_filt.as<u8>());
+  } else if (n) {
     HIPCHK(hipMemcpyAsync(c->in_words.p, words, n * wbytes, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->in_filt.p, filtered, n, hipMemcpyHostToDevice, st));
   }
@@ -1413,6 +1481,32 @@ int humid_dedup_run(humid_ctx *c, const uint64_t *words, const uint8_t *filtered
   (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
   if (rc == HUMID_OK && summary) *summary = s;
   return rc;
+}
+
+int humid_dedup_run(humid_ctx *c, const uint64_t *words, const uint8_t *filtered, uint64_t n_reads,
+                    uint32_t word_nt, uint32_t distance, uint32_t method, uint32_t *cluster_id,
+                    uint8_t *keep, humid_summary *summary) {
+  return run_host(c, words, filtered, nullptr, n_reads, word_nt, distance, method, cluster_id, keep, summary);
+}
+
+int humid_dedup_run_bases(humid_ctx *c, const uint8_t *bases, uint64_t n_reads, uint32_t word_nt, uint32_t distance,
+                          uint32_t method, uint32_t *cluster_id, uint8_t *keep, humid_summary *summary) {
+  if (n_reads && !bases) return fail(c, HUMID_E_INVALID, "null buffer");
+  return run_host(c, nullptr, nullptr, bases ? bases : (const uint8_t *)"", n_reads, word_nt, distance, method,
+                  cluster_id, keep, summary);
+}
+
+// the packed words and flags of the last humid_dedup_run_bases (what makeWord would have returned)
+int humid_get_packed_words(humid_ctx *c, uint64_t *words, uint8_t *filtered) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (!c->have_run) return fail(c, HUMID_E_STATE, "no completed dedup run in this context");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t n = (size_t)c->N, wbytes = c->word_nt > 32 ? 16 : 8;
+  if (n * wbytes > c->in_words.cap || n > c->in_filt.cap) return fail(c, HUMID_E_STATE, "the last run did not go through a host entry point");
+  if (n && words) HIPCHK(hipMemcpyAsync(words, c->in_words.p, n * wbytes, hipMemcpyDeviceToHost, c->stream));
+  if (n && filtered) HIPCHK(hipMemcpyAsync(filtered, c->in_filt.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return HUMID_OK;
 }
 
 #define NEED_RUN()                                                                            \

@@ -7,6 +7,45 @@
 #include "common.hip.h"
 
 // --------------------------------------------------------------------------------
+// 0. word packing on the device (makeWord, /root/reference/src/fastq.cc:146-161)
+// --------------------------------------------------------------------------------
+// bases[n_reads][word_nt]: the symbols getNucleotides (src/fastq.cc:116-144) assembled for every
+// record -- header UMI, then the leading bases of every file's read, 'N' where a read was short --
+// as the ASCII the FastQ holds.  A -> 0, C -> 1, G -> 2, T -> 3; any other byte -> the code of 'G'
+// and the word is filtered (src/fastq.cc:151-158).  First symbol in the most significant bits.
+// A workgroup copies its 256 rows into LDS with coalesced 4-byte loads, then every thread packs one.
+template <bool WIDE>
+__global__ void __launch_bounds__(256)
+k_pack_bases(const u8 *__restrict__ bases, u32 n_reads, u32 word_nt, u64 *__restrict__ words, u8 *__restrict__ filtered) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ u32 rows[256 * 64 / 4];
+  const u32 r0 = blockIdx.x * 256;
+  const u32 n_rows = (n_reads - r0 < 256) ? n_reads - r0 : 256;
+  const size_t byte0 = (size_t)r0 * word_nt;
+  const u32 n_bytes = n_rows * word_nt;
+  // the tile starts at byte0, which need not be 4-aligned: copy from the aligned address below it
+  const u32 skew = (u32)((uintptr_t)(bases + byte0) & 3);
+  const u32 *src = (const u32 *)(bases + byte0 - skew);
+  const u32 n_dw = (skew + n_bytes + 3) / 4;
+  for (u32 k = threadIdx.x; k < n_dw; k += 256) rows[k] = src[k];
+  __syncthreads();
+  if (threadIdx.x >= n_rows) return;
+  const u8 *row = (const u8 *)rows + skew + threadIdx.x * word_nt;
+  u64 hi = 0, lo = 0;
+  bool filt = false;
+  for (u32 i = 0; i < word_nt; i++) {
+    const u32 ch = row[i];
+    u32 code = ((ch >> 1) ^ (ch >> 2)) & 3u;                  // A 0, C 1, G 2, T 3
+    if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') { code = 2; filt = true; }
+    if (WIDE) hi = (hi << 2) | (lo >> 62);
+    lo = (lo << 2) | code;
+  }
+  if (WIDE) { words[2 * (size_t)(r0 + threadIdx.x)] = hi; words[2 * (size_t)(r0 + threadIdx.x) + 1] = lo; }
+  else words[r0 + threadIdx.x] = lo;
+  filtered[r0 + threadIdx.x] = filt ? 1 : 0;
+}
+
+// --------------------------------------------------------------------------------
 // 1. exact counts: open-address hash of packed words
 // --------------------------------------------------------------------------------
 // One 16-byte slot per word so that the key probe and both atomics touch ONE line.

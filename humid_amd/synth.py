@@ -14,7 +14,7 @@ import os
 
 import numpy as np
 
-__all__ = ["synth_words", "synth_wide_words", "synth_fastq", "CONFIG_SEEDS", "pack_bases"]
+__all__ = ["synth_words", "synth_wide_words", "synth_fastq", "fast_fastq", "CONFIG_SEEDS", "pack_bases"]
 
 CONFIG_SEEDS = {1: 1001, 2: 1002, 3: 1003, 4: 1004, 5: 1005}
 
@@ -214,3 +214,51 @@ def synth_fastq(out_dir: str, n_reads: int, seed: int, n_files: int = 1, umi_len
                 seq = _ALPHA[umi[r]].tobytes().decode()
                 fh.write("@r%d\n%s\n+\n%s\n" % (j, seq, "I" * umi_len))
     return names
+
+
+def fast_fastq(path: str, n_reads: int, seed: int, read_len: int = 150, umi_len: int = 8, mate: int = 0,
+               p_sub: float = 1e-3, chunk: int = 1_000_000):
+    """Large FastQ files for end-to-end timing (bench.py's e2e leg, tools/bench_cli.py), written with
+    numpy in chunks: fixed-width records `@r<9 digits>[_<UMI>]\n<read>\n+\n<quality>\n`.  The molecule
+    of read i (n_reads/4 molecules, uniformly drawn) and its UMI depend on `seed` only, the read
+    sequence on (seed, mate): files written with mate = 0, 1 form a pair; the UMI goes into the header
+    of mate 0 when umi_len > 0.  Returns the file size."""
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    n_mol = n_reads // 4 + 1
+    base = np.random.Generator(np.random.PCG64(seed))
+    mol_umi = alpha[base.integers(0, 4, size=(n_mol, max(umi_len, 1)), dtype=np.uint8)]
+    mrng = np.random.Generator(np.random.PCG64([seed, 1000 + mate]))
+    mol_seq = alpha[mrng.integers(0, 4, size=(n_mol, read_len), dtype=np.uint8)]
+    with_umi = umi_len > 0 and mate == 0
+    rec_len = 2 + 9 + (1 + umi_len if with_umi else 0) + 1 + read_len + 3 + read_len + 1
+    full = np.empty((min(chunk, max(n_reads, 1)), rec_len), dtype=np.uint8)   # one buffer, reused by every chunk
+    with open(path, "wb") as fh:
+        for c0 in range(0, n_reads, chunk):
+            c1 = min(n_reads, c0 + chunk)
+            m = c1 - c0
+            crng = np.random.Generator(np.random.PCG64([seed, 7, c0]))       # same molecules for both mates
+            mol = crng.integers(0, n_mol, size=m)
+            erng = np.random.Generator(np.random.PCG64([seed, 9 + mate, c0]))
+            seq = mol_seq[mol]
+            k = int(erng.binomial(m * read_len, p_sub))            # sparse substitutions
+            if k:
+                pos = erng.integers(0, m * read_len, size=k)
+                seq.reshape(-1)[pos] = alpha[erng.integers(0, 4, size=k, dtype=np.uint8)]
+            num = np.arange(c0, c1, dtype=np.int64)
+            idx = np.empty((m, 9), dtype=np.uint8)
+            for d in range(9):
+                idx[:, 8 - d] = (num // 10 ** d) % 10 + 48
+            buf = full[:m]
+            p = 0
+            buf[:, p:p + 2] = np.frombuffer(b"@r", dtype=np.uint8); p += 2
+            buf[:, p:p + 9] = idx; p += 9
+            if with_umi:
+                buf[:, p] = ord("_"); p += 1
+                buf[:, p:p + umi_len] = mol_umi[mol][:, :umi_len]; p += umi_len
+            buf[:, p] = ord("\n"); p += 1
+            buf[:, p:p + read_len] = seq; p += read_len
+            buf[:, p:p + 3] = np.frombuffer(b"\n+\n", dtype=np.uint8); p += 3
+            buf[:, p:p + read_len] = ord("I"); p += read_len
+            buf[:, p] = ord("\n")
+            buf.tofile(fh)
+    return os.path.getsize(path)

@@ -100,6 +100,15 @@ const char *humid_last_error(const humid_ctx *ctx);   /* ctx may be NULL */
  * in front and one scattered store per read at the end (the round-1 form, also taken by itself for
  * read sets beyond ~180 M / ~67 M reads). */
 int  humid_ctx_set_option(humid_ctx *ctx, const char *key, int64_t value);
+/* Optional: one slab of device memory for a run over about n_reads reads, so that the first run does
+ * not pay ~35 separate allocations (the `humid` host calls it while pass 1 still parses).  Never
+ * fails for lack of memory: without a slab the buffers are allocated one by one as before. */
+int  humid_ctx_reserve(humid_ctx *ctx, uint64_t n_reads, uint32_t word_nt);
+/* Page-locked host memory for the buffers of humid_dedup_run*: copies from / to it run at the full
+ * PCIe rate (pageable buffers are staged by the runtime at a fraction of it: 5 GB/s measured).
+ * NULL when the allocation fails -- ordinary memory works everywhere, only slower. */
+void *humid_host_alloc(uint64_t bytes);
+void  humid_host_free(void *p);
 
 /* ---- the whole hot path ----------------------------------------------------
  * Replaces, between FastQ pass 1 and pass 2:
@@ -124,6 +133,17 @@ int humid_dedup_run_device(humid_ctx *ctx, const uint64_t *d_words, const uint8_
                            uint64_t n_reads, uint32_t word_nt, uint32_t distance,
                            uint32_t method, uint32_t *d_cluster_id, uint8_t *d_keep,
                            humid_summary *summary);
+
+/* The same with the word packing on the device (makeWord, src/fastq.cc:146-161): bases[n_reads *
+ * word_nt] holds, per record, the word_nt symbols getNucleotides (src/fastq.cc:116-144) assembles --
+ * header UMI, then the leading bases of every file's read, 'N' where a read or UMI was short -- as
+ * the ASCII bytes of the FastQ.  A/C/G/T -> 0/1/2/3; any other byte counts as 'G' and filters the
+ * word (src/fastq.cc:151-158).  humid_get_packed_words returns the words and flags the device made
+ * (u64[n_reads], or u64[2 n_reads] above 32 nt; u8[n_reads]). */
+int humid_dedup_run_bases(humid_ctx *ctx, const uint8_t *bases, uint64_t n_reads, uint32_t word_nt,
+                          uint32_t distance, uint32_t method, uint32_t *cluster_id, uint8_t *keep,
+                          humid_summary *summary);
+int humid_get_packed_words(humid_ctx *ctx, uint64_t *words, uint8_t *filtered);
 
 /* ---- results of the last run, per unique word in Trie::walk() order ---------
  * (what a caller would read through Result<NLeaf>{leaf,path}, src/humid.cc:117,178,307;

@@ -87,14 +87,19 @@ def test_fast_and_streaming_host_paths_write_identical_files(tmp_path):
     files = synth_fastq(str(tmp_path / "in"), 30000, 321, n_files=2, umi_len=8, read_len=40, p_sub=4e-3,
                         p_n=2e-3)
     outs = []
-    for name, env in (("fast", {"HUMID_THREADS": "5"}), ("slow", {"HUMID_HOST_SLOW": "1"})):
+    # fast: records from the mapping, words packed on the GPU, plain outputs through a shared mapping;
+    # devicepack: raw symbols uploaded, words packed on the GPU; nopinned: pageable staging; bufwrite: outputs through the buffered writer; slow: streaming
+    for name, env in (("fast", {"HUMID_THREADS": "5"}), ("slow", {"HUMID_HOST_SLOW": "1"}),
+                      ("devicepack", {"HUMID_DEVICE_PACK": "1", "HUMID_THREADS": "3"}), ("nopinned", {"HUMID_NO_PINNED": "1"}),
+                      ("bufwrite", {"HUMID_NO_MAPPED_WRITE": "1"}), ("onethread", {"HUMID_THREADS": "1"})):
         out = str(tmp_path / name)
         e = dict(os.environ)
         e.update(env)
         subprocess.check_call([HUMID, "-d", out, "-l", "/dev/null", "-a", "-s"] + files, env=e)
         outs.append(out)
-    for fn in sorted(os.listdir(outs[0])):
-        assert open(os.path.join(outs[0], fn), "rb").read() == open(os.path.join(outs[1], fn), "rb").read(), fn
+    for other in outs[1:]:
+        for fn in sorted(os.listdir(outs[0])):
+            assert open(os.path.join(outs[0], fn), "rb").read() == open(os.path.join(other, fn), "rb").read(), (other, fn)
     assert len(os.listdir(outs[0])) == 8     # 2 dedup + 2 annotated + 4 .dat
 
 

@@ -567,3 +567,38 @@ def test_sharded_world1_nccl():
             assert s[k] == osum[k]
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------
+# device-side word packing (makeWord, src/fastq.cc:146-161, on the GPU: humid_dedup_run_bases)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 5, 23, 24, 32, 33, 47, 64])
+def test_device_packing_matches_make_word(dd1, n):
+    """raw symbols in (ACGT, N, lower case, other bytes), packed words + filtered flags out: equal to
+    the oracle's makeWord restatement symbol by symbol, and the run on them equal to the run on words"""
+    rng = np.random.default_rng(n)
+    for n_reads in (0, 1, 255, 256, 257, 5000):
+        alphabet = np.frombuffer(b"ACGTACGTACGTACGTACGTACGTACGTNacgt.*", dtype=np.uint8)
+        mol = rng.integers(0, max(n_reads // 3, 1), size=n_reads)
+        clean = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(max(n_reads // 3, 1), n))]
+        bases = clean[mol].copy() if n_reads else np.zeros((0, n), np.uint8)
+        noise = rng.random(bases.shape) < 0.01
+        bases[noise] = alphabet[rng.integers(0, len(alphabet), size=int(noise.sum()))]
+        cid, keep, s = dd1.run_bases(bases, word_nt=n, distance=1)
+        w, f = dd1.packed_words()
+        # the oracle's makeWord on every row
+        ew = np.zeros((n_reads, 2) if n > 32 else n_reads, np.uint64)
+        ef = np.zeros(n_reads, np.uint8)
+        for i in range(n_reads):
+            data, fl = orc.make_word(bases[i].tobytes().decode("latin-1"))
+            if n > 32:
+                ew[i, 0], ew[i, 1] = orc.pack_word(data[:n - 32]), orc.pack_word(data[n - 32:])
+            else:
+                ew[i] = orc.pack_word(data)
+            ef[i] = fl
+        assert np.array_equal(f, ef)
+        assert np.array_equal(w, ew)
+        if n_reads:
+            cid2, keep2, s2 = dd1.run(ew, ef, word_nt=n, distance=1)
+            assert np.array_equal(cid, cid2) and np.array_equal(keep, keep2)
+            assert all(s[k] == s2[k] for k in ("total", "usable", "unique", "clusters", "edges"))
