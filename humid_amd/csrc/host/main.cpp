@@ -57,7 +57,7 @@ void usage(const char *argv0) {
                "Deduplicate a dataset.\n"
                "  -n  word length\n  -m  allowed mismatches\n  -l  log file name\n  -d  output directory\n"
                "  -s  calculate statistics\n  -q  write deduplicated FastQ files (flag turns it OFF)\n"
-               "  -a  write annotated FastQ files\n  -e  use edit distance (Levenshtein neighbours; -m <= 3)\n"
+               "  -a  write annotated FastQ files\n  -e  use edit distance (Levenshtein neighbours; -m <= 5)\n"
                "  -x  use maximum clustering method\n",
                argv0);
 }
@@ -189,8 +189,8 @@ int main(int argc, char **argv) {
   }
   Args a;
   if (!parse(argc, argv, a)) { usage(argv[0]); return 2; }
-  if (a.edit && a.distance > 3) {
-    std::fprintf(stderr, "humid: edit distance (-e) is supported for -m <= 3 by the HIP path\n");
+  if (a.edit && a.distance > 5) {
+    std::fprintf(stderr, "humid: edit distance (-e) is supported for -m <= 5 by the HIP path\n");
     return 2;
   }
   if (a.word_length == 0 || a.word_length > 64) {

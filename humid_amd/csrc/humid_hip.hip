@@ -874,7 +874,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
 static ComboFields plan_fields(const ComboPlan &plan, u32 cb);
 static int unique_edges(humid_ctx *c, const u64 *d_edges, u64 raw, u32 U, u64 *n_edges_out);
 
-// ---- edit distance (-e): neighbour pairs under Levenshtein distance 2 or 3 --------------------------
+// ---- edit distance (-e): neighbour pairs under Levenshtein distance 2 .. 5 --------------------------
 // (distance <= 1 is the Hamming search: equal lengths leave no room for a lone insertion.)
 // Pigeonhole with shifts.  The plan of the Hamming search cuts the word into s segments and looks at
 // every combination of k = s - d of them: d edits damage at most d segments, so some combination is
@@ -886,7 +886,12 @@ static int unique_edges(humid_ctx *c, const u64 *d_edges, u64 raw, u32 U, u64 *n
 // members [a, b) of the combination shifted, a == b: none -- the words' own segments (X) are joined
 // with the segments read at the shifted positions (Y); candidates are verified by the dynamic
 // programme (lev_band1).  Every unordered pair is found from one of its two sides;
-// duplicates go away in a final sort + unique.  Result: c->e_edges (ascending), *n_edges_out.
+// duplicates go away in a final sort + unique.
+// d = 4, 5 allow TWO insertion/deletion pairs: every untouched member t of a combination then sits at
+// an offset o_t in {-2 .. +2} of its own, and the offsets form a walk that starts and ends at 0 (equal
+// lengths) with one unit step per insertion or deletion: |o_0| + sum |o_t - o_{t-1}| + |o_last| <= 4.
+// All such offset vectors are joined (up to a global sign: the mirrored vector finds the same pairs
+// from their other side); d <= 3 is the special case 0..0 1..1 0..0.  Verification: lev_band2.  Result: c->e_edges (ascending), *n_edges_out.
 // part_rank / part_world: this caller's share of the joins (multi-GPU: every rank holds the whole
 // unique array and runs every part_world-th join; the shares are gathered and made unique by
 // humid_stage_unique_edges).  make_unique = false leaves the raw list in c->e_raw.
@@ -925,16 +930,41 @@ static int edit_edges(humid_ctx *c, const WT *g_word, u32 U, u32 word_nt, u32 di
     const ComboFields cfx = plan_fields(plan, cb);
     TRY(sort_keys_of(cfx, c->e_kx, c->e_vx));
     const u32 k = cfx.nf;
-    for (u32 a = 0; a <= k; a++) {
-      for (u32 b = a; b <= k; b++) {
-        if (a == b && a != 0) continue;                       // the unshifted pattern once
+    // offset vectors o[0 .. k) in [-D, D], D = d / 2, walk cost <= 2 D, first non-zero entry positive
+    const int D = (int)(distance / 2);
+    std::vector<std::vector<int>> patterns;
+    {
+      std::vector<int> o(k, 0);
+      std::function<void(u32, int, bool)> rec = [&](u32 t, int cost, bool signed_yet) {
+        if (t == k) {
+          const int total = cost + (k ? (o[k - 1] < 0 ? -o[k - 1] : o[k - 1]) : 0);
+          if (total <= 2 * D) patterns.push_back(o);
+          return;
+        }
+        for (int v = -D; v <= D; v++) {
+          if (!signed_yet && v < 0) continue;                 // canonical sign
+          const int prev = t ? o[t - 1] : 0;
+          const int step = v > prev ? v - prev : prev - v;
+          if (cost + step > 2 * D) continue;
+          o[t] = v;
+          rec(t + 1, cost + step, signed_yet || v != 0);
+        }
+      };
+      rec(0, 0, false);
+    }
+    for (const std::vector<int> &o : patterns) {
+      {
         ComboFields cfy = cfx;
-        bool valid = true;
-        for (u32 t = a; t < b; t++) {
-          if (cfy.shift[t] < 2) { valid = false; break; }     // the last segment has nowhere to go
-          cfy.shift[t] = (u8)(cfy.shift[t] - 2);              // one nucleotide towards the end
+        bool valid = true, shifted = false;
+        for (u32 t = 0; t < k; t++) {
+          // offset +1 = one nucleotide towards the end of the word = a field shift lower by 2 bits
+          const int sh = (int)cfy.shift[t] - 2 * o[t];
+          if (sh < 0 || sh + (int)cfy.width[t] > (int)(2 * word_nt)) { valid = false; break; }   // off the word
+          cfy.shift[t] = (u8)sh;
+          shifted = shifted || o[t] != 0;
         }
         if (!valid) continue;
+        const u32 a = 0, b = shifted ? 1u : 0u;                // (a != b: Y keys differ from X keys)
         if (join_no++ % part_world != part_rank) continue;     // another rank's join
         const void *ky = c->e_kx.p;
         const u32 *vy = c->e_vx.as<u32>();
@@ -944,14 +974,13 @@ static int edit_edges(humid_ctx *c, const WT *g_word, u32 U, u32 word_nt, u32 di
           vy = c->e_vy.as<u32>();
         }
         HIPCHK(hipMemsetAsync(c->pc.as<u32>() + U, 0, 4, st));
-        if (k32)
-          hipLaunchKernelGGL((k_edit_join<false, u32, WT>), dim3(blocks_for(U)), dim3(256), 0, st, c->e_kx.as<u32>(),
-                             c->e_vx.as<u32>(), (const u32 *)ky, vy, U, g_word, word_nt, distance, c->pc.as<u32>(),
-                             (const u32 *)nullptr, (u64 *)nullptr);
-        else
-          hipLaunchKernelGGL((k_edit_join<false, u64, WT>), dim3(blocks_for(U)), dim3(256), 0, st, c->e_kx.as<u64>(),
-                             c->e_vx.as<u32>(), (const u64 *)ky, vy, U, g_word, word_nt, distance, c->pc.as<u32>(),
-                             (const u32 *)nullptr, (u64 *)nullptr);
+#define EDIT_JOIN(FILL, KT, BAND, PC, POFF, OUT)                                                              \
+  hipLaunchKernelGGL((k_edit_join<FILL, KT, WT, BAND>), dim3(blocks_for(U)), dim3(256), 0, st, c->e_kx.as<KT>(), \
+                     c->e_vx.as<u32>(), (const KT *)ky, vy, U, g_word, word_nt, distance, PC, POFF, OUT)
+        if (k32) { if (D <= 1) EDIT_JOIN(false, u32, 1, c->pc.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr);
+                   else EDIT_JOIN(false, u32, 2, c->pc.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr); }
+        else { if (D <= 1) EDIT_JOIN(false, u64, 1, c->pc.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr);
+               else EDIT_JOIN(false, u64, 2, c->pc.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr); }
         TRY(exscan_u32(c, c->pc.as<u32>(), c->poff.as<u32>(), (u64)U + 1));
         HIPCHK(hipGetLastError());
         TRY(read_counters(c, c->poff.as<u32>() + U));
@@ -966,14 +995,11 @@ static int edit_edges(humid_ctx *c, const WT *g_word, u32 U, u32 word_nt, u32 di
           c->e_raw.release();
           c->e_raw = bigger;
         }
-        if (k32)
-          hipLaunchKernelGGL((k_edit_join<true, u32, WT>), dim3(blocks_for(U)), dim3(256), 0, st, c->e_kx.as<u32>(),
-                             c->e_vx.as<u32>(), (const u32 *)ky, vy, U, g_word, word_nt, distance, (u32 *)nullptr,
-                             c->poff.as<u32>(), c->e_raw.as<u64>() + raw);
-        else
-          hipLaunchKernelGGL((k_edit_join<true, u64, WT>), dim3(blocks_for(U)), dim3(256), 0, st, c->e_kx.as<u64>(),
-                             c->e_vx.as<u32>(), (const u64 *)ky, vy, U, g_word, word_nt, distance, (u32 *)nullptr,
-                             c->poff.as<u32>(), c->e_raw.as<u64>() + raw);
+        if (k32) { if (D <= 1) EDIT_JOIN(true, u32, 1, (u32 *)nullptr, c->poff.as<u32>(), c->e_raw.as<u64>() + raw);
+                   else EDIT_JOIN(true, u32, 2, (u32 *)nullptr, c->poff.as<u32>(), c->e_raw.as<u64>() + raw); }
+        else { if (D <= 1) EDIT_JOIN(true, u64, 1, (u32 *)nullptr, c->poff.as<u32>(), c->e_raw.as<u64>() + raw);
+               else EDIT_JOIN(true, u64, 2, (u32 *)nullptr, c->poff.as<u32>(), c->e_raw.as<u64>() + raw); }
+#undef EDIT_JOIN
         raw += found;
       }
     }
@@ -1240,7 +1266,7 @@ static int run_device(humid_ctx *c, const WT *d_words, const u8 *d_filt, u64 n_r
   u32 n_pair_segs = 0;
   if (c->edit && distance >= 2) {
     // -e: Levenshtein neighbours (src/humid.cc:140-158); distance <= 1 IS the Hamming search
-    if (distance > 3) return fail(c, HUMID_E_UNSUPPORTED, "edit distance %u > 3 is not supported", distance);
+    if (distance > 5) return fail(c, HUMID_E_UNSUPPORTED, "edit distance %u > 5 is not supported", distance);
     u64 E = 0;
     TRY(edit_edges<WT>(c, c->s_word.as<WT>(), U, word_nt, distance, &E));
     static const u64 no_edges = 0;
@@ -2201,7 +2227,7 @@ int humid_stage_pairs_edit(humid_ctx *c, const uint64_t *d_g_word, uint64_t n_un
   if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
   if (!d_edges || !n_edges || part_world == 0 || part_rank >= part_world) return fail(c, HUMID_E_INVALID, "bad argument");
   TRY(check_run_args(c, n_unique, word_nt, 0));
-  if (distance > 3) return fail(c, HUMID_E_UNSUPPORTED, "edit distance %u > 3 is not supported", distance);
+  if (distance > 5) return fail(c, HUMID_E_UNSUPPORTED, "edit distance %u > 5 is not supported", distance);
   HIPCHK(hipSetDevice(c->device));
   *d_edges = nullptr;
   *n_edges = 0;

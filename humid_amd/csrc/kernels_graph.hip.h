@@ -230,7 +230,8 @@ k_select_keyrange(const u64 *__restrict__ s_word, u32 n, ComboFields cf, u64 klo
 // --------------------------------------------------------------------------------
 // 3b. edit distance (-e, /root/reference/src/humid.cc:140-158)
 // --------------------------------------------------------------------------------
-// Levenshtein distance between two n-nucleotide words, exact up to 3 (returns >= 4 otherwise).
+// Levenshtein distance between two n-nucleotide words, exact up to 3 (returns >= 4 otherwise;
+// lev_band2 below: exact up to 5).
 // Equal lengths: d edits hold at most d/2 insertions and as many deletions, so for d <= 3 an
 // optimal alignment never leaves the diagonals -1, 0, +1.  Row i keeps D[i][i-1], D[i][i],
 // D[i][i+1] (L, M, R).
@@ -252,13 +253,46 @@ __device__ __forceinline__ u32 lev_band1(WT x, WT y, u32 n) {
   return M;
 }
 
+// The same with FIVE diagonals (-2 .. +2): exact up to distance 5 (at most two insertions and two
+// deletions between equal-length words).  v[t] = D[i][i + t - 2]; cells outside the matrix are INF.
+template <class WT>
+__device__ __forceinline__ u32 lev_band2(WT x, WT y, u32 n) {
+  const u32 INF = 64;
+  u32 v[5] = {INF, INF, 0, 1, 2};                        // row 0: D[0][j] = j
+  if (n < 1) v[3] = INF;
+  if (n < 2) v[4] = INF;
+  for (u32 i = 0; i < n; i++) {                          // row i -> row i + 1
+    const u32 xs = w_sym(x, n, i);                       // x_{i+1}
+    u32 nv[5];
+#pragma unroll
+    for (u32 t = 0; t < 5; t++) {
+      const int j = (int)i + 1 + (int)t - 2;             // column of the new cell, 0 .. n
+      u32 best = INF;
+      if (j >= 0 && j <= (int)n) {
+        if (j >= 1) best = v[t] + (xs != w_sym(y, n, (u32)j - 1) ? 1u : 0u);      // diagonal
+        if (t + 1 < 5) best = min(best, v[t + 1] + 1u);                            // x_{i+1} deleted
+        if (t >= 1 && j >= 1) best = min(best, nv[t - 1] + 1u);                    // y_j inserted
+      }
+      nv[t] = best < INF ? best : INF;
+    }
+#pragma unroll
+    for (u32 t = 0; t < 5; t++) v[t] = nv[t];
+  }
+  return v[2];
+}
+
+template <u32 BAND, class WT>
+__device__ __forceinline__ u32 lev_band(WT x, WT y, u32 n) {
+  return BAND == 1 ? lev_band1(x, y, n) : lev_band2(x, y, n);
+}
+
 // Candidate join of one combination and one shift pattern: X = the words' own segments (sorted by
 // key), Y = the same segments read at shifted positions (sorted by key).  Thread per X entry: the
 // run of equal keys in Y is found by binary search, every candidate is verified by the dynamic
 // programme.  COUNT: pc[t] = pairs found; FILL: (smaller rank << 32 | larger rank) from poff[t].
 // A pair may come out several times (both roles, several combinations): the list is made unique
 // afterwards.
-template <bool FILL, class KeyT, class WT>
+template <bool FILL, class KeyT, class WT, u32 BAND>
 __global__ void __launch_bounds__(256)
 k_edit_join(const KeyT *__restrict__ KX, const u32 *__restrict__ VX, const KeyT *__restrict__ KY,
             const u32 *__restrict__ VY, u32 n, const WT *__restrict__ words, u32 word_nt, u32 distance,
@@ -279,7 +313,7 @@ k_edit_join(const KeyT *__restrict__ KX, const u32 *__restrict__ VX, const KeyT 
   for (u32 j = lo; j < n && KY[j] == key; j++) {
     const u32 ry = VY[j];
     if (ry == rx) continue;
-    if (lev_band1(wx, words[ry], word_nt) > distance) continue;
+    if (lev_band<BAND>(wx, words[ry], word_nt) > distance) continue;
     if (FILL) edges[e++] = rx < ry ? (((u64)rx << 32) | ry) : (((u64)ry << 32) | rx);
     else found++;
   }

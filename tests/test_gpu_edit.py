@@ -53,6 +53,44 @@ def test_edit_indel_families(dd, seed, d, maximum):
     check_edit(dd, words, filt, n, d, maximum)
 
 
+@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("d", [4, 5])
+@pytest.mark.parametrize("maximum", [False, True])
+def test_edit_two_indel_pairs(dd, seed, d, maximum):
+    """-e -m 4 / 5: up to two insertions and two deletions (offset vectors in [-2, 2], five-diagonal
+    dynamic programme).  Families whose members carry several indels, so pairs at distance 4 and 5 with
+    text shifted by two positions exist; every array against the oracle's trie search."""
+    rng = np.random.default_rng(900 + 10 * d + seed)
+    n = int(rng.integers(8, 25))
+    n_reads = int(rng.integers(300, 2500))
+    bases = rng.integers(0, 4, size=(max(2, n_reads // 15), n))
+    words = np.zeros(n_reads, dtype=np.uint64)
+    for r in range(n_reads):
+        sq = bases[rng.integers(0, len(bases))].tolist()
+        for _ in range(int(rng.integers(0, 3))):            # up to two deletion + insertion events
+            del sq[int(rng.integers(0, n))]
+            sq.insert(int(rng.integers(0, n)), int(rng.integers(0, 4)))
+        if rng.random() < 0.3:
+            sq[int(rng.integers(0, n))] = int(rng.integers(0, 4))
+        words[r] = orc.pack_word(sq)
+    filt = (rng.random(n_reads) < 0.02).astype(np.uint8)
+    check_edit(dd, words, filt, n, d, maximum)
+
+
+def test_edit_two_shifted_stretches_are_found(dd):
+    """a hand-made pair at edit distance 4 whose middle is shifted by TWO positions: found with -m 4,
+    not with -m 3"""
+    n = 20
+    a = [0, 1, 2, 3, 0, 1, 2, 3, 1, 1, 2, 2, 3, 3, 0, 0, 1, 2, 3, 0]
+    b = a[2:] + [2, 1]                      # two deletions in front, two insertions at the end
+    c = a[:3] + a[5:] + [3, 3]              # two deletions inside, two insertions at the end
+    words = np.array([orc.pack_word(x) for x in (a, b, c)] * 3, dtype=np.uint64)
+    filt = np.zeros(len(words), np.uint8)
+    s4 = check_edit(dd, words, filt, n, 4, False)
+    s3 = check_edit(dd, words, filt, n, 3, False)
+    assert s4["edges"] > s3["edges"]
+
+
 @pytest.mark.parametrize("n", [4, 9, 24, 32])
 @pytest.mark.parametrize("d", [2, 3])
 def test_edit_finds_more_than_hamming(dd, n, d):
@@ -96,7 +134,7 @@ def test_edit_unsupported_cases(dd):
     w = np.zeros(4, np.uint64)
     f = np.zeros(4, np.uint8)
     with pytest.raises(humid_amd.HumidError) as e:
-        dd.run(w, f, word_nt=24, distance=4, edit=True)
+        dd.run(w, f, word_nt=24, distance=6, edit=True)
     assert e.value.code == -2
     dd.run(w, f, word_nt=24, distance=1, edit=False)                  # the option does not stick
 
