@@ -33,7 +33,7 @@ typedef unsigned long long ull;
 #define NONE32 0xffffffffu
 
 enum { CTR_UNIQUE = 0, CTR_USABLE, CTR_EDGES, CTR_NONSINGLE, CTR_MEMBERS, CTR_SPECIAL,
-       CTR_CLUSTERS, CTR_OVERFULL, CTR_N = 16 };
+       CTR_CLUSTERS, CTR_OVERFULL, CTR_BIGMASK /* combos with a bucket beyond k_pairs' walk */, CTR_N = 16 };
 
 // --------------------------------------------------------------------------------
 // device helpers

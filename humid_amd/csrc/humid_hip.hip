@@ -81,6 +81,7 @@ struct humid_ctx {
   DBuf pc, poff, share_edges;                                                     // multi-GPU pair-search share
   DBuf own_words;                                                                 // multi-GPU dense count
   DBuf heads;                                                                     // big-component heads
+  DBuf big_runs;            // k_big_runs: (start, length, first tile) of the buckets beyond k_pairs' walk, per combination
   DBuf had;                 // k_pairs: first-phase "found a pair" flags, one byte per combination and position
   DBuf e_kx, e_vx, e_ky, e_vy, e_raw, e_sorted, e_edges, e_head, e_hpos;   // edit-distance neighbour search
   bool edit = false;         // option "edit_distance": Levenshtein instead of Hamming neighbours (-e)
@@ -106,6 +107,7 @@ struct humid_ctx {
   bool slots_done = false;   // slot_out already written by k_finalize_nodes (one-GPU fusion)
   int count_mode = 0;        // 0: hash-partitioned LDS tables (default), 1: one global HBM table
   u32 force_segments = 0;    // 0: automatic pigeonhole plan; else the number of segments s
+  u32 walk_max = PT2_TILE;   // k_pairs compares a position with this many followers; longer buckets go to k_pairs_tiles (0: never)
   bool coop_big = true;      // big components: workgroup-cooperative kernel (directional method)
   bool last_count_lds = false;
   bool last_count_ordered = false;
@@ -734,7 +736,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
   ENSURE(c->parent, (size_t)U * 4);
   ENSURE(c->csize, (size_t)U * 4);
   ENSURE(c->cur, (size_t)U * 4);
-  HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_EDGES], 0, (CTR_OVERFULL - CTR_EDGES + 1) * sizeof(ull), st));
+  HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_EDGES], 0, (CTR_BIGMASK - CTR_EDGES + 1) * sizeof(ull), st));
   hipLaunchKernelGGL(k_graph_init, dim3(blocks_for((u64)U + 1)), dim3(256), 0, st, c->parent.as<u32>(),
                      c->deg.as<u32>(), c->csize.as<u32>(), c->cur.as<u32>(), U);
   u64 E = 0, M = 0, Mbig = 0;
@@ -750,6 +752,10 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
   };
   const bool given = ext_edges != nullptr;
   const bool search = !given && distance > 0 && U > 1;
+  // directional method: only neighbour pairs a climb or a flood can cross join two components
+  // (joins_for_clustering); maximum method: all of them
+  const u32 *join_cnt = (method & 1) ? nullptr : g_cnt;
+
   // one bucket holding every word (d >= n, or d too large for any pigeonhole plan): U^2 / 2
   // comparisons and, at such distances, nearly as many pairs -- beyond a few 10^5 words the pair
   // list cannot fit 32-bit CSR offsets anyway; refuse before spending minutes to find that out
@@ -759,12 +765,69 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
   if (given && n_ext_edges) {
     hipLaunchKernelGGL(k_edges_apply<false>, dim3(grid_stride_blocks(n_ext_edges)), dim3(256), 0, st, ext_edges,
                        n_ext_edges, U, c->deg.as<u32>(), c->parent.as<u32>(), (const u32 *)nullptr,
-                       (u32 *)nullptr, (u32 *)nullptr, c->d_ctr);
+                       (u32 *)nullptr, (u32 *)nullptr, c->d_ctr, join_cnt);
     hipLaunchKernelGGL(k_comp_stats, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
                        c->parent.as<u32>(), U, c->csize.as<u32>());
     hipLaunchKernelGGL(k_comp_count, dim3(512), dim3(256), 0, st, c->deg.as<u32>(), c->parent.as<u32>(),
                        c->csize.as<u32>(), U, c->d_ctr);
   }
+  // buckets beyond k_pairs' bounded walk (c->walk_max words; 0 = walk to the end of the bucket)
+  const u32 walk_max = c->walk_max;
+  u64 big_mask = 0;
+  std::vector<BigRun> h_runs[MAX_COMBOS];
+  auto walked = [&](u32 seg, const WT *&W, const u32 *&V) {
+    W = seg ? c->seg_ws.as<WT>() + (size_t)(seg - 1) * U : g_word;
+    V = seg ? c->seg_vs.as<u32>() + (size_t)(seg - 1) * U : nullptr;
+  };
+  auto big_find = [&](u32 seg) -> int {
+    const WT *W; const u32 *V;
+    walked(seg, W, V);
+    const u32 cap = U / (walk_max + 2) + 1;                       // runs are disjoint and longer than walk_max + 1
+    ENSURE(c->big_runs, (size_t)MAX_COMBOS * cap * sizeof(BigRun) + 16);
+    u32 *d_n = (u32 *)((char *)c->big_runs.p + (size_t)MAX_COMBOS * cap * sizeof(BigRun));
+    BigRun *d_runs = c->big_runs.as<BigRun>() + (size_t)seg * cap;
+    HIPCHK(hipMemsetAsync(d_n, 0, 4, st));
+    hipLaunchKernelGGL(k_big_runs<WT>, dim3(blocks_for(U)), dim3(256), 0, st, W, U, w_from<WT>(plan.mask[seg]), walk_max,
+                       d_runs, cap, d_n);
+    u32 n_runs = 0;
+    HIPCHK(hipMemcpyAsync(&n_runs, d_n, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (n_runs > cap) return fail(c, HUMID_E_INVALID, "more large buckets (%u) than fit the input (%u)", n_runs, cap);
+    std::vector<BigRun> &r = h_runs[seg];
+    r.resize(n_runs);
+    if (n_runs) HIPCHK(hipMemcpy(r.data(), d_runs, (size_t)n_runs * sizeof(BigRun), hipMemcpyDeviceToHost));
+    std::sort(r.begin(), r.end(), [](const BigRun &x, const BigRun &y) { return x.start < y.start; });
+    ull tiles = 0;
+    for (BigRun &x : r) {
+      const ull nt = ((ull)x.len + PT2_TILE - 1) / PT2_TILE;
+      x.tile0 = tiles;
+      tiles += nt * (nt + 1) / 2;
+    }
+    r.push_back(BigRun{0u, 0u, tiles});                           // sentinel: the total
+    if (n_runs) HIPCHK(hipMemcpy(d_runs, r.data(), (size_t)n_runs * sizeof(BigRun), hipMemcpyHostToDevice));
+    return HUMID_OK;
+  };
+  auto big_tiles = [&](u32 seg, int mode) -> int {
+    const std::vector<BigRun> &r = h_runs[seg];
+    if (r.size() < 2) return HUMID_OK;
+    const WT *W; const u32 *V;
+    walked(seg, W, V);
+    const u32 cap = U / (walk_max + 2) + 1;
+    const ull tiles = r.back().tile0;
+    const u32 grid = (u32)std::min<ull>(tiles, 1u << 20);
+#define BIG_TILES(P0, M)                                                                                          \
+  hipLaunchKernelGGL((k_pairs_tiles<P0, M, WT>), dim3(grid), dim3(PT2_THREADS), 0, st, W, V,                       \
+                     c->big_runs.as<BigRun>() + (size_t)seg * cap, (u32)r.size() - 1, tiles, d_masks, seg, distance, \
+                     walk_max, c->deg.as<u32>(), c->parent.as<u32>(), c->nbr_off.as<u32>(), c->cur.as<u32>(),      \
+                     c->nbr_idx.as<u32>(), join_cnt)
+    if (seg == 0 && mode == PM_COUNT) BIG_TILES(true, PM_COUNT);
+    else if (seg == 0) BIG_TILES(true, PM_FILL);
+    else if (mode == PM_COUNT) BIG_TILES(false, PM_COUNT);
+    else BIG_TILES(false, PM_FILL);
+#undef BIG_TILES
+    HIPCHK(hipGetLastError());
+    return HUMID_OK;
+  };
   if (search) {
     const u32 nseg = plan.ncombo;
     n_pair_segs = nseg < 8 ? nseg : 8;
@@ -783,7 +846,8 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
         hipLaunchKernelGGL((k_pairs<true, PM_COUNT, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
                            (const u32 *)nullptr, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, c->deg.as<u32>(),
                            c->parent.as<u32>(), (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
-                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u8>());
+                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u8>(), walk_max,
+                           &c->d_ctr[CTR_BIGMASK], join_cnt);
       } else {
         u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
         const u32 kb = plan.key_bits ? plan.key_bits : 1;
@@ -802,7 +866,8 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
         hipLaunchKernelGGL((k_pairs<false, PM_COUNT, WT>), dim3(blocks_for(U)), dim3(256), 0, st, ws,
                            vs, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, c->deg.as<u32>(), c->parent.as<u32>(),
                            (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
-                           (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u8>() + (size_t)seg * U);
+                           (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u8>() + (size_t)seg * U, walk_max,
+                           &c->d_ctr[CTR_BIGMASK], join_cnt);
       }
       if (seg < 8) HIPCHK(hipEventRecord(c->kev[21 + 2 * seg], st));
     }
@@ -819,6 +884,27 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
     // the degrees summed in 64 bits (k_comp_count): the 32-bit scan below it may have wrapped
     if (c->h_ctr[CTR_EDGES] > 0xffffffffull)
       return fail(c, HUMID_E_OVERFLOW, "%llu neighbour pairs exceed the 32-bit adjacency offsets", (ull)(c->h_ctr[CTR_EDGES] / 2));
+    big_mask = search ? c->h_ctr[CTR_BIGMASK] : 0;
+    if (big_mask) {
+      // some bucket is longer than k_pairs walks: find those runs, count their remaining pairs as
+      // tiles, and take the component statistics and the offsets again
+      for (u32 seg = 0; seg < plan.ncombo; seg++)
+        if (big_mask >> seg & 1) {
+          TRY(big_find(seg));
+          TRY(big_tiles(seg, PM_COUNT));
+        }
+      HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_EDGES], 0, 3 * sizeof(ull), st));
+      HIPCHK(hipMemsetAsync(c->csize.p, 0, (size_t)U * 4, st));
+      hipLaunchKernelGGL(k_comp_stats, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
+                         c->parent.as<u32>(), U, c->csize.as<u32>());
+      hipLaunchKernelGGL(k_comp_count, dim3(512), dim3(256), 0, st, c->deg.as<u32>(), c->parent.as<u32>(),
+                         c->csize.as<u32>(), U, c->d_ctr);
+      TRY(exscan_u32(c, c->deg.as<u32>(), c->nbr_off.as<u32>(), (u64)U + 1));
+      HIPCHK(hipGetLastError());
+      TRY(read_counters(c, c->nbr_off.as<u32>() + U));
+      if (c->h_ctr[CTR_EDGES] > 0xffffffffull)
+        return fail(c, HUMID_E_OVERFLOW, "%llu neighbour pairs exceed the 32-bit adjacency offsets", (ull)(c->h_ctr[CTR_EDGES] / 2));
+    }
     const u64 twoE = c->h_ctr[CTR_N - 1] & 0xffffffffull;
     E = twoE / 2;
     M = c->h_ctr[CTR_NONSINGLE];
@@ -839,14 +925,17 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
         hipLaunchKernelGGL((k_pairs<true, PM_FILL, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
                            (const u32 *)nullptr, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, (u32 *)nullptr,
                            (u32 *)nullptr, c->nbr_off.as<u32>(), c->cur.as<u32>(), c->nbr_idx.as<u32>(),
-                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u8>());
+                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u8>(), walk_max);
+        if (big_mask & 1) TRY(big_tiles(0, PM_FILL));
       } else {
         const u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
         const WT *ws = c->seg_ws.as<WT>() + (size_t)(seg - 1) * U;
         hipLaunchKernelGGL((k_pairs<false, PM_FILL, WT>), dim3(blocks_for(U)), dim3(256), 0, st, ws,
                            vs, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
                            c->nbr_off.as<u32>(), c->cur.as<u32>(), c->nbr_idx.as<u32>(),
-                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u8>() + (size_t)seg * U);
+                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u8>() + (size_t)seg * U,
+                           walk_max);
+        if (big_mask >> seg & 1) TRY(big_tiles(seg, PM_FILL));
       }
       if (seg < 8) HIPCHK(hipEventRecord(c->kev[5 + 2 * seg], st));
     }
@@ -1435,6 +1524,11 @@ int humid_ctx_set_option(humid_ctx *c, const char *key, int64_t value) {
     c->coop_big = value != 0;
     return HUMID_OK;
   }
+  if (strcmp(key, "bucket_walk") == 0) {
+    if (value < 0 || value > (1 << 24)) return fail(c, HUMID_E_INVALID, "bucket_walk must be 0 (no limit) .. 2^24");
+    c->walk_max = (u32)value;
+    return HUMID_OK;
+  }
   if (strcmp(key, "plan_segments") == 0) {
     if (value < 0 || value > 32) return fail(c, HUMID_E_INVALID, "plan_segments must be 0 (auto) .. 32");
     c->force_segments = (u32)value;
@@ -1693,7 +1787,8 @@ int humid_cluster_graph(humid_ctx *c, const uint32_t *count, const uint32_t *nbr
   HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_EDGES], 0, 3 * sizeof(ull), st));
   hipLaunchKernelGGL(k_iota, dim3(blocks_for(U)), dim3(256), 0, st, c->parent.as<u32>(), U);
   hipLaunchKernelGGL(k_union_csr, dim3(blocks_for(U)), dim3(256), 0, st, c->nbr_off.as<u32>(),
-                     c->nbr_idx.as<u32>(), U, c->parent.as<u32>());
+                     c->nbr_idx.as<u32>(), U, c->parent.as<u32>(),
+                     method == HUMID_METHOD_MAXIMUM ? (const u32 *)nullptr : c->s_cnt.as<u32>());
   hipLaunchKernelGGL(k_comp_stats, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
                      c->parent.as<u32>(), U, c->csize.as<u32>());
   hipLaunchKernelGGL(k_comp_count, dim3(512), dim3(256), 0, st, c->deg.as<u32>(), c->parent.as<u32>(),

@@ -241,7 +241,8 @@ k_comp_heads(const u64 *__restrict__ mkeys, u32 n_members, u32 *__restrict__ hea
 //  * no neighbours: the leaf creates its own cluster (src/humid.cc:179-187 with an empty list:
 //    maxNeighbour_ returns the leaf, cluster.cc:39-51);
 //  * components of exactly two leaves a < b (one centre + one satellite: the bulk of the
-//    non-trivial components on UMI data): closed form of the same loop, done by a's lane;
+//    non-trivial components on UMI data): closed form of the same loop, done by a's lane (the
+//    root: uf_union keeps the smaller index on top);
 //  * every other leaf is marked unassigned for k_cluster_small / k_cluster_components.
 template <bool MAXIMUM>
 __global__ void __launch_bounds__(256)
@@ -253,9 +254,17 @@ k_cluster_trivial(const u32 *__restrict__ deg, const u32 *__restrict__ P, const 
   if (a >= n) return;
   if (deg[a] == 0) { cl_of[a] = a + 1; maxleaf[a] = a; cl_size[a] = cnt[a]; return; }
   const u32 root = P[a];                           // flattened by k_comp_stats
-  if (csize[root] != 2) { cl_of[a] = 0; return; }
+  const u32 members = csize[root];
+  // alone in its component although it has neighbours (joins_for_clustering: none of them within
+  // reach of a climb or a flood): the same as no neighbours
+  if (members == 1) { cl_of[a] = a + 1; maxleaf[a] = a; cl_size[a] = cnt[a]; return; }
+  if (members != 2) { cl_of[a] = 0; return; }
   if (root != a) return;                           // b: written by a's lane
-  const u32 b = idx[off[a]];
+  u32 b = a;                                       // the other member: the neighbour with the same root
+  for (u32 k = off[a]; k < off[a + 1]; k++) {
+    const u32 nb = idx[k];
+    if (P[nb] == root) { b = nb; break; }
+  }
   const u64 ca = cnt[a], cb = cnt[b];
   if (MAXIMUM) {                                   // whole component, maxLeaf = first strict maximum
     cl_of[a] = a + 1; cl_of[b] = a + 1;
@@ -289,7 +298,7 @@ k_cluster_small(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u3
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n || deg[u] == 0 || P[u] != u) return;
   const u32 target = csize[u];
-  if (target > SMALL_COMP || target == 2) return;   // pairs: k_cluster_trivial; big: k_cluster_components
+  if (target > SMALL_COMP || target <= 2) return;   // one, two: k_cluster_trivial; big: k_cluster_components
   u32 mem[SMALL_COMP];
   u32 st[2 * SMALL_COMP];
   u32 nm = 1;
@@ -298,7 +307,7 @@ k_cluster_small(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u3
     const u32 v = mem[q];
     for (u32 k = off[v]; k < off[v + 1] && nm < target; k++) {
       const u32 nb = idx[k];
-      bool seen = false;
+      bool seen = P[nb] != u;                         // a neighbour outside this component (joins_for_clustering)
       for (u32 t = 0; t < nm; t++) seen |= (mem[t] == nb);
       if (!seen) mem[nm++] = nb;
     }

@@ -103,12 +103,26 @@ __device__ __forceinline__ void uf_union(u32 *P, u32 a, u32 b) {
 // second runs on to the end of the bucket anywhere in [0, n).
 enum { PM_COUNT = 0, PM_FILL = 1, PM_EMIT_COUNT = 2, PM_EMIT_FILL = 3 };
 
+// The forest of `parent` only has to keep together what the clustering can move between.  The
+// directional method climbs to and floods along neighbours whose counts differ by a factor two
+// (src/cluster.cc:39-69: every step tests atLeastDouble_); a neighbour pair with similar counts is
+// never crossed, so it need not join two components.  cnt == nullptr (maximum method, which floods
+// every edge, src/cluster.cc:72-80): every pair joins.  Finer components = more of them in flight
+// and no order to respect between them: 10^6 single-read words that are all neighbours of
+// neighbours are 10^6 independent one-leaf components instead of one chain walked leaf by leaf.
+__device__ __forceinline__ bool joins_for_clustering(const u32 *__restrict__ cnt, u32 a, u32 b) {
+  if (!cnt) return true;
+  const u64 ca = cnt[a], cb = cnt[b];
+  return at_least_double(ca, cb) || at_least_double(cb, ca);
+}
+
 template <bool PASS0, int MODE, class WT>
 __global__ void __launch_bounds__(256)
 k_pairs(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, u32 i0, u32 n_i, WT mask,
         EarlierMasksT<WT> em, u32 cb, u32 distance, u32 *deg, u32 *parent,
         const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, u32 *__restrict__ pc,
-        const u32 *__restrict__ poff, u64 *__restrict__ edges, u8 *__restrict__ had) {
+        const u32 *__restrict__ poff, u64 *__restrict__ edges, u8 *__restrict__ had,
+        u32 walk_max = 0, ull *big = nullptr, const u32 *__restrict__ cnt = nullptr) {
   HUMID_GUARD_LAST_VGPR();
   // W: the words IN THE ORDER WALKED (the sorted unique array for the prefix combo, a gathered
   // copy in bucket order for the sorted combos), so the inner loop is one sequential, coalesced
@@ -124,7 +138,13 @@ k_pairs(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, u32 i0, u32 
   const u32 ri = PASS0 ? i : V[i];
   u32 found = 0;
   u64 e = (MODE == PM_EMIT_FILL) ? (u64)poff[t] : 0;
-  for (u32 j = i + 1; j < n; j++) {
+  // walk_max > 0: a position compares itself with at most the next walk_max words of its bucket;
+  // a bucket that goes on beyond that is reported in *big (bit cb) and its remaining pairs
+  // (j - i > walk_max) belong to k_pairs_tiles -- a thread per position is quadratic in a lane
+  // on a bucket of 10^5 words, the tiles spread the same comparisons over the whole device
+  const u32 jend = (walk_max && n - i > walk_max + 1) ? i + walk_max + 1 : n;
+  u32 j = i + 1;
+  for (; j < jend; j++) {
     const WT x = w_xor(wi, W[j]);
     if (w_hits(x, mask)) break;                    // left the bucket
     if (w_mismatch(x) > distance) continue;
@@ -140,7 +160,7 @@ k_pairs(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, u32 i0, u32 
     } else if (MODE == PM_COUNT) {
       found++;
       atomicAdd(&deg[rj], 1u);
-      uf_union(parent, ri, rj);
+      if (joins_for_clustering(cnt, ri, rj)) uf_union(parent, ri, rj);
     } else if (MODE == PM_EMIT_COUNT) {
       found++;
     } else {
@@ -150,6 +170,100 @@ k_pairs(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, u32 i0, u32 
   if (MODE == PM_COUNT && found) atomicAdd(&deg[ri], found);
   if (MODE == PM_COUNT && had) had[t] = found ? 1 : 0;
   if (MODE == PM_EMIT_COUNT) pc[t] = found;
+  if (MODE == PM_COUNT && big && j == jend && jend < n && !w_hits(w_xor(wi, W[jend]), mask))
+    atomicOr(big, 1ull << cb);
+}
+
+// ---- large buckets: the pairs k_pairs leaves out, as tiles ------------------------------------
+// A run is a bucket (maximal stretch of equal key in the walked order) longer than walk_max + 1.
+// Its pairs (i, j) with j - i > walk_max are cut into PT2_TILE x PT2_TILE squares of the upper
+// triangle; one workgroup compares one square: the 'b' side staged in LDS and read by every lane
+// at the same address (a broadcast, no bank conflict), PT2_ROWS words of the 'a' side per thread in
+// registers, so one LDS read feeds PT2_ROWS xor/popcount comparisons.  Found pairs are as rare
+// here as anywhere and take the same actions as in k_pairs.
+#define PT2_THREADS 256
+#define PT2_ROWS 4
+#define PT2_TILE (PT2_THREADS * PT2_ROWS)      // 1024 words a side; also the walk_max of k_pairs
+struct BigRun { u32 start, len; ull tile0; };  // tile0: running sum of nt (nt + 1) / 2 over the runs before
+
+// heads of the runs: position i starts a bucket and the bucket still holds position i + walk_max + 1.
+// The end is found by bisection: inside the walked order equal keys are contiguous.
+template <class WT>
+__global__ void k_big_runs(const WT *__restrict__ W, u32 n, WT mask, u32 walk_max, BigRun *runs, u32 cap,
+                           u32 *n_runs) {
+  HUMID_GUARD_LAST_VGPR();
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || n - i <= walk_max + 1) return;
+  const WT wi = W[i];
+  if (w_hits(w_xor(wi, W[i + walk_max + 1]), mask)) return;
+  if (i > 0 && !w_hits(w_xor(wi, W[i - 1]), mask)) return;       // not the first of its bucket
+  u32 lo = i + walk_max + 1, hi = n;                              // W[lo] in the bucket, W[hi] not (or hi == n)
+  while (hi - lo > 1) {
+    const u32 mid = lo + (hi - lo) / 2;
+    if (w_hits(w_xor(wi, W[mid]), mask)) hi = mid; else lo = mid;
+  }
+  const u32 k = atomicAdd(n_runs, 1u);
+  if (k < cap) { runs[k].start = i; runs[k].len = hi - i; runs[k].tile0 = 0; }
+}
+
+template <bool PASS0, int MODE, class WT>
+__global__ void __launch_bounds__(PT2_THREADS)
+k_pairs_tiles(const WT *__restrict__ W, const u32 *__restrict__ V, const BigRun *__restrict__ runs, u32 n_runs,
+              ull total_tiles, EarlierMasksT<WT> em, u32 cb, u32 distance, u32 walk_max, u32 *deg, u32 *parent,
+              const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, const u32 *__restrict__ cnt) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ WT sb[PT2_TILE];
+  for (ull q = blockIdx.x; q < total_tiles; q += gridDim.x) {
+    u32 lo = 0, hi = n_runs;                                      // the run whose tiles hold q
+    while (hi - lo > 1) {
+      const u32 mid = (lo + hi) / 2;
+      if (runs[mid].tile0 <= q) lo = mid; else hi = mid;
+    }
+    const u32 s = runs[lo].start, L = runs[lo].len;
+    const ull r = q - runs[lo].tile0;                             // r = b (b + 1) / 2 + a, a <= b
+    u32 b = (u32)((sqrt(8.0 * (double)r + 1.0) - 1.0) * 0.5);
+    while ((ull)b * (b + 1) / 2 > r) b--;
+    while ((ull)(b + 1) * (b + 2) / 2 <= r) b++;
+    const u32 a = (u32)(r - (ull)b * (b + 1) / 2);
+    if ((b - a) * PT2_TILE + PT2_TILE - 1 <= walk_max) continue;  // every pair of the square is k_pairs'
+    const u32 b0 = b * PT2_TILE, nb = L - b0 < PT2_TILE ? L - b0 : PT2_TILE;
+    __syncthreads();                                              // the previous square is done with sb
+    for (u32 u = threadIdx.x; u < nb; u += PT2_THREADS) sb[u] = W[s + b0 + u];
+    WT wa[PT2_ROWS];
+    u32 lim[PT2_ROWS];                                            // j > lim: the pair is this kernel's
+#pragma unroll
+    for (u32 k = 0; k < PT2_ROWS; k++) {
+      const u32 ia = a * PT2_TILE + k * PT2_THREADS + threadIdx.x;
+      const bool ok = ia < L;
+      wa[k] = W[s + (ok ? ia : 0)];
+      lim[k] = ok ? s + ia + walk_max : 0xffffffffu;
+    }
+    __syncthreads();
+    for (u32 u = 0; u < nb; u++) {
+      const WT wb = sb[u];
+      const u32 j = s + b0 + u;
+#pragma unroll
+      for (u32 k = 0; k < PT2_ROWS; k++) {
+        const WT x = w_xor(wa[k], wb);
+        if (w_mismatch(x) > distance || j <= lim[k]) continue;
+        bool first = true;
+#pragma unroll
+        for (u32 qq = 0; qq < MAX_COMBOS; qq++)
+          first = first && !(qq < cb && !w_hits(x, em.m[qq]));
+        if (!first) continue;
+        const u32 i = lim[k] - walk_max;
+        const u32 ri = PASS0 ? i : V[i], rj = PASS0 ? j : V[j];
+        if (MODE == PM_FILL) {
+          nbr_idx[nbr_off[ri] + atomicAdd(&cur[ri], 1u)] = rj;
+          nbr_idx[nbr_off[rj] + atomicAdd(&cur[rj], 1u)] = ri;
+        } else {
+          atomicAdd(&deg[ri], 1u);
+          atomicAdd(&deg[rj], 1u);
+          if (joins_for_clustering(cnt, ri, rj)) uf_union(parent, ri, rj);
+        }
+      }
+    }
+  }
 }
 
 // words of a sorted combo in bucket order (one gather per combo instead of one per comparison)
@@ -165,7 +279,8 @@ __global__ void k_gather_bucket_words(const WT *__restrict__ s_word, const u32 *
 template <bool FILL>
 __global__ void __launch_bounds__(256)
 k_edges_apply(const u64 *__restrict__ edges, u64 n_edges, u32 n_nodes, u32 *deg, u32 *parent,
-              const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, ull *ctr) {
+              const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, ull *ctr,
+              const u32 *__restrict__ cnt = nullptr) {
   HUMID_GUARD_LAST_VGPR();
   for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n_edges; k += (u64)gridDim.x * blockDim.x) {
     const u64 ed = edges[k];
@@ -177,7 +292,7 @@ k_edges_apply(const u64 *__restrict__ edges, u64 n_edges, u32 n_nodes, u32 *deg,
     } else {
       atomicAdd(&deg[a], 1u);
       atomicAdd(&deg[b], 1u);
-      uf_union(parent, a, b);
+      if (joins_for_clustering(cnt, a, b)) uf_union(parent, a, b);
     }
   }
 }
@@ -445,13 +560,14 @@ __global__ void k_iota(u32 *p, u32 n) {
   if (i < n) p[i] = i;
 }
 
-// explicit-graph entry point: union every CSR entry (u, nbr)
-__global__ void k_union_csr(const u32 *__restrict__ off, const u32 *__restrict__ idx, u32 n, u32 *P) {
+// explicit-graph entry point: union every CSR entry (u, nbr) the clustering can cross
+__global__ void k_union_csr(const u32 *__restrict__ off, const u32 *__restrict__ idx, u32 n, u32 *P,
+                            const u32 *__restrict__ cnt) {
   HUMID_GUARD_LAST_VGPR();
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n) return;
   for (u32 k = off[u]; k < off[u + 1]; k++)
-    if (idx[k] != u) uf_union(P, u, idx[k]);
+    if (idx[k] > u && joins_for_clustering(cnt, u, idx[k])) uf_union(P, u, idx[k]);   // lists are symmetric (checked)
 }
 
 // members of the BIG components, keyed (root << 32 | rank); unordered, sorted afterwards

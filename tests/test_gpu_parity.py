@@ -378,6 +378,54 @@ def test_large_bucket(dd):
     check_against_oracle(dd, words, np.zeros(n_reads, np.uint8), 24, 1, True)
 
 
+@pytest.mark.parametrize("walk", [1, 7, 300])
+@pytest.mark.parametrize("cfg", [(120_000, 24, 1), (60_000, 12, 2), (40_000, 16, 3), (20_000, 40, 2)])
+def test_tiles_take_over_beyond_the_bucket_walk(dd1, walk, cfg):
+    """k_pairs bounded to `walk` followers: every bucket longer than that is completed by k_big_runs +
+    k_pairs_tiles (squares of the upper triangle, the partly-near squares filtered pair by pair).  With a
+    tiny walk nearly every bucket of every combination takes that road: all arrays against the oracle."""
+    n_reads, n, d = cfg
+    dd1.set_option("bucket_walk", walk)
+    try:
+        if n <= 32:
+            words, filt = synth_words(n_reads, 5 + walk, n, p_sub=8e-3, p_n=1e-3)
+            check_against_oracle(dd1, words, filt, n, d, False)
+            check_against_oracle(dd1, words, filt, n, d, True, deep=False)
+        else:
+            from humid_amd.synth import synth_wide_words
+            words, filt = synth_wide_words(n_reads, 5 + walk, n, p_sub=8e-3, p_n=1e-3)
+            check_against_oracle(dd1, words, filt, n, d, False)
+    finally:
+        dd1.set_option("bucket_walk", 1024)
+
+
+def one_prefix_words(rng, n_words, n, prefix_nt, reads_per_word=1.3):
+    """n_words DISTINCT n-nt words that all start with the same prefix_nt nucleotides, each read once
+    or a few times; read order shuffled"""
+    tail_bits = 2 * (n - prefix_nt)
+    tails = rng.choice(1 << tail_bits, size=n_words, replace=False).astype(np.uint64)
+    prefix = np.uint64(int(rng.integers(0, 4 ** prefix_nt))) << np.uint64(tail_bits)
+    uniq = prefix | tails
+    reps = rng.poisson(reads_per_word - 1, size=n_words) + 1
+    words = np.repeat(uniq, reps)
+    rng.shuffle(words)
+    return words
+
+
+@pytest.mark.parametrize("d", [1, 2])
+def test_one_prefix_shared_by_200k_words(dd, d):
+    """skew the pigeonhole cannot split: 200 000 distinct 24-nt words with the same first 12
+    nucleotides, so the bucket of the first-half key (d = 1) / of the leading segments (d = 2) holds
+    every one of them -- 2 * 10^10 pairs in one bucket, taken by k_pairs_tiles; the exact-count
+    partition sees one 9-nt prefix only and falls back by itself.  Everything against the oracle."""
+    rng = np.random.default_rng(40 + d)
+    words = one_prefix_words(rng, 200_000, 24, 12)
+    filt = (rng.random(len(words)) < 1e-3).astype(np.uint8)
+    s = check_against_oracle(dd, words, filt, 24, d, False)
+    assert s["unique"] >= 199_000 and s["edges"] > 0
+    check_against_oracle(dd, words, filt, 24, d, True, deep=False)
+
+
 def test_long_chain_component(dd):
     """a path-shaped component thousands of leaves deep (the reference recursion overflows here)"""
     # words 0..L-1 in unary-like Gray walk: consecutive words differ in one nucleotide
