@@ -48,14 +48,18 @@ HOST_EXE = os.path.join(HERE, "humid")
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
     """The `humid` command-line host (C++17, g++): FastQ streaming + the C ABI."""
-    srcs = [os.path.join(HOST_DIR, f) for f in ("main.cpp", "fastq_io.cpp", "fastq_mmap.cpp", "fast_inflate.cpp", "words.cpp")]
-    deps = srcs + [os.path.join(HOST_DIR, f) for f in ("fastq_io.hpp", "fastq_mmap.hpp", "fast_inflate.hpp", "words.hpp")] + [HDR]
+    srcs = [os.path.join(HOST_DIR, f) for f in ("main.cpp", "sharded.cpp", "fastq_io.cpp", "fastq_mmap.cpp", "fast_inflate.cpp", "words.cpp")]
+    deps = srcs + [os.path.join(HOST_DIR, f) for f in ("fastq_io.hpp", "fastq_mmap.hpp", "fast_inflate.hpp", "words.hpp", "sharded.hpp")] + [HDR]
     build_hip(force=False, verbose=verbose)
     if not force and os.path.exists(HOST_EXE) and \
             all(os.path.getmtime(p) <= os.path.getmtime(HOST_EXE) for p in deps + [SO]):
         return HOST_EXE
-    cmd = ["g++", "-O3", "-std=c++17", "-Wall", "-Wextra", "-o", HOST_EXE] + srcs + \
-          ["-L" + HERE, "-lhumid_hip", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link,/opt/rocm/lib"]
+    # sharded.cpp calls the HIP runtime (memory, streams, peer copies) and uses RCCL's types; librccl
+    # itself is loaded with dlopen when a -g N run wants it
+    cmd = ["g++", "-O3", "-std=c++17", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__", "-isystem", "/opt/rocm/include",
+           "-o", HOST_EXE] + srcs + \
+          ["-L" + HERE, "-lhumid_hip", "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-lz", "-lpthread",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=ROOT)

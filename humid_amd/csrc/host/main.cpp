@@ -31,6 +31,7 @@
 #include <thread>
 
 #include "fast_inflate.hpp"
+#include "sharded.hpp"
 #include "words.hpp"
 
 using namespace humid_host;
@@ -49,16 +50,18 @@ struct Args {
   bool maximum = false;        // -x
   std::vector<std::string> files;
   std::string dump_words;      // --dump-words (development: stop after pass 1, no GPU)
+  unsigned gpus = 1;           // -g (not in the reference): ranks the read set is sharded over, one GPU each
 };
 
 void usage(const char *argv0) {
   std::fprintf(stderr,
-               "usage: %s [-n 24] [-m 1] [-l /dev/stderr] [-d .] [-s] [-q] [-a] [-e] [-x] files...\n"
+               "usage: %s [-n 24] [-m 1] [-l /dev/stderr] [-d .] [-s] [-q] [-a] [-e] [-x] [-g 1] files...\n"
                "Deduplicate a dataset.\n"
                "  -n  word length\n  -m  allowed mismatches\n  -l  log file name\n  -d  output directory\n"
                "  -s  calculate statistics\n  -q  write deduplicated FastQ files (flag turns it OFF)\n"
                "  -a  write annotated FastQ files\n  -e  use edit distance (Levenshtein neighbours; -m <= 5)\n"
-               "  -x  use maximum clustering method\n",
+               "  -x  use maximum clustering method\n"
+               "  -g  GPUs to shard the read set over (1..16; default 1 or $HUMID_GPUS; -n <= 32, no -e beyond -m 1)\n",
                argv0);
 }
 
@@ -74,6 +77,7 @@ bool parse(int argc, char **argv, Args &a) {
     else if (t == "-m") { const char *v = need("-m"); if (!v) return false; a.distance = std::strtoull(v, nullptr, 10); }
     else if (t == "-l") { const char *v = need("-l"); if (!v) return false; a.log_name = v; }
     else if (t == "-d") { const char *v = need("-d"); if (!v) return false; a.dir_name = v; }
+    else if (t == "-g") { const char *v = need("-g"); if (!v) return false; a.gpus = (unsigned)std::strtoul(v, nullptr, 10); }
     else if (t == "--dump-words") { const char *v = need("--dump-words"); if (!v) return false; a.dump_words = v; }
     else if (t == "-s") a.stats = !a.stats;
     else if (t == "-q") a.filter = !a.filter;
@@ -197,6 +201,17 @@ int main(int argc, char **argv) {
     std::fprintf(stderr, "humid: word length %zu is not supported by the HIP path (1..64)\n", a.word_length);
     return 2;
   }
+  if (a.gpus == 1 && getenv("HUMID_GPUS")) a.gpus = (unsigned)std::strtoul(getenv("HUMID_GPUS"), nullptr, 10);
+  if (a.gpus < 1 || a.gpus > 16) {
+    std::fprintf(stderr, "humid: -g takes 1 .. 16 GPUs\n");
+    return 2;
+  }
+  if (a.gpus > 1 && (a.word_length > 32 || (a.edit && a.distance > 1))) {
+    std::fprintf(stderr, "humid: -g %u: words longer than 32 nt and edit distances beyond 1 run on one GPU only\n", a.gpus);
+    return 2;
+  }
+  // HUMID_FORCE_SHARDED=1: the rank orchestration also for -g 1 (one rank; exercises the transport)
+  const bool sharded = a.gpus > 1 || getenv("HUMID_FORCE_SHARDED") != nullptr;
   std::ofstream log(a.log_name.c_str(), std::ios::out | std::ios::binary);
 
   // The HIP runtime and the context come up (a few hundred ms) while pass 1 parses the files.
@@ -212,7 +227,7 @@ int main(int argc, char **argv) {
   std::atomic<long long> n_known{-1};                   // -1: not yet; 0: no slab wanted
   uint8_t *pinned = nullptr;                            // written by the init thread, read after its join
   uint64_t pin_bytes = 0;
-  if (a.dump_words.empty())
+  if (a.dump_words.empty() && !sharded)
     ctx_init.th = std::thread([&] {
       const auto ti = std::chrono::steady_clock::now();
       auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - ti).count(); };
@@ -292,7 +307,7 @@ int main(int argc, char **argv) {
   // HUMID_DEVICE_PACK=1: the host only gathers the raw symbols and the GPU packs them
   // (humid_dedup_run_bases).  Not the default: 24 raw bytes per read instead of 9 packed ones cross
   // PCIe, which costs more than the host's packing saves (profiles/r02d_cli_e2e.txt).
-  const bool device_pack = fast && a.dump_words.empty() && getenv("HUMID_DEVICE_PACK") != nullptr;
+  const bool device_pack = fast && a.dump_words.empty() && !sharded && getenv("HUMID_DEVICE_PACK") != nullptr;
   uint64_t n_records = 0;
   if (fast) {
     size_t n = maps[0].records();
@@ -359,7 +374,7 @@ int main(int argc, char **argv) {
   // ---- the hot path on the GPU ----
   phase("pass 1 done");
   if (ctx_init.th.joinable()) ctx_init.th.join();
-  if (ctx_rc != HUMID_OK || !ctx) {
+  if (!sharded && (ctx_rc != HUMID_OK || !ctx)) {
     std::fprintf(stderr, "humid: %s\n", ctx_err.c_str());
     return 1;
   }
@@ -396,14 +411,25 @@ int main(int argc, char **argv) {
   t = start_message(log, a.edit ? "Calculating neighbours using Levenshtein distance"     // src/humid.cc:142
                                 : "Calculating neighbours using Hamming distance");
   const uint32_t method = a.maximum ? HUMID_METHOD_MAXIMUM : HUMID_METHOD_DIRECTIONAL;
-  int rc = device_pack
+  ShardedResult shr;
+  int rc;
+  if (sharded) {
+    // the read set in input-order shards, one rank (thread + context + GPU) per shard: sharded.cpp
+    rc = sharded_dedup(run_words, run_filt, N, (uint32_t)a.word_length, a.edit ? (uint32_t)std::min<size_t>(a.distance, 1) : (uint32_t)a.distance,
+                       method, a.gpus, a.stats, cluster_id, keep, shr);
+    sum = shr.sum;
+    if (rc == HUMID_OK && getenv("HUMID_TIMING"))
+      std::fprintf(stderr, "[humid]   %u ranks, bulk data by %s: set-up %.1f ms, ranks %.1f ms\n", a.gpus,
+                   shr.comm.c_str(), shr.ms_init, shr.ms_run);
+  } else
+  rc = device_pack
                ? humid_dedup_run_bases(ctx, bases.data(), N, (uint32_t)a.word_length, (uint32_t)a.distance, method,
                                        cluster_id, keep, &sum)
                : humid_dedup_run(ctx, run_words, run_filt, N, (uint32_t)a.word_length,
                                  (uint32_t)a.distance, method, cluster_id, keep, &sum);
   if (rc != HUMID_OK) {
     log << "failed.\n";
-    std::fprintf(stderr, "humid: %s\n", humid_last_error(ctx));
+    std::fprintf(stderr, "humid: %s\n", sharded ? shr.error.c_str() : humid_last_error(ctx));
     humid_ctx_destroy(ctx);
     return 1;
   }
@@ -589,7 +615,13 @@ int main(int argc, char **argv) {
     t = start_message(log, "Calculating count and neighbour stats");
     const char *names[3] = {"/counts.dat", "/neigh.dat", "/clusters.dat"};
     int ok = 1;
-    for (uint32_t which = 0; which < 3 && ok == 1; which++) ok = write_hist(ctx, which, a.dir_name + names[which]);
+    for (uint32_t which = 0; which < 3 && ok == 1; which++) {
+      if (!sharded) { ok = write_hist(ctx, which, a.dir_name + names[which]); continue; }
+      std::ofstream out(a.dir_name + names[which], std::ios::out | std::ios::binary);   // gathered by the ranks
+      for (auto &kv : shr.hist[which]) out << kv.first << ' ' << kv.second << '\n';
+      out.close();
+      if (out.fail()) ok = -1;
+    }
     end_message(log, t);
     if (ok == 0) { std::fprintf(stderr, "humid: %s\n", humid_last_error(ctx)); humid_ctx_destroy(ctx); return 1; }
     std::ofstream out(a.dir_name + "/stats.dat", std::ios::out | std::ios::binary);

@@ -1,0 +1,49 @@
+// sharded.hpp -- `humid -g N`: the hot path over N GPUs of one node, driven from the C++ host.
+//
+// The reference is a single process on one CPU (/root/reference/src/humid.cc:369-409); this is the
+// multi-GPU form BASELINE.json's north_star asks for ("the host stays C++ ... the read set shards
+// across the GPUs").  The parsed words are cut into N shards in input order, one rank (a host thread
+// with its own humid_ctx, stream and device) per shard; the ranks run the "exchange" orchestration of
+// DESIGN.md section 4a over the stage entry points of include/humid_hip.h (humid_stage_*), the same
+// sequence humid_amd/sharded.py drives from Python:
+//
+//   1. histogram of the top word bits per rank -> balanced, ordered value ranges (host arithmetic)
+//   2. usable words -> owner of their value range            (exchange of 8 B per read)
+//   3. exact counts at the owner (LDS tables)                 (humid_stage_count_dense)
+//   4. neighbour pairs per pigeonhole combination             (exchange of 16 B per unique word and
+//                                                              combination, pairs all-gathered)
+//   5. compact graph over the pairs' endpoints, clustered replicated; ids from prefix counts
+//   6. per-read results back to the home shard                (exchange of 4 B per read)
+//
+// Bulk data moves between the ranks' device buffers with RCCL (grouped ncclSend / ncclRecv over
+// xGMI; librccl is loaded on demand) when every rank has a GPU of its own, and with peer copies
+// (hipMemcpyAsync device to device) otherwise -- which is also how several ranks can share one GPU
+// (tests/test_cli_gpu.py runs 2 and 3 ranks on the one GPU of the test box).  The few host-side
+// numbers (histograms, split sizes) are exchanged through the process's own memory.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../../include/humid_hip.h"
+
+namespace humid_host {
+
+struct ShardedResult {
+  humid_summary sum{};
+  // -s: counts.dat / neigh.dat / clusters.dat as (key, value), ascending keys (src/humid.cc:301-349)
+  std::vector<std::pair<uint64_t, uint64_t>> hist[3];
+  std::string error;
+  std::string comm;          // "rccl" or "copy": what moved the bulk data
+  double ms_init = 0, ms_run = 0;
+};
+
+// words[n_reads] packed (word_nt <= 32), filtered[n_reads]; cluster_id / keep: host outputs.
+// n_ranks 2..16; rank r runs on device r % (visible devices).  want_hist: fill ShardedResult::hist.
+// Returns HUMID_OK or a HUMID_E_* code with ShardedResult::error set.
+int sharded_dedup(const uint64_t *words, const uint8_t *filtered, uint64_t n_reads, uint32_t word_nt,
+                  uint32_t distance, uint32_t method, unsigned n_ranks, bool want_hist, uint32_t *cluster_id,
+                  uint8_t *keep, ShardedResult &out);
+
+}  // namespace humid_host

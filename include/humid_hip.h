@@ -99,7 +99,11 @@ const char *humid_last_error(const humid_ctx *ctx);   /* ctx may be NULL */
  * "tile_partition": 1 (default) = reads reach their count buckets, and results their reads, through
  * the hand-written LDS-staged partition (two coalesced passes each way); 0 = library radix passes
  * in front and one scattered store per read at the end (the round-1 form, also taken by itself for
- * read sets beyond ~180 M / ~67 M reads). */
+ * read sets beyond ~180 M / ~67 M reads).
+ * "bucket_walk": how many following words of its pigeonhole bucket a position is compared with by
+ * its own thread (default 1024); the pairs further apart inside longer buckets are compared as
+ * 1024 x 1024 tiles by whole workgroups.  0 = no bound (every pair by the position's thread, the
+ * round-1 form: quadratic per lane on buckets of 10^5 words).  Results do not depend on it. */
 int  humid_ctx_set_option(humid_ctx *ctx, const char *key, int64_t value);
 /* Optional: one slab of device memory for a run over about n_reads reads, so that the first run does
  * not pay ~35 separate allocations (the `humid` host calls it while pass 1 still parses).  Never

@@ -184,3 +184,73 @@ def test_cli_output_write_errors_are_not_silent(tmp_path):
         # the same command with a writable output succeeds
         os.unlink(str(out / name))
         assert subprocess.call([HUMID, "-d", str(out), "-l", str(tmp_path / "log.txt"), src]) == 0
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+@pytest.mark.parametrize("case", [
+    dict(n_files=2, umi_len=8, umi_in_header=True, word_nt=24, d=1, x=False, n=40_000),
+    dict(n_files=1, umi_len=8, umi_in_header=True, word_nt=24, d=2, x=True, n=12_000),
+    dict(n_files=2, umi_len=0, umi_in_header=False, word_nt=12, d=1, x=False, n=9_000),
+])
+def test_cli_sharded_over_ranks_writes_the_single_gpu_files(case, ranks, tmp_path):
+    """`humid -g N` (csrc/host/sharded.cpp: the exchange orchestration driven from the C++ host, one
+    rank per shard of the reads in input order).  The test box has ONE GPU, so the ranks share it and
+    exchange through peer copies (HUMID_COMM=copy is what -g picks by itself then); every output file --
+    deduplicated and annotated FastQ, the three histograms, stats.dat -- must be byte-identical to the
+    single-GPU run's, and the single-GPU run is checked against the oracle."""
+    case = dict(case)
+    word_nt, d, x, n = case.pop("word_nt"), case.pop("d"), case.pop("x"), case.pop("n")
+    files = synth_fastq(str(tmp_path / "in"), n, 77, p_sub=4e-3, p_n=2e-3, read_len=36, short_frac=0.01, **case)
+    outs = {}
+    for g in (1, ranks):
+        out = str(tmp_path / ("out%d" % g))
+        cmd = [HUMID, "-n", str(word_nt), "-m", str(d), "-d", out, "-l", str(tmp_path / ("log%d.txt" % g)),
+               "-s", "-a", "-g", str(g)]
+        if x:
+            cmd.append("-x")
+        r = subprocess.run(cmd + files, capture_output=True, text=True, env=dict(os.environ, HUMID_TIMING="1"))
+        assert r.returncode == 0, r.stderr
+        if g > 1:
+            assert "%d ranks, bulk data by copy" % g in r.stderr
+        outs[g] = {f: open(os.path.join(out, f), "rb").read() for f in sorted(os.listdir(out))}
+    assert sorted(outs[1]) == sorted(outs[ranks]) and len(outs[1]) == 2 * len(files) + 4
+    for f in outs[1]:
+        assert outs[1][f] == outs[ranks][f], f
+    words, filt, recs, _ = expected_words(files, word_nt)
+    p, cid, keep = run_oracle(words, filt, word_nt, d, x)
+    base = os.path.basename(files[0])
+    annot = read_fastq(os.path.join(str(tmp_path / ("out%d" % ranks)), base.replace(".fastq", "_annotated.fastq")))
+    assert annot == [(recs[0][i][0] + ":%d" % cid[i],) + recs[0][i][1:] for i in range(n)]
+
+
+def test_cli_sharded_rccl_transport_with_one_rank(tmp_path):
+    """the RCCL transport of `-g` (grouped ncclSend/ncclRecv on the context's stream, librccl loaded on
+    demand) needs a GPU per rank.  The test box has one, so the transport runs here with ONE rank
+    (HUMID_FORCE_SHARDED=1: the rank orchestration instead of the single-GPU call; every exchange is a
+    send to and a receive from rank 0 itself) and must write the single-GPU files; two ranks on one GPU
+    are refused.  More ranks over RCCL run on the multi-GPU node only."""
+    files = synth_fastq(str(tmp_path / "in"), 20_000, 5, n_files=2, umi_len=8, umi_in_header=True, read_len=36,
+                        p_sub=4e-3, p_n=2e-3)
+    outs = {}
+    for tag, env in (("plain", {}), ("rccl", dict(HUMID_FORCE_SHARDED="1", HUMID_COMM="rccl", HUMID_TIMING="1"))):
+        out = str(tmp_path / tag)
+        r = subprocess.run([HUMID, "-d", out, "-l", "/dev/null", "-s", "-a"] + files, capture_output=True, text=True,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        if tag == "rccl":
+            assert "1 ranks, bulk data by rccl" in r.stderr, r.stderr
+        outs[tag] = {f: open(os.path.join(out, f), "rb").read() for f in sorted(os.listdir(out))}
+    assert outs["plain"] == outs["rccl"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([HUMID, "-g", "2", "-d", str(tmp_path / "o"), "-l", "/dev/null"] + files, capture_output=True,
+                           text=True, env=dict(os.environ, HUMID_COMM="rccl"))
+        assert r.returncode == 1 and "one GPU per rank" in r.stderr
+
+
+def test_cli_sharded_refuses_what_needs_one_gpu(tmp_path):
+    files = synth_fastq(str(tmp_path / "in"), 200, 5, n_files=1, read_len=30)
+    for extra in (["-n", "40"], ["-e", "-m", "2"], ["-g", "17"]):
+        r = subprocess.run([HUMID, "-g", "2", "-d", str(tmp_path / "o"), "-l", "/dev/null"] + extra + files,
+                           capture_output=True, text=True)
+        assert r.returncode == 2, (extra, r.stderr)
