@@ -28,6 +28,7 @@
 #include "fastq_io.hpp"
 #include "fastq_mmap.hpp"
 #include <iterator>
+#include <memory>
 #include <thread>
 
 #include "fast_inflate.hpp"
@@ -227,6 +228,9 @@ int main(int argc, char **argv) {
   std::atomic<long long> n_known{-1};                   // -1: not yet; 0: no slab wanted
   uint8_t *pinned = nullptr;                            // written by the init thread, read after its join
   uint64_t pin_bytes = 0;
+  // -g: the ranks (threads with a context, a stream and a communicator each) come up the same way
+  std::unique_ptr<ShardedSession> ranks;
+  if (a.dump_words.empty() && sharded) ranks.reset(new ShardedSession(a.gpus));
   if (a.dump_words.empty() && !sharded)
     ctx_init.th = std::thread([&] {
       const auto ti = std::chrono::steady_clock::now();
@@ -415,8 +419,8 @@ int main(int argc, char **argv) {
   int rc;
   if (sharded) {
     // the read set in input-order shards, one rank (thread + context + GPU) per shard: sharded.cpp
-    rc = sharded_dedup(run_words, run_filt, N, (uint32_t)a.word_length, a.edit ? (uint32_t)std::min<size_t>(a.distance, 1) : (uint32_t)a.distance,
-                       method, a.gpus, a.stats, cluster_id, keep, shr);
+    rc = ranks->run(run_words, run_filt, N, (uint32_t)a.word_length, a.edit ? (uint32_t)std::min<size_t>(a.distance, 1) : (uint32_t)a.distance,
+                    method, a.stats, cluster_id, keep, shr);
     sum = shr.sum;
     if (rc == HUMID_OK && getenv("HUMID_TIMING"))
       std::fprintf(stderr, "[humid]   %u ranks, bulk data by %s: set-up %.1f ms, ranks %.1f ms\n", a.gpus,

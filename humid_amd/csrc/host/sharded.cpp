@@ -73,6 +73,20 @@ struct Group {
   std::vector<Pub> pub;
   // -s histograms, merged under mu
   std::map<uint64_t, uint64_t> hist_counts, hist_neigh;
+  // the ranks come up (context, stream, communicator) while the host still parses; then they wait here
+  int job_state = 0;                       // 0: not yet, 1: go, 2: there will be none
+  struct Job *job = nullptr;
+  bool wait_for_job() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return job_state != 0 || failed.load(); });
+    return job_state == 1 && !failed.load();
+  }
+  void post_job(struct Job *j) {
+    std::lock_guard<std::mutex> lk(mu);
+    job = j;
+    job_state = j ? 1 : 2;
+    cv.notify_all();
+  }
 
   void fail(int code, const std::string &text) {
     std::lock_guard<std::mutex> lk(mu);
@@ -265,7 +279,7 @@ struct Job {
 
 #define STEP(expr) do { if (!(expr)) return false; } while (0)
 
-bool run_rank(Rank &k, Job &job) {
+bool run_rank(Rank &k) {
   Group &g = k.g;
   const unsigned P = g.P, r = k.r;
   STEP(k.hip_ok(hipSetDevice(g.device[r]), "hipSetDevice"));
@@ -279,6 +293,8 @@ bool run_rank(Rank &k, Job &job) {
     STEP(k.together());                                           // rank 0 made the id before the threads started
     STEP(k.nccl_ok(g.rccl.CommInitRank(&k.comm, (int)P, g.nccl_id, (int)r), "ncclCommInitRank"));
   }
+  if (!g.wait_for_job()) return g.job_state == 2 && !g.failed.load();       // no job: a clean end
+  Job &job = *g.job;
   hipStream_t st = k.st;
   const uint32_t n = job.word_nt, d = job.distance;
   const uint64_t r0 = job.n_reads * r / P, r1 = job.n_reads * (r + 1) / P, n_local = r1 - r0;
@@ -487,60 +503,87 @@ bool run_rank(Rank &k, Job &job) {
 
 }  // namespace
 
-int sharded_dedup(const uint64_t *words, const uint8_t *filtered, uint64_t n_reads, uint32_t word_nt,
-                  uint32_t distance, uint32_t method, unsigned n_ranks, bool want_hist, uint32_t *cluster_id,
-                  uint8_t *keep, ShardedResult &out) {
-  const auto t0 = std::chrono::steady_clock::now();
-  auto ms_since = [&](std::chrono::steady_clock::time_point t) {
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
-  };
-  if (n_ranks < 1 || n_ranks > MAX_RANKS) { out.error = "-g takes 1 .. 16 ranks"; return HUMID_E_INVALID; }
-  if (word_nt == 0 || word_nt > 32) { out.error = "-g: words longer than 32 nt run on one GPU only"; return HUMID_E_UNSUPPORTED; }
-  if (n_reads >= 0x7fffffffull * n_ranks) { out.error = "-g: more than 2^31-1 reads per rank"; return HUMID_E_OVERFLOW; }
-  int n_dev = 0;
-  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) { out.error = "no HIP device"; return HUMID_E_HIP; }
+struct ShardedSession::Impl {
   Group g;
+  std::vector<std::thread> threads;
+  std::thread starter;
+  std::string early_error;
+  int early_code = HUMID_OK;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double ms_init = 0;
+  std::atomic<unsigned> ready{0};
+};
+
+static double ms_since(std::chrono::steady_clock::time_point t) {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+}
+
+ShardedSession::ShardedSession(unsigned n_ranks) : p_(new Impl) {
+  Impl &m = *p_;
+  Group &g = m.g;
   g.P = n_ranks;
+  if (n_ranks < 1 || n_ranks > MAX_RANKS) { m.early_error = "-g takes 1 .. 16 ranks"; m.early_code = HUMID_E_INVALID; return; }
   g.device.resize(n_ranks);
-  for (unsigned r = 0; r < n_ranks; r++) g.device[r] = (int)(r % (unsigned)n_dev);
   g.slot.resize(n_ranks);
   g.pub.resize(n_ranks);
-  // RCCL needs a GPU per rank; HUMID_COMM=copy|rccl overrides the choice
-  const char *want = getenv("HUMID_COMM");
-  const bool distinct = n_ranks <= (unsigned)n_dev;
-  g.use_rccl = want ? std::strcmp(want, "rccl") == 0 : distinct;
-  if (g.use_rccl && !distinct) { out.error = "HUMID_COMM=rccl needs one GPU per rank"; return HUMID_E_INVALID; }
-  if (g.use_rccl) {
-    if (!g.rccl.load()) {
-      std::fprintf(stderr, "humid: librccl.so not usable (%s): ranks exchange through peer copies\n", dlerror());
-      g.use_rccl = false;
-    } else if (g.rccl.GetUniqueId(&g.nccl_id) != ncclSuccess) {
-      std::fprintf(stderr, "humid: ncclGetUniqueId failed: ranks exchange through peer copies\n");
-      g.use_rccl = false;
-    }
-  }
-  if (!g.use_rccl)                                   // peer copies: let the devices see each other's memory
-    for (int a = 0; a < n_dev && a < (int)n_ranks; a++)
-      for (int b = 0; b < n_dev && b < (int)n_ranks; b++)
-        if (a != b && hipSetDevice(a) == hipSuccess) (void)hipDeviceEnablePeerAccess(b, 0);
-  (void)hipGetLastError();
-  out.comm = g.use_rccl ? "rccl" : "copy";
-
-  Job job{words, filtered, n_reads, word_nt, distance, method, want_hist, cluster_id, keep, {}};
-  std::vector<std::thread> threads;
-  std::vector<int> codes(n_ranks, HUMID_OK);
-  out.ms_init = ms_since(t0);
-  const auto t1 = std::chrono::steady_clock::now();
-  for (unsigned r = 0; r < n_ranks; r++)
-    threads.emplace_back([&, r] {
-      Rank k(g, r);
-      if (!run_rank(k, job)) {
-        codes[r] = k.code != HUMID_OK ? k.code : HUMID_E_HIP;
-        g.fail(codes[r], "rank " + std::to_string(r) + ": " + k.err);
+  // everything that touches the HIP runtime happens on the starter thread: the caller goes on parsing
+  m.starter = std::thread([&m, n_ranks] {
+    Group &g = m.g;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) { g.fail(HUMID_E_HIP, "no HIP device"); return; }
+    for (unsigned r = 0; r < n_ranks; r++) g.device[r] = (int)(r % (unsigned)n_dev);
+    // RCCL needs a GPU per rank; HUMID_COMM=copy|rccl overrides the choice
+    const char *want = getenv("HUMID_COMM");
+    const bool distinct = n_ranks <= (unsigned)n_dev;
+    g.use_rccl = want ? std::strcmp(want, "rccl") == 0 : distinct;
+    if (g.use_rccl && !distinct) { g.fail(HUMID_E_INVALID, "HUMID_COMM=rccl needs one GPU per rank"); return; }
+    if (g.use_rccl) {
+      if (!g.rccl.load()) {
+        std::fprintf(stderr, "humid: librccl.so not usable (%s): ranks exchange through peer copies\n", dlerror());
+        g.use_rccl = false;
+      } else if (g.rccl.GetUniqueId(&g.nccl_id) != ncclSuccess) {
+        std::fprintf(stderr, "humid: ncclGetUniqueId failed: ranks exchange through peer copies\n");
+        g.use_rccl = false;
       }
-    });
-  for (auto &t : threads) t.join();
+    }
+    if (!g.use_rccl)                                   // peer copies: let the devices see each other's memory
+      for (int a = 0; a < n_dev && a < (int)n_ranks; a++)
+        for (int b = 0; b < n_dev && b < (int)n_ranks; b++)
+          if (a != b && hipSetDevice(a) == hipSuccess) (void)hipDeviceEnablePeerAccess(b, 0);
+    (void)hipGetLastError();
+    m.ms_init = ms_since(m.t0);
+    for (unsigned r = 0; r < n_ranks; r++)
+      m.threads.emplace_back([&m, r] {
+        Group &g = m.g;
+        Rank k(g, r);
+        if (!run_rank(k)) g.fail(k.code != HUMID_OK ? k.code : HUMID_E_HIP, "rank " + std::to_string(r) + ": " + k.err);
+      });
+  });
+}
+
+ShardedSession::~ShardedSession() {
+  if (p_->starter.joinable()) p_->starter.join();
+  p_->g.post_job(nullptr);                             // ranks still waiting for a job leave
+  for (auto &t : p_->threads) if (t.joinable()) t.join();
+  delete p_;
+}
+
+int ShardedSession::run(const uint64_t *words, const uint8_t *filtered, uint64_t n_reads, uint32_t word_nt,
+                        uint32_t distance, uint32_t method, bool want_hist, uint32_t *cluster_id, uint8_t *keep,
+                        ShardedResult &out) {
+  Impl &m = *p_;
+  Group &g = m.g;
+  if (m.early_code != HUMID_OK) { out.error = m.early_error; return m.early_code; }
+  if (word_nt == 0 || word_nt > 32) { out.error = "-g: words longer than 32 nt run on one GPU only"; return HUMID_E_UNSUPPORTED; }
+  if (n_reads >= 0x7fffffffull * g.P) { out.error = "-g: more than 2^31-1 reads per rank"; return HUMID_E_OVERFLOW; }
+  if (m.starter.joinable()) m.starter.join();
+  out.ms_init = m.ms_init;
+  Job job{words, filtered, n_reads, word_nt, distance, method, want_hist, cluster_id, keep, {}};
+  const auto t1 = std::chrono::steady_clock::now();
+  g.post_job(&job);
+  for (auto &t : m.threads) t.join();
   out.ms_run = ms_since(t1);
+  out.comm = g.use_rccl ? "rccl" : "copy";
   if (g.failed.load()) {
     out.error = g.fail_text;
     return g.fail_code != HUMID_OK ? g.fail_code : HUMID_E_HIP;
@@ -553,9 +596,9 @@ int sharded_dedup(const uint64_t *words, const uint8_t *filtered, uint64_t n_rea
     std::vector<uint32_t> size(out.sum.clusters + 1, 0);
     for (uint64_t i = 0; i < n_reads; i++)
       if (!filtered[i] && cluster_id[i] <= out.sum.clusters) size[cluster_id[i]]++;
-    std::map<uint64_t, uint64_t> m;
-    for (uint64_t c = 1; c <= out.sum.clusters; c++) m[size[c]]++;
-    out.hist[2].assign(m.begin(), m.end());
+    std::map<uint64_t, uint64_t> hm;
+    for (uint64_t c = 1; c <= out.sum.clusters; c++) hm[size[c]]++;
+    out.hist[2].assign(hm.begin(), hm.end());
   }
   return HUMID_OK;
 }

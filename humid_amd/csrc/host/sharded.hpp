@@ -39,11 +39,26 @@ struct ShardedResult {
   double ms_init = 0, ms_run = 0;
 };
 
-// words[n_reads] packed (word_nt <= 32), filtered[n_reads]; cluster_id / keep: host outputs.
-// n_ranks 2..16; rank r runs on device r % (visible devices).  want_hist: fill ShardedResult::hist.
-// Returns HUMID_OK or a HUMID_E_* code with ShardedResult::error set.
-int sharded_dedup(const uint64_t *words, const uint8_t *filtered, uint64_t n_reads, uint32_t word_nt,
-                  uint32_t distance, uint32_t method, unsigned n_ranks, bool want_hist, uint32_t *cluster_id,
-                  uint8_t *keep, ShardedResult &out);
+// One multi-rank run.  The constructor returns at once: a starter thread brings up the HIP runtime,
+// picks the transport and starts one thread per rank (rank r on device r % visible devices), each of
+// which creates its context, stream and communicator and then waits -- so all of that (RCCL's
+// communicator set-up alone takes a second on 8 GPUs) overlaps the host's first pass over the FastQ
+// files.  run() hands the parsed words over and returns when every rank is done.
+class ShardedSession {
+ public:
+  explicit ShardedSession(unsigned n_ranks);          // 1 .. 16
+  ~ShardedSession();                                  // ranks that never got a job leave quietly
+  ShardedSession(const ShardedSession &) = delete;
+  ShardedSession &operator=(const ShardedSession &) = delete;
+  // words[n_reads] packed (word_nt <= 32), filtered[n_reads]; cluster_id / keep: host outputs.
+  // want_hist: fill ShardedResult::hist.  Returns HUMID_OK or a HUMID_E_* code with
+  // ShardedResult::error set.  Once per session.
+  int run(const uint64_t *words, const uint8_t *filtered, uint64_t n_reads, uint32_t word_nt, uint32_t distance,
+          uint32_t method, bool want_hist, uint32_t *cluster_id, uint8_t *keep, ShardedResult &out);
+
+ private:
+  struct Impl;
+  Impl *p_;
+};
 
 }  // namespace humid_host
