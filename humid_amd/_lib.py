@@ -29,6 +29,21 @@ class HumidSummary(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+HOST_ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, u64p, u64p, C.c_void_p, u64p, u64p, C.c_int, C.c_void_p)
+
+
+class HumidComm(C.Structure):
+    """humid_comm of include/humid_hip.h: what moves bytes between ranks for humid_dedup_run_exchange"""
+    _fields_ = [("user", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32),
+                ("host_all_gather", HOST_ALL_GATHER_FN), ("exchange", EXCHANGE_FN)]
+
+
+class HumidExchangeInfo(C.Structure):
+    _fields_ = [("unique_local", C.c_uint64), ("id_base", C.c_uint64), ("n_nodes", C.c_uint64),
+                ("n_pairs", C.c_uint64), ("d_unique_count", C.c_void_p), ("d_compact_edges", C.c_void_p)]
+
+
 # every symbol include/humid_hip.h declares: (restype, argtypes)
 SYMBOLS = {
     "humid_abi_version": (C.c_uint32, []),
@@ -105,6 +120,9 @@ SYMBOLS = {
                                          C.c_uint32, C.POINTER(C.c_void_p), u64p]),
     "humid_stage_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                       C.c_void_p, C.c_void_p]),
+    "humid_dedup_run_exchange": (C.c_int, [C.c_void_p, C.POINTER(HumidComm), C.c_void_p, C.c_void_p, C.c_uint64,
+                                           C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                           C.POINTER(HumidSummary), C.POINTER(HumidExchangeInfo)]),
     "humid_at_least_double": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_int)]),
 }
 

@@ -119,48 +119,6 @@ struct DevBuf {                            // device memory of one rank, grown o
   template <class T> T *as() const { return (T *)p; }
 };
 
-struct Range { uint64_t lo = 1, hi = 0, expected = 0; };   // lo > hi: empty
-
-// P ordered, disjoint, covering value ranges with balanced usable-read counts, cut at histogram bins
-// (humid_amd/sharded.py splitters_from_hist; identical on every rank)
-std::vector<Range> splitters_from_hist(const std::vector<uint64_t> &hist, unsigned P, unsigned word_nt, unsigned bits) {
-  const unsigned shift = 2 * word_nt - bits;
-  const size_t n_bins = hist.size();
-  std::vector<uint64_t> cum(n_bins);
-  uint64_t total = 0;
-  for (size_t i = 0; i < n_bins; i++) { total += hist[i]; cum[i] = total; }
-  std::vector<size_t> bounds{0};
-  for (unsigned k = 1; k < P; k++) {
-    const uint64_t target = (total * k + P - 1) / P;
-    size_t b = (size_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin()) + 1;
-    b = std::min(std::max(b, bounds.back()), n_bins);
-    bounds.push_back(b);
-  }
-  bounds.push_back(n_bins);
-  std::vector<Range> out(P);
-  for (unsigned r = 0; r < P; r++) {
-    const size_t b0 = bounds[r], b1 = bounds[r + 1];
-    if (b1 <= b0) continue;
-    out[r].lo = (uint64_t)b0 << shift;
-    out[r].hi = (r == P - 1 || ((uint64_t)b1 << shift) == 0) ? ~0ull : ((uint64_t)b1 << shift) - 1;
-    out[r].expected = cum[b1 - 1] - (b0 ? cum[b0 - 1] : 0);
-  }
-  return out;
-}
-
-// count_order for humid_stage_count_dense from the global histogram (sharded.py _order_hint)
-int order_hint(const std::vector<uint64_t> &hist, const Range &rg, unsigned word_nt, unsigned bits) {
-  if (rg.lo > rg.hi) return -1;
-  const unsigned shift = 2 * word_nt - bits;
-  const size_t b0 = (size_t)(rg.lo >> shift), b1 = std::min<size_t>((size_t)(rg.hi >> shift), hist.size() - 1);
-  if (b1 + 1 - b0 < 4) return -1;
-  double sum = 0, mx = 0;
-  for (size_t b = b0; b <= b1; b++) { sum += (double)hist[b]; mx = std::max(mx, (double)hist[b]); }
-  if (sum < 65536) return -1;
-  const double ratio = mx / (sum / (double)(b1 + 1 - b0));
-  return ratio <= 1.25 ? 1 : (ratio > 2.5 ? 0 : -1);
-}
-
 struct Rank {
   Group &g;
   const unsigned r;
@@ -201,13 +159,11 @@ struct Rank {
     return false;
   }
 
-  // host numbers of all ranks: every rank publishes n values, gets the P x n table
-  template <class T>
-  bool host_all_gather(const T *mine, size_t n, std::vector<T> &all) {
-    g.slot[r].assign((const uint8_t *)mine, (const uint8_t *)mine + n * sizeof(T));
+  // host numbers of all ranks: every rank publishes `bytes` bytes, gets the P x bytes table
+  bool host_all_gather_bytes(const void *mine, uint64_t bytes, void *all) {
+    g.slot[r].assign((const uint8_t *)mine, (const uint8_t *)mine + bytes);
     if (!together()) return false;
-    all.resize((size_t)g.P * n);
-    for (unsigned q = 0; q < g.P; q++) std::memcpy(all.data() + (size_t)q * n, g.slot[q].data(), n * sizeof(T));
+    for (unsigned q = 0; q < g.P; q++) std::memcpy((uint8_t *)all + (size_t)q * bytes, g.slot[q].data(), bytes);
     return together();                    // nobody overwrites its slot before all have read it
   }
 
@@ -246,24 +202,6 @@ struct Rank {
     if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize (exchange)")) return false;
     return together();                    // the senders may reuse their buffers
   }
-  // all-to-all of `elem`-byte items with split sizes in items
-  bool all_to_all(const void *send, const std::vector<uint64_t> &send_items, void *recv,
-                  const std::vector<uint64_t> &recv_items, size_t elem) {
-    std::vector<uint64_t> so(g.P), sc(g.P), ro(g.P), rc(g.P);
-    uint64_t a = 0, b = 0;
-    for (unsigned q = 0; q < g.P; q++) {
-      so[q] = a; sc[q] = send_items[q] * elem; a += sc[q];
-      ro[q] = b; rc[q] = recv_items[q] * elem; b += rc[q];
-    }
-    return exchange(send, so, sc, recv, ro, rc);
-  }
-  // all-gather of n_all[r] items per rank into rank order
-  bool all_gather_v(const void *send, const std::vector<uint64_t> &n_all, void *recv, size_t elem) {
-    std::vector<uint64_t> so(g.P, 0), sc(g.P, n_all[r] * elem), ro(g.P), rc(g.P);
-    uint64_t b = 0;
-    for (unsigned q = 0; q < g.P; q++) { ro[q] = b; rc[q] = n_all[q] * elem; b += rc[q]; }
-    return exchange(send, so, sc, recv, ro, rc);
-  }
 };
 
 struct Job {
@@ -296,11 +234,10 @@ bool run_rank(Rank &k) {
   if (!g.wait_for_job()) return g.job_state == 2 && !g.failed.load();       // no job: a clean end
   Job &job = *g.job;
   hipStream_t st = k.st;
-  const uint32_t n = job.word_nt, d = job.distance;
   const uint64_t r0 = job.n_reads * r / P, r1 = job.n_reads * (r + 1) / P, n_local = r1 - r0;
 
   // this rank's shard of the reads, in input order
-  DevBuf d_w, d_f, d_cid, d_keep, d_hist, recv_w, e_loc, got, e_all, ret;
+  DevBuf d_w, d_f, d_cid, d_keep;
   STEP(k.hip_ok(d_w.ensure(n_local * 8 + 8), "hipMalloc"));
   STEP(k.hip_ok(d_f.ensure(n_local + 8), "hipMalloc"));
   STEP(k.hip_ok(d_cid.ensure(n_local * 4 + 8), "hipMalloc"));
@@ -309,195 +246,60 @@ bool run_rank(Rank &k) {
     STEP(k.hip_ok(hipMemcpyAsync(d_w.p, job.words + r0, n_local * 8, hipMemcpyHostToDevice, st), "hipMemcpyAsync (words)"));
     STEP(k.hip_ok(hipMemcpyAsync(d_f.p, job.filtered + r0, n_local, hipMemcpyHostToDevice, st), "hipMemcpyAsync (flags)"));
   }
-
-  // ---- 1. histograms of all ranks -> value ranges and every split size of the word exchange ----
-  uint32_t n_combos1 = 0, pbits = 0;
-  STEP(k.lib_ok(humid_stage_plan_info(k.ctx, n, d, 1, &n_combos1, &pbits)));
-  if (pbits < 1) {
-    k.code = HUMID_E_UNSUPPORTED;
-    k.err = "-g: a distance this close to the word length leaves no prefix to cut value ranges at; use one GPU";
+  // the pass itself is the library's (humid_dedup_run_exchange); this file moves the bytes
+  humid_comm cm;
+  cm.user = &k;
+  cm.rank = r;
+  cm.world = P;
+  cm.host_all_gather = [](void *user, const void *mine, uint64_t bytes, void *all) -> int {
+    return ((Rank *)user)->host_all_gather_bytes(mine, bytes, all) ? 0 : -1;
+  };
+  cm.exchange = [](void *user, const void *d_send, const uint64_t *so, const uint64_t *sb, void *d_recv,
+                   const uint64_t *ro, const uint64_t *rb, int, void *) -> int {
+    Rank &k = *(Rank *)user;
+    const unsigned P = k.g.P;
+    return k.exchange(d_send, std::vector<uint64_t>(so, so + P), std::vector<uint64_t>(sb, sb + P), d_recv,
+                      std::vector<uint64_t>(ro, ro + P), std::vector<uint64_t>(rb, rb + P)) ? 0 : -1;
+  };
+  humid_summary sum;
+  humid_exchange_info info;
+  std::memset(&sum, 0, sizeof sum);
+  std::memset(&info, 0, sizeof info);
+  const int rc = humid_dedup_run_exchange(k.ctx, &cm, d_w.as<uint64_t>(), d_f.as<uint8_t>(), n_local, job.word_nt, job.distance,
+                                          job.method, d_cid.as<uint32_t>(), d_keep.as<uint8_t>(), &sum, &info);
+  if (rc != HUMID_OK) {
+    if (k.code == HUMID_OK) { k.code = rc; k.err = humid_last_error(k.ctx); }           // (a transport error keeps its own text)
     return false;
   }
-  const unsigned bits = std::min<unsigned>(std::min<unsigned>(HIST_BITS, 2 * n), pbits);
-  const size_t n_bins = (size_t)1 << bits;
-  STEP(k.hip_ok(d_hist.ensure(n_bins * 4), "hipMalloc"));
-  STEP(k.hip_ok(hipMemsetAsync(d_hist.p, 0, n_bins * 4, st), "hipMemsetAsync"));
-  STEP(k.lib_ok(humid_stage_histogram(k.ctx, d_w.as<uint64_t>(), d_f.as<uint8_t>(), n_local, n, bits, d_hist.as<uint32_t>())));
-  std::vector<uint32_t> h_hist(n_bins), all_hist;
-  STEP(k.hip_ok(hipMemcpyAsync(h_hist.data(), d_hist.p, n_bins * 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync (histogram)"));
-  STEP(k.hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"));
-  STEP(k.host_all_gather(h_hist.data(), n_bins, all_hist));
-  std::vector<uint64_t> hist_sum(n_bins, 0);
-  std::vector<std::vector<uint64_t>> cum(P, std::vector<uint64_t>(n_bins + 1, 0));     // per rank, cumulative
-  for (unsigned q = 0; q < P; q++)
-    for (size_t b = 0; b < n_bins; b++) {
-      const uint64_t v = all_hist[(size_t)q * n_bins + b];
-      hist_sum[b] += v;
-      cum[q][b + 1] = cum[q][b] + v;
-    }
-  const std::vector<Range> ranges = splitters_from_hist(hist_sum, P, n, bits);
-  const unsigned shift = 2 * n - bits;
-  auto in_range = [&](unsigned src, unsigned owner) -> uint64_t {      // usable reads of rank src in owner's range
-    const Range &rg = ranges[owner];
-    if (rg.lo > rg.hi) return 0;
-    const size_t b0 = (size_t)(rg.lo >> shift), b1 = std::min<size_t>((size_t)(rg.hi >> shift), n_bins - 1) + 1;
-    return cum[src][b1] - cum[src][b0];
-  };
-  std::vector<uint64_t> send_counts(P), recv_counts(P), lo(P), hi(P);
-  uint64_t n_send = 0, n_recv = 0;
-  for (unsigned q = 0; q < P; q++) {
-    send_counts[q] = in_range(r, q);
-    recv_counts[q] = in_range(q, r);
-    n_send += send_counts[q];
-    n_recv += recv_counts[q];
-    lo[q] = ranges[q].lo;
-    hi[q] = ranges[q].hi;
-  }
-  uint64_t lo_r = ranges[r].lo, hi_r = ranges[r].hi;
-  if (lo_r > hi_r) { lo_r = 0; hi_r = ~0ull; }                                           // empty range: nothing arrives
-  STEP(k.lib_ok(humid_ctx_set_option(k.ctx, "count_order", order_hint(hist_sum, ranges[r], n, bits))));
-  STEP(k.lib_ok(humid_ctx_set_option(k.ctx, "count_mode", 0)));
-
-  // ---- 2. usable words -> owner of their range (stable: input order inside every block) ----
-  const uint64_t *d_routed = nullptr;
-  const uint32_t *d_perm = nullptr;
-  STEP(k.lib_ok(humid_stage_route(k.ctx, d_w.as<uint64_t>(), d_f.as<uint8_t>(), n_local, lo.data(), hi.data(), P,
-                                  send_counts.data(), &d_routed, &d_perm)));
-  STEP(k.hip_ok(recv_w.ensure(n_recv * 8 + 8), "hipMalloc"));
-  STEP(k.all_to_all(d_routed, send_counts, recv_w.p, recv_counts, 8));
-  STEP(k.lib_ok(humid_stage_route_check(k.ctx)));
-
-  // ---- 3. exact counts of the received words (all usable, all in this rank's range) ----
-  const uint64_t shard_begin[2] = {0, n_recv};
-  uint64_t cnt_one = 0, u_local = 0, usable_local = 0;
-  STEP(k.lib_ok(humid_stage_count_dense(k.ctx, recv_w.as<uint64_t>(), nullptr, n_recv, n, lo_r, hi_r, shard_begin, 1,
-                                        &cnt_one, &u_local, &usable_local)));
-  const uint64_t meta[3] = {u_local, usable_local, n_local};
-  std::vector<uint64_t> metas;
-  STEP(k.host_all_gather(meta, 3, metas));
-  uint64_t u_total = 0, goff = 0, usable = 0, total = 0;
-  for (unsigned q = 0; q < P; q++) {
-    if (q < r) goff += metas[3 * q];
-    u_total += metas[3 * q];
-    usable += metas[3 * q + 1];
-    total += metas[3 * q + 2];
-  }
-  if (u_total >= 0xffffffffull) { k.code = HUMID_E_OVERFLOW; k.err = "more than 2^32-2 unique words in total"; return false; }
-  const uint64_t *lw = nullptr;
-  const uint32_t *lc = nullptr, *lfirst = nullptr;
-  if (u_local) STEP(k.lib_ok(humid_stage_unique(k.ctx, &lw, &lc, &lfirst)));
-  if (job.want_hist && u_local) {                                                       // counts.dat: leaf -> count
-    std::vector<uint32_t> h(u_local);
-    STEP(k.hip_ok(hipMemcpy(h.data(), lc, u_local * 4, hipMemcpyDeviceToHost), "hipMemcpy (counts)"));
-    std::map<uint64_t, uint64_t> m;
-    for (uint32_t v : h) m[v]++;
-    std::lock_guard<std::mutex> lk(g.mu);
-    for (auto &kv : m) g.hist_counts[kv.first] += kv.second;
-  }
-
-  // ---- 4. neighbour pairs in global unique indices, each with the counts of its endpoints ----
-  uint64_t e_mine = 0;                                                                  // 16-byte records in e_loc
-  auto append_pairs = [&](const uint64_t *rec, uint64_t n_rec) -> bool {
-    if (!n_rec) return true;
-    if ((e_mine + n_rec) * 16 > e_loc.cap) {                                            // grow, keeping what is there
-      DevBuf bigger;
-      STEP(k.hip_ok(bigger.ensure((e_mine + n_rec) * 32), "hipMalloc"));
-      if (e_mine) STEP(k.hip_ok(hipMemcpyAsync(bigger.p, e_loc.p, e_mine * 16, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync"));
-      STEP(k.hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"));
-      std::swap(bigger.p, e_loc.p);
-      std::swap(bigger.cap, e_loc.cap);
-    }
-    STEP(k.hip_ok(hipMemcpyAsync(e_loc.as<uint8_t>() + e_mine * 16, rec, n_rec * 16, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync"));
-    STEP(k.hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"));                     // rec is a view the next call overwrites
-    e_mine += n_rec;
-    return true;
-  };
-  if (d > 0 && u_total > 1) {
-    uint32_t n_combos = 0, pb2 = 0;
-    STEP(k.lib_ok(humid_stage_plan_info(k.ctx, n, d, u_total, &n_combos, &pb2)));
-    const uint64_t *rec = nullptr;
-    uint64_t n_rec = 0;
-    if (u_local > 1) {
-      STEP(k.lib_ok(humid_stage_pairs_keyed(k.ctx, lw, u_local, 0, goff, lc, n, d, u_total, 0, &rec, &n_rec)));
-      STEP(append_pairs(rec, n_rec));
-    }
-    for (uint32_t cb = 1; cb < n_combos; cb++) {
-      const uint64_t *items = nullptr;
-      std::vector<uint64_t> sc(P, 0), all_sc, rc(P);
-      STEP(k.lib_ok(humid_stage_combo_route(k.ctx, lw, lc, u_local, goff, n, d, u_total, cb, P, &items, sc.data())));
-      STEP(k.host_all_gather(sc.data(), P, all_sc));
-      uint64_t n_got = 0;
-      for (unsigned q = 0; q < P; q++) { rc[q] = all_sc[(size_t)q * P + r]; n_got += rc[q]; }
-      STEP(k.hip_ok(got.ensure(n_got * 16 + 16), "hipMalloc"));
-      STEP(k.all_to_all(items, sc, got.p, rc, 16));
-      if (n_got > 1) {
-        STEP(k.lib_ok(humid_stage_pairs_keyed(k.ctx, got.as<uint64_t>(), n_got, 1, 0, nullptr, n, d, u_total, cb, &rec, &n_rec)));
-        STEP(append_pairs(rec, n_rec));
-      }
-    }
-  }
-  std::vector<uint64_t> e_counts;
-  STEP(k.host_all_gather(&e_mine, 1, e_counts));
-  uint64_t E = 0;
-  for (uint64_t v : e_counts) E += v;
-  STEP(k.hip_ok(e_all.ensure(E * 16 + 16), "hipMalloc"));
-  STEP(k.hip_ok(e_loc.ensure(16), "hipMalloc"));
-  STEP(k.all_gather_v(e_loc.p, e_counts, e_all.p, 16));
-
-  // ---- 5. compact graph over the pairs' endpoints (replicated); ids by closed-form prefix counts ----
-  const uint32_t *nodes = nullptr, *node_cnt = nullptr, *ccid = nullptr;
-  const uint64_t *cedges = nullptr;
-  const uint8_t *cismax = nullptr;
-  uint64_t M = 0, C_c = 0;
-  humid_summary gs;
-  std::memset(&gs, 0, sizeof gs);
-  if (E) {
-    STEP(k.lib_ok(humid_stage_compact_nodes(k.ctx, e_all.as<uint64_t>(), E, 2, &nodes, &M, &cedges, &node_cnt)));
-    if (job.want_hist && r == 0) {                                                       // neigh.dat: degree of every leaf
-      std::vector<uint64_t> he(E);
-      STEP(k.hip_ok(hipMemcpy(he.data(), cedges, E * 8, hipMemcpyDeviceToHost), "hipMemcpy (edges)"));
-      std::vector<uint32_t> deg(M, 0);
-      for (uint64_t e : he) { deg[e >> 32]++; deg[e & 0xffffffffull]++; }
-      std::lock_guard<std::mutex> lk(g.mu);
-      for (uint32_t v : deg) g.hist_neigh[v]++;
-    }
-    // (the graph runs over the compact node list: its "words" are only carried for the accessors)
-    STEP(k.lib_ok(humid_stage_graph_edges(k.ctx, (const uint64_t *)nodes, node_cnt, M, cedges, E, n, d, job.method, &ccid,
-                                          &cismax, &gs)));
-    C_c = gs.clusters;
-  }
-  if (job.want_hist && r == 0 && u_total > M) {
-    std::lock_guard<std::mutex> lk(g.mu);
-    g.hist_neigh[0] += u_total - M;
-  }
-  const uint64_t clusters = u_total - M + C_c;
-  if (clusters >= (1ull << 31)) { k.code = HUMID_E_OVERFLOW; k.err = "cluster ids exceed 31 bits"; return false; }
-  const uint32_t *l_cid = nullptr;
-  const uint8_t *l_ismax = nullptr;
-  STEP(k.lib_ok(humid_stage_exchange_ids(k.ctx, nodes, ccid, cismax, M, C_c, goff, u_local, &l_cid, &l_ismax)));
-
-  // ---- 6. per-read results at the owner, back to the home shards ----
-  const uint32_t *packed = nullptr;
-  uint64_t n_packed = 0;
-  STEP(k.lib_ok(humid_stage_map_dense(k.ctx, l_cid, l_ismax, &packed, &n_packed)));
-  if (n_packed != n_recv) { k.code = HUMID_E_INVALID; k.err = "map_dense returned a different number of reads than were counted"; return false; }
-  STEP(k.hip_ok(ret.ensure(n_send * 4 + 8), "hipMalloc"));
-  STEP(k.all_to_all(packed, recv_counts, ret.p, send_counts, 4));
-  STEP(k.lib_ok(humid_stage_scatter(k.ctx, d_perm, ret.as<uint32_t>(), n_send, n_local, d_cid.as<uint32_t>(), d_keep.as<uint8_t>())));
   if (n_local) {
     STEP(k.hip_ok(hipMemcpyAsync(job.cluster_id + r0, d_cid.p, n_local * 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync (ids)"));
     STEP(k.hip_ok(hipMemcpyAsync(job.keep + r0, d_keep.p, n_local, hipMemcpyDeviceToHost, st), "hipMemcpyAsync (keep)"));
   }
-  STEP(k.hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"));
-  if (r == 0) {
-    job.sum = gs;                                                                       // the kernel times of the graph stage
-    job.sum.total = total;
-    job.sum.usable = usable;
-    job.sum.unique = u_total;
-    job.sum.clusters = clusters;
-    job.sum.edges = E;
-    job.sum.nonsingle = M;
+  if (job.want_hist) {
+    if (info.unique_local) {                                                            // counts.dat: leaf -> count
+      std::vector<uint32_t> h(info.unique_local);
+      STEP(k.hip_ok(hipMemcpyAsync(h.data(), info.d_unique_count, info.unique_local * 4, hipMemcpyDeviceToHost, st), "hipMemcpy (counts)"));
+      STEP(k.hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"));
+      std::map<uint64_t, uint64_t> m;
+      for (uint32_t v : h) m[v]++;
+      std::lock_guard<std::mutex> lk(g.mu);
+      for (auto &kv : m) g.hist_counts[kv.first] += kv.second;
+    }
+    if (r == 0) {                                                                       // neigh.dat: degree of every leaf
+      std::vector<uint32_t> deg(info.n_nodes, 0);
+      if (info.n_pairs) {
+        std::vector<uint64_t> he(info.n_pairs);
+        STEP(k.hip_ok(hipMemcpyAsync(he.data(), info.d_compact_edges, info.n_pairs * 8, hipMemcpyDeviceToHost, st), "hipMemcpy (edges)"));
+        STEP(k.hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"));
+        for (uint64_t e : he) { deg[e >> 32]++; deg[e & 0xffffffffull]++; }
+      }
+      std::lock_guard<std::mutex> lk(g.mu);
+      for (uint32_t v : deg) g.hist_neigh[v]++;
+      if (sum.unique > info.n_nodes) g.hist_neigh[0] += sum.unique - info.n_nodes;
+    }
   }
+  STEP(k.hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"));
+  if (r == 0) job.sum = sum;
   return k.together();                                                                  // peers may still be copying from this rank's buffers
 }
 

@@ -85,6 +85,7 @@ struct humid_ctx {
   DBuf had;                 // k_pairs: first-phase "found a pair" flags, one byte per combination and position
   DBuf e_kx, e_vx, e_ky, e_vy, e_raw, e_sorted, e_edges, e_head, e_hpos;   // edit-distance neighbour search
   bool edit = false;         // option "edit_distance": Levenshtein instead of Hamming neighbours (-e)
+  DBuf xr_hist, xr_recv, xr_eloc, xr_got, xr_eall, xr_ret;   // humid_dedup_run_exchange: histogram, received words, pair records, received items, results
   DBuf x_slot, x_slot_s, x_cnt, x_cnts, x_rec, x_ncnt, x_route, x_creator, x_base, x_mark, x_markcr, x_scan, x_lcid, x_lismax,
        x_items, x_w, x_id, x_ids, x_ends, x_ends_s, x_head, x_hpos, x_nodes, x_cedges;   // multi-GPU exchange mode
   DBuf w_sorted, w_head, w_hpos, w_start;                                         // wide-word (sorted) counts
@@ -1451,7 +1452,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->in_bases, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
-                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->big_runs, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->big_runs, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles, &c->xr_hist, &c->xr_recv, &c->xr_eloc, &c->xr_got, &c->xr_eall, &c->xr_ret,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->seg_ws, &c->csize, &c->cur, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -1806,6 +1807,265 @@ int humid_cluster_graph(humid_ctx *c, const uint32_t *count, const uint32_t *nbr
   HIPCHK(hipStreamSynchronize(st));
   if (n_clusters) *n_clusters = (u32)C;
   return export_clusters(c, U, C, cl_size, cl_max_count, cl_max_leaf);
+}
+
+// ---- the exchange-mode pass of one rank (include/humid_hip.h: humid_dedup_run_exchange) ----------
+namespace {
+struct XRange { u64 lo = 1, hi = 0; };                         // lo > hi: empty
+
+// P ordered, disjoint, covering value ranges with balanced usable-read counts, cut at histogram bins;
+// the same arithmetic on every rank (and in humid_amd/sharded.py splitters_from_hist)
+void x_splitters(const std::vector<u64> &hist, u32 P, u32 word_nt, u32 bits, std::vector<XRange> &out) {
+  const u32 shift = 2 * word_nt - bits;
+  const size_t n_bins = hist.size();
+  std::vector<u64> cum(n_bins);
+  u64 total = 0;
+  for (size_t i = 0; i < n_bins; i++) { total += hist[i]; cum[i] = total; }
+  std::vector<size_t> bounds{0};
+  for (u32 k = 1; k < P; k++) {
+    const u64 target = (total * k + P - 1) / P;
+    size_t b = (size_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin()) + 1;
+    bounds.push_back(std::min(std::max(b, bounds.back()), n_bins));
+  }
+  bounds.push_back(n_bins);
+  out.assign(P, XRange());
+  for (u32 r = 0; r < P; r++) {
+    const size_t b0 = bounds[r], b1 = bounds[r + 1];
+    if (b1 <= b0) continue;
+    out[r].lo = (u64)b0 << shift;
+    out[r].hi = r == P - 1 ? ~0ull : ((u64)b1 << shift) - 1;          // (b1 << shift == 2^64 wraps to 0: hi = top)
+  }
+}
+
+// count_order for the owner's count from the global histogram: 1 = the words of this value range are
+// spread evenly (word-ordered LDS buckets fit), 0 = clearly not, -1 = let the count stage sample
+int x_order_hint(const std::vector<u64> &hist, const XRange &rg, u32 word_nt, u32 bits) {
+  if (rg.lo > rg.hi) return -1;
+  const u32 shift = 2 * word_nt - bits;
+  const size_t b0 = (size_t)(rg.lo >> shift), b1 = std::min<size_t>((size_t)(rg.hi >> shift), hist.size() - 1);
+  if (b1 + 1 - b0 < 4) return -1;
+  double sum = 0, mx = 0;
+  for (size_t b = b0; b <= b1; b++) { sum += (double)hist[b]; mx = std::max(mx, (double)hist[b]); }
+  if (sum < 65536) return -1;
+  const double ratio = mx / (sum / (double)(b1 + 1 - b0));
+  return ratio <= 1.25 ? 1 : (ratio > 2.5 ? 0 : -1);
+}
+}  // namespace
+
+// host numbers of all ranks
+static int x_host_gather(humid_ctx *c, const humid_comm *cm, const void *mine, u64 bytes, void *all) {
+  if (!cm || cm->world == 1) { memcpy(all, mine, bytes); return HUMID_OK; }
+  if (cm->host_all_gather(cm->user, mine, bytes, all) < 0) return fail(c, HUMID_E_COMM, "humid_comm.host_all_gather failed");
+  return HUMID_OK;
+}
+// items of `elem` bytes: send_items[q] to rank q (laid out in rank order in d_send, or the same
+// send_items[rank] items to everybody when `same`), recv_items[q] from rank q in rank order in d_recv.
+// One rank: a local copy.
+static int x_exchange(humid_ctx *c, const humid_comm *cm, const void *d_send, const u64 *send_items, bool same,
+                      void *d_recv, const u64 *recv_items, u64 elem) {
+  const u32 P = cm ? cm->world : 1, r = cm ? cm->rank : 0;
+  u64 so[MAX_RANKS], sb[MAX_RANKS], ro[MAX_RANKS], rb[MAX_RANKS];
+  u64 a = 0, b = 0;
+  for (u32 q = 0; q < P; q++) {
+    so[q] = same ? 0 : a; sb[q] = (same ? send_items[r] : send_items[q]) * elem; a += sb[q];
+    ro[q] = b; rb[q] = recv_items[q] * elem; b += rb[q];
+  }
+  if (sb[r] != rb[r]) return fail(c, HUMID_E_INVALID, "exchange: this rank's own split sizes differ");
+  if (P == 1) {
+    if (sb[0]) HIPCHK(hipMemcpyAsync(d_recv, d_send, sb[0], hipMemcpyDeviceToDevice, c->stream));
+    return HUMID_OK;
+  }
+  if (cm->exchange(cm->user, d_send, so, sb, d_recv, ro, rb, same ? 1 : 0, (void *)c->stream) < 0)
+    return fail(c, HUMID_E_COMM, "humid_comm.exchange failed");
+  return HUMID_OK;
+}
+
+int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t *d_words, const uint8_t *d_filtered,
+                             uint64_t n_local, uint32_t word_nt, uint32_t distance, uint32_t method,
+                             uint32_t *d_cluster_id, uint8_t *d_keep, humid_summary *summary, humid_exchange_info *info) {
+  if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  const u32 P = cm ? cm->world : 1, r = cm ? cm->rank : 0;
+  if (P == 0 || P > MAX_RANKS || r >= P) return fail(c, HUMID_E_UNSUPPORTED, "1 .. %d ranks", MAX_RANKS);
+  if (P > 1 && (!cm->host_all_gather || !cm->exchange)) return fail(c, HUMID_E_INVALID, "humid_comm without callbacks");
+  TRY(check_run_args(c, n_local, word_nt, method));
+  if (n_local && (!d_words || !d_filtered || !d_cluster_id || !d_keep)) return fail(c, HUMID_E_INVALID, "null buffer");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const auto t_begin = std::chrono::steady_clock::now();
+  const u32 n = word_nt, d = distance;
+  // ---- 1. histograms of all ranks -> value ranges and every split size of the word exchange ----
+  u32 nc1 = 0, pbits = 0;
+  TRY(humid_stage_plan_info(c, n, d, 1, &nc1, &pbits));
+  if (pbits < 1) return fail(c, HUMID_E_UNSUPPORTED, "distance %u over %u-nt words leaves no prefix to cut value ranges at", d, n);
+  const u32 bits = std::min<u32>(std::min<u32>(12u, 2 * n), pbits);
+  const size_t n_bins = (size_t)1 << bits;
+  ENSURE(c->xr_hist, n_bins * 4);
+  TRY(humid_stage_histogram(c, d_words, d_filtered, n_local, n, bits, c->xr_hist.as<u32>()));
+  std::vector<u32> h_hist(n_bins), all_hist((size_t)P * n_bins);
+  HIPCHK(hipMemcpyAsync(h_hist.data(), c->xr_hist.p, n_bins * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  TRY(x_host_gather(c, cm, h_hist.data(), n_bins * 4, all_hist.data()));
+  std::vector<u64> hist_sum(n_bins, 0), cum((size_t)P * (n_bins + 1), 0);
+  for (u32 q = 0; q < P; q++)
+    for (size_t b = 0; b < n_bins; b++) {
+      const u64 v = all_hist[(size_t)q * n_bins + b];
+      hist_sum[b] += v;
+      cum[(size_t)q * (n_bins + 1) + b + 1] = cum[(size_t)q * (n_bins + 1) + b] + v;
+    }
+  std::vector<XRange> ranges;
+  x_splitters(hist_sum, P, n, bits, ranges);
+  const u32 shift = 2 * n - bits;
+  auto in_range = [&](u32 src, u32 owner) -> u64 {                  // usable reads of rank src in owner's range
+    const XRange &rg = ranges[owner];
+    if (rg.lo > rg.hi) return 0;
+    const size_t b0 = (size_t)(rg.lo >> shift), b1 = std::min<size_t>((size_t)(rg.hi >> shift), n_bins - 1) + 1;
+    return cum[(size_t)src * (n_bins + 1) + b1] - cum[(size_t)src * (n_bins + 1) + b0];
+  };
+  u64 send_counts[MAX_RANKS], recv_counts[MAX_RANKS], lo[MAX_RANKS], hi[MAX_RANKS];
+  u64 n_send = 0, n_recv = 0;
+  for (u32 q = 0; q < P; q++) {
+    send_counts[q] = in_range(r, q);
+    recv_counts[q] = in_range(q, r);
+    n_send += send_counts[q];
+    n_recv += recv_counts[q];
+    lo[q] = ranges[q].lo;
+    hi[q] = ranges[q].hi;
+  }
+  if (n_recv > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "%llu reads arrive at rank %u: more than 2^31-1", (ull)n_recv, r);
+  u64 lo_r = ranges[r].lo, hi_r = ranges[r].hi;
+  if (lo_r > hi_r) { lo_r = 0; hi_r = ~0ull; }                      // empty range: nothing arrives
+  const int saved_order = c->count_order, saved_mode = c->count_mode;
+  c->count_order = x_order_hint(hist_sum, ranges[r], n, bits);
+  c->count_mode = 0;
+  struct Restore { humid_ctx *c; int o, m; ~Restore() { c->count_order = o; c->count_mode = m; } } restore{c, saved_order, saved_mode};
+
+  // ---- 2. usable words -> owner of their range (stable: input order inside every block) ----
+  const u64 *d_routed = nullptr;
+  const u32 *d_perm = nullptr;
+  TRY(humid_stage_route(c, d_words, d_filtered, n_local, lo, hi, P, send_counts, &d_routed, &d_perm));
+  ENSURE(c->xr_recv, n_recv * 8 + 8);
+  TRY(x_exchange(c, cm, d_routed, send_counts, false, c->xr_recv.p, recv_counts, 8));
+
+  // ---- 3. exact counts of the received words (all usable, all in this rank's range) ----
+  const u64 shard_begin[2] = {0, n_recv};
+  u64 cnt_one = 0, u_local = 0, usable_local = 0;
+  TRY(humid_stage_count_dense(c, c->xr_recv.as<u64>(), nullptr, n_recv, n, lo_r, hi_r, shard_begin, 1, &cnt_one, &u_local,
+                              &usable_local));
+  TRY(humid_stage_route_check(c));                                  // (the stream has drained: no extra wait)
+  const u64 meta[3] = {u_local, usable_local, n_local};
+  u64 metas[3 * MAX_RANKS];
+  TRY(x_host_gather(c, cm, meta, sizeof meta, metas));
+  u64 u_total = 0, goff = 0, usable = 0, total = 0;
+  for (u32 q = 0; q < P; q++) {
+    if (q < r) goff += metas[3 * q];
+    u_total += metas[3 * q];
+    usable += metas[3 * q + 1];
+    total += metas[3 * q + 2];
+  }
+  if (u_total >= 0xffffffffull) return fail(c, HUMID_E_OVERFLOW, "more than 2^32-2 unique words in total");
+  const u64 *lw = nullptr;
+  const u32 *lc = nullptr, *lfirst = nullptr;
+  if (u_local) TRY(humid_stage_unique(c, &lw, &lc, &lfirst));
+
+  // ---- 4. neighbour pairs in global unique indices, each with the counts of its endpoints ----
+  u64 e_mine = 0;                                                    // 16-byte records in xr_eloc
+  auto append_pairs = [&](const u64 *rec, u64 n_rec) -> int {
+    if (!n_rec) return HUMID_OK;
+    if ((e_mine + n_rec) * 16 > c->xr_eloc.cap) {                    // grow, keeping what is there
+      DBuf bigger;
+      HIPCHK(bigger.ensure((e_mine + n_rec) * 32, nullptr));
+      if (e_mine) HIPCHK(hipMemcpyAsync(bigger.p, c->xr_eloc.p, e_mine * 16, hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
+      c->xr_eloc.release();
+      c->xr_eloc = bigger;                                           // (DBuf owns nothing by itself: a plain hand-over)
+    }
+    HIPCHK(hipMemcpyAsync(c->xr_eloc.as<u8>() + e_mine * 16, rec, n_rec * 16, hipMemcpyDeviceToDevice, st));
+    e_mine += n_rec;
+    return HUMID_OK;
+  };
+  if (d > 0 && u_total > 1) {
+    u32 n_combos = 0, pb2 = 0;
+    TRY(humid_stage_plan_info(c, n, d, u_total, &n_combos, &pb2));
+    const u64 *rec = nullptr;
+    u64 n_rec = 0;
+    if (u_local > 1) {
+      TRY(humid_stage_pairs_keyed(c, lw, u_local, 0, goff, lc, n, d, u_total, 0, &rec, &n_rec));
+      TRY(append_pairs(rec, n_rec));
+    }
+    for (u32 cb = 1; cb < n_combos; cb++) {
+      const u64 *items = nullptr;
+      u64 sc[MAX_RANKS] = {0}, all_sc[MAX_RANKS * MAX_RANKS], rc[MAX_RANKS];
+      TRY(humid_stage_combo_route(c, lw, lc, u_local, goff, n, d, u_total, cb, P, &items, sc));
+      TRY(x_host_gather(c, cm, sc, P * 8, all_sc));
+      u64 n_got = 0;
+      for (u32 q = 0; q < P; q++) { rc[q] = all_sc[(size_t)q * P + r]; n_got += rc[q]; }
+      ENSURE(c->xr_got, n_got * 16 + 16);
+      TRY(x_exchange(c, cm, items, sc, false, c->xr_got.p, rc, 16));
+      if (n_got > 1) {
+        TRY(humid_stage_pairs_keyed(c, c->xr_got.as<u64>(), n_got, 1, 0, nullptr, n, d, u_total, cb, &rec, &n_rec));
+        TRY(append_pairs(rec, n_rec));
+      }
+    }
+  }
+  u64 e_counts[MAX_RANKS];
+  TRY(x_host_gather(c, cm, &e_mine, 8, e_counts));
+  u64 E = 0;
+  for (u32 q = 0; q < P; q++) E += e_counts[q];
+  const u64 *d_eall = c->xr_eloc.as<u64>();
+  if (P > 1) {
+    ENSURE(c->xr_eall, E * 16 + 16);
+    ENSURE(c->xr_eloc, 16);
+    TRY(x_exchange(c, cm, c->xr_eloc.p, e_counts, true, c->xr_eall.p, e_counts, 16));
+    d_eall = c->xr_eall.as<u64>();
+  }
+
+  // ---- 5. compact graph over the pairs' endpoints (replicated); ids by closed-form prefix counts ----
+  const u32 *nodes = nullptr, *node_cnt = nullptr, *ccid = nullptr;
+  const u64 *cedges = nullptr;
+  const u8 *cismax = nullptr;
+  u64 M = 0, C_c = 0;
+  humid_summary gs;
+  memset(&gs, 0, sizeof gs);
+  if (E) {
+    TRY(humid_stage_compact_nodes(c, d_eall, E, 2, &nodes, &M, &cedges, &node_cnt));
+    // (the graph runs over the compact node list: its "words" are only carried for the accessors)
+    TRY(humid_stage_graph_edges(c, (const u64 *)nodes, node_cnt, M, cedges, E, n, d, method, &ccid, &cismax, &gs));
+    C_c = gs.clusters;
+  }
+  const u64 clusters = u_total - M + C_c;
+  if (clusters >= (1ull << 31)) return fail(c, HUMID_E_OVERFLOW, "cluster ids exceed 31 bits");
+  const u32 *l_cid = nullptr;
+  const u8 *l_ismax = nullptr;
+  TRY(humid_stage_exchange_ids(c, nodes, ccid, cismax, M, C_c, goff, u_local, &l_cid, &l_ismax));
+
+  // ---- 6. per-read results at the owner, back to the home shards ----
+  const u32 *packed = nullptr;
+  u64 n_packed = 0;
+  TRY(humid_stage_map_dense(c, l_cid, l_ismax, &packed, &n_packed));
+  if (n_packed != n_recv) return fail(c, HUMID_E_INVALID, "map_dense returned %llu reads, %llu were counted", (ull)n_packed, (ull)n_recv);
+  ENSURE(c->xr_ret, n_send * 4 + 8);
+  TRY(x_exchange(c, cm, packed, recv_counts, false, c->xr_ret.p, send_counts, 4));
+  TRY(humid_stage_scatter(c, d_perm, c->xr_ret.as<u32>(), n_send, n_local, d_cluster_id, d_keep));
+  HIPCHK(hipStreamSynchronize(st));
+  if (summary) {
+    *summary = gs;                                                   // the kernel times of the graph stage
+    summary->total = total;
+    summary->usable = usable;
+    summary->unique = u_total;
+    summary->clusters = clusters;
+    summary->edges = E;
+    summary->nonsingle = M;
+    summary->ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  if (info) {
+    info->unique_local = u_local;
+    info->id_base = goff;
+    info->n_nodes = M;
+    info->n_pairs = E;
+    info->d_unique_count = lc;
+    info->d_compact_edges = cedges;
+  }
+  return HUMID_OK;
 }
 
 int humid_at_least_double(humid_ctx *c, uint64_t a, uint64_t b, int *result) {
@@ -2423,10 +2683,27 @@ int humid_stage_route(humid_ctx *c, const uint64_t *d_words, const uint8_t *d_fi
   ENSURE(c->perm, (size_t)n * 4);
   ENSURE(c->x_route, (size_t)(tot ? tot : 1) * 8);
   u32 *tile_cnt = c->route_tiles.as<u32>(), *bad = tile_cnt + (size_t)n_tiles * MAX_RANKS;
-  hipLaunchKernelGGL(k_route_tile_hist, dim3(n_tiles), dim3(1024), 0, st, d_words, d_filtered, n, rg, n_ranks, tile_cnt, bad);
+  // ranges cut at the bins of a prefix histogram (every boundary a multiple of 2^shift, at most
+  // ROUTE_BINS bins below the last boundary): owners come from a table in LDS
+  u64 bits_or = 0, top_lo = 0;
+  for (u32 q = 0; q < n_ranks; q++)
+    if (range_lo[q] <= range_hi[q]) {
+      bits_or |= range_lo[q] | (range_hi[q] + 1);
+      top_lo = std::max<u64>(top_lo, range_lo[q]);
+    }
+  const u32 shift = bits_or ? (u32)__builtin_ctzll(bits_or) : 63u;
+  const bool table = (top_lo >> shift) < ROUTE_BINS;
+  if (table)
+    hipLaunchKernelGGL(k_route_tile_hist<true>, dim3(n_tiles), dim3(1024), 0, st, d_words, d_filtered, n, rg, n_ranks, shift, tile_cnt, bad);
+  else
+    hipLaunchKernelGGL(k_route_tile_hist<false>, dim3(n_tiles), dim3(1024), 0, st, d_words, d_filtered, n, rg, n_ranks, shift, tile_cnt, bad);
   hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(1024), 0, st, tile_cnt, n_tiles, ob, bad);
-  hipLaunchKernelGGL(k_route_scatter, dim3(n_tiles), dim3(1024), 0, st, d_words, d_filtered, n, rg, n_ranks,
-                     (const u32 *)tile_cnt, c->x_route.as<u64>(), c->perm.as<u32>());
+  if (table)
+    hipLaunchKernelGGL(k_route_scatter<true>, dim3(n_tiles), dim3(1024), 0, st, d_words, d_filtered, n, rg, n_ranks, shift,
+                       (const u32 *)tile_cnt, c->x_route.as<u64>(), c->perm.as<u32>());
+  else
+    hipLaunchKernelGGL(k_route_scatter<false>, dim3(n_tiles), dim3(1024), 0, st, d_words, d_filtered, n, rg, n_ranks, shift,
+                       (const u32 *)tile_cnt, c->x_route.as<u64>(), c->perm.as<u32>());
   HIPCHK(hipGetLastError());
   c->route_checked = false;
   c->route_bad = bad;

@@ -354,34 +354,57 @@ __device__ __forceinline__ u32 owner_of_word(const OwnerRanges &rg, u32 n_ranks,
   return o;
 }
 
+// Owner of a word through a table in LDS when the value ranges are cut at the bins of a <= 12-bit
+// prefix histogram (they are: humid_amd/sharded.py, csrc/host/sharded.cpp): own[w >> shift], filled by
+// the block itself from the ranges (4 bins per thread).  One LDS read per read instead of 16 pairs of
+// 64-bit compares.  TABLE = false: the compare loop (ranges of any other shape).
+#define ROUTE_BINS 4096u
+template <bool TABLE>
+__device__ __forceinline__ void route_fill_table(u8 *own, const OwnerRanges &rg, u32 n_ranks, u32 shift) {
+  if (!TABLE) return;
+  for (u32 b = threadIdx.x; b < ROUTE_BINS; b += blockDim.x) own[b] = (u8)owner_of_word(rg, n_ranks, (u64)b << shift);
+  __syncthreads();
+}
+template <bool TABLE>
+__device__ __forceinline__ u32 route_owner(const u8 *own, const OwnerRanges &rg, u32 n_ranks, u32 shift, u64 w) {
+  if (!TABLE) return owner_of_word(rg, n_ranks, w);
+  const u64 b = w >> shift;
+  return own[b < ROUTE_BINS ? (u32)b : ROUTE_BINS - 1];
+}
+
+// per tile of ROUTE_TILE reads: usable reads of every owner.  All loads of a thread are issued before
+// the first is used; a wave counts an owner with one ballot, lane q keeps owner q's count.
+template <bool TABLE>
 __global__ void __launch_bounds__(1024)
 k_route_tile_hist(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n, OwnerRanges rg,
-                  u32 n_ranks, u32 *__restrict__ tile_cnt, u32 *__restrict__ bad) {
+                  u32 n_ranks, u32 shift, u32 *__restrict__ tile_cnt, u32 *__restrict__ bad) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u32 cnt[MAX_RANKS];
+  __shared__ u8 own[TABLE ? ROUTE_BINS : 4];
   if (blockIdx.x == 0 && threadIdx.x == 0) bad[0] = 0;       // k_route_scan (next launch) may raise it
   if (threadIdx.x < MAX_RANKS) cnt[threadIdx.x] = 0;
-  __syncthreads();
   const u32 beg = blockIdx.x * ROUTE_TILE;
-  u32 mine[MAX_RANKS];
-#pragma unroll
-  for (u32 q = 0; q < MAX_RANKS; q++) mine[q] = 0;
+  u64 w[ROUTE_TILE / 1024];
+  u8 f[ROUTE_TILE / 1024];
 #pragma unroll
   for (u32 k = 0; k < ROUTE_TILE / 1024; k++) {
     const u32 j = beg + k * 1024 + threadIdx.x;
-    if (j < n && !filtered[j]) {
-      const u32 o = owner_of_word(rg, n_ranks, words[j]);
+    f[k] = j < n ? filtered[j] : (u8)1;
+    w[k] = j < n ? words[j] : 0;
+  }
+  route_fill_table<TABLE>(own, rg, n_ranks, shift);
+  if (!TABLE) __syncthreads();
+  const u32 lane = threadIdx.x & 63;
+  u32 acc = 0;
 #pragma unroll
-      for (u32 q = 0; q < MAX_RANKS; q++) mine[q] += (o == q) ? 1u : 0u;
+  for (u32 k = 0; k < ROUTE_TILE / 1024; k++) {
+    const u32 o = f[k] ? MAX_RANKS : route_owner<TABLE>(own, rg, n_ranks, shift, w[k]);
+    for (u32 q = 0; q < n_ranks; q++) {
+      const u64 m = __ballot(o == q);
+      if (lane == q) acc += (u32)__popcll(m);
     }
   }
-#pragma unroll
-  for (u32 q = 0; q < MAX_RANKS; q++) {
-    u32 x = mine[q];
-#pragma unroll
-    for (u32 d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
-    if ((threadIdx.x & 63) == 0 && x) atomicAdd(&cnt[q], x);
-  }
+  if (lane < n_ranks && acc) atomicAdd(&cnt[lane], acc);
   __syncthreads();
   if (threadIdx.x < MAX_RANKS) tile_cnt[blockIdx.x * MAX_RANKS + threadIdx.x] = cnt[threadIdx.x];
 }
@@ -410,44 +433,60 @@ k_route_scan(u32 *tile_cnt, u32 n_tiles, OwnerBases ob, u32 *bad) {
   if (lane == 0 && run != ob.b[q + 1]) bad[0] = 1;
 }
 
+// stable scatter of a tile: position = tile offset of the owner + usable reads of that owner before
+// this one inside the tile.  Loads first (all in flight), then per round and wave one ballot per
+// owner (rank inside the wave + the wave's count), ONE pass of 16 threads that turns the
+// [round][wave][owner] counts into offsets, then the stores: two barriers per tile.
+template <bool TABLE>
 __global__ void __launch_bounds__(1024)
 k_route_scatter(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n, OwnerRanges rg,
-                u32 n_ranks, const u32 *__restrict__ tile_off, u64 *__restrict__ routed, u32 *__restrict__ perm) {
+                u32 n_ranks, u32 shift, const u32 *__restrict__ tile_off, u64 *__restrict__ routed,
+                u32 *__restrict__ perm) {
   HUMID_GUARD_LAST_VGPR();
-  __shared__ u32 wcnt[16][MAX_RANKS];      // this batch: reads of every owner per wave
-  __shared__ u32 run[MAX_RANKS];           // reads of every owner in the batches before
+  constexpr u32 R = ROUTE_TILE / 1024;
+  __shared__ u32 wcnt[R][16][MAX_RANKS];   // reads of every owner per round and wave -> their offsets
+  __shared__ u8 own[TABLE ? ROUTE_BINS : 4];
   const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const u64 lt = (1ull << lane) - 1ull;
-  if (threadIdx.x < MAX_RANKS) run[threadIdx.x] = tile_off[blockIdx.x * MAX_RANKS + threadIdx.x];
   const u32 beg = blockIdx.x * ROUTE_TILE;
-  for (u32 k = 0; k < ROUTE_TILE / 1024; k++) {
-    const u32 j = beg + k * 1024 + threadIdx.x;
-    u32 o = MAX_RANKS + 1;
-    u64 w = 0;
-    if (j < n && !filtered[j]) { w = words[j]; o = owner_of_word(rg, n_ranks, w); }
-    u32 rank_in_wave = 0;
+  u64 w[R];
+  u8 f[R];
 #pragma unroll
-    for (u32 q = 0; q < MAX_RANKS; q++) {
-      const u64 m = __ballot(o == q);
-      if (o == q) rank_in_wave = (u32)__popcll(m & lt);
-      if (lane == 0) wcnt[wave][q] = (u32)__popcll(m);
-    }
-    __syncthreads();
-    if (o < n_ranks) {
-      u32 before = run[o];
-      for (u32 w2 = 0; w2 < wave; w2++) before += wcnt[w2][o];
-      const u32 pos = before + rank_in_wave;
-      routed[pos] = w;
-      perm[pos] = j;
-    }
-    __syncthreads();
-    if (threadIdx.x < MAX_RANKS) {
-      u32 t = 0;
-      for (u32 w2 = 0; w2 < 16; w2++) t += wcnt[w2][threadIdx.x];
-      run[threadIdx.x] += t;
-    }
-    __syncthreads();
+  for (u32 k = 0; k < R; k++) {
+    const u32 j = beg + k * 1024 + threadIdx.x;
+    f[k] = j < n ? filtered[j] : (u8)1;
+    w[k] = j < n ? words[j] : 0;
   }
+  route_fill_table<TABLE>(own, rg, n_ranks, shift);
+  u32 o[R], rk[R];
+#pragma unroll
+  for (u32 k = 0; k < R; k++) {
+    o[k] = f[k] ? MAX_RANKS : route_owner<TABLE>(own, rg, n_ranks, shift, w[k]);
+    rk[k] = 0;
+    for (u32 q = 0; q < n_ranks; q++) {
+      const u64 m = __ballot(o[k] == q);
+      if (o[k] == q) rk[k] = (u32)__popcll(m & lt);
+      if (lane == q) wcnt[k][wave][q] = (u32)__popcll(m);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < n_ranks) {
+    u32 run = tile_off[blockIdx.x * MAX_RANKS + threadIdx.x];
+    for (u32 k = 0; k < R; k++)
+      for (u32 w2 = 0; w2 < 16; w2++) {
+        const u32 c = wcnt[k][w2][threadIdx.x];
+        wcnt[k][w2][threadIdx.x] = run;
+        run += c;
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (u32 k = 0; k < R; k++)
+    if (o[k] < n_ranks) {
+      const u32 pos = wcnt[k][wave][o[k]] + rk[k];
+      routed[pos] = w[k];
+      perm[pos] = beg + k * 1024 + threadIdx.x;
+    }
 }
 
 // ---- cluster ids of one rank's unique words from the replicated compact graph ----

@@ -290,6 +290,72 @@ class HipStageOps(Context):
         self._call(self._lib.humid_stage_kernel_ms, C.byref(a), C.byref(b), C.byref(m))
         return dict(ms_k_insert=a.value, ms_k_map=b.value, count_mode_used=m.value)
 
+    def run_exchange(self, dist, d_w, d_f, d_cid, d_keep, word_nt, distance, method):
+        """the whole exchange-mode pass in ONE library call (humid_dedup_run_exchange): the stage sequence
+        runs inside the library, torch.distributed only moves the bytes (humid_comm callbacks)"""
+        world, rank = dist.get_world_size(), dist.get_rank()
+        dev = self.device
+        err = []
+
+        def host_all_gather(_user, mine, nbytes, out):
+            try:
+                src = torch.frombuffer((C.c_uint8 * nbytes).from_address(mine), dtype=torch.uint8)
+                inp = src.to(dev) if dev.type == "cuda" else src.clone()
+                allb = torch.empty(world * nbytes, dtype=torch.uint8, device=inp.device)
+                _all_gather_flat(dist, allb, inp, world)
+                host = allb.cpu().numpy()                    # (kept alive until the bytes are copied out)
+                C.memmove(out, host.ctypes.data, world * nbytes)
+                return 0
+            except Exception as e:  # pragma: no cover  (reported through HUMID_E_COMM)
+                err.append(e)
+                return -1
+
+        def exchange(_user, d_send, so, sb, d_recv, ro, rb, all_gather, _stream):
+            try:
+                so, sb = [so[q] for q in range(world)], [sb[q] for q in range(world)]
+                ro, rb = [ro[q] for q in range(world)], [rb[q] for q in range(world)]
+                out = self._bytes(d_recv, ro[-1] + rb[-1])
+                if all_gather:                              # the same bytes to everybody
+                    inp = self._bytes(d_send, sb[0])
+                    if all(x == rb[0] for x in rb):
+                        _all_gather_flat(dist, out, inp, world)
+                    else:
+                        got, _ = _all_gather_var(dist, inp, world)
+                        out.copy_(got)
+                else:
+                    inp = self._bytes(d_send, so[-1] + sb[-1])
+                    _all_to_all_v(dist, out, inp, rb, sb, world, rank)
+                return 0
+            except Exception as e:  # pragma: no cover
+                err.append(e)
+                return -1
+
+        cm = _lib.HumidComm(None, rank, world, _lib.HOST_ALL_GATHER_FN(host_all_gather), _lib.EXCHANGE_FN(exchange))
+        s = _lib.HumidSummary()
+        info = _lib.HumidExchangeInfo()
+        self._enter()
+        rc = self._lib.humid_dedup_run_exchange(self._h, C.byref(cm), self._p(d_w), self._p(d_f), d_w.numel(), word_nt,
+                                                distance, method, self._p(d_cid), self._p(d_keep), C.byref(s), C.byref(info))
+        if err:
+            raise err[0]
+        self._check(rc)
+        self._exit()
+        return s.asdict()
+
+    def _bytes(self, ptr, n):
+        """torch uint8 view of ctx-owned (or caller) device memory; views of the persistent buffers are
+        kept: the pointers stay the same from pass to pass"""
+        if n == 0 or not ptr:
+            return torch.empty(0, dtype=torch.uint8, device=self.device)
+        key = (int(ptr), int(n))
+        cache = self.__dict__.setdefault("_views", {})
+        t = cache.get(key)
+        if t is None:
+            if len(cache) > 64:
+                cache.clear()
+            t = cache[key] = _wrap(ptr, n, "|u1", torch.uint8, self.device)
+        return t
+
     def map(self, l_cid, l_ismax, out_cid, out_keep):
         self._call(self._lib.humid_stage_map, self._p(l_cid), self._p(l_ismax), out_cid.numel(),
                    self._p(out_cid), self._p(out_keep))
@@ -493,6 +559,9 @@ class ShardedDedup:
         self.partition_search = partition_search
         self._n_max = None
         self.trace = {} if os.environ.get("HUMID_SHARD_TRACE") else None
+        # HUMID_PY_ORCHESTRATION=1 (or a trace): the stage-by-stage Python form of the exchange mode
+        # below instead of the library's single call -- same entry points, same results
+        self.py_orchestration = bool(os.environ.get("HUMID_PY_ORCHESTRATION")) or self.trace is not None
 
     def run(self, d_w, d_f, d_cid, d_keep):
         """d_w int64[n_local] packed words, d_f uint8[n_local]; writes d_cid int32[n_local] and
@@ -520,6 +589,10 @@ class ShardedDedup:
         return self._run_allgather(d_w, d_f, d_cid, d_keep)
 
     def _run_exchange(self, d_w, d_f, d_cid, d_keep, bits):
+        if hasattr(self.ops, "run_exchange") and not self.py_orchestration:
+            summ = self.ops.run_exchange(self.dist, d_w, d_f, d_cid, d_keep, self.word_nt, self.distance, self.method)
+            self.summary = summ
+            return summ
         dist, P, r, ops = self.dist, self.world, self.rank, self.ops
         dev = d_w.device
         n_local = d_w.numel()

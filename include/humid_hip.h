@@ -349,6 +349,48 @@ int humid_stage_compact_nodes(humid_ctx *ctx, const uint64_t *d_edges, uint64_t 
                               uint32_t record_stride, const uint32_t **d_nodes, uint64_t *n_nodes,
                               const uint64_t **d_compact_edges, const uint32_t **d_node_counts);
 
+/* ---- the whole exchange-mode pass of one rank in ONE call --------------------------------------
+ * humid_dedup_run_exchange runs, for this rank's shard of the reads (input order), the sequence the
+ * stage entry points above make up -- histogram, value ranges, word exchange, counts, pairs per
+ * combination, compact graph, result exchange, scatter -- with everything between the exchanges inside
+ * the library (persistent buffers, no host language in between).  What only the caller can do, moving
+ * bytes between ranks, it does through humid_comm:
+ *   host_all_gather: every rank contributes `bytes` bytes of HOST memory; all[world * bytes] receives the
+ *     contributions in rank order (blocking).
+ *   exchange: DEVICE memory; rank q is sent d_send[send_off[q] .. + send_bytes[q]) and what rank q sends
+ *     here arrives at d_recv[recv_off[q] ..), recv_bytes[q] long -- for every q including this rank
+ *     itself.  Two shapes occur: an all-to-all (all_gather = 0: both sides laid out in rank order,
+ *     send_off and recv_off the running sums of the sizes) and an all-gather (all_gather = 1: send_off
+ *     all 0, send_bytes all equal: the same bytes go to everybody).  The transfer must be ordered after the work queued on `stream` (the
+ *     context's stream) and either complete or be ordered before later work on that stream when the
+ *     call returns (grouped ncclSend/ncclRecv on `stream` do exactly that).
+ * Both return 0 or a negative value, which ends the run with HUMID_E_COMM.  With world == 1 neither is
+ * called (comm may then be NULL).  Every rank must make the call with the same word_nt, distance and
+ * method.  *summary receives the totals of the WHOLE read set (identical on all ranks; ms_* are this
+ * rank's); *info what a caller needs for the statistics files.  Limits: word_nt <= 32, at most 16
+ * ranks, a pigeonhole plan with a prefix (distance < word_nt): HUMID_E_UNSUPPORTED otherwise. */
+#define HUMID_E_COMM        -7   /* a humid_comm callback failed                        */
+typedef struct humid_comm {
+  void *user;
+  uint32_t rank, world;
+  int (*host_all_gather)(void *user, const void *mine, uint64_t bytes, void *all);
+  int (*exchange)(void *user, const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes,
+                  void *d_recv, const uint64_t *recv_off, const uint64_t *recv_bytes, int all_gather,
+                  void *stream);
+} humid_comm;
+typedef struct humid_exchange_info {
+  uint64_t unique_local;             /* unique words this rank owns (its value range)             */
+  uint64_t id_base;                  /* walk index of the first of them                           */
+  uint64_t n_nodes;                  /* unique words with neighbours, all ranks (compact graph)   */
+  uint64_t n_pairs;                  /* neighbour pairs, all ranks                                */
+  const uint32_t *d_unique_count;    /* device: counts of this rank's unique words (counts.dat)   */
+  const uint64_t *d_compact_edges;   /* device: the pairs over compact node indices (a << 32 | b) */
+} humid_exchange_info;
+int humid_dedup_run_exchange(humid_ctx *ctx, const humid_comm *comm, const uint64_t *d_words,
+                             const uint8_t *d_filtered, uint64_t n_local, uint32_t word_nt,
+                             uint32_t distance, uint32_t method, uint32_t *d_cluster_id, uint8_t *d_keep,
+                             humid_summary *summary, humid_exchange_info *info);
+
 /* src/cluster.cc:31-33 atLeastDouble_, evaluated on the device (parity probe). */
 int humid_at_least_double(humid_ctx *ctx, uint64_t a, uint64_t b, int *result);
 

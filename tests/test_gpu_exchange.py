@@ -206,3 +206,68 @@ def test_edit_distance_virtual_ranks(P, d):
         assert used == "allgather"
         assert np.array_equal(cid, ocid[offs[r]:offs[r + 1]]) and np.array_equal(keep, okeep[offs[r]:offs[r + 1]])
         assert s["clusters"] == osum["clusters"]
+
+
+@pytest.mark.parametrize("P", [1, 2, 5, 16])
+@pytest.mark.parametrize("aligned", [True, False])
+def test_route_is_the_stable_owner_major_order(P, aligned):
+    """humid_stage_route alone: routed words = the usable words in owner-major order, input order inside
+    every owner's block, perm = their read indices.  aligned: value ranges cut at the bins of a 12-bit
+    prefix histogram (owners from the LDS table); otherwise arbitrary cuts (the compare loop).  A wrong
+    count must be reported by humid_stage_route_check."""
+    import torch
+    import humid_amd
+    from humid_amd.sharded import HipStageOps
+    rng = np.random.default_rng(P * 2 + aligned)
+    n_reads, n = 300_001, 24
+    words, filt = synth_words(n_reads, 3 + P, n, p_sub=2e-3, p_n=5e-3)
+    top = (1 << 64) - 1
+    cuts = sorted(int(x) for x in rng.integers(1, 1 << 12, size=P - 1))          # bins
+    if aligned:
+        edges = [0] + [c << (2 * n - 12) for c in cuts] + [None]
+    else:
+        edges = [0] + [(c << (2 * n - 12)) + int(rng.integers(1, 1 << 20)) for c in cuts] + [None]
+    ranges = []
+    for q in range(P):
+        lo, hi = edges[q], (top if q == P - 1 else edges[q + 1] - 1)
+        ranges.append((lo, hi, 0) if lo <= hi else (1, 0, 0))                      # equal cuts: an empty range
+    owner = np.full(n_reads, P, np.int64)
+    for q, (lo, hi, _) in enumerate(ranges):
+        if lo <= hi:
+            owner[(words >= np.uint64(lo)) & (words <= np.uint64(hi))] = q
+    owner[filt != 0] = P
+    order = np.argsort(owner, kind="stable")
+    n_send = int((owner < P).sum())
+    send_counts = [int((owner == q).sum()) for q in range(P)]
+    ops = HipStageOps(0)
+    dev = torch.device("cuda:0")
+    d_w = torch.from_numpy(words.view(np.int64).copy()).to(dev)
+    d_f = torch.from_numpy(filt.copy()).to(dev)
+    routed, perm = ops.route(d_w, d_f, ranges, send_counts)
+    ops.route_check()
+    assert np.array_equal(perm.cpu().numpy()[:n_send].view(np.uint32), order[:n_send].astype(np.uint32))
+    assert np.array_equal(routed.cpu().numpy().view(np.uint64), words[order[:n_send]])
+    if P > 1 and send_counts[0] > 0:
+        bad = list(send_counts)
+        bad[0] -= 1
+        bad[1] += 1
+        ops.route(d_w, d_f, ranges, bad)
+        with pytest.raises(humid_amd.HumidError):
+            ops.route_check()
+    ops.close()
+
+
+@pytest.mark.parametrize("P", [1, 3])
+def test_stage_by_stage_python_form_still_matches(P, monkeypatch):
+    """the exchange mode exists twice over the same entry points: the library's single call
+    (humid_dedup_run_exchange, the default with the HIP ops) and the stage-by-stage Python form
+    (HUMID_PY_ORCHESTRATION=1, also what the oracle-backed gloo tests drive).  Same results."""
+    words, filt = synth_words(150_000, 23, 24, p_sub=4e-3, p_n=2e-3)
+    ocid, okeep, osum, _ = orc.dedup_run(words, filt, 24, 2, 0)
+    monkeypatch.setenv("HUMID_PY_ORCHESTRATION", "1")
+    out, offs = run_ranks(P, words, filt, 24, 2, 0, "exchange")
+    for r in range(P):
+        cid, keep, s, used = out[r]
+        assert used == "exchange"
+        assert np.array_equal(cid, ocid[offs[r]:offs[r + 1]]) and np.array_equal(keep, okeep[offs[r]:offs[r + 1]])
+        assert s["edges"] == osum["edges"] and s["clusters"] == osum["clusters"]
