@@ -1809,6 +1809,9 @@ int humid_cluster_graph(humid_ctx *c, const uint32_t *count, const uint32_t *nbr
   return export_clusters(c, U, C, cl_size, cl_max_count, cl_max_leaf);
 }
 
+static int compact_nodes_impl(humid_ctx *c, const uint64_t *d_edges, uint64_t n_edges, uint32_t record_stride, u64 id_bound,
+                              const uint32_t **d_nodes, uint64_t *n_nodes, const uint64_t **d_compact_edges,
+                              const uint32_t **d_node_counts);
 // ---- the exchange-mode pass of one rank (include/humid_hip.h: humid_dedup_run_exchange) ----------
 namespace {
 struct XRange { u64 lo = 1, hi = 0; };                         // lo > hi: empty
@@ -1943,13 +1946,17 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   const u64 *d_routed = nullptr;
   const u32 *d_perm = nullptr;
   TRY(humid_stage_route(c, d_words, d_filtered, n_local, lo, hi, P, send_counts, &d_routed, &d_perm));
-  ENSURE(c->xr_recv, n_recv * 8 + 8);
-  TRY(x_exchange(c, cm, d_routed, send_counts, false, c->xr_recv.p, recv_counts, 8));
+  const u64 *recv_w = d_routed;                                     // one rank: what was routed is what arrives
+  if (P > 1) {
+    ENSURE(c->xr_recv, n_recv * 8 + 8);
+    TRY(x_exchange(c, cm, d_routed, send_counts, false, c->xr_recv.p, recv_counts, 8));
+    recv_w = c->xr_recv.as<u64>();
+  }
 
   // ---- 3. exact counts of the received words (all usable, all in this rank's range) ----
   const u64 shard_begin[2] = {0, n_recv};
   u64 cnt_one = 0, u_local = 0, usable_local = 0;
-  TRY(humid_stage_count_dense(c, c->xr_recv.as<u64>(), nullptr, n_recv, n, lo_r, hi_r, shard_begin, 1, &cnt_one, &u_local,
+  TRY(humid_stage_count_dense(c, recv_w, nullptr, n_recv, n, lo_r, hi_r, shard_begin, 1, &cnt_one, &u_local,
                               &usable_local));
   TRY(humid_stage_route_check(c));                                  // (the stream has drained: no extra wait)
   const u64 meta[3] = {u_local, usable_local, n_local};
@@ -1999,10 +2006,14 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
       TRY(x_host_gather(c, cm, sc, P * 8, all_sc));
       u64 n_got = 0;
       for (u32 q = 0; q < P; q++) { rc[q] = all_sc[(size_t)q * P + r]; n_got += rc[q]; }
-      ENSURE(c->xr_got, n_got * 16 + 16);
-      TRY(x_exchange(c, cm, items, sc, false, c->xr_got.p, rc, 16));
+      const u64 *got = items;
+      if (P > 1) {
+        ENSURE(c->xr_got, n_got * 16 + 16);
+        TRY(x_exchange(c, cm, items, sc, false, c->xr_got.p, rc, 16));
+        got = c->xr_got.as<u64>();
+      }
       if (n_got > 1) {
-        TRY(humid_stage_pairs_keyed(c, c->xr_got.as<u64>(), n_got, 1, 0, nullptr, n, d, u_total, cb, &rec, &n_rec));
+        TRY(humid_stage_pairs_keyed(c, got, n_got, 1, 0, nullptr, n, d, u_total, cb, &rec, &n_rec));
         TRY(append_pairs(rec, n_rec));
       }
     }
@@ -2027,7 +2038,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   humid_summary gs;
   memset(&gs, 0, sizeof gs);
   if (E) {
-    TRY(humid_stage_compact_nodes(c, d_eall, E, 2, &nodes, &M, &cedges, &node_cnt));
+    TRY(compact_nodes_impl(c, d_eall, E, 2, u_total, &nodes, &M, &cedges, &node_cnt));
     // (the graph runs over the compact node list: its "words" are only carried for the accessors)
     TRY(humid_stage_graph_edges(c, (const u64 *)nodes, node_cnt, M, cedges, E, n, d, method, &ccid, &cismax, &gs));
     C_c = gs.clusters;
@@ -2043,9 +2054,13 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   u64 n_packed = 0;
   TRY(humid_stage_map_dense(c, l_cid, l_ismax, &packed, &n_packed));
   if (n_packed != n_recv) return fail(c, HUMID_E_INVALID, "map_dense returned %llu reads, %llu were counted", (ull)n_packed, (ull)n_recv);
-  ENSURE(c->xr_ret, n_send * 4 + 8);
-  TRY(x_exchange(c, cm, packed, recv_counts, false, c->xr_ret.p, send_counts, 4));
-  TRY(humid_stage_scatter(c, d_perm, c->xr_ret.as<u32>(), n_send, n_local, d_cluster_id, d_keep));
+  const u32 *ret = packed;
+  if (P > 1) {
+    ENSURE(c->xr_ret, n_send * 4 + 8);
+    TRY(x_exchange(c, cm, packed, recv_counts, false, c->xr_ret.p, send_counts, 4));
+    ret = c->xr_ret.as<u32>();
+  }
+  TRY(humid_stage_scatter(c, d_perm, ret, n_send, n_local, d_cluster_id, d_keep));
   HIPCHK(hipStreamSynchronize(st));
   if (summary) {
     *summary = gs;                                                   // the kernel times of the graph stage
@@ -2392,10 +2407,18 @@ int humid_stage_combo_route(humid_ctx *c, const uint64_t *d_word, const uint32_t
   const u32 n = (u32)n_unique;
   if (n == 0) return HUMID_OK;
   if (!d_word) return fail(c, HUMID_E_INVALID, "null buffer");
+  ENSURE(c->x_items, (size_t)n * 16);
+  if (n_ranks == 1) {                                  // everything stays here: no owners, no sort, no host wait
+    hipLaunchKernelGGL(k_route_items, dim3(blocks_for(n)), dim3(256), 0, st, d_word, d_count, (const u32 *)nullptr, n,
+                       (u64)id_base, c->x_items.as<ulonglong2>());
+    HIPCHK(hipGetLastError());
+    counts[0] = n;
+    *d_items = c->x_items.as<u64>();
+    return HUMID_OK;
+  }
   ENSURE(c->owner, (size_t)n);
   ENSURE(c->owner_sorted, (size_t)n);
   ENSURE(c->x_ids, (size_t)n * 4);
-  ENSURE(c->x_items, (size_t)n * 16);
   hipLaunchKernelGGL(k_combo_owner, dim3(blocks_for(n)), dim3(256), 0, st, d_word, n, plan_fields(plan, combo),
                      n_ranks, c->owner.as<u8>());
   {
@@ -2524,7 +2547,18 @@ int humid_stage_pairs_keyed(humid_ctx *c, const uint64_t *d_items, uint64_t n_it
 // distinct endpoints of an edge list, ascending, and the edges relabelled to positions in that list.
 // record_stride 1: d_edges[k] = (a << 32 | b).  record_stride 2: the 16-byte records of
 // humid_stage_pairs_keyed; *d_node_counts then holds the count of every node.
+static int compact_nodes_impl(humid_ctx *c, const uint64_t *d_edges, uint64_t n_edges, uint32_t record_stride, u64 id_bound,
+                              const uint32_t **d_nodes, uint64_t *n_nodes, const uint64_t **d_compact_edges,
+                              const uint32_t **d_node_counts);
 int humid_stage_compact_nodes(humid_ctx *c, const uint64_t *d_edges, uint64_t n_edges, uint32_t record_stride,
+                              const uint32_t **d_nodes, uint64_t *n_nodes, const uint64_t **d_compact_edges,
+                              const uint32_t **d_node_counts) {
+  return compact_nodes_impl(c, d_edges, n_edges, record_stride, 0, d_nodes, n_nodes, d_compact_edges, d_node_counts);
+}
+// id_bound > 0: every endpoint is below it (the caller knows the number of unique words): the distinct
+// endpoints are found with a mark array and one scan over the ids -- no sort (four radix passes over
+// the 2E endpoints and their per-pass memsets were a tenth of the multi-GPU pass)
+static int compact_nodes_impl(humid_ctx *c, const uint64_t *d_edges, uint64_t n_edges, uint32_t record_stride, u64 id_bound,
                               const uint32_t **d_nodes, uint64_t *n_nodes, const uint64_t **d_compact_edges,
                               const uint32_t **d_node_counts) {
   if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
@@ -2540,6 +2574,40 @@ int humid_stage_compact_nodes(humid_ctx *c, const uint64_t *d_edges, uint64_t n_
   const u32 E = (u32)n_edges;
   if (E == 0) return HUMID_OK;
   if (!d_edges) return fail(c, HUMID_E_INVALID, "null buffer");
+  if (id_bound > 0 && id_bound <= (1ull << 28)) {
+    const u32 B = (u32)id_bound;
+    ENSURE(c->x_head, (size_t)B + 16);                       // mark bytes
+    ENSURE(c->x_ends, (size_t)B * 4);                        // count by id
+    ENSURE(c->x_hpos, ((size_t)B + 1) * 4);                  // position by id
+    ENSURE(c->x_cedges, (size_t)E * 8);
+    HIPCHK(hipMemsetAsync(c->x_head.p, 0, (size_t)B + 1, st));
+    HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_OVERFULL], 0, sizeof(ull), st));
+    hipLaunchKernelGGL(k_mark_ends, dim3(blocks_for(E)), dim3(256), 0, st, d_edges, E, record_stride, B, c->x_head.as<u8>(),
+                       c->x_ends.as<u32>(), c->d_ctr);
+    {
+      auto as_u32 = rocprim::make_transform_iterator(c->x_head.as<u8>(), [] __device__(u8 v) { return (u32)v; });
+      size_t bytes = 0;
+      HIPCHK(rocprim::exclusive_scan(nullptr, bytes, as_u32, c->x_hpos.as<u32>(), 0u, (size_t)B + 1, rocprim::plus<u32>(), st));
+      ENSURE(c->tmp, bytes);
+      HIPCHK(rocprim::exclusive_scan(c->tmp.p, bytes, as_u32, c->x_hpos.as<u32>(), 0u, (size_t)B + 1, rocprim::plus<u32>(), st));
+    }
+    HIPCHK(hipGetLastError());
+    TRY(read_counters(c, c->x_hpos.as<u32>() + B));
+    if (c->h_ctr[CTR_OVERFULL]) return fail(c, HUMID_E_INVALID, "pair record with an index beyond the unique words");
+    const u32 M = (u32)(c->h_ctr[CTR_N - 1] & 0xffffffffull);
+    ENSURE(c->x_nodes, ((size_t)M + 1) * 4);
+    ENSURE(c->x_ncnt, ((size_t)M + 1) * 4);
+    hipLaunchKernelGGL(k_marked_nodes, dim3(blocks_for(B)), dim3(256), 0, st, c->x_head.as<u8>(), c->x_hpos.as<u32>(),
+                       c->x_ends.as<u32>(), B, record_stride == 2, c->x_nodes.as<u32>(), c->x_ncnt.as<u32>());
+    hipLaunchKernelGGL(k_relabel_pairs, dim3(blocks_for(E)), dim3(256), 0, st, d_edges, E, record_stride, B, c->x_hpos.as<u32>(),
+                       c->x_cedges.as<u64>());
+    HIPCHK(hipGetLastError());
+    *d_nodes = c->x_nodes.as<u32>();
+    *n_nodes = M;
+    *d_compact_edges = c->x_cedges.as<u64>();
+    if (d_node_counts && record_stride == 2) *d_node_counts = c->x_ncnt.as<u32>();
+    return HUMID_OK;
+  }
   const u32 n2 = 2 * E;
   ENSURE(c->x_ends, (size_t)n2 * 4);
   ENSURE(c->x_ends_s, (size_t)n2 * 4);
@@ -2679,7 +2747,7 @@ int humid_stage_route(humid_ctx *c, const uint64_t *d_words, const uint8_t *d_fi
   ob.b[MAX_RANKS] = (u32)tot;
   if (tot > n) return fail(c, HUMID_E_INVALID, "send_counts exceed n_reads");
   const u32 n_tiles = (n + ROUTE_TILE - 1) / ROUTE_TILE;
-  ENSURE(c->route_tiles, ((size_t)n_tiles * MAX_RANKS + 16) * 4);
+  ENSURE(c->route_tiles, ((size_t)n_tiles * MAX_RANKS + 16) * 4 + ROUTE_BINS);   // tile counts | bad flag | owner table
   ENSURE(c->perm, (size_t)n * 4);
   ENSURE(c->x_route, (size_t)(tot ? tot : 1) * 8);
   u32 *tile_cnt = c->route_tiles.as<u32>(), *bad = tile_cnt + (size_t)n_tiles * MAX_RANKS;
@@ -2693,17 +2761,21 @@ int humid_stage_route(humid_ctx *c, const uint64_t *d_words, const uint8_t *d_fi
     }
   const u32 shift = bits_or ? (u32)__builtin_ctzll(bits_or) : 63u;
   const bool table = (top_lo >> shift) < ROUTE_BINS;
-  if (table)
-    hipLaunchKernelGGL(k_route_tile_hist<true>, dim3(n_tiles), dim3(1024), 0, st, d_words, d_filtered, n, rg, n_ranks, shift, tile_cnt, bad);
-  else
-    hipLaunchKernelGGL(k_route_tile_hist<false>, dim3(n_tiles), dim3(1024), 0, st, d_words, d_filtered, n, rg, n_ranks, shift, tile_cnt, bad);
+  u8 *d_table = (u8 *)(bad + 4);
+  if (table) {
+    hipLaunchKernelGGL(k_route_table, dim3(1), dim3(1024), 0, st, rg, n_ranks, shift, d_table);
+    hipLaunchKernelGGL(k_route_tile_hist<true>, dim3(n_tiles), dim3(1024), 0, st, d_words, d_filtered, n, rg, n_ranks, shift,
+                       (const u8 *)d_table, tile_cnt, bad);
+  } else
+    hipLaunchKernelGGL(k_route_tile_hist<false>, dim3(n_tiles), dim3(1024), 0, st, d_words, d_filtered, n, rg, n_ranks, shift,
+                       (const u8 *)d_table, tile_cnt, bad);
   hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(1024), 0, st, tile_cnt, n_tiles, ob, bad);
   if (table)
     hipLaunchKernelGGL(k_route_scatter<true>, dim3(n_tiles), dim3(1024), 0, st, d_words, d_filtered, n, rg, n_ranks, shift,
-                       (const u32 *)tile_cnt, c->x_route.as<u64>(), c->perm.as<u32>());
+                       (const u8 *)d_table, (const u32 *)tile_cnt, c->x_route.as<u64>(), c->perm.as<u32>());
   else
     hipLaunchKernelGGL(k_route_scatter<false>, dim3(n_tiles), dim3(1024), 0, st, d_words, d_filtered, n, rg, n_ranks, shift,
-                       (const u32 *)tile_cnt, c->x_route.as<u64>(), c->perm.as<u32>());
+                       (const u8 *)d_table, (const u32 *)tile_cnt, c->x_route.as<u64>(), c->perm.as<u32>());
   HIPCHK(hipGetLastError());
   c->route_checked = false;
   c->route_bad = bad;

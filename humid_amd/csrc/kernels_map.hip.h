@@ -233,7 +233,7 @@ k_route_items(const u64 *__restrict__ words, const u32 *__restrict__ counts, con
   HUMID_GUARD_LAST_VGPR();
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
-  const u32 i = perm[k];
+  const u32 i = perm ? perm[k] : k;                  // perm == null: one rank, the array goes as it stands
   items[k] = make_ulonglong2(words[i], (id_base + i) | ((u64)(counts ? counts[i] : 0u) << 32));
 }
 
@@ -331,6 +331,44 @@ __global__ void k_pack_cedges(const u32 *__restrict__ cends, u32 n_edges, u64 *_
   if (k < n_edges) out[k] = ((u64)cends[2 * k] << 32) | cends[2 * k + 1];
 }
 
+// ---- compact node list through a mark array (ids below a known bound) instead of a sort ----
+// mark[id] = 1 and cnt_of[id] = count for both ends of every pair record (equal values race freely)
+__global__ void k_mark_ends(const u64 *__restrict__ records, u32 n_edges, u32 stride, u32 id_bound,
+                            u8 *__restrict__ mark, u32 *__restrict__ cnt_of, ull *ctr) {
+  HUMID_GUARD_LAST_VGPR();
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_edges) return;
+  const u64 e = records[(size_t)k * stride];
+  const u32 a = (u32)(e >> 32), b = (u32)e;
+  if (a >= id_bound || b >= id_bound) { ctr[CTR_OVERFULL] = 1; return; }
+  mark[a] = 1;
+  mark[b] = 1;
+  if (stride == 2) {
+    const u64 cc = records[(size_t)k * 2 + 1];
+    cnt_of[a] = (u32)cc;
+    cnt_of[b] = (u32)(cc >> 32);
+  }
+}
+// pos = exclusive scan of mark: nodes[pos[id]] = id, node_cnt[pos[id]] = cnt_of[id] for the marked ids
+__global__ void k_marked_nodes(const u8 *__restrict__ mark, const u32 *__restrict__ pos, const u32 *__restrict__ cnt_of,
+                               u32 id_bound, bool counts, u32 *__restrict__ nodes, u32 *__restrict__ node_cnt) {
+  HUMID_GUARD_LAST_VGPR();
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= id_bound || !mark[i]) return;
+  const u32 q = pos[i];
+  nodes[q] = i;
+  if (counts) node_cnt[q] = cnt_of[i];
+}
+__global__ void k_relabel_pairs(const u64 *__restrict__ records, u32 n_edges, u32 stride, u32 id_bound,
+                                const u32 *__restrict__ pos, u64 *__restrict__ out) {
+  HUMID_GUARD_LAST_VGPR();
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_edges) return;
+  const u64 e = records[(size_t)k * stride];
+  const u32 a = (u32)(e >> 32), b = (u32)e;
+  out[k] = (a < id_bound && b < id_bound) ? (((u64)pos[a] << 32) | pos[b]) : 0ull;
+}
+
 // routed copy of the usable reads' words (owner-major order of humid_stage_owner_perm)
 __global__ void __launch_bounds__(256)
 k_route_words(const u64 *__restrict__ words, const u32 *__restrict__ perm, u32 n, u64 *__restrict__ out) {
@@ -359,10 +397,17 @@ __device__ __forceinline__ u32 owner_of_word(const OwnerRanges &rg, u32 n_ranks,
 // the block itself from the ranges (4 bins per thread).  One LDS read per read instead of 16 pairs of
 // 64-bit compares.  TABLE = false: the compare loop (ranges of any other shape).
 #define ROUTE_BINS 4096u
+// the table is computed once (k_route_table, one block) and copied into LDS by every workgroup: filling it
+// from the ranges in each of the ~1200 workgroups cost as many instructions as the routing itself
+__global__ void __launch_bounds__(1024)
+k_route_table(OwnerRanges rg, u32 n_ranks, u32 shift, u8 *__restrict__ table) {
+  HUMID_GUARD_LAST_VGPR();
+  for (u32 b = threadIdx.x; b < ROUTE_BINS; b += blockDim.x) table[b] = (u8)owner_of_word(rg, n_ranks, (u64)b << shift);
+}
 template <bool TABLE>
-__device__ __forceinline__ void route_fill_table(u8 *own, const OwnerRanges &rg, u32 n_ranks, u32 shift) {
+__device__ __forceinline__ void route_fill_table(u8 *own, const u8 *__restrict__ table) {
   if (!TABLE) return;
-  for (u32 b = threadIdx.x; b < ROUTE_BINS; b += blockDim.x) own[b] = (u8)owner_of_word(rg, n_ranks, (u64)b << shift);
+  for (u32 b = threadIdx.x; b < ROUTE_BINS / 4; b += blockDim.x) ((u32 *)own)[b] = ((const u32 *)table)[b];
   __syncthreads();
 }
 template <bool TABLE>
@@ -377,10 +422,10 @@ __device__ __forceinline__ u32 route_owner(const u8 *own, const OwnerRanges &rg,
 template <bool TABLE>
 __global__ void __launch_bounds__(1024)
 k_route_tile_hist(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n, OwnerRanges rg,
-                  u32 n_ranks, u32 shift, u32 *__restrict__ tile_cnt, u32 *__restrict__ bad) {
+                  u32 n_ranks, u32 shift, const u8 *__restrict__ table, u32 *__restrict__ tile_cnt, u32 *__restrict__ bad) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u32 cnt[MAX_RANKS];
-  __shared__ u8 own[TABLE ? ROUTE_BINS : 4];
+  __shared__ __attribute__((aligned(16))) u8 own[TABLE ? ROUTE_BINS : 4];
   if (blockIdx.x == 0 && threadIdx.x == 0) bad[0] = 0;       // k_route_scan (next launch) may raise it
   if (threadIdx.x < MAX_RANKS) cnt[threadIdx.x] = 0;
   const u32 beg = blockIdx.x * ROUTE_TILE;
@@ -392,7 +437,7 @@ k_route_tile_hist(const u64 *__restrict__ words, const u8 *__restrict__ filtered
     f[k] = j < n ? filtered[j] : (u8)1;
     w[k] = j < n ? words[j] : 0;
   }
-  route_fill_table<TABLE>(own, rg, n_ranks, shift);
+  route_fill_table<TABLE>(own, table);
   if (!TABLE) __syncthreads();
   const u32 lane = threadIdx.x & 63;
   u32 acc = 0;
@@ -440,12 +485,12 @@ k_route_scan(u32 *tile_cnt, u32 n_tiles, OwnerBases ob, u32 *bad) {
 template <bool TABLE>
 __global__ void __launch_bounds__(1024)
 k_route_scatter(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n, OwnerRanges rg,
-                u32 n_ranks, u32 shift, const u32 *__restrict__ tile_off, u64 *__restrict__ routed,
-                u32 *__restrict__ perm) {
+                u32 n_ranks, u32 shift, const u8 *__restrict__ table, const u32 *__restrict__ tile_off,
+                u64 *__restrict__ routed, u32 *__restrict__ perm) {
   HUMID_GUARD_LAST_VGPR();
   constexpr u32 R = ROUTE_TILE / 1024;
   __shared__ u32 wcnt[R][16][MAX_RANKS];   // reads of every owner per round and wave -> their offsets
-  __shared__ u8 own[TABLE ? ROUTE_BINS : 4];
+  __shared__ __attribute__((aligned(16))) u8 own[TABLE ? ROUTE_BINS : 4];
   const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const u64 lt = (1ull << lane) - 1ull;
   const u32 beg = blockIdx.x * ROUTE_TILE;
@@ -457,7 +502,7 @@ k_route_scatter(const u64 *__restrict__ words, const u8 *__restrict__ filtered, 
     f[k] = j < n ? filtered[j] : (u8)1;
     w[k] = j < n ? words[j] : 0;
   }
-  route_fill_table<TABLE>(own, rg, n_ranks, shift);
+  route_fill_table<TABLE>(own, table);
   u32 o[R], rk[R];
 #pragma unroll
   for (u32 k = 0; k < R; k++) {
