@@ -1,5 +1,6 @@
 // sharded.cpp -- see sharded.hpp.  Host C++ above the C ABI: HIP runtime calls for memory, streams and
-// peer copies, RCCL (loaded on demand) for the exchanges, humid_stage_* for all the compute.
+// peer copies, RCCL (loaded on demand) for the exchanges; the pass itself is the library's
+// humid_dedup_run_exchange.
 #include "sharded.hpp"
 
 #include <dlfcn.h>
@@ -20,7 +21,6 @@
 namespace humid_host {
 namespace {
 
-constexpr unsigned HIST_BITS = 12;      // top word bits of the range histogram (humid_amd/sharded.py)
 constexpr unsigned MAX_RANKS = 16;      // humid_stage_route / humid_stage_combo_route (kernels_map.hip.h)
 
 // ---- RCCL, loaded when a run wants it (the single-GPU start-up never pays for the library) ----

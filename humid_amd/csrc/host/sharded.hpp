@@ -3,17 +3,10 @@
 // The reference is a single process on one CPU (/root/reference/src/humid.cc:369-409); this is the
 // multi-GPU form BASELINE.json's north_star asks for ("the host stays C++ ... the read set shards
 // across the GPUs").  The parsed words are cut into N shards in input order, one rank (a host thread
-// with its own humid_ctx, stream and device) per shard; the ranks run the "exchange" orchestration of
-// DESIGN.md section 4a over the stage entry points of include/humid_hip.h (humid_stage_*), the same
-// sequence humid_amd/sharded.py drives from Python:
-//
-//   1. histogram of the top word bits per rank -> balanced, ordered value ranges (host arithmetic)
-//   2. usable words -> owner of their value range            (exchange of 8 B per read)
-//   3. exact counts at the owner (LDS tables)                 (humid_stage_count_dense)
-//   4. neighbour pairs per pigeonhole combination             (exchange of 16 B per unique word and
-//                                                              combination, pairs all-gathered)
-//   5. compact graph over the pairs' endpoints, clustered replicated; ids from prefix counts
-//   6. per-read results back to the home shard                (exchange of 4 B per read)
+// with its own humid_ctx, stream and device) per shard; every rank makes ONE library call per run,
+// humid_dedup_run_exchange (include/humid_hip.h, DESIGN.md section 4a: histogram -> value ranges -> word
+// exchange -> counts -> pairs per combination -> compact graph -> result exchange), and this file
+// supplies the humid_comm callbacks that move bytes between the ranks.
 //
 // Bulk data moves between the ranks' device buffers with RCCL (grouped ncclSend / ncclRecv over
 // xGMI; librccl is loaded on demand) when every rank has a GPU of its own, and with peer copies

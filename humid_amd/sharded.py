@@ -6,8 +6,9 @@ points of include/humid_hip.h:
 mode "exchange" (default, 2..16 ranks) -- every word travels to the rank that owns its VALUE range;
 per-rank work and traffic stay constant as ranks are added (weak scaling):
 
-  1. local histogram of the top word bits + all-reduce (16 KB) -> P ordered, balanced value ranges,
-     cut at boundaries of the prefix combination of the pigeonhole plan;
+  1. local histogram of the top word bits, all-gathered (P x 16 KB) -> P ordered, balanced value
+     ranges, cut at boundaries of the prefix combination of the pigeonhole plan, and every split size
+     of the word exchange;
   2. all-to-all of the usable words to their range owners (8 B per read leaves the rank once);
   3. the owner counts its words (LDS tables, as on one GPU); its ascending unique array is a slice
      of Trie::walk() order, global index = sum of the lower ranks' unique counts + local index;
@@ -38,6 +39,11 @@ without a usable prefix) -- every rank sees every word.  Per pass:
      rank scatters them (humid_stage_owner_perm / humid_stage_scatter).  Both sides derive the
      split sizes from the value ranges, so the streams carry no indices.  (Fallback for > 16
      ranks: humid_stage_map + reduce-scatter of N-sized arrays.)
+
+With the HIP ops the exchange mode is ONE library call per pass (humid_dedup_run_exchange): the stage
+sequence runs inside libhumid_hip.so and this module only supplies the two humid_comm callbacks
+(HipStageOps.run_exchange).  The stage-by-stage form below drives the same entry points from Python
+(HUMID_PY_ORCHESTRATION=1; the oracle-backed CPU ops of the gloo tests always take it).
 
 The compute is behind an `ops` object: HipStageOps (libhumid_hip.so through the C ABI) in
 production; the CPU tests drive the same orchestration over gloo with an oracle-backed ops
