@@ -247,6 +247,7 @@ bool run_rank(Rank &k) {
     STEP(k.hip_ok(hipMemcpyAsync(d_f.p, job.filtered + r0, n_local, hipMemcpyHostToDevice, st), "hipMemcpyAsync (flags)"));
   }
   // the pass itself is the library's (humid_dedup_run_exchange); this file moves the bytes
+  if (P == 1) humid_ctx_set_option(k.ctx, "force_comm", 1);    // (HUMID_FORCE_SHARDED: the point is to run the transport)
   humid_comm cm;
   cm.user = &k;
   cm.rank = r;

@@ -108,6 +108,7 @@ struct humid_ctx {
   bool slots_done = false;   // slot_out already written by k_finalize_nodes (one-GPU fusion)
   int count_mode = 0;        // 0: hash-partitioned LDS tables (default), 1: one global HBM table
   u32 force_segments = 0;    // 0: automatic pigeonhole plan; else the number of segments s
+  bool force_comm = false;   // humid_dedup_run_exchange: call the humid_comm callbacks even with one rank (transport tests)
   u32 walk_max = PT2_TILE;   // k_pairs compares a position with this many followers; longer buckets go to k_pairs_tiles (0: never)
   bool coop_big = true;      // big components: workgroup-cooperative kernel (directional method)
   bool last_count_lds = false;
@@ -1525,6 +1526,10 @@ int humid_ctx_set_option(humid_ctx *c, const char *key, int64_t value) {
     c->coop_big = value != 0;
     return HUMID_OK;
   }
+  if (strcmp(key, "force_comm") == 0) {
+    c->force_comm = value != 0;
+    return HUMID_OK;
+  }
   if (strcmp(key, "bucket_walk") == 0) {
     if (value < 0 || value > (1 << 24)) return fail(c, HUMID_E_INVALID, "bucket_walk must be 0 (no limit) .. 2^24");
     c->walk_max = (u32)value;
@@ -1857,7 +1862,7 @@ int x_order_hint(const std::vector<u64> &hist, const XRange &rg, u32 word_nt, u3
 
 // host numbers of all ranks
 static int x_host_gather(humid_ctx *c, const humid_comm *cm, const void *mine, u64 bytes, void *all) {
-  if (!cm || cm->world == 1) { memcpy(all, mine, bytes); return HUMID_OK; }
+  if (!cm || (cm->world == 1 && !c->force_comm)) { memcpy(all, mine, bytes); return HUMID_OK; }
   if (cm->host_all_gather(cm->user, mine, bytes, all) < 0) return fail(c, HUMID_E_COMM, "humid_comm.host_all_gather failed");
   return HUMID_OK;
 }
@@ -1874,7 +1879,7 @@ static int x_exchange(humid_ctx *c, const humid_comm *cm, const void *d_send, co
     ro[q] = b; rb[q] = recv_items[q] * elem; b += rb[q];
   }
   if (sb[r] != rb[r]) return fail(c, HUMID_E_INVALID, "exchange: this rank's own split sizes differ");
-  if (P == 1) {
+  if (P == 1 && !(cm && c->force_comm)) {
     if (sb[0]) HIPCHK(hipMemcpyAsync(d_recv, d_send, sb[0], hipMemcpyDeviceToDevice, c->stream));
     return HUMID_OK;
   }
@@ -1889,12 +1894,13 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
   const u32 P = cm ? cm->world : 1, r = cm ? cm->rank : 0;
   if (P == 0 || P > MAX_RANKS || r >= P) return fail(c, HUMID_E_UNSUPPORTED, "1 .. %d ranks", MAX_RANKS);
-  if (P > 1 && (!cm->host_all_gather || !cm->exchange)) return fail(c, HUMID_E_INVALID, "humid_comm without callbacks");
+  if ((P > 1 || (cm && c->force_comm)) && (!cm->host_all_gather || !cm->exchange)) return fail(c, HUMID_E_INVALID, "humid_comm without callbacks");
   TRY(check_run_args(c, n_local, word_nt, method));
   if (n_local && (!d_words || !d_filtered || !d_cluster_id || !d_keep)) return fail(c, HUMID_E_INVALID, "null buffer");
   HIPCHK(hipSetDevice(c->device));
   hipStream_t st = c->stream;
   const auto t_begin = std::chrono::steady_clock::now();
+  const bool moves = P > 1 || (cm && c->force_comm);                 // bytes go through the callbacks
   const u32 n = word_nt, d = distance;
   // ---- 1. histograms of all ranks -> value ranges and every split size of the word exchange ----
   u32 nc1 = 0, pbits = 0;
@@ -1947,7 +1953,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   const u32 *d_perm = nullptr;
   TRY(humid_stage_route(c, d_words, d_filtered, n_local, lo, hi, P, send_counts, &d_routed, &d_perm));
   const u64 *recv_w = d_routed;                                     // one rank: what was routed is what arrives
-  if (P > 1) {
+  if (moves) {
     ENSURE(c->xr_recv, n_recv * 8 + 8);
     TRY(x_exchange(c, cm, d_routed, send_counts, false, c->xr_recv.p, recv_counts, 8));
     recv_w = c->xr_recv.as<u64>();
@@ -2007,7 +2013,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
       u64 n_got = 0;
       for (u32 q = 0; q < P; q++) { rc[q] = all_sc[(size_t)q * P + r]; n_got += rc[q]; }
       const u64 *got = items;
-      if (P > 1) {
+      if (moves) {
         ENSURE(c->xr_got, n_got * 16 + 16);
         TRY(x_exchange(c, cm, items, sc, false, c->xr_got.p, rc, 16));
         got = c->xr_got.as<u64>();
@@ -2023,7 +2029,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   u64 E = 0;
   for (u32 q = 0; q < P; q++) E += e_counts[q];
   const u64 *d_eall = c->xr_eloc.as<u64>();
-  if (P > 1) {
+  if (moves) {
     ENSURE(c->xr_eall, E * 16 + 16);
     ENSURE(c->xr_eloc, 16);
     TRY(x_exchange(c, cm, c->xr_eloc.p, e_counts, true, c->xr_eall.p, e_counts, 16));
@@ -2055,7 +2061,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   TRY(humid_stage_map_dense(c, l_cid, l_ismax, &packed, &n_packed));
   if (n_packed != n_recv) return fail(c, HUMID_E_INVALID, "map_dense returned %llu reads, %llu were counted", (ull)n_packed, (ull)n_recv);
   const u32 *ret = packed;
-  if (P > 1) {
+  if (moves) {
     ENSURE(c->xr_ret, n_send * 4 + 8);
     TRY(x_exchange(c, cm, packed, recv_counts, false, c->xr_ret.p, send_counts, 4));
     ret = c->xr_ret.as<u32>();

@@ -613,6 +613,17 @@ def test_sharded_world1_nccl():
         assert np.array_equal(d_k.cpu().numpy(), okeep)
         for k in ("total", "usable", "unique", "clusters"):
             assert s[k] == osum[k]
+        # the same through the humid_comm callbacks (all_to_all_single / all_gather_into_tensor of RCCL on
+        # views of the library's buffers): with one rank the library would not call them by itself
+        d_c.zero_()
+        d_k.zero_()
+        sd.ops.set_option("force_comm", 1)
+        for _ in range(2):
+            s = sd.run(d_w, d_f, d_c, d_k)
+        sd.ops.set_option("force_comm", 0)
+        assert np.array_equal(d_c.cpu().numpy().view(np.uint32), ocid)
+        assert np.array_equal(d_k.cpu().numpy(), okeep)
+        assert s["edges"] == osum["edges"] and s["clusters"] == osum["clusters"]
     finally:
         dist.destroy_process_group()
 
