@@ -37,6 +37,17 @@ void parallel_ranges(size_t n, unsigned threads, const std::function<void(size_t
   for (auto &t : pool) t.join();
 }
 
+void MappedFastq::drop_pages(unsigned threads) const {
+  if (!data || size < (1u << 20)) return;
+  const size_t page = 4096;
+  const uintptr_t lo = ((uintptr_t)data + page - 1) & ~(uintptr_t)(page - 1), hi = ((uintptr_t)data + size) & ~(uintptr_t)(page - 1);
+  if (hi <= lo) return;
+  const size_t pages = (hi - lo) / page;
+  parallel_ranges(pages, threads, [&](size_t b, size_t e, unsigned) {
+    if (e > b) madvise((void *)(lo + b * page), (e - b) * page, MADV_DONTNEED);
+  });
+}
+
 MappedFastq::~MappedFastq() {
   if (data) munmap((void *)data, size);
   if (fd_ >= 0) close(fd_);
