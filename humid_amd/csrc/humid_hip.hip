@@ -853,6 +853,28 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
       } else {
         u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
         const u32 kb = plan.key_bits ? plan.key_bits : 1;
+        WT *ws = c->seg_ws.as<WT>() + (size_t)(seg - 1) * U;
+        // a key that is ONE stretch of the word (a single segment, or neighbouring segments): the
+        // words themselves are the sort keys over that bit range and come out in bucket order, the
+        // ranks ride along as values -- no key array, and no gather of the words afterwards (44 us
+        // and 320 MB of traffic at 10 M reads; the 8-byte keys cost the sort 19 us more:
+        // tools/sort_probe.hip)
+        u32 bit_lo = 0, bit_n = 0;
+        bool stretch = std::is_same<WT, u64>::value && plan.nfield[seg] >= 1;
+        for (u32 f = 0; stretch && f < plan.nfield[seg]; f++) {
+          if (f + 1 < plan.nfield[seg] && plan.shift[seg][f] != plan.shift[seg][f + 1] + plan.width[seg][f + 1]) stretch = false;
+          bit_n += plan.width[seg][f];
+          bit_lo = plan.shift[seg][f];
+        }
+        if (stretch && bit_n >= 1 && bit_lo + bit_n <= 64) {
+          rocprim::counting_iterator<u32> ranks(0);
+          size_t bytes = 0;
+          HIPCHK(rocprim::radix_sort_pairs<onesweep_cfg>(nullptr, bytes, (const u64 *)g_word, (u64 *)ws, ranks, vs, (size_t)U, bit_lo,
+                                                         bit_lo + bit_n, st));
+          ENSURE(c->tmp, bytes);
+          HIPCHK(rocprim::radix_sort_pairs<onesweep_cfg>(c->tmp.p, bytes, (const u64 *)g_word, (u64 *)ws, ranks, vs, (size_t)U, bit_lo,
+                                                         bit_lo + bit_n, st));
+        } else {
         if (kb <= 32) {
           hipLaunchKernelGGL((k_combo_keys<u32, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, fields_of(seg),
                              c->seg_k0.as<u32>(), c->seg_v0.as<u32>());
@@ -862,8 +884,8 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
                              c->seg_k0.as<u64>(), c->seg_v0.as<u32>());
           TRY(sort_pairs<u64, u32>(c, c->seg_k0.as<u64>(), c->seg_ks.as<u64>(), c->seg_v0.as<u32>(), vs, U, 0, kb));
         }
-        WT *ws = c->seg_ws.as<WT>() + (size_t)(seg - 1) * U;
         hipLaunchKernelGGL(k_gather_bucket_words<WT>, dim3(blocks_for(U)), dim3(256), 0, st, g_word, vs, U, ws);
+        }
         if (seg < 8) HIPCHK(hipEventRecord(c->kev[20 + 2 * seg], st));
         hipLaunchKernelGGL((k_pairs<false, PM_COUNT, WT>), dim3(blocks_for(U)), dim3(256), 0, st, ws,
                            vs, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, c->deg.as<u32>(), c->parent.as<u32>(),
