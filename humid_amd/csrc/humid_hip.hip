@@ -715,6 +715,29 @@ static int stage_count_wide(humid_ctx *c, const W2 *d_words, const u8 *d_filt, u
   return HUMID_OK;
 }
 
+// A combination whose key is ONE stretch of the word (a single segment, or neighbouring segments):
+// the words themselves are the sort keys over that bit range and come out in bucket order (ws), the
+// positions ride along as values (vs) -- no key array, and no gather of the words afterwards (44 us
+// and 320 MB of traffic at 10 M reads; the 8-byte keys cost the sort 19 us more: tools/sort_probe.hip).
+// *done = false: the key is not one stretch, nothing was queued.
+static int sort_words_by_stretch(humid_ctx *c, const ComboPlan &plan, u32 cb, const u64 *W, u32 n, u64 *ws, u32 *vs, bool *done) {
+  u32 bit_lo = 0, bit_n = 0;
+  bool stretch = plan.nfield[cb] >= 1;
+  for (u32 f = 0; stretch && f < plan.nfield[cb]; f++) {
+    if (f + 1 < plan.nfield[cb] && plan.shift[cb][f] != plan.shift[cb][f + 1] + plan.width[cb][f + 1]) stretch = false;
+    bit_n += plan.width[cb][f];
+    bit_lo = plan.shift[cb][f];
+  }
+  *done = stretch && bit_n >= 1 && bit_lo + bit_n <= 64;
+  if (!*done) return HUMID_OK;
+  rocprim::counting_iterator<u32> pos(0);
+  size_t bytes = 0;
+  HIPCHK(rocprim::radix_sort_pairs<onesweep_cfg>(nullptr, bytes, W, ws, pos, vs, (size_t)n, bit_lo, bit_lo + bit_n, c->stream));
+  ENSURE(c->tmp, bytes);
+  HIPCHK(rocprim::radix_sort_pairs<onesweep_cfg>(c->tmp.p, bytes, W, ws, pos, vs, (size_t)n, bit_lo, bit_lo + bit_n, c->stream));
+  return HUMID_OK;
+}
+
 // ---- stage B: neighbours + clusters over a sorted unique array ---------------------------
 // g_word[U] ascending, g_cnt[U] (device; the context's own arrays on one GPU, the gathered
 // arrays of all ranks on several).  Leaves deg/nbr_off/nbr_idx/cl_of/maxleaf/cl_size/flag/
@@ -854,26 +877,10 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
         u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
         const u32 kb = plan.key_bits ? plan.key_bits : 1;
         WT *ws = c->seg_ws.as<WT>() + (size_t)(seg - 1) * U;
-        // a key that is ONE stretch of the word (a single segment, or neighbouring segments): the
-        // words themselves are the sort keys over that bit range and come out in bucket order, the
-        // ranks ride along as values -- no key array, and no gather of the words afterwards (44 us
-        // and 320 MB of traffic at 10 M reads; the 8-byte keys cost the sort 19 us more:
-        // tools/sort_probe.hip)
-        u32 bit_lo = 0, bit_n = 0;
-        bool stretch = std::is_same<WT, u64>::value && plan.nfield[seg] >= 1;
-        for (u32 f = 0; stretch && f < plan.nfield[seg]; f++) {
-          if (f + 1 < plan.nfield[seg] && plan.shift[seg][f] != plan.shift[seg][f + 1] + plan.width[seg][f + 1]) stretch = false;
-          bit_n += plan.width[seg][f];
-          bit_lo = plan.shift[seg][f];
-        }
-        if (stretch && bit_n >= 1 && bit_lo + bit_n <= 64) {
-          rocprim::counting_iterator<u32> ranks(0);
-          size_t bytes = 0;
-          HIPCHK(rocprim::radix_sort_pairs<onesweep_cfg>(nullptr, bytes, (const u64 *)g_word, (u64 *)ws, ranks, vs, (size_t)U, bit_lo,
-                                                         bit_lo + bit_n, st));
-          ENSURE(c->tmp, bytes);
-          HIPCHK(rocprim::radix_sort_pairs<onesweep_cfg>(c->tmp.p, bytes, (const u64 *)g_word, (u64 *)ws, ranks, vs, (size_t)U, bit_lo,
-                                                         bit_lo + bit_n, st));
+        bool stretch = false;
+        if (std::is_same<WT, u64>::value)
+          TRY(sort_words_by_stretch(c, plan, seg, (const u64 *)g_word, U, (u64 *)ws, vs, &stretch));
+        if (stretch) {
         } else {
         if (kb <= 32) {
           hipLaunchKernelGGL((k_combo_keys<u32, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, fields_of(seg),
@@ -2546,17 +2553,21 @@ int humid_stage_pairs_keyed(humid_ctx *c, const uint64_t *d_items, uint64_t n_it
     hipLaunchKernelGGL(k_split_items, dim3(blocks_for(n)), dim3(256), 0, st, (const ulonglong2 *)d_items, n,
                        c->x_w.as<u64>(), c->x_id.as<u32>(), c->x_cnt.as<u32>());
     const u32 kb = plan.key_bits ? plan.key_bits : 1;
-    if (kb <= 32) {
-      hipLaunchKernelGGL((k_combo_keys<u32, u64>), dim3(blocks_for(n)), dim3(256), 0, st, c->x_w.as<u64>(), n,
-                         plan_fields(plan, combo), c->seg_k0.as<u32>(), c->seg_v0.as<u32>());
-      TRY(sort_pairs<u32, u32>(c, c->seg_k0.as<u32>(), c->seg_ks.as<u32>(), c->seg_v0.as<u32>(), c->seg_vs.as<u32>(), n, 0, kb));
-    } else {
-      hipLaunchKernelGGL((k_combo_keys<u64, u64>), dim3(blocks_for(n)), dim3(256), 0, st, c->x_w.as<u64>(), n,
-                         plan_fields(plan, combo), c->seg_k0.as<u64>(), c->seg_v0.as<u32>());
-      TRY(sort_pairs<u64, u32>(c, c->seg_k0.as<u64>(), c->seg_ks.as<u64>(), c->seg_v0.as<u32>(), c->seg_vs.as<u32>(), n, 0, kb));
+    bool stretch = false;
+    TRY(sort_words_by_stretch(c, plan, combo, c->x_w.as<u64>(), n, c->seg_ws.as<u64>(), c->seg_vs.as<u32>(), &stretch));
+    if (!stretch) {
+      if (kb <= 32) {
+        hipLaunchKernelGGL((k_combo_keys<u32, u64>), dim3(blocks_for(n)), dim3(256), 0, st, c->x_w.as<u64>(), n,
+                           plan_fields(plan, combo), c->seg_k0.as<u32>(), c->seg_v0.as<u32>());
+        TRY(sort_pairs<u32, u32>(c, c->seg_k0.as<u32>(), c->seg_ks.as<u32>(), c->seg_v0.as<u32>(), c->seg_vs.as<u32>(), n, 0, kb));
+      } else {
+        hipLaunchKernelGGL((k_combo_keys<u64, u64>), dim3(blocks_for(n)), dim3(256), 0, st, c->x_w.as<u64>(), n,
+                           plan_fields(plan, combo), c->seg_k0.as<u64>(), c->seg_v0.as<u32>());
+        TRY(sort_pairs<u64, u32>(c, c->seg_k0.as<u64>(), c->seg_ks.as<u64>(), c->seg_v0.as<u32>(), c->seg_vs.as<u32>(), n, 0, kb));
+      }
+      hipLaunchKernelGGL(k_gather_bucket_words<u64>, dim3(blocks_for(n)), dim3(256), 0, st, c->x_w.as<u64>(),
+                         c->seg_vs.as<u32>(), n, c->seg_ws.as<u64>());
     }
-    hipLaunchKernelGGL(k_gather_bucket_words<u64>, dim3(blocks_for(n)), dim3(256), 0, st, c->x_w.as<u64>(),
-                       c->seg_vs.as<u32>(), n, c->seg_ws.as<u64>());
     // pairs of positions in the received array (V = bucket order -> received position)
     TRY(emit_pairs(c, c->seg_ws.as<u64>(), c->seg_vs.as<u32>(), n, plan, combo, distance, &E));
     id_of = c->x_id.as<u32>();

@@ -326,8 +326,15 @@ class HipStageOps(Context):
                     if all(x == rb[0] for x in rb):
                         _all_gather_flat(dist, out, inp, world)
                     else:
-                        got, _ = _all_gather_var(dist, inp, world)
-                        out.copy_(got)
+                        # different lengths, all known (the library gathered them): grouped point-to-point
+                        # messages straight into place where the backend has them, else the padded form
+                        try:
+                            if _bounce(dist, inp):
+                                raise NotImplementedError
+                            dist.all_to_all([out[ro[q]:ro[q] + rb[q]] for q in range(world)], [inp] * world)
+                        except (RuntimeError, NotImplementedError, AttributeError, ValueError):
+                            got, _ = _all_gather_var(dist, inp, world)
+                            out.copy_(got)
                 else:
                     inp = self._bytes(d_send, so[-1] + sb[-1])
                     _all_to_all_v(dist, out, inp, rb, sb, world, rank)
