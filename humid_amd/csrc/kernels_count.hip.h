@@ -238,8 +238,18 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
     if (threadIdx.x == 0) { ucount[b] = 0; pusable[b] = 0; }
     return;
   }
+  // a thread's first four positions are requested before the table is cleared (their latency hides
+  // behind the clearing and its barrier: buckets hold ~350 reads, i.e. 1-2 positions per thread) and
+  // stay in registers for the second pass below; the rest (buckets beyond 1024 reads) one by one
+  u64 kq[4];
+  u32 vq[4];
+#pragma unroll
+  for (u32 q = 0; q < 4; q++) {
+    const u32 i = beg + threadIdx.x + 256u * q;
+    if (i < end) { vq[q] = vals[i]; kq[q] = keys[i]; }
+  }
   for (u32 s = threadIdx.x; s <= LDS_SLOTS; s += 256) { lkey[s] = EMPTY_KEY; lcnt[s] = 0; lfirst[s] = NONE32; }
-  if (threadIdx.x == 0) lcount = 0;
+  if (threadIdx.x == 0) { lcount = 0; lds[0] = 0; }
   __syncthreads();
   const u32 hshift = 64 - pb - LDS_SLOT_BITS;   // table index = the key bits just below the bucket bits
   u32 usable = 0;
@@ -269,25 +279,20 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
     atomicMin(&lfirst[s], v);
     return true;
   };
-  {
-    // a thread's first four positions are loaded together (one round trip to memory instead of
-    // four: buckets hold ~700 reads, i.e. 3 positions per thread), the rest one by one
-    u64 kq[4];
-    u32 vq[4];
 #pragma unroll
-    for (u32 q = 0; q < 4; q++) {
-      const u32 i = beg + threadIdx.x + 256u * q;
-      if (i < end) { vq[q] = vals[i]; kq[q] = keys[i]; }
-    }
-#pragma unroll
-    for (u32 q = 0; q < 4; q++) {
-      const u32 i = beg + threadIdx.x + 256u * q;
-      if (i < end && !overflow && !insert(i, vq[q], kq[q])) overflow = true;
-    }
-    for (u32 i = beg + threadIdx.x + 1024u; i < end && !overflow; i += 256)
-      if (!insert(i, vals[i], keys[i])) overflow = true;
+  for (u32 q = 0; q < 4; q++) {
+    const u32 i = beg + threadIdx.x + 256u * q;
+    if (i < end && !overflow && !insert(i, vq[q], kq[q])) overflow = true;
   }
+  for (u32 i = beg + threadIdx.x + 1024u; i < end && !overflow; i += 256)
+    if (!insert(i, vals[i], keys[i])) overflow = true;
   if (overflow) ctr[CTR_OVERFULL] = 1;
+  {                                           // usable reads of the bucket: one LDS add per wave, before the barrier
+    u32 x = usable;
+#pragma unroll
+    for (u32 d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+    if ((threadIdx.x & 63) == 0 && x) atomicAdd(&lds[0], x);
+  }
   __syncthreads();
   // registered entries -> padded arrays (index < unique words <= reads of the bucket = padded
   // room); lfirst[s] is then reused as entry -> index
@@ -336,9 +341,7 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
     pad_cf[beg + li] = make_uint2(lcnt[s], lfirst[s]);
     lfirst[s] = li;
   }
-  if (threadIdx.x == 0) ucount[b] = n_uniq;
-  const u32 tu = block_sum(usable, lds);
-  if (threadIdx.x == 0) pusable[b] = tu;
+  if (threadIdx.x == 0) { ucount[b] = n_uniq; pusable[b] = lds[0]; }
   __syncthreads();
   // second pass: every position learns the padded slot of its word (coalesced store; the
   // per-read outputs are produced later in this same partition order, see k_read_map_bucket)
@@ -355,21 +358,12 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
     const u32 li = lfirst[s];
     pslot[i] = (li < end - beg) ? beg + li : NOSLOT;
   };
-  {
-    u64 kq[4];
-    u32 vq[4];
 #pragma unroll
-    for (u32 q = 0; q < 4; q++) {
-      const u32 i = beg + threadIdx.x + 256u * q;
-      if (i < end) { vq[q] = vals[i]; kq[q] = keys[i]; }
-    }
-#pragma unroll
-    for (u32 q = 0; q < 4; q++) {
-      const u32 i = beg + threadIdx.x + 256u * q;
-      if (i < end) locate(i, vq[q], kq[q]);
-    }
-    for (u32 i = beg + threadIdx.x + 1024u; i < end; i += 256) locate(i, vals[i], keys[i]);
+  for (u32 q = 0; q < 4; q++) {
+    const u32 i = beg + threadIdx.x + 256u * q;
+    if (i < end) locate(i, vq[q], kq[q]);
   }
+  for (u32 i = beg + threadIdx.x + 1024u; i < end; i += 256) locate(i, vals[i], keys[i]);
 }
 
 // totals over the buckets: U = sum ucount, usable = sum pusable (a few blocks, two atomics each;
