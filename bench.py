@@ -107,9 +107,12 @@ def e2e_leg(n_reads, word_nt, distance):
                     phases["device detail"] = line[7:].strip()
                 elif line.startswith("[humid]   init thread"):
                     phases["init thread"] = line[7:].strip()
-                elif line.startswith("[humid]"):
-                    name, val = line[7:].rsplit(None, 2)[0].strip(), line.split()[-2]
-                    phases[name] = float(val)
+                elif line.startswith("[humid]") and "epoch" not in line:
+                    try:
+                        name, val = line[7:].rsplit(None, 2)[0].strip(), line.split()[-2]
+                        phases[name] = float(val)
+                    except (ValueError, IndexError):      # a line of another shape: not a phase time
+                        pass
             kept = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out))
             if best is None or dt < best["t_e2e_s"]:
                 best = {"t_e2e_s": round(dt, 4), "e2e_reads_per_s": round(n_reads / dt, 1),
