@@ -715,6 +715,37 @@ static int stage_count_wide(humid_ctx *c, const W2 *d_words, const u8 *d_filt, u
   return HUMID_OK;
 }
 
+// buckets longer than k_pairs' bounded walk, over the walked order W[0, n) of one combination: device list at
+// c->big_runs + slot * cap (start, length, first tile), host copy in `runs` with the total as a last entry
+template <class WT>
+static int find_big_runs(humid_ctx *c, const WT *W, u32 n, WT mask, u32 walk_max, u32 slot, std::vector<BigRun> &runs,
+                         const BigRun **d_runs_out) {
+  hipStream_t st = c->stream;
+  const u32 cap = n / (walk_max + 2) + 1;                         // runs are disjoint and longer than walk_max + 1
+  ENSURE(c->big_runs, (size_t)MAX_COMBOS * cap * sizeof(BigRun) + 16);
+  u32 *d_n = (u32 *)((char *)c->big_runs.p + (size_t)MAX_COMBOS * cap * sizeof(BigRun));
+  BigRun *d_runs = c->big_runs.as<BigRun>() + (size_t)slot * cap;
+  HIPCHK(hipMemsetAsync(d_n, 0, 4, st));
+  hipLaunchKernelGGL(k_big_runs<WT>, dim3(blocks_for(n)), dim3(256), 0, st, W, n, mask, walk_max, d_runs, cap, d_n);
+  u32 n_runs = 0;
+  HIPCHK(hipMemcpyAsync(&n_runs, d_n, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (n_runs > cap) return fail(c, HUMID_E_INVALID, "more large buckets (%u) than fit the input (%u)", n_runs, cap);
+  runs.resize(n_runs);
+  if (n_runs) HIPCHK(hipMemcpy(runs.data(), d_runs, (size_t)n_runs * sizeof(BigRun), hipMemcpyDeviceToHost));
+  std::sort(runs.begin(), runs.end(), [](const BigRun &x, const BigRun &y) { return x.start < y.start; });
+  ull tiles = 0;
+  for (BigRun &x : runs) {
+    const ull nt = ((ull)x.len + PT2_TILE - 1) / PT2_TILE;
+    x.tile0 = tiles;
+    tiles += nt * (nt + 1) / 2;
+  }
+  runs.push_back(BigRun{0u, 0u, tiles});                          // sentinel: the total
+  if (n_runs) HIPCHK(hipMemcpy(d_runs, runs.data(), (size_t)n_runs * sizeof(BigRun), hipMemcpyHostToDevice));
+  *d_runs_out = d_runs;
+  return HUMID_OK;
+}
+
 // A combination whose key is ONE stretch of the word (a single segment, or neighbouring segments):
 // the words themselves are the sort keys over that bit range and come out in bucket order (ws), the
 // positions ride along as values (vs) -- no key array, and no gather of the words afterwards (44 us
@@ -807,30 +838,8 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
   auto big_find = [&](u32 seg) -> int {
     const WT *W; const u32 *V;
     walked(seg, W, V);
-    const u32 cap = U / (walk_max + 2) + 1;                       // runs are disjoint and longer than walk_max + 1
-    ENSURE(c->big_runs, (size_t)MAX_COMBOS * cap * sizeof(BigRun) + 16);
-    u32 *d_n = (u32 *)((char *)c->big_runs.p + (size_t)MAX_COMBOS * cap * sizeof(BigRun));
-    BigRun *d_runs = c->big_runs.as<BigRun>() + (size_t)seg * cap;
-    HIPCHK(hipMemsetAsync(d_n, 0, 4, st));
-    hipLaunchKernelGGL(k_big_runs<WT>, dim3(blocks_for(U)), dim3(256), 0, st, W, U, w_from<WT>(plan.mask[seg]), walk_max,
-                       d_runs, cap, d_n);
-    u32 n_runs = 0;
-    HIPCHK(hipMemcpyAsync(&n_runs, d_n, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (n_runs > cap) return fail(c, HUMID_E_INVALID, "more large buckets (%u) than fit the input (%u)", n_runs, cap);
-    std::vector<BigRun> &r = h_runs[seg];
-    r.resize(n_runs);
-    if (n_runs) HIPCHK(hipMemcpy(r.data(), d_runs, (size_t)n_runs * sizeof(BigRun), hipMemcpyDeviceToHost));
-    std::sort(r.begin(), r.end(), [](const BigRun &x, const BigRun &y) { return x.start < y.start; });
-    ull tiles = 0;
-    for (BigRun &x : r) {
-      const ull nt = ((ull)x.len + PT2_TILE - 1) / PT2_TILE;
-      x.tile0 = tiles;
-      tiles += nt * (nt + 1) / 2;
-    }
-    r.push_back(BigRun{0u, 0u, tiles});                           // sentinel: the total
-    if (n_runs) HIPCHK(hipMemcpy(d_runs, r.data(), (size_t)n_runs * sizeof(BigRun), hipMemcpyHostToDevice));
-    return HUMID_OK;
+    const BigRun *d_runs = nullptr;
+    return find_big_runs<WT>(c, W, U, w_from<WT>(plan.mask[seg]), walk_max, seg, h_runs[seg], &d_runs);
   };
   auto big_tiles = [&](u32 seg, int mode) -> int {
     const std::vector<BigRun> &r = h_runs[seg];
@@ -2492,30 +2501,66 @@ static int emit_pairs(humid_ctx *c, const u64 *W, const u32 *V, u32 n, const Com
   ENSURE(c->pc, ((size_t)n + 1) * 4);
   ENSURE(c->poff, ((size_t)n + 1) * 4);
   HIPCHK(hipMemsetAsync(c->pc.as<u32>() + n, 0, 4, st));
+  HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_BIGMASK], 0, sizeof(ull), st));
+  // the walk of a position is bounded as on one GPU; buckets beyond it are finished as tiles below
+  const u32 walk_max = c->walk_max;
   const dim3 grid(blocks_for(n)), blk(256);
   if (V)
     hipLaunchKernelGGL((k_pairs<false, PM_EMIT_COUNT, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
                        cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
-                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr);
+                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr, walk_max,
+                       &c->d_ctr[CTR_BIGMASK]);
   else
     hipLaunchKernelGGL((k_pairs<true, PM_EMIT_COUNT, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
                        cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
-                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr);
+                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr, walk_max,
+                       &c->d_ctr[CTR_BIGMASK]);
   TRY(exscan_u32(c, c->pc.as<u32>(), c->poff.as<u32>(), (u64)n + 1));
   HIPCHK(hipGetLastError());
   TRY(read_counters(c, c->poff.as<u32>() + n));
-  const u64 E = c->h_ctr[CTR_N - 1] & 0xffffffffull;
-  *E_out = E;
-  if (E == 0) return HUMID_OK;
-  ENSURE(c->share_edges, (size_t)E * 8);
-  if (V)
-    hipLaunchKernelGGL((k_pairs<false, PM_EMIT_FILL, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
-                       cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
-                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr);
-  else
-    hipLaunchKernelGGL((k_pairs<true, PM_EMIT_FILL, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
-                       cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
-                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr);
+  u64 E = c->h_ctr[CTR_N - 1] & 0xffffffffull;
+  // pairs further apart than the walk inside large buckets: counted, then appended behind the others
+  std::vector<BigRun> runs;
+  const BigRun *d_runs = nullptr;
+  u64 E_far = 0;
+  ull tiles = 0;
+  if (c->h_ctr[CTR_BIGMASK]) {
+    TRY(find_big_runs<u64>(c, W, n, plan.mask[cb].lo, walk_max, 0, runs, &d_runs));
+    tiles = runs.back().tile0;
+  }
+  const u32 tgrid = (u32)std::min<ull>(tiles ? tiles : 1, 1u << 20);
+#define EMIT_TILES(P0, M)                                                                                              \
+  hipLaunchKernelGGL((k_pairs_tiles<P0, M, u64>), dim3(tgrid), dim3(PT2_THREADS), 0, st, W, V, d_runs, (u32)runs.size() - 1, \
+                     tiles, d_masks, cb, distance, walk_max, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr,         \
+                     (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, c->share_edges.as<u64>(), &c->d_ctr[CTR_SPECIAL])
+  if (tiles) {
+    HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_SPECIAL], 0, sizeof(ull), st));
+    if (V) EMIT_TILES(false, PM_EMIT_COUNT); else EMIT_TILES(true, PM_EMIT_COUNT);
+    HIPCHK(hipGetLastError());
+    TRY(read_counters(c));
+    E_far = c->h_ctr[CTR_SPECIAL];
+  }
+  if (E + E_far > 0xffffffffull) return fail(c, HUMID_E_OVERFLOW, "%llu neighbour pairs in one share", (ull)(E + E_far));
+  *E_out = E + E_far;
+  if (E + E_far == 0) return HUMID_OK;
+  ENSURE(c->share_edges, (size_t)(E + E_far) * 8);
+  if (E) {
+    if (V)
+      hipLaunchKernelGGL((k_pairs<false, PM_EMIT_FILL, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
+                         cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
+                         (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr, walk_max);
+    else
+      hipLaunchKernelGGL((k_pairs<true, PM_EMIT_FILL, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
+                         cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
+                         (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr, walk_max);
+  }
+  if (E_far) {
+    const ull at = E;                                               // the cursor of the append starts behind k_pairs' pairs
+    HIPCHK(hipMemcpyAsync(&c->d_ctr[CTR_SPECIAL], &at, sizeof(ull), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));                               // (`at` is a host temporary)
+    if (V) EMIT_TILES(false, PM_EMIT_FILL); else EMIT_TILES(true, PM_EMIT_FILL);
+  }
+#undef EMIT_TILES
   HIPCHK(hipGetLastError());
   return HUMID_OK;
 }

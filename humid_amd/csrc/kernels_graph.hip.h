@@ -170,7 +170,7 @@ k_pairs(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, u32 i0, u32 
   if (MODE == PM_COUNT && found) atomicAdd(&deg[ri], found);
   if (MODE == PM_COUNT && had) had[t] = found ? 1 : 0;
   if (MODE == PM_EMIT_COUNT) pc[t] = found;
-  if (MODE == PM_COUNT && big && j == jend && jend < n && !w_hits(w_xor(wi, W[jend]), mask))
+  if ((MODE == PM_COUNT || MODE == PM_EMIT_COUNT) && big && j == jend && jend < n && !w_hits(w_xor(wi, W[jend]), mask))
     atomicOr(big, 1ull << cb);
 }
 
@@ -210,9 +210,13 @@ template <bool PASS0, int MODE, class WT>
 __global__ void __launch_bounds__(PT2_THREADS)
 k_pairs_tiles(const WT *__restrict__ W, const u32 *__restrict__ V, const BigRun *__restrict__ runs, u32 n_runs,
               ull total_tiles, EarlierMasksT<WT> em, u32 cb, u32 distance, u32 walk_max, u32 *deg, u32 *parent,
-              const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, const u32 *__restrict__ cnt) {
+              const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, const u32 *__restrict__ cnt,
+              u64 *__restrict__ edges = nullptr, ull *ecount = nullptr) {
   HUMID_GUARD_LAST_VGPR();
+  // PM_EMIT_COUNT: *ecount += pairs found (one add per wave and square); PM_EMIT_FILL: the pairs are
+  // appended to edges[] at *ecount (which the caller set to the pairs already there)
   __shared__ WT sb[PT2_TILE];
+  u32 emitted = 0;
   for (ull q = blockIdx.x; q < total_tiles; q += gridDim.x) {
     u32 lo = 0, hi = n_runs;                                      // the run whose tiles hold q
     while (hi - lo > 1) {
@@ -256,13 +260,22 @@ k_pairs_tiles(const WT *__restrict__ W, const u32 *__restrict__ V, const BigRun 
         if (MODE == PM_FILL) {
           nbr_idx[nbr_off[ri] + atomicAdd(&cur[ri], 1u)] = rj;
           nbr_idx[nbr_off[rj] + atomicAdd(&cur[rj], 1u)] = ri;
-        } else {
+        } else if (MODE == PM_COUNT) {
           atomicAdd(&deg[ri], 1u);
           atomicAdd(&deg[rj], 1u);
           if (joins_for_clustering(cnt, ri, rj)) uf_union(parent, ri, rj);
+        } else if (MODE == PM_EMIT_COUNT) {
+          emitted++;
+        } else {
+          edges[atomicAdd(ecount, 1ull)] = ri < rj ? (((u64)ri << 32) | rj) : (((u64)rj << 32) | ri);
         }
       }
     }
+  }
+  if (MODE == PM_EMIT_COUNT) {
+#pragma unroll
+    for (u32 dd = 32; dd >= 1; dd >>= 1) emitted += __shfl_xor(emitted, dd);
+    if ((threadIdx.x & 63) == 0 && emitted) atomicAdd(ecount, (ull)emitted);
   }
 }
 

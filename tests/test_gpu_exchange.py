@@ -12,7 +12,7 @@ from oracle import pyoracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def run_ranks(P, words, filt, n, d, method, mode, sizes=None, plan_segments=0, passes=1, edit=False):
+def run_ranks(P, words, filt, n, d, method, mode, sizes=None, plan_segments=0, passes=1, edit=False, bucket_walk=None):
     import torch
     from fake_dist import FakeDist, FakeWorld
     from humid_amd.sharded import HipStageOps, ShardedDedup
@@ -30,6 +30,8 @@ def run_ranks(P, words, filt, n, d, method, mode, sizes=None, plan_segments=0, p
             ops = HipStageOps(0)
             if plan_segments:
                 ops.set_option("plan_segments", plan_segments)
+            if bucket_walk is not None:
+                ops.set_option("bucket_walk", bucket_walk)
             sd = ShardedDedup(device=0, word_nt=n, distance=d, method=method, ops=ops,
                               dist=FakeDist(world, r), mode=mode, edit=edit)
             w = torch.from_numpy(words[offs[r]:offs[r + 1]].view(np.int64).copy()).to(dev)
@@ -271,3 +273,32 @@ def test_stage_by_stage_python_form_still_matches(P, monkeypatch):
         assert used == "exchange"
         assert np.array_equal(cid, ocid[offs[r]:offs[r + 1]]) and np.array_equal(keep, okeep[offs[r]:offs[r + 1]])
         assert s["edges"] == osum["edges"] and s["clusters"] == osum["clusters"]
+
+
+@pytest.mark.parametrize("P,walk", [(1, 3), (3, 3), (2, 200), (4, None)])
+def test_exchange_large_buckets_go_through_the_tiles(P, walk):
+    """the pair search of the exchange mode (emit_pairs: count, scan, fill into an edge list) with the
+    bounded walk: buckets longer than the walk are finished by k_pairs_tiles in its emitting modes.
+    Small walks on ordinary words (nearly every bucket takes that road) and the default walk on words
+    that share one 12-nt prefix (a 30 000-word bucket), d = 1 and 2, against the oracle."""
+    rng = np.random.default_rng(17 + P)
+    if walk is None:
+        tails = rng.choice(1 << 24, size=30_000, replace=False).astype(np.uint64)
+        uniq = (np.uint64(0x3c5a96) << np.uint64(24)) | tails
+        words = np.repeat(uniq, rng.poisson(0.4, size=len(uniq)) + 1)
+        rng.shuffle(words)
+        extra, ef = synth_words(40_000, 5, 24, p_sub=4e-3, p_n=1e-3)
+        words = np.concatenate([words, extra])
+        filt = np.concatenate([np.zeros(len(words) - len(extra), np.uint8), ef])
+        perm = rng.permutation(len(words))
+        words, filt = words[perm], filt[perm]
+    else:
+        words, filt = synth_words(90_000, 40 + P, 24, p_sub=6e-3, p_n=1e-3)
+    for d in (1, 2):
+        ocid, okeep, osum, _ = orc.dedup_run(words, filt, 24, d, 0)
+        out, offs = run_ranks(P, words, filt, 24, d, 0, "exchange", bucket_walk=walk)
+        for r in range(P):
+            cid, keep, s, used = out[r]
+            assert used == "exchange"
+            assert np.array_equal(cid, ocid[offs[r]:offs[r + 1]]) and np.array_equal(keep, okeep[offs[r]:offs[r + 1]])
+            assert s["edges"] == osum["edges"] and s["clusters"] == osum["clusters"]
