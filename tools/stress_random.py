@@ -47,6 +47,8 @@ def make_case(rng):
         w, f = synth_words(n_reads, seed, n, p_sub=p_sub, p_n=1e-3, mode=kind,
                            genome_bp=int(rng.choice([2000, 50_000, 4_000_000])))
     edit = (not wide) and d in (2, 3) and n_reads <= 70_000 and rng.random() < 0.5
+    if (not wide) and n_reads <= 5000 and rng.random() < 0.15:   # two insertion/deletion pairs (round 2)
+        edit, d = True, int(rng.choice([4, 5]))
     if edit and rng.random() < 0.5:                       # families with deletions + insertions
         from test_oracle_vs_bruteforce import indel_words
         w = indel_words(np.random.default_rng(seed), n_reads, n, p_indel=0.4)
@@ -68,6 +70,10 @@ def main():
         if desc["kind"] == "dense" and d >= 2 and desc["reads"] > 70_000:
             d = desc["d"] = 1                                     # the single-thread oracle would take minutes
         edit = desc["edit"]
+        # round 2: the bounded bucket walk (tiles beyond it) with random bounds, single GPU and exchange
+        walk = int(rng.choice([1024, 1024, 1, 6, 80]))
+        desc["walk"] = walk
+        dd.set_option("bucket_walk", walk)
         ocid, okeep, osum, _ = orc.dedup_run(w, f, n, d, method, edit=edit)
         cid, keep, s = dd.run(w, f, word_nt=n, distance=d, method=method, edit=edit)
         ok = np.array_equal(cid, ocid) and np.array_equal(keep, okeep) and \
@@ -75,7 +81,7 @@ def main():
         ok_x = True
         if not desc["wide"] and desc["reads"] > 1 and not edit:
             P = int(rng.integers(2, 6))
-            out, offs = run_ranks(P, w, f, n, d, method, "exchange")
+            out, offs = run_ranks(P, w, f, n, d, method, "exchange", bucket_walk=walk)
             for r in range(P):
                 c2, k2, s2, used = out[r]
                 ok_x = ok_x and np.array_equal(c2, ocid[offs[r]:offs[r + 1]]) and \
