@@ -355,6 +355,8 @@ def main():
                    "sharding": "single GPU" if not world_sharded else (
                        "reads sharded by input order; RCCL all-to-all of the packed words to value-range "
                        "owners, keyed exchange of unique words, all-gather of the neighbour pairs"
+                       + ("; split sizes and counts through shared memory between the ranks' processes"
+                          if getattr(sd, "shm_used", False) else "")
                        if sd.mode_used == "exchange" else
                        "reads sharded by input order; RCCL all-gather of the packed words")},
         "summary": {k: int(last[k]) for k in ("total", "usable", "unique", "clusters", "edges") if k in last},

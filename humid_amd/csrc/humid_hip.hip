@@ -18,7 +18,13 @@
 //                     multi-GPU result return.
 // Sorts and scans are rocPRIM (header-only, compiled in).  No CPU fallback lives here: every
 // entry point either runs on the GPU or fails.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <atomic>
+#include <cerrno>
 #include <chrono>
 
 #include "common.hip.h"
@@ -2167,6 +2173,77 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
     info->d_compact_edges = cedges;
   }
   return HUMID_OK;
+}
+
+// ---- host_all_gather through shared memory (ranks = processes of one node) ----------------------
+struct humid_shm {
+  std::string name;
+  u32 rank = 0, world = 1;
+  u64 slot_bytes = 0, map_bytes = 0, calls = 0;
+  u8 *base = nullptr;
+  bool owner = false;
+  std::atomic<u64> *arrive() const { return (std::atomic<u64> *)base; }                 // [world], 64 B apart
+  u8 *slot(u32 bank, u32 q) const { return base + 64ull * (world + 1) + ((u64)bank * world + q) * slot_bytes; }
+};
+
+int humid_shm_open(humid_shm **out, const char *name, uint32_t rank, uint32_t world, uint64_t slot_bytes) {
+  if (!out || !name || world == 0 || rank >= world || slot_bytes == 0) return fail(nullptr, HUMID_E_INVALID, "humid_shm_open: bad argument");
+  slot_bytes = (slot_bytes + 63) & ~63ull;
+  const u64 bytes = 64ull * (world + 1) + 2ull * world * slot_bytes;
+  int fd = -1;
+  if (rank == 0) {
+    shm_unlink(name);
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) return fail(nullptr, HUMID_E_COMM, "shm_open(%s): %s", name, strerror(errno));
+    if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(name); return fail(nullptr, HUMID_E_COMM, "ftruncate: %s", strerror(errno)); }
+  } else {
+    for (int tries = 0; tries < 30000; tries++) {                      // rank 0 may still be on its way
+      fd = shm_open(name, O_RDWR, 0600);
+      if (fd >= 0) {
+        struct stat sb;
+        if (fstat(fd, &sb) == 0 && (u64)sb.st_size >= bytes) break;   // created AND sized
+        close(fd);
+        fd = -1;
+      }
+      usleep(1000);
+    }
+    if (fd < 0) return fail(nullptr, HUMID_E_COMM, "shared segment %s did not appear", name);
+  }
+  void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) return fail(nullptr, HUMID_E_COMM, "mmap of %s: %s", name, strerror(errno));
+  humid_shm *h = new (std::nothrow) humid_shm;
+  if (!h) { munmap(m, bytes); return fail(nullptr, HUMID_E_NOMEM, "out of host memory"); }
+  h->name = name; h->rank = rank; h->world = world; h->slot_bytes = slot_bytes; h->map_bytes = bytes;
+  h->base = (u8 *)m; h->owner = rank == 0;                             // (a fresh segment is zero: counters start at 0)
+  *out = h;
+  return HUMID_OK;
+}
+
+int humid_shm_all_gather(void *shm, const void *mine, uint64_t bytes, void *all) {
+  humid_shm *h = (humid_shm *)shm;
+  if (!h || !mine || !all || bytes > h->slot_bytes) return -1;
+  const u64 seq = ++h->calls;
+  const u32 bank = (u32)(seq & 1);
+  memcpy(h->slot(bank, h->rank), mine, bytes);
+  h->arrive()[8 * h->rank].store(seq, std::memory_order_release);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (u32 q = 0; q < h->world; q++) {
+    u32 spins = 0;
+    while (h->arrive()[8 * q].load(std::memory_order_acquire) < seq)
+      if ((++spins & 0xffffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) return -1;
+    memcpy((u8 *)all + (u64)q * bytes, h->slot(bank, q), bytes);
+  }
+  // the bank is written again two calls from now; by then every rank has arrived at the call in
+  // between, i.e. has finished reading this one
+  return 0;
+}
+
+void humid_shm_close(humid_shm *h) {
+  if (!h) return;
+  if (h->base) munmap(h->base, h->map_bytes);
+  if (h->owner) shm_unlink(h->name.c_str());
+  delete h;
 }
 
 int humid_at_least_double(humid_ctx *c, uint64_t a, uint64_t b, int *result) {

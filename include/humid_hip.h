@@ -393,6 +393,19 @@ int humid_dedup_run_exchange(humid_ctx *ctx, const humid_comm *comm, const uint6
                              uint32_t distance, uint32_t method, uint32_t *d_cluster_id, uint8_t *d_keep,
                              humid_summary *summary, humid_exchange_info *info);
 
+/* A ready-made humid_comm.host_all_gather for ranks that are PROCESSES OF ONE NODE: a POSIX shared-memory
+ * segment with one slot and one arrival counter per rank (a gather is a store into the own slot, a
+ * release of the counter and a spin on the others': a few microseconds, where a collective of the
+ * process group costs ~100 us of launches and waits for a 16 KB table).  Rank 0 creates the segment
+ * `name` (e.g. "/humid_<pid>"), the others attach to it (they wait up to ~30 s for it to appear); every
+ * rank then passes humid_shm_all_gather as host_all_gather and its handle as `user` -- or, when it needs
+ * `user` for its own exchange callback, calls humid_shm_all_gather(handle, ...) from its own wrapper.
+ * A gather is at most slot_bytes per rank (humid_dedup_run_exchange needs 16 KB: the histogram table). */
+typedef struct humid_shm humid_shm;
+int  humid_shm_open(humid_shm **out, const char *name, uint32_t rank, uint32_t world, uint64_t slot_bytes);
+int  humid_shm_all_gather(void *shm, const void *mine, uint64_t bytes, void *all);
+void humid_shm_close(humid_shm *shm);
+
 /* src/cluster.cc:31-33 atLeastDouble_, evaluated on the device (parity probe). */
 int humid_at_least_double(humid_ctx *ctx, uint64_t a, uint64_t b, int *result);
 
