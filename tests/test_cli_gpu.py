@@ -254,3 +254,21 @@ def test_cli_sharded_refuses_what_needs_one_gpu(tmp_path):
         r = subprocess.run([HUMID, "-g", "2", "-d", str(tmp_path / "o"), "-l", "/dev/null"] + extra + files,
                            capture_output=True, text=True)
         assert r.returncode == 2, (extra, r.stderr)
+
+
+@pytest.mark.parametrize("n_reads", [0, 1, 2, 7])
+def test_cli_sharded_tiny_inputs(n_reads, tmp_path):
+    """fewer reads than ranks, empty shards, an empty file: `-g 3` still writes what `-g 1` writes"""
+    if n_reads:
+        files = synth_fastq(str(tmp_path / "in"), n_reads, 3, n_files=1, umi_len=8, umi_in_header=True, read_len=30)
+    else:
+        os.makedirs(tmp_path / "in")
+        files = [str(tmp_path / "in" / "empty.fastq")]
+        open(files[0], "w").close()
+    outs = {}
+    for g in (1, 3):
+        out = str(tmp_path / ("o%d" % g))
+        r = subprocess.run([HUMID, "-g", str(g), "-d", out, "-l", "/dev/null", "-s", "-a"] + files, capture_output=True, text=True)
+        assert r.returncode == 0, (g, r.stderr)
+        outs[g] = {f: open(os.path.join(out, f), "rb").read() for f in sorted(os.listdir(out))}
+    assert outs[1] == outs[3]
