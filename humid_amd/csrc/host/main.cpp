@@ -63,7 +63,7 @@ void usage(const char *argv0) {
                "  -s  calculate statistics\n  -q  write deduplicated FastQ files (flag turns it OFF)\n"
                "  -a  write annotated FastQ files\n  -e  use edit distance (Levenshtein neighbours; -m <= 5)\n"
                "  -x  use maximum clustering method\n"
-               "  -g  GPUs to shard the read set over (1..16; default 1 or $HUMID_GPUS; -n <= 32, no -e beyond -m 1)\n",
+               "  -g  GPUs to shard the read set over (1..16; default 1 or $HUMID_GPUS; no -e beyond -m 1)\n",
                argv0);
 }
 
@@ -218,8 +218,8 @@ int main(int argc, char **argv) {
     std::fprintf(stderr, "humid: -g takes 1 .. 16 GPUs\n");
     return 2;
   }
-  if (a.gpus > 1 && (a.word_length > 32 || (a.edit && a.distance > 1))) {
-    std::fprintf(stderr, "humid: -g %u: words longer than 32 nt and edit distances beyond 1 run on one GPU only\n", a.gpus);
+  if (a.gpus > 1 && a.edit && a.distance > 1) {
+    std::fprintf(stderr, "humid: -g %u: edit distances beyond 1 run on one GPU only\n", a.gpus);
     return 2;
   }
   // HUMID_FORCE_SHARDED=1: the rank orchestration also for -g 1 (one rank; exercises the transport)

@@ -238,12 +238,13 @@ bool run_rank(Rank &k) {
 
   // this rank's shard of the reads, in input order
   DevBuf d_w, d_f, d_cid, d_keep;
-  STEP(k.hip_ok(d_w.ensure(n_local * 8 + 8), "hipMalloc"));
+  const uint64_t wpr = job.word_nt > 32 ? 2 : 1;                                        // uint64 per word (include/humid_hip.h)
+  STEP(k.hip_ok(d_w.ensure(n_local * 8 * wpr + 8), "hipMalloc"));
   STEP(k.hip_ok(d_f.ensure(n_local + 8), "hipMalloc"));
   STEP(k.hip_ok(d_cid.ensure(n_local * 4 + 8), "hipMalloc"));
   STEP(k.hip_ok(d_keep.ensure(n_local + 8), "hipMalloc"));
   if (n_local) {
-    STEP(k.hip_ok(hipMemcpyAsync(d_w.p, job.words + r0, n_local * 8, hipMemcpyHostToDevice, st), "hipMemcpyAsync (words)"));
+    STEP(k.hip_ok(hipMemcpyAsync(d_w.p, job.words + r0 * wpr, n_local * 8 * wpr, hipMemcpyHostToDevice, st), "hipMemcpyAsync (words)"));
     STEP(k.hip_ok(hipMemcpyAsync(d_f.p, job.filtered + r0, n_local, hipMemcpyHostToDevice, st), "hipMemcpyAsync (flags)"));
   }
   // the pass itself is the library's (humid_dedup_run_exchange); this file moves the bytes
@@ -377,7 +378,7 @@ int ShardedSession::run(const uint64_t *words, const uint8_t *filtered, uint64_t
   Impl &m = *p_;
   Group &g = m.g;
   if (m.early_code != HUMID_OK) { out.error = m.early_error; return m.early_code; }
-  if (word_nt == 0 || word_nt > 32) { out.error = "-g: words longer than 32 nt run on one GPU only"; return HUMID_E_UNSUPPORTED; }
+  if (word_nt == 0 || word_nt > 64) { out.error = "-g: word length 1 .. 64"; return HUMID_E_UNSUPPORTED; }
   if (n_reads >= 0x7fffffffull * g.P) { out.error = "-g: more than 2^31-1 reads per rank"; return HUMID_E_OVERFLOW; }
   if (m.starter.joinable()) m.starter.join();
   out.ms_init = m.ms_init;

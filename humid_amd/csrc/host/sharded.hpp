@@ -43,7 +43,7 @@ class ShardedSession {
   ~ShardedSession();                                  // ranks that never got a job leave quietly
   ShardedSession(const ShardedSession &) = delete;
   ShardedSession &operator=(const ShardedSession &) = delete;
-  // words[n_reads] packed (word_nt <= 32), filtered[n_reads]; cluster_id / keep: host outputs.
+  // words[n_reads] packed (two uint64 per read for word_nt > 32), filtered[n_reads]; cluster_id / keep: host outputs.
   // want_hist: fill ShardedResult::hist.  Returns HUMID_OK or a HUMID_E_* code with
   // ShardedResult::error set.  Once per session.
   int run(const uint64_t *words, const uint8_t *filtered, uint64_t n_reads, uint32_t word_nt, uint32_t distance,

@@ -97,6 +97,7 @@ struct humid_ctx {
   DBuf had;                 // k_pairs: first-phase "found a pair" flags, one byte per combination and position
   DBuf e_kx, e_vx, e_ky, e_vy, e_raw, e_sorted, e_edges, e_head, e_hpos;   // edit-distance neighbour search
   bool edit = false;         // option "edit_distance": Levenshtein instead of Hamming neighbours (-e)
+  DBuf xr_heads, xr_send, xr_zero;                             // the same for two-word words: heads, routed words, an all-usable flag array
   DBuf xr_hist, xr_recv, xr_eloc, xr_got, xr_eall, xr_ret;   // humid_dedup_run_exchange: histogram, received words, pair records, received items, results
   DBuf x_slot, x_slot_s, x_cnt, x_cnts, x_rec, x_ncnt, x_route, x_creator, x_base, x_mark, x_markcr, x_scan, x_lcid, x_lismax,
        x_items, x_w, x_id, x_ids, x_ends, x_ends_s, x_head, x_hpos, x_nodes, x_cedges;   // multi-GPU exchange mode
@@ -1539,7 +1540,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->in_bases, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
-                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->big_runs, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles, &c->xr_hist, &c->xr_recv, &c->xr_eloc, &c->xr_got, &c->xr_eall, &c->xr_ret,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->big_runs, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles, &c->xr_hist, &c->xr_recv, &c->xr_eloc, &c->xr_got, &c->xr_eall, &c->xr_ret, &c->xr_heads, &c->xr_send, &c->xr_zero,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->seg_ws, &c->csize, &c->cur, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -1903,6 +1904,10 @@ int humid_cluster_graph(humid_ctx *c, const uint32_t *count, const uint32_t *nbr
 static int compact_nodes_impl(humid_ctx *c, const uint64_t *d_edges, uint64_t n_edges, uint32_t record_stride, u64 id_bound,
                               const uint32_t **d_nodes, uint64_t *n_nodes, const uint64_t **d_compact_edges,
                               const uint32_t **d_node_counts);
+static int combo_route_wide(humid_ctx *c, const W2 *d_word, const u32 *d_count, u32 n, u64 id_base, const ComboPlan &plan,
+                            u32 combo, u32 n_ranks, const Item3 **d_items, u64 *counts);
+static int pairs_keyed_wide(humid_ctx *c, const void *d_items, u32 n, bool interleaved, u64 id_base, const u32 *d_count,
+                            const ComboPlan &plan, u32 combo, u32 distance, const u64 **d_records, u64 *n_edges);
 // ---- the exchange-mode pass of one rank (include/humid_hip.h: humid_dedup_run_exchange) ----------
 namespace {
 struct XRange { u64 lo = 1, hi = 0; };                         // lo > hi: empty
@@ -1981,21 +1986,33 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   const u32 P = cm ? cm->world : 1, r = cm ? cm->rank : 0;
   if (P == 0 || P > MAX_RANKS || r >= P) return fail(c, HUMID_E_UNSUPPORTED, "1 .. %d ranks", MAX_RANKS);
   if ((P > 1 || (cm && c->force_comm)) && (!cm->host_all_gather || !cm->exchange)) return fail(c, HUMID_E_INVALID, "humid_comm without callbacks");
-  TRY(check_run_args(c, n_local, word_nt, method));
+  TRY(check_run_args(c, n_local, word_nt, method, 64));
   if (n_local && (!d_words || !d_filtered || !d_cluster_id || !d_keep)) return fail(c, HUMID_E_INVALID, "null buffer");
   HIPCHK(hipSetDevice(c->device));
   hipStream_t st = c->stream;
   const auto t_begin = std::chrono::steady_clock::now();
+  // 33 <= word_nt <= 64: two uint64 per read.  Value ranges are decided by the top 64 bits of the word
+  // (its "head"): histogram, splitters and routing run on an array of heads exactly as they do on
+  // one-word words of 32 nucleotides; what travels and what is counted are the two-word words.
+  const bool wide = word_nt > 32;
+  const u32 head_nt = wide ? 32u : word_nt;
+  const u64 *heads = d_words;
+  if (wide && n_local) {
+    ENSURE(c->xr_heads, (size_t)n_local * 8);
+    hipLaunchKernelGGL(k_wide_head64, dim3(blocks_for(n_local)), dim3(256), 0, st, (const W2 *)d_words, (u32)n_local,
+                       2 * (word_nt - 32), c->xr_heads.as<u64>());
+    heads = c->xr_heads.as<u64>();
+  }
   const bool moves = P > 1 || (cm && c->force_comm);                 // bytes go through the callbacks
   const u32 n = word_nt, d = distance;
   // ---- 1. histograms of all ranks -> value ranges and every split size of the word exchange ----
   u32 nc1 = 0, pbits = 0;
   TRY(humid_stage_plan_info(c, n, d, 1, &nc1, &pbits));
   if (pbits < 1) return fail(c, HUMID_E_UNSUPPORTED, "distance %u over %u-nt words leaves no prefix to cut value ranges at", d, n);
-  const u32 bits = std::min<u32>(std::min<u32>(12u, 2 * n), pbits);
+  const u32 bits = std::min<u32>(std::min<u32>(12u, 2 * head_nt), pbits);
   const size_t n_bins = (size_t)1 << bits;
   ENSURE(c->xr_hist, n_bins * 4);
-  TRY(humid_stage_histogram(c, d_words, d_filtered, n_local, n, bits, c->xr_hist.as<u32>()));
+  TRY(humid_stage_histogram(c, heads, d_filtered, n_local, head_nt, bits, c->xr_hist.as<u32>()));
   std::vector<u32> h_hist(n_bins), all_hist((size_t)P * n_bins);
   HIPCHK(hipMemcpyAsync(h_hist.data(), c->xr_hist.p, n_bins * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -2008,8 +2025,8 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
       cum[(size_t)q * (n_bins + 1) + b + 1] = cum[(size_t)q * (n_bins + 1) + b] + v;
     }
   std::vector<XRange> ranges;
-  x_splitters(hist_sum, P, n, bits, ranges);
-  const u32 shift = 2 * n - bits;
+  x_splitters(hist_sum, P, head_nt, bits, ranges);
+  const u32 shift = 2 * head_nt - bits;
   auto in_range = [&](u32 src, u32 owner) -> u64 {                  // usable reads of rank src in owner's range
     const XRange &rg = ranges[owner];
     if (rg.lo > rg.hi) return 0;
@@ -2030,26 +2047,56 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   u64 lo_r = ranges[r].lo, hi_r = ranges[r].hi;
   if (lo_r > hi_r) { lo_r = 0; hi_r = ~0ull; }                      // empty range: nothing arrives
   const int saved_order = c->count_order, saved_mode = c->count_mode;
-  c->count_order = x_order_hint(hist_sum, ranges[r], n, bits);
+  c->count_order = x_order_hint(hist_sum, ranges[r], head_nt, bits);
   c->count_mode = 0;
   struct Restore { humid_ctx *c; int o, m; ~Restore() { c->count_order = o; c->count_mode = m; } } restore{c, saved_order, saved_mode};
 
   // ---- 2. usable words -> owner of their range (stable: input order inside every block) ----
   const u64 *d_routed = nullptr;
   const u32 *d_perm = nullptr;
-  TRY(humid_stage_route(c, d_words, d_filtered, n_local, lo, hi, P, send_counts, &d_routed, &d_perm));
+  TRY(humid_stage_route(c, heads, d_filtered, n_local, lo, hi, P, send_counts, &d_routed, &d_perm));
+  const u64 wbytes = wide ? 16 : 8;
+  if (wide) {                                                        // the routed order, now of the two-word words
+    ENSURE(c->xr_send, n_send * 16 + 16);
+    if (n_send)
+      hipLaunchKernelGGL(k_gather_w2, dim3(blocks_for(n_send)), dim3(256), 0, st, (const W2 *)d_words, d_perm, (u32)n_send,
+                         c->xr_send.as<W2>());
+    d_routed = c->xr_send.as<u64>();
+  }
   const u64 *recv_w = d_routed;                                     // one rank: what was routed is what arrives
   if (moves) {
-    ENSURE(c->xr_recv, n_recv * 8 + 8);
-    TRY(x_exchange(c, cm, d_routed, send_counts, false, c->xr_recv.p, recv_counts, 8));
+    ENSURE(c->xr_recv, n_recv * wbytes + 16);
+    TRY(x_exchange(c, cm, d_routed, send_counts, false, c->xr_recv.p, recv_counts, wbytes));
     recv_w = c->xr_recv.as<u64>();
   }
 
   // ---- 3. exact counts of the received words (all usable, all in this rank's range) ----
   const u64 shard_begin[2] = {0, n_recv};
   u64 cnt_one = 0, u_local = 0, usable_local = 0;
-  TRY(humid_stage_count_dense(c, recv_w, nullptr, n_recv, n, lo_r, hi_r, shard_begin, 1, &cnt_one, &u_local,
-                              &usable_local));
+  if (!wide) {
+    TRY(humid_stage_count_dense(c, recv_w, nullptr, n_recv, n, lo_r, hi_r, shard_begin, 1, &cnt_one, &u_local,
+                                &usable_local));
+  } else {
+    // counts by sorting (kernels_wide.hip.h), as on one GPU; every received read is usable
+    c->have_run = c->have_graph = false;
+    c->graph_mode = false;
+    c->N = c->U = c->E = c->M = c->C = c->usable = 0;
+    c->word_nt = n;
+    c->dense_mode = true;
+    c->stage_map_timed = false;
+    if (n_recv) {
+      ENSURE(c->xr_zero, n_recv + 16);
+      HIPCHK(hipMemsetAsync(c->xr_zero.p, 0, n_recv, st));
+      humid_summary ws;
+      memset(&ws, 0, sizeof ws);
+      c->N = n_recv;
+      TRY(stage_count_wide(c, (const W2 *)recv_w, c->xr_zero.as<u8>(), (u32)n_recv, n, ws));
+      HIPCHK(hipStreamSynchronize(st));
+      if (c->usable != n_recv) return fail(c, HUMID_E_INVALID, "a filtered read among the routed wide words");
+    }
+    u_local = c->U;
+    usable_local = c->usable;
+  }
   TRY(humid_stage_route_check(c));                                  // (the stream has drained: no extra wait)
   const u64 meta[3] = {u_local, usable_local, n_local};
   u64 metas[3 * MAX_RANKS];
@@ -2085,27 +2132,37 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   if (d > 0 && u_total > 1) {
     u32 n_combos = 0, pb2 = 0;
     TRY(humid_stage_plan_info(c, n, d, u_total, &n_combos, &pb2));
+    const ComboPlan wplan = make_plan(n, d, u_total, c->force_segments);      // (the wide helpers take the plan itself)
+    const u64 ibytes = wide ? sizeof(Item3) : 16;
     const u64 *rec = nullptr;
     u64 n_rec = 0;
     if (u_local > 1) {
-      TRY(humid_stage_pairs_keyed(c, lw, u_local, 0, goff, lc, n, d, u_total, 0, &rec, &n_rec));
+      if (wide) TRY(pairs_keyed_wide(c, lw, (u32)u_local, false, goff, lc, wplan, 0, d, &rec, &n_rec));
+      else TRY(humid_stage_pairs_keyed(c, lw, u_local, 0, goff, lc, n, d, u_total, 0, &rec, &n_rec));
       TRY(append_pairs(rec, n_rec));
     }
     for (u32 cb = 1; cb < n_combos; cb++) {
       const u64 *items = nullptr;
       u64 sc[MAX_RANKS] = {0}, all_sc[MAX_RANKS * MAX_RANKS], rc[MAX_RANKS];
-      TRY(humid_stage_combo_route(c, lw, lc, u_local, goff, n, d, u_total, cb, P, &items, sc));
+      if (wide) {
+        const Item3 *it3 = nullptr;
+        TRY(combo_route_wide(c, (const W2 *)lw, lc, (u32)u_local, goff, wplan, cb, P, &it3, sc));
+        items = (const u64 *)it3;
+      } else
+        TRY(humid_stage_combo_route(c, lw, lc, u_local, goff, n, d, u_total, cb, P, &items, sc));
       TRY(x_host_gather(c, cm, sc, P * 8, all_sc));
       u64 n_got = 0;
       for (u32 q = 0; q < P; q++) { rc[q] = all_sc[(size_t)q * P + r]; n_got += rc[q]; }
+      if (n_got > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "%llu unique words arrive at rank %u for one combination", (ull)n_got, r);
       const u64 *got = items;
       if (moves) {
-        ENSURE(c->xr_got, n_got * 16 + 16);
-        TRY(x_exchange(c, cm, items, sc, false, c->xr_got.p, rc, 16));
+        ENSURE(c->xr_got, n_got * ibytes + 32);
+        TRY(x_exchange(c, cm, items, sc, false, c->xr_got.p, rc, ibytes));
         got = c->xr_got.as<u64>();
       }
       if (n_got > 1) {
-        TRY(humid_stage_pairs_keyed(c, got, n_got, 1, 0, nullptr, n, d, u_total, cb, &rec, &n_rec));
+        if (wide) TRY(pairs_keyed_wide(c, got, (u32)n_got, true, 0, nullptr, wplan, cb, d, &rec, &n_rec));
+        else TRY(humid_stage_pairs_keyed(c, got, n_got, 1, 0, nullptr, n, d, u_total, cb, &rec, &n_rec));
         TRY(append_pairs(rec, n_rec));
       }
     }
@@ -2132,7 +2189,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   if (E) {
     TRY(compact_nodes_impl(c, d_eall, E, 2, u_total, &nodes, &M, &cedges, &node_cnt));
     // (the graph runs over the compact node list: its "words" are only carried for the accessors)
-    TRY(humid_stage_graph_edges(c, (const u64 *)nodes, node_cnt, M, cedges, E, n, d, method, &ccid, &cismax, &gs));
+    TRY(humid_stage_graph_edges(c, (const u64 *)nodes, node_cnt, M, cedges, E, head_nt, d, method, &ccid, &cismax, &gs));   // (the pairs are given: the word length only labels the context)
     C_c = gs.clusters;
   }
   const u64 clusters = u_total - M + C_c;
@@ -2541,7 +2598,8 @@ int humid_stage_plan_info(humid_ctx *c, uint32_t word_nt, uint32_t distance, uin
   if (n_combos) *n_combos = plan.ncombo;
   if (prefix_bits) {
     const u32 mp = min_prefix_bits(word_nt, distance, force);
-    *prefix_bits = mp < (u32)__builtin_popcountll(plan.mask[0].lo) ? mp : (u32)__builtin_popcountll(plan.mask[0].lo);
+    const u32 mbits = (u32)__builtin_popcountll(plan.mask[0].lo) + (u32)__builtin_popcountll(plan.mask[0].hi);   // (.hi: two-word words)
+    *prefix_bits = mp < mbits ? mp : mbits;
   }
   return HUMID_OK;
 }
@@ -2582,7 +2640,7 @@ int humid_stage_combo_route(humid_ctx *c, const uint64_t *d_word, const uint32_t
   ENSURE(c->owner, (size_t)n);
   ENSURE(c->owner_sorted, (size_t)n);
   ENSURE(c->x_ids, (size_t)n * 4);
-  hipLaunchKernelGGL(k_combo_owner, dim3(blocks_for(n)), dim3(256), 0, st, d_word, n, plan_fields(plan, combo),
+  hipLaunchKernelGGL(k_combo_owner<u64>, dim3(blocks_for(n)), dim3(256), 0, st, (const u64 *)d_word, n, plan_fields(plan, combo),
                      n_ranks, c->owner.as<u8>());
   {
     using part_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
@@ -2611,12 +2669,15 @@ int humid_stage_combo_route(humid_ctx *c, const uint64_t *d_word, const uint32_t
 
 // pairs among W[0, n) walked in bucket order of combination cb -> c->share_edges, as
 // (V[i] << 32 | V[j]) ordered by value; V == null: positions themselves
-static int emit_pairs(humid_ctx *c, const u64 *W, const u32 *V, u32 n, const ComboPlan &plan, u32 cb,
+extern "C++" {
+template <class WT>
+static int emit_pairs(humid_ctx *c, const WT *W, const u32 *V, u32 n, const ComboPlan &plan, u32 cb,
                       u32 distance, u64 *E_out) {
   hipStream_t st = c->stream;
   *E_out = 0;
-  EarlierMasksT<u64> d_masks;
-  for (u32 t = 0; t < MAX_COMBOS; t++) d_masks.m[t] = plan.mask[t].lo;
+  EarlierMasksT<WT> d_masks;
+  for (u32 t = 0; t < MAX_COMBOS; t++) d_masks.m[t] = w_from<WT>(plan.mask[t]);
+  const WT cmask = w_from<WT>(plan.mask[cb]);
   ENSURE(c->pc, ((size_t)n + 1) * 4);
   ENSURE(c->poff, ((size_t)n + 1) * 4);
   HIPCHK(hipMemsetAsync(c->pc.as<u32>() + n, 0, 4, st));
@@ -2625,12 +2686,12 @@ static int emit_pairs(humid_ctx *c, const u64 *W, const u32 *V, u32 n, const Com
   const u32 walk_max = c->walk_max;
   const dim3 grid(blocks_for(n)), blk(256);
   if (V)
-    hipLaunchKernelGGL((k_pairs<false, PM_EMIT_COUNT, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
+    hipLaunchKernelGGL((k_pairs<false, PM_EMIT_COUNT, WT>), grid, blk, 0, st, W, V, n, 0u, n, cmask, d_masks,
                        cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
                        (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr, walk_max,
                        &c->d_ctr[CTR_BIGMASK]);
   else
-    hipLaunchKernelGGL((k_pairs<true, PM_EMIT_COUNT, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
+    hipLaunchKernelGGL((k_pairs<true, PM_EMIT_COUNT, WT>), grid, blk, 0, st, W, V, n, 0u, n, cmask, d_masks,
                        cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
                        (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr, walk_max,
                        &c->d_ctr[CTR_BIGMASK]);
@@ -2644,12 +2705,12 @@ static int emit_pairs(humid_ctx *c, const u64 *W, const u32 *V, u32 n, const Com
   u64 E_far = 0;
   ull tiles = 0;
   if (c->h_ctr[CTR_BIGMASK]) {
-    TRY(find_big_runs<u64>(c, W, n, plan.mask[cb].lo, walk_max, 0, runs, &d_runs));
+    TRY(find_big_runs<WT>(c, W, n, cmask, walk_max, 0, runs, &d_runs));
     tiles = runs.back().tile0;
   }
   const u32 tgrid = (u32)std::min<ull>(tiles ? tiles : 1, 1u << 20);
 #define EMIT_TILES(P0, M)                                                                                              \
-  hipLaunchKernelGGL((k_pairs_tiles<P0, M, u64>), dim3(tgrid), dim3(PT2_THREADS), 0, st, W, V, d_runs, (u32)runs.size() - 1, \
+  hipLaunchKernelGGL((k_pairs_tiles<P0, M, WT>), dim3(tgrid), dim3(PT2_THREADS), 0, st, W, V, d_runs, (u32)runs.size() - 1, \
                      tiles, d_masks, cb, distance, walk_max, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr,         \
                      (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, c->share_edges.as<u64>(), &c->d_ctr[CTR_SPECIAL])
   if (tiles) {
@@ -2665,11 +2726,11 @@ static int emit_pairs(humid_ctx *c, const u64 *W, const u32 *V, u32 n, const Com
   ENSURE(c->share_edges, (size_t)(E + E_far) * 8);
   if (E) {
     if (V)
-      hipLaunchKernelGGL((k_pairs<false, PM_EMIT_FILL, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
+      hipLaunchKernelGGL((k_pairs<false, PM_EMIT_FILL, WT>), grid, blk, 0, st, W, V, n, 0u, n, cmask, d_masks,
                          cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
                          (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr, walk_max);
     else
-      hipLaunchKernelGGL((k_pairs<true, PM_EMIT_FILL, u64>), grid, blk, 0, st, W, V, n, 0u, n, plan.mask[cb].lo, d_masks,
+      hipLaunchKernelGGL((k_pairs<true, PM_EMIT_FILL, WT>), grid, blk, 0, st, W, V, n, 0u, n, cmask, d_masks,
                          cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
                          (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr, walk_max);
   }
@@ -2683,6 +2744,101 @@ static int emit_pairs(humid_ctx *c, const u64 *W, const u32 *V, u32 n, const Com
   HIPCHK(hipGetLastError());
   return HUMID_OK;
 }
+}  // extern "C++"
+
+// ---- two-word (wide) words in the exchange pass: items of 24 bytes (hi, lo, id | count << 32) ----
+// humid_stage_combo_route for W2: this rank's unique words in destination-major order
+static int combo_route_wide(humid_ctx *c, const W2 *d_word, const u32 *d_count, u32 n, u64 id_base, const ComboPlan &plan,
+                            u32 combo, u32 n_ranks, const Item3 **d_items, u64 *counts) {
+  hipStream_t st = c->stream;
+  *d_items = nullptr;
+  for (u32 q = 0; q < n_ranks; q++) counts[q] = 0;
+  if (n == 0) return HUMID_OK;
+  ENSURE(c->x_items, (size_t)n * sizeof(Item3));
+  if (n_ranks == 1) {
+    hipLaunchKernelGGL(k_route_items_w2, dim3(blocks_for(n)), dim3(256), 0, st, d_word, d_count, (const u32 *)nullptr, n, id_base,
+                       c->x_items.as<Item3>());
+    HIPCHK(hipGetLastError());
+    counts[0] = n;
+    *d_items = c->x_items.as<Item3>();
+    return HUMID_OK;
+  }
+  ENSURE(c->owner, (size_t)n);
+  ENSURE(c->owner_sorted, (size_t)n);
+  ENSURE(c->x_ids, (size_t)n * 4);
+  hipLaunchKernelGGL(k_combo_owner<W2>, dim3(blocks_for(n)), dim3(256), 0, st, d_word, n, plan_fields(plan, combo), n_ranks,
+                     c->owner.as<u8>());
+  {
+    rocprim::counting_iterator<u32> vin(0);
+    size_t bytes = 0;
+    HIPCHK(rocprim::radix_sort_pairs<onesweep_cfg>(nullptr, bytes, c->owner.as<u8>(), c->owner_sorted.as<u8>(), vin, c->x_ids.as<u32>(),
+                                                   (size_t)n, 0, 8, st));
+    ENSURE(c->tmp, bytes);
+    HIPCHK(rocprim::radix_sort_pairs<onesweep_cfg>(c->tmp.p, bytes, c->owner.as<u8>(), c->owner_sorted.as<u8>(), vin, c->x_ids.as<u32>(),
+                                                   (size_t)n, 0, 8, st));
+  }
+  ENSURE(c->small, (size_t)(n_ranks + 2) * 4);
+  hipLaunchKernelGGL(k_owner_bounds, dim3(1), dim3(256), 0, st, c->owner_sorted.as<u8>(), n, n_ranks, c->small.as<u32>());
+  hipLaunchKernelGGL(k_route_items_w2, dim3(blocks_for(n)), dim3(256), 0, st, d_word, d_count, c->x_ids.as<u32>(), n, id_base,
+                     c->x_items.as<Item3>());
+  std::vector<u32> b(n_ranks + 2);
+  HIPCHK(hipMemcpyAsync(b.data(), c->small.p, (n_ranks + 2) * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  for (u32 q = 0; q < n_ranks; q++) counts[q] = b[q + 1] - b[q];
+  *d_items = c->x_items.as<Item3>();
+  return HUMID_OK;
+}
+
+// humid_stage_pairs_keyed for W2.  items: received Item3 records (interleaved) or, for combination 0, the
+// plain ascending W2 array with ids id_base + index and counts d_count
+static int pairs_keyed_wide(humid_ctx *c, const void *d_items, u32 n, bool interleaved, u64 id_base, const u32 *d_count,
+                            const ComboPlan &plan, u32 combo, u32 distance, const u64 **d_records, u64 *n_edges) {
+  hipStream_t st = c->stream;
+  *d_records = nullptr;
+  *n_edges = 0;
+  if (n < 2 || distance == 0) return HUMID_OK;
+  u64 E = 0;
+  const u32 *id_of = nullptr, *cnt_of = d_count;
+  if (!interleaved) {
+    TRY(emit_pairs<W2>(c, (const W2 *)d_items, nullptr, n, plan, 0, distance, &E));
+  } else {
+    ENSURE(c->x_w, (size_t)n * sizeof(W2));
+    ENSURE(c->x_id, (size_t)n * 4);
+    ENSURE(c->x_cnt, (size_t)n * 4);
+    ENSURE(c->seg_k0, (size_t)n * 8);
+    ENSURE(c->seg_v0, (size_t)n * 4);
+    ENSURE(c->seg_ks, (size_t)n * 8);
+    ENSURE(c->seg_vs, (size_t)n * 4);
+    ENSURE(c->seg_ws, (size_t)n * sizeof(W2));
+    hipLaunchKernelGGL(k_split_items_w2, dim3(blocks_for(n)), dim3(256), 0, st, (const Item3 *)d_items, n, c->x_w.as<W2>(),
+                       c->x_id.as<u32>(), c->x_cnt.as<u32>());
+    const u32 kb = plan.key_bits ? plan.key_bits : 1;
+    if (kb <= 32) {
+      hipLaunchKernelGGL((k_combo_keys<u32, W2>), dim3(blocks_for(n)), dim3(256), 0, st, c->x_w.as<W2>(), n, plan_fields(plan, combo),
+                         c->seg_k0.as<u32>(), c->seg_v0.as<u32>());
+      TRY(sort_pairs<u32, u32>(c, c->seg_k0.as<u32>(), c->seg_ks.as<u32>(), c->seg_v0.as<u32>(), c->seg_vs.as<u32>(), n, 0, kb));
+    } else {
+      hipLaunchKernelGGL((k_combo_keys<u64, W2>), dim3(blocks_for(n)), dim3(256), 0, st, c->x_w.as<W2>(), n, plan_fields(plan, combo),
+                         c->seg_k0.as<u64>(), c->seg_v0.as<u32>());
+      TRY(sort_pairs<u64, u32>(c, c->seg_k0.as<u64>(), c->seg_ks.as<u64>(), c->seg_v0.as<u32>(), c->seg_vs.as<u32>(), n, 0, kb));
+    }
+    hipLaunchKernelGGL(k_gather_bucket_words<W2>, dim3(blocks_for(n)), dim3(256), 0, st, c->x_w.as<W2>(), c->seg_vs.as<u32>(), n,
+                       c->seg_ws.as<W2>());
+    TRY(emit_pairs<W2>(c, c->seg_ws.as<W2>(), c->seg_vs.as<u32>(), n, plan, combo, distance, &E));
+    id_of = c->x_id.as<u32>();
+    cnt_of = c->x_cnt.as<u32>();
+  }
+  *n_edges = E;
+  if (E == 0) return HUMID_OK;
+  ENSURE(c->x_rec, (size_t)E * 16);
+  hipLaunchKernelGGL(k_edge_records, dim3(blocks_for(E)), dim3(256), 0, st, c->share_edges.as<u64>(), (u32)E, id_of, (u32)id_base,
+                     cnt_of, c->x_rec.as<ulonglong2>());
+  HIPCHK(hipGetLastError());
+  *d_records = c->x_rec.as<u64>();
+  return HUMID_OK;
+}
+
 
 int humid_stage_pairs_keyed(humid_ctx *c, const uint64_t *d_items, uint64_t n_items, int interleaved,
                             uint64_t id_base, const uint32_t *d_count, uint32_t word_nt, uint32_t distance,

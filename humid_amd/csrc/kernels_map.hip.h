@@ -208,12 +208,13 @@ k_scatter_results(const u32 *__restrict__ perm, const u32 *__restrict__ packed, 
 // --------------------------------------------------------------------------------
 // owner rank of a unique word for combination `cf`: a hash of its key, so that all words of one
 // bucket meet on one rank whatever the key distribution is
+template <class WT>
 __global__ void __launch_bounds__(256)
-k_combo_owner(const u64 *__restrict__ words, u32 n, ComboFields cf, u32 n_ranks, u8 *__restrict__ owner) {
+k_combo_owner(const WT *__restrict__ words, u32 n, ComboFields cf, u32 n_ranks, u8 *__restrict__ owner) {
   HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const u64 w = words[i];
+  const WT w = words[i];
   u64 k = 0;
 #pragma unroll
   for (u32 f = 0; f < MAX_FIELDS; f++) {
@@ -235,6 +236,43 @@ k_route_items(const u64 *__restrict__ words, const u32 *__restrict__ counts, con
   if (k >= n) return;
   const u32 i = perm ? perm[k] : k;                  // perm == null: one rank, the array goes as it stands
   items[k] = make_ulonglong2(words[i], (id_base + i) | ((u64)(counts ? counts[i] : 0u) << 32));
+}
+
+// ---- the same for two-word (wide) words: 24-byte items (hi, lo, id | count << 32) ----
+struct Item3 { u64 hi, lo, idc; };
+__global__ void __launch_bounds__(256)
+k_route_items_w2(const W2 *__restrict__ words, const u32 *__restrict__ counts, const u32 *__restrict__ perm, u32 n,
+                 u64 id_base, Item3 *__restrict__ items) {
+  HUMID_GUARD_LAST_VGPR();
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const u32 i = perm ? perm[k] : k;
+  const W2 w = words[i];
+  items[k] = Item3{w.hi, w.lo, (id_base + i) | ((u64)(counts ? counts[i] : 0u) << 32)};
+}
+__global__ void k_split_items_w2(const Item3 *__restrict__ items, u32 n, W2 *__restrict__ w, u32 *__restrict__ id,
+                                 u32 *__restrict__ cnt) {
+  HUMID_GUARD_LAST_VGPR();
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const Item3 it = items[k];
+  w[k] = W2{it.hi, it.lo};
+  id[k] = (u32)it.idc;
+  cnt[k] = (u32)(it.idc >> 32);
+}
+// the top 64 bits of a wide word's 2n-bit value (hbits = 2 (n - 32) bits live in .hi): value ranges cut
+// at the bins of a <= 12-bit prefix histogram are decided by these bits alone
+__global__ void k_wide_head64(const W2 *__restrict__ w, u32 n, u32 hbits, u64 *__restrict__ out) {
+  HUMID_GUARD_LAST_VGPR();
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const W2 x = w[i];
+  out[i] = hbits >= 64 ? x.hi : ((x.hi << (64 - hbits)) | (x.lo >> hbits));
+}
+__global__ void k_gather_w2(const W2 *__restrict__ w, const u32 *__restrict__ perm, u32 n, W2 *__restrict__ out) {
+  HUMID_GUARD_LAST_VGPR();
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = w[perm[k]];
 }
 
 __global__ void k_split_items(const ulonglong2 *__restrict__ items, u32 n, u64 *__restrict__ w,

@@ -352,7 +352,7 @@ class HipStageOps(Context):
         s = _lib.HumidSummary()
         info = _lib.HumidExchangeInfo()
         self._enter()
-        rc = self._lib.humid_dedup_run_exchange(self._h, C.byref(cm), self._p(d_w), self._p(d_f), d_w.numel(), word_nt,
+        rc = self._lib.humid_dedup_run_exchange(self._h, C.byref(cm), self._p(d_w), self._p(d_f), d_w.shape[0], word_nt,
                                                 distance, method, self._p(d_cid), self._p(d_keep), C.byref(s), C.byref(info))
         if err:
             raise err[0]
@@ -596,8 +596,7 @@ class ShardedDedup:
         # -e: distance <= 1 IS the Hamming search (equal-length words); 2 and 3 run in the all-gather
         # mode, the joins of the shifted-segment search dealt out over the ranks
         self.edit = bool(edit) and distance >= 2
-        if word_nt > 32:
-            raise NotImplementedError("words longer than 32 nt are single-GPU only")
+        # 33 <= word_nt <= 64 (two int64 per read, tensors of shape [n, 2]): the library's exchange pass only
         import os
         import torch.distributed as tdist
         self.mode = mode or os.environ.get("HUMID_SHARD_MODE", "exchange")
@@ -638,6 +637,12 @@ class ShardedDedup:
         return summ
 
     def _run(self, d_w, d_f, d_cid, d_keep):
+        if self.word_nt > 32:
+            if not hasattr(self.ops, "run_exchange") or self.py_orchestration or self.edit:
+                raise NotImplementedError("words longer than 32 nt: the library's exchange pass only (HIP ops, no -e)")
+            self.mode_used = "exchange"
+            self.summary = self.ops.run_exchange(self.dist, d_w, d_f, d_cid, d_keep, self.word_nt, self.distance, self.method)
+            return self.summary
         if self.mode == "exchange" and hasattr(self.ops, "combo_route") and \
                 self.world <= getattr(self.ops, "max_ranks_dense", 0):
             _, pbits = self.ops.plan_info(self.word_nt, self.distance, 1)

@@ -369,8 +369,9 @@ int humid_stage_compact_nodes(humid_ctx *ctx, const uint64_t *d_edges, uint64_t 
  * Both return 0 or a negative value, which ends the run with HUMID_E_COMM.  With world == 1 neither is
  * called (comm may then be NULL).  Every rank must make the call with the same word_nt, distance and
  * method.  *summary receives the totals of the WHOLE read set (identical on all ranks; ms_* are this
- * rank's); *info what a caller needs for the statistics files.  Limits: word_nt <= 32, at most 16
- * ranks, a pigeonhole plan with a prefix (distance < word_nt): HUMID_E_UNSUPPORTED otherwise. */
+ * rank's); *info what a caller needs for the statistics files.  word_nt 1 .. 64 (above 32: two uint64 per
+ * read, as in humid_dedup_run).  Limits: at most 16 ranks, a pigeonhole plan with a prefix (distance <
+ * word_nt): HUMID_E_UNSUPPORTED otherwise. */
 #define HUMID_E_COMM        -7   /* a humid_comm callback failed                        */
 typedef struct humid_comm {
   void *user;

@@ -191,6 +191,8 @@ def test_cli_output_write_errors_are_not_silent(tmp_path):
     dict(n_files=2, umi_len=8, umi_in_header=True, word_nt=24, d=1, x=False, n=40_000),
     dict(n_files=1, umi_len=8, umi_in_header=True, word_nt=24, d=2, x=True, n=12_000),
     dict(n_files=2, umi_len=0, umi_in_header=False, word_nt=12, d=1, x=False, n=9_000),
+    dict(n_files=2, umi_len=8, umi_in_header=True, word_nt=48, d=1, x=False, n=20_000),    # two-word (wide) words
+    dict(n_files=2, umi_len=12, umi_in_header=False, umi_file=True, word_nt=64, d=2, x=True, n=6_000),
 ])
 def test_cli_sharded_over_ranks_writes_the_single_gpu_files(case, ranks, tmp_path):
     """`humid -g N` (csrc/host/sharded.cpp: the exchange orchestration driven from the C++ host, one
@@ -250,7 +252,7 @@ def test_cli_sharded_rccl_transport_with_one_rank(tmp_path):
 
 def test_cli_sharded_refuses_what_needs_one_gpu(tmp_path):
     files = synth_fastq(str(tmp_path / "in"), 200, 5, n_files=1, read_len=30)
-    for extra in (["-n", "40"], ["-e", "-m", "2"], ["-g", "17"]):
+    for extra in (["-e", "-m", "2"], ["-g", "17"]):
         r = subprocess.run([HUMID, "-g", "2", "-d", str(tmp_path / "o"), "-l", "/dev/null"] + extra + files,
                            capture_output=True, text=True)
         assert r.returncode == 2, (extra, r.stderr)

@@ -302,3 +302,20 @@ def test_exchange_large_buckets_go_through_the_tiles(P, walk):
             assert used == "exchange"
             assert np.array_equal(cid, ocid[offs[r]:offs[r + 1]]) and np.array_equal(keep, okeep[offs[r]:offs[r + 1]])
             assert s["edges"] == osum["edges"] and s["clusters"] == osum["clusters"]
+
+
+@pytest.mark.parametrize("P", [1, 2, 3])
+@pytest.mark.parametrize("n,d", [(33, 1), (40, 2), (48, 1), (64, 2)])
+def test_exchange_wide_words(P, n, d):
+    """33 <= word_nt <= 64 on several ranks (round 2): value ranges from the words' top 64 bits, two-word
+    words routed and counted by sorting at their owners, 24-byte items for the other combinations --
+    every rank's shard against one oracle run over the whole read set"""
+    from humid_amd.synth import synth_wide_words
+    words, filt = synth_wide_words(30_000, 100 * P + n + d, n, p_sub=6e-3, p_n=2e-3)
+    ocid, okeep, osum, _ = orc.dedup_run(words, filt, n, d, 0)
+    out, offs = run_ranks(P, words, filt, n, d, 0, "exchange")
+    for r in range(P):
+        cid, keep, s, used = out[r]
+        assert used == "exchange"
+        assert np.array_equal(cid, ocid[offs[r]:offs[r + 1]]) and np.array_equal(keep, okeep[offs[r]:offs[r + 1]])
+        assert s["edges"] == osum["edges"] and s["clusters"] == osum["clusters"] and s["unique"] == osum["unique"]
