@@ -93,6 +93,7 @@ struct humid_ctx {
   DBuf pc, poff, share_edges;                                                     // multi-GPU pair-search share
   DBuf own_words;                                                                 // multi-GPU dense count
   DBuf heads;                                                                     // big-component heads
+  DBuf small_roots;         // k_comp_count: roots of the components of 3 .. 32 leaves (k_cluster_small works off this list)
   DBuf big_runs;            // k_big_runs: (start, length, first tile) of the buckets beyond k_pairs' walk, per combination
   DBuf had;                 // k_pairs: first-phase "found a pair" flags, one byte per combination and position
   DBuf e_kx, e_vx, e_ky, e_vy, e_raw, e_sorted, e_edges, e_head, e_hpos;   // edit-distance neighbour search
@@ -360,13 +361,14 @@ static int cluster_stage(humid_ctx *c, const u32 *g_cnt, u32 U, u64 M, u64 Mbig,
                        c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
                        c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
   if (M > 0) {
+    const u64 small_cap = M / 3 + 1;                  // listed roots: components of >= 3 of the M leaves with neighbours
     if (method == HUMID_METHOD_MAXIMUM)
-      hipLaunchKernelGGL(k_cluster_small<true>, dim3(blocks_for(U, 128)), dim3(128), 0, st, c->deg.as<u32>(),
-                         c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
+      hipLaunchKernelGGL(k_cluster_small<true>, dim3(blocks_for(small_cap, 128)), dim3(128), 0, st, c->small_roots.as<u32>(),
+                         (const ull *)c->d_ctr, c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
                          c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
     else
-      hipLaunchKernelGGL(k_cluster_small<false>, dim3(blocks_for(U, 128)), dim3(128), 0, st, c->deg.as<u32>(),
-                         c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
+      hipLaunchKernelGGL(k_cluster_small<false>, dim3(blocks_for(small_cap, 128)), dim3(128), 0, st, c->small_roots.as<u32>(),
+                         (const ull *)c->d_ctr, c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
                          c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
     if (Mbig > 0) {
       ENSURE(c->mk0, (size_t)Mbig * 8);
@@ -838,7 +840,8 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
   ENSURE(c->parent, (size_t)U * 4);
   ENSURE(c->csize, (size_t)U * 4);
   ENSURE(c->cur, (size_t)U * 4);
-  HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_EDGES], 0, (CTR_BIGMASK - CTR_EDGES + 1) * sizeof(ull), st));
+  ENSURE(c->small_roots, ((size_t)U / 3 + 2) * 4);
+  HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_EDGES], 0, (CTR_SMALLROOTS - CTR_EDGES + 1) * sizeof(ull), st));
   hipLaunchKernelGGL(k_graph_init, dim3(blocks_for((u64)U + 1)), dim3(256), 0, st, c->parent.as<u32>(),
                      c->deg.as<u32>(), c->csize.as<u32>(), c->cur.as<u32>(), U);
   u64 E = 0, M = 0, Mbig = 0;
@@ -871,7 +874,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
     hipLaunchKernelGGL(k_comp_stats, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
                        c->parent.as<u32>(), U, c->csize.as<u32>());
     hipLaunchKernelGGL(k_comp_count, dim3(512), dim3(256), 0, st, c->deg.as<u32>(), c->parent.as<u32>(),
-                       c->csize.as<u32>(), U, c->d_ctr);
+                       c->csize.as<u32>(), U, c->d_ctr, c->small_roots.as<u32>());
   }
   // buckets beyond k_pairs' bounded walk (c->walk_max words; 0 = walk to the end of the bucket)
   const u32 walk_max = c->walk_max;
@@ -960,7 +963,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
     hipLaunchKernelGGL(k_comp_stats, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
                        c->parent.as<u32>(), U, c->csize.as<u32>());
     hipLaunchKernelGGL(k_comp_count, dim3(512), dim3(256), 0, st, c->deg.as<u32>(), c->parent.as<u32>(),
-                       c->csize.as<u32>(), U, c->d_ctr);
+                       c->csize.as<u32>(), U, c->d_ctr, c->small_roots.as<u32>());
   }
   TRY(exscan_u32(c, c->deg.as<u32>(), c->nbr_off.as<u32>(), (u64)U + 1));
   if (search || (given && n_ext_edges)) {
@@ -980,11 +983,12 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
           TRY(big_tiles(seg, PM_COUNT));
         }
       HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_EDGES], 0, 3 * sizeof(ull), st));
+      HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_SMALLROOTS], 0, sizeof(ull), st));
       HIPCHK(hipMemsetAsync(c->csize.p, 0, (size_t)U * 4, st));
       hipLaunchKernelGGL(k_comp_stats, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
                          c->parent.as<u32>(), U, c->csize.as<u32>());
       hipLaunchKernelGGL(k_comp_count, dim3(512), dim3(256), 0, st, c->deg.as<u32>(), c->parent.as<u32>(),
-                         c->csize.as<u32>(), U, c->d_ctr);
+                         c->csize.as<u32>(), U, c->d_ctr, c->small_roots.as<u32>());
       TRY(exscan_u32(c, c->deg.as<u32>(), c->nbr_off.as<u32>(), (u64)U + 1));
       HIPCHK(hipGetLastError());
       TRY(read_counters(c, c->nbr_off.as<u32>() + U));
@@ -1540,7 +1544,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->in_bases, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
-                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->big_runs, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles, &c->xr_hist, &c->xr_recv, &c->xr_eloc, &c->xr_got, &c->xr_eall, &c->xr_ret, &c->xr_heads, &c->xr_send, &c->xr_zero,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->big_runs, &c->small_roots, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles, &c->xr_hist, &c->xr_recv, &c->xr_eloc, &c->xr_got, &c->xr_eall, &c->xr_ret, &c->xr_heads, &c->xr_send, &c->xr_zero,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->seg_ws, &c->csize, &c->cur, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -1876,8 +1880,10 @@ int humid_cluster_graph(humid_ctx *c, const uint32_t *count, const uint32_t *nbr
   HIPCHK(hipMemcpyAsync(c->nbr_off.p, nbr_off, (size_t)(U + 1) * 4, hipMemcpyHostToDevice, st));
   if (twoE) HIPCHK(hipMemcpyAsync(c->nbr_idx.p, nbr_idx, (size_t)twoE * 4, hipMemcpyHostToDevice, st));
   ENSURE(c->csize, (size_t)U * 4);
+  ENSURE(c->small_roots, ((size_t)U / 3 + 2) * 4);
   HIPCHK(hipMemsetAsync(c->csize.p, 0, (size_t)U * 4, st));
   HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_EDGES], 0, 3 * sizeof(ull), st));
+  HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_SMALLROOTS], 0, sizeof(ull), st));
   hipLaunchKernelGGL(k_iota, dim3(blocks_for(U)), dim3(256), 0, st, c->parent.as<u32>(), U);
   hipLaunchKernelGGL(k_union_csr, dim3(blocks_for(U)), dim3(256), 0, st, c->nbr_off.as<u32>(),
                      c->nbr_idx.as<u32>(), U, c->parent.as<u32>(),
@@ -1885,7 +1891,7 @@ int humid_cluster_graph(humid_ctx *c, const uint32_t *count, const uint32_t *nbr
   hipLaunchKernelGGL(k_comp_stats, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
                      c->parent.as<u32>(), U, c->csize.as<u32>());
   hipLaunchKernelGGL(k_comp_count, dim3(512), dim3(256), 0, st, c->deg.as<u32>(), c->parent.as<u32>(),
-                     c->csize.as<u32>(), U, c->d_ctr);
+                     c->csize.as<u32>(), U, c->d_ctr, c->small_roots.as<u32>());
   HIPCHK(hipGetLastError());
   TRY(read_counters(c));   // also drains the stream: hdeg is a host temporary
   TRY(cluster_stage(c, c->s_cnt.as<u32>(), U, c->h_ctr[CTR_NONSINGLE], c->h_ctr[CTR_MEMBERS], method));

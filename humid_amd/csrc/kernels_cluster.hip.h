@@ -291,14 +291,18 @@ k_cluster_trivial(const u32 *__restrict__ deg, const u32 *__restrict__ P, const 
 // private memory.  No sort, no scratch.
 template <bool MAXIMUM>
 __global__ void __launch_bounds__(128)
-k_cluster_small(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *__restrict__ csize,
-                u32 n, const u32 *__restrict__ cnt, const u32 *__restrict__ off,
+k_cluster_small(const u32 *__restrict__ roots, const ull *__restrict__ ctr, const u32 *__restrict__ P,
+                const u32 *__restrict__ csize, u32 n, const u32 *__restrict__ cnt, const u32 *__restrict__ off,
                 const u32 *__restrict__ idx, u32 *cl_of, u32 *maxleaf, u64 *cl_size) {
   HUMID_GUARD_LAST_VGPR();
-  u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= n || deg[u] == 0 || P[u] != u) return;
+  // one lane per LISTED root (k_comp_count: components of 3 .. SMALL_COMP leaves; one and two leaves:
+  // k_cluster_trivial; more: k_cluster_components / k_cluster_big_coop)
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (u32)ctr[CTR_SMALLROOTS]) return;
+  const u32 u = roots[t];
+  if (u >= n) return;
   const u32 target = csize[u];
-  if (target > SMALL_COMP || target <= 2) return;   // one, two: k_cluster_trivial; big: k_cluster_components
+  if (target > SMALL_COMP || target <= 2) return;
   u32 mem[SMALL_COMP];
   u32 st[2 * SMALL_COMP];
   u32 nm = 1;

@@ -527,21 +527,64 @@ __global__ void k_comp_stats(const u32 *__restrict__ deg, u32 *P, u32 n, u32 *cs
 // M = leaves with >= 1 neighbour, Mbig = those in components larger than SMALL_COMP, and the sum of
 // the degrees (= 2E) in 64 bits: the CSR offsets are 32-bit, so the host must see an overflow
 // BEFORE it sizes nbr_idx from a wrapped scan
+#define CC_ROOTS 2048u      // listed roots a workgroup of k_comp_count holds before it flushes them
 __global__ void __launch_bounds__(256)
 k_comp_count(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *__restrict__ csize, u32 n,
-             ull *ctr) {
+             ull *ctr, u32 *__restrict__ small_roots) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u32 lds[4];
   __shared__ ull ldeg;
-  if (threadIdx.x == 0) ldeg = 0;
+  __shared__ u32 lroots[CC_ROOTS], lroots_n, lroots_base;
+  if (threadIdx.x == 0) { ldeg = 0; lroots_n = 0; }
+  __syncthreads();
   u32 m = 0, mb = 0;
   ull ds = 0;
-  for (u32 u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
-    const u32 dg = deg[u];
-    if (dg) {
-      m++;
-      ds += dg;
-      if (csize[P[u]] > SMALL_COMP) mb++;              // P was flattened by k_comp_stats
+  const u32 lane = threadIdx.x & 63;
+  for (u32 u0 = blockIdx.x * blockDim.x; u0 < n; u0 += gridDim.x * blockDim.x) {     // (whole waves stay in the loop: ballot below)
+    const u32 u = u0 + threadIdx.x;
+    bool small_root = false;
+    if (u < n) {
+      const u32 dg = deg[u];
+      if (dg) {
+        m++;
+        ds += dg;
+        const u32 root = P[u];                           // P was flattened by k_comp_stats
+        const u32 cs = csize[root];
+        if (cs > SMALL_COMP) mb++;
+        small_root = root == u && cs > 2 && cs <= SMALL_COMP;
+      }
+    }
+    // the roots of the components k_cluster_small takes, as a dense list: a thread per LISTED root there
+    // instead of a thread per leaf that mostly finds nothing to do.  Collected per workgroup in LDS
+    // and flushed with ONE global atomic when the buffer fills or the loop ends (a single-address
+    // atomic per wave cost 100 us here: ~40 k of them serialise at ~12 ns each).
+    if (small_roots) {
+      const u64 bm = __ballot(small_root);
+      if (bm) {
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&lroots_n, (u32)__popcll(bm));
+        base = __shfl(base, 0);
+        if (small_root) lroots[base + (u32)__popcll(bm & ((1ull << lane) - 1ull))] = u;
+      }
+      __syncthreads();
+      if (lroots_n > CC_ROOTS - 256u) {                  // the next round might not fit: flush (uniform decision)
+        const u32 cntl = lroots_n;
+        if (threadIdx.x == 0) lroots_base = (u32)atomicAdd(&ctr[CTR_SMALLROOTS], (ull)cntl);
+        __syncthreads();
+        for (u32 k = threadIdx.x; k < cntl; k += blockDim.x) small_roots[lroots_base + k] = lroots[k];
+        __syncthreads();
+        if (threadIdx.x == 0) lroots_n = 0;
+        __syncthreads();
+      }
+    }
+  }
+  if (small_roots) {
+    __syncthreads();
+    const u32 cntl = lroots_n;
+    if (cntl) {
+      if (threadIdx.x == 0) lroots_base = (u32)atomicAdd(&ctr[CTR_SMALLROOTS], (ull)cntl);
+      __syncthreads();
+      for (u32 k = threadIdx.x; k < cntl; k += blockDim.x) small_roots[lroots_base + k] = lroots[k];
     }
   }
   const u32 tm = block_sum(m, lds);                    // (its barriers also publish ldeg = 0)
