@@ -95,7 +95,7 @@ struct humid_ctx {
   DBuf heads;                                                                     // big-component heads
   DBuf small_roots;         // k_comp_count: roots of the components of 3 .. 32 leaves (k_cluster_small works off this list)
   DBuf big_runs;            // k_big_runs: (start, length, first tile) of the buckets beyond k_pairs' walk, per combination
-  DBuf had;                 // k_pairs: first-phase "found a pair" flags, one byte per combination and position
+  DBuf had;                 // k_pairs: per combination and position, pairs found in the first phase (<< 24) | distance to the first one
   DBuf e_kx, e_vx, e_ky, e_vy, e_raw, e_sorted, e_edges, e_head, e_hpos;   // edit-distance neighbour search
   bool edit = false;         // option "edit_distance": Levenshtein instead of Hamming neighbours (-e)
   DBuf xr_heads, xr_send, xr_zero;                             // the same for two-word words: heads, routed words, an all-usable flag array
@@ -914,7 +914,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
   if (search) {
     const u32 nseg = plan.ncombo;
     n_pair_segs = nseg < 8 ? nseg : 8;
-    ENSURE(c->had, (size_t)nseg * U);                       // per combination: this position found a pair
+    ENSURE(c->had, (size_t)nseg * U * 4);                   // per combination and position: pairs found, distance to the first
     if (nseg > 1) {
       ENSURE(c->seg_k0, (size_t)U * 8);
       ENSURE(c->seg_v0, (size_t)U * 4);
@@ -929,7 +929,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
         hipLaunchKernelGGL((k_pairs<true, PM_COUNT, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
                            (const u32 *)nullptr, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, c->deg.as<u32>(),
                            c->parent.as<u32>(), (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
-                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u8>(), walk_max,
+                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u32>(), walk_max,
                            &c->d_ctr[CTR_BIGMASK], join_cnt);
       } else {
         u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
@@ -955,7 +955,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
         hipLaunchKernelGGL((k_pairs<false, PM_COUNT, WT>), dim3(blocks_for(U)), dim3(256), 0, st, ws,
                            vs, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, c->deg.as<u32>(), c->parent.as<u32>(),
                            (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
-                           (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u8>() + (size_t)seg * U, walk_max,
+                           (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u32>() + (size_t)seg * U, walk_max,
                            &c->d_ctr[CTR_BIGMASK], join_cnt);
       }
       if (seg < 8) HIPCHK(hipEventRecord(c->kev[21 + 2 * seg], st));
@@ -1015,7 +1015,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
         hipLaunchKernelGGL((k_pairs<true, PM_FILL, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
                            (const u32 *)nullptr, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, (u32 *)nullptr,
                            (u32 *)nullptr, c->nbr_off.as<u32>(), c->cur.as<u32>(), c->nbr_idx.as<u32>(),
-                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u8>(), walk_max);
+                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u32>(), walk_max);
         if (big_mask & 1) TRY(big_tiles(0, PM_FILL));
       } else {
         const u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
@@ -1023,7 +1023,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
         hipLaunchKernelGGL((k_pairs<false, PM_FILL, WT>), dim3(blocks_for(U)), dim3(256), 0, st, ws,
                            vs, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
                            c->nbr_off.as<u32>(), c->cur.as<u32>(), c->nbr_idx.as<u32>(),
-                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u8>() + (size_t)seg * U,
+                           (u32 *)nullptr, (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u32>() + (size_t)seg * U,
                            walk_max);
         if (big_mask >> seg & 1) TRY(big_tiles(seg, PM_FILL));
       }
@@ -1295,19 +1295,19 @@ static int stage_pairs_share(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt
       if (seg == 0 && phase == 0)
         hipLaunchKernelGGL((k_pairs<true, PM_EMIT_COUNT, u64>), grid, blk, 0, st, g_word, vs, U, p_lo, n_sel[0], plan.mask[0].lo,
                            d_masks, 0u, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr,
-                           (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u8 *)nullptr);
+                           (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u32 *)nullptr);
       else if (seg == 0)
         hipLaunchKernelGGL((k_pairs<true, PM_EMIT_FILL, u64>), grid, blk, 0, st, g_word, vs, U, p_lo, n_sel[0], plan.mask[0].lo,
                            d_masks, 0u, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr,
-                           (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u8 *)nullptr);
+                           (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u32 *)nullptr);
       else if (phase == 0)
         hipLaunchKernelGGL((k_pairs<false, PM_EMIT_COUNT, u64>), grid, blk, 0, st, ws, vs, n_sel[seg], 0u, n_sel[seg],
                            plan.mask[seg].lo, d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
-                           (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u8 *)nullptr);
+                           (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u32 *)nullptr);
       else
         hipLaunchKernelGGL((k_pairs<false, PM_EMIT_FILL, u64>), grid, blk, 0, st, ws, vs, n_sel[seg], 0u, n_sel[seg],
                            plan.mask[seg].lo, d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
-                           (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u8 *)nullptr);
+                           (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u32 *)nullptr);
     }
     if (phase == 0) {
       TRY(exscan_u32(c, c->pc.as<u32>(), c->poff.as<u32>(), T + 1));
@@ -2694,12 +2694,12 @@ static int emit_pairs(humid_ctx *c, const WT *W, const u32 *V, u32 n, const Comb
   if (V)
     hipLaunchKernelGGL((k_pairs<false, PM_EMIT_COUNT, WT>), grid, blk, 0, st, W, V, n, 0u, n, cmask, d_masks,
                        cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
-                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr, walk_max,
+                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u32 *)nullptr, walk_max,
                        &c->d_ctr[CTR_BIGMASK]);
   else
     hipLaunchKernelGGL((k_pairs<true, PM_EMIT_COUNT, WT>), grid, blk, 0, st, W, V, n, 0u, n, cmask, d_masks,
                        cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
-                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr, walk_max,
+                       (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u32 *)nullptr, walk_max,
                        &c->d_ctr[CTR_BIGMASK]);
   TRY(exscan_u32(c, c->pc.as<u32>(), c->poff.as<u32>(), (u64)n + 1));
   HIPCHK(hipGetLastError());
@@ -2734,11 +2734,11 @@ static int emit_pairs(humid_ctx *c, const WT *W, const u32 *V, u32 n, const Comb
     if (V)
       hipLaunchKernelGGL((k_pairs<false, PM_EMIT_FILL, WT>), grid, blk, 0, st, W, V, n, 0u, n, cmask, d_masks,
                          cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
-                         (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr, walk_max);
+                         (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u32 *)nullptr, walk_max);
     else
       hipLaunchKernelGGL((k_pairs<true, PM_EMIT_FILL, WT>), grid, blk, 0, st, W, V, n, 0u, n, cmask, d_masks,
                          cb, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, (u32 *)nullptr,
-                         (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u8 *)nullptr, walk_max);
+                         (u32 *)nullptr, c->pc.as<u32>(), c->poff.as<u32>(), c->share_edges.as<u64>(), (u32 *)nullptr, walk_max);
   }
   if (E_far) {
     const ull at = E;                                               // the cursor of the append starts behind k_pairs' pairs

@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256)
 k_pairs(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, u32 i0, u32 n_i, WT mask,
         EarlierMasksT<WT> em, u32 cb, u32 distance, u32 *deg, u32 *parent,
         const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, u32 *__restrict__ pc,
-        const u32 *__restrict__ poff, u64 *__restrict__ edges, u8 *__restrict__ had,
+        const u32 *__restrict__ poff, u64 *__restrict__ edges, u32 *__restrict__ had,
         u32 walk_max = 0, ull *big = nullptr, const u32 *__restrict__ cnt = nullptr) {
   HUMID_GUARD_LAST_VGPR();
   // W: the words IN THE ORDER WALKED (the sorted unique array for the prefix combo, a gathered
@@ -131,12 +131,22 @@ k_pairs(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, u32 i0, u32 
   if (t >= n_i) return;
   // second phase: only the few positions that found a pair in the first walk their bucket again
   // (had[] / pc[] were written by the matching first-phase launch: same grid, same t)
-  if (MODE == PM_FILL && had && !had[t]) return;
+  // had[t] = pairs found (capped, << 24) | distance to the first one: a position with ONE pair -- nearly all
+  // of them -- writes its two CSR entries without walking its bucket a second time
+  const u32 h = (MODE == PM_FILL && had) ? had[t] : 0u;
+  if (MODE == PM_FILL && had && !h) return;
   if (MODE == PM_EMIT_FILL && pc[t] == 0) return;
   const u32 i = i0 + t;
+  if (MODE == PM_FILL && (h >> 24) == 1u && (h & 0xffffffu)) {
+    const u32 j = i + (h & 0xffffffu);
+    const u32 ri = PASS0 ? i : V[i], rj = PASS0 ? j : V[j];
+    nbr_idx[nbr_off[ri] + atomicAdd(&cur[ri], 1u)] = rj;
+    nbr_idx[nbr_off[rj] + atomicAdd(&cur[rj], 1u)] = ri;
+    return;
+  }
   const WT wi = W[i];
   const u32 ri = PASS0 ? i : V[i];
-  u32 found = 0;
+  u32 found = 0, first_off = 0;
   u64 e = (MODE == PM_EMIT_FILL) ? (u64)poff[t] : 0;
   // walk_max > 0: a position compares itself with at most the next walk_max words of its bucket;
   // a bucket that goes on beyond that is reported in *big (bit cb) and its remaining pairs
@@ -158,6 +168,7 @@ k_pairs(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, u32 i0, u32 
       nbr_idx[nbr_off[ri] + atomicAdd(&cur[ri], 1u)] = rj;
       nbr_idx[nbr_off[rj] + atomicAdd(&cur[rj], 1u)] = ri;
     } else if (MODE == PM_COUNT) {
+      if (!found) first_off = j - i;
       found++;
       atomicAdd(&deg[rj], 1u);
       if (joins_for_clustering(cnt, ri, rj)) uf_union(parent, ri, rj);
@@ -168,7 +179,7 @@ k_pairs(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, u32 i0, u32 
     }
   }
   if (MODE == PM_COUNT && found) atomicAdd(&deg[ri], found);
-  if (MODE == PM_COUNT && had) had[t] = found ? 1 : 0;
+  if (MODE == PM_COUNT && had) had[t] = found ? (((found < 255u ? found : 255u) << 24) | (first_off < (1u << 24) ? first_off : 0u)) : 0u;
   if (MODE == PM_EMIT_COUNT) pc[t] = found;
   if ((MODE == PM_COUNT || MODE == PM_EMIT_COUNT) && big && j == jend && jend < n && !w_hits(w_xor(wi, W[jend]), mask))
     atomicOr(big, 1ull << cb);
