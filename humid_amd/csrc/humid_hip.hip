@@ -104,6 +104,7 @@ struct humid_ctx {
        x_items, x_w, x_id, x_ids, x_ends, x_ends_s, x_head, x_hpos, x_nodes, x_cedges;   // multi-GPU exchange mode
   DBuf w_sorted, w_head, w_hpos, w_start;                                         // wide-word (sorted) counts
   DBuf pt_work, unperm_rec, route_tiles;                                                     // LDS-staged partition / un-permute (kernels_part.hip.h)
+  bool pt_padded = true;            // level 1 of the tile partition into padded coarse bins (no histogram pass); false after an overflow
   bool use_tile_partition = true;   // option "tile_partition": 0 = library radix passes + one-kernel un-permute (round 1)
   bool last_part_tiled = false;     // kev[39]..kev[40] bracket the second-level scatter of the last count
   bool route_checked = true;        // no humid_stage_route since the last humid_stage_route_check
@@ -534,6 +535,7 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   HIPCHK(hipMemsetAsync(c->d_ctr, 0, CTR_N * sizeof(ull), st));
   const bool check_range = !(range_lo == 0 && range_hi == ~0ull);
   c->last_part_tiled = c->use_tile_partition && pb <= 2 * 9;
+  bool used_padded = false;
   if (c->last_part_tiled) {
     // hand-written partition (kernels_part.hip.h): two levels of LDS-staged scatter; excluded reads
     // (filtered, or outside this rank's value range) never enter it
@@ -552,21 +554,40 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
     in.key = PartKeyOp{ordered ? 1u : 0u, km.lo, km.scale};
     const u32 tiles1 = (N + PT_TILE - 1) / PT_TILE, tiles2 = tiles1 + nb1;
     const ReadsSrc src{in};
-    hipLaunchKernelGGL(k_pt_hist1<ReadsSrc>, dim3(tiles1 < 512 ? tiles1 : 512), dim3(1024), 0, st, src, N, d1, hist1);
-    hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, hist1, d1, d2, cbase, tprefix, c->pbeg.as<u32>(),
-                       c->ucount.as<u32>() + n_parts);
+    // Two levels and keys that spread evenly over the coarse bins (hashed keys always do, word-ordered
+    // keys were only chosen because their prefix does): level 1 scatters into PADDED coarse bins of a
+    // fixed room (mean + 12.5 % + 1024) and needs no histogram pass over the reads in front; the bins'
+    // counts are the cursors it leaves behind.  A bin that outgrows its room (heavily duplicated words:
+    // all reads of a word share a bin) is reported, the run discarded, and this context goes back to the
+    // histogram form (pt_padded = false).
+    const bool padded = d2 > 0 && c->pt_padded;
+    const u32 cap1 = padded ? (u32)std::min<u64>(0xffffffffull / nb1, (u64)N / nb1 + (u64)N / nb1 / 8 + 1024) : 0u;
+    const size_t room1 = padded ? (size_t)nb1 * cap1 : (size_t)N;
+    used_padded = padded;
+    if (padded) {
+      ENSURE(c->pad_word, room1 * 8);
+      ENSURE(c->pslot, room1 * 4);
+    }
     // level-1 output: the final arrays when there is no second level, else scratch that is dead until
     // k_dedup_lds writes it (pad_word, pslot)
     u64 *k1 = d2 ? c->pad_word.as<u64>() : c->pk_keys.as<u64>();
     u32 *v1 = d2 ? c->pslot.as<u32>() : c->pk_vals.as<u32>();
+    if (!padded) {
+      hipLaunchKernelGGL(k_pt_hist1<ReadsSrc>, dim3(tiles1 < 512 ? tiles1 : 512), dim3(1024), 0, st, src, N, d1, hist1);
+      hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, hist1, d1, d2, cbase, tprefix, c->pbeg.as<u32>(),
+                         c->ucount.as<u32>() + n_parts, 0u);
+    }
     hipLaunchKernelGGL((k_pt_scatter<1, ReadsSrc>), dim3(tiles1), dim3(1024), 0, st, src, N, (const u64 *)nullptr,
                        (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr, d1, d2, cbase, cursor1, k1, v1,
-                       (u32 *)nullptr);
+                       (u32 *)nullptr, cap1, c->d_ctr);
+    if (padded)
+      hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, (const u32 *)cursor1, d1, d2, cbase, tprefix, c->pbeg.as<u32>(),
+                         c->ucount.as<u32>() + n_parts, cap1);
     HIPCHK(hipEventRecord(c->kev[39], st));
     if (d2) {
-      hipLaunchKernelGGL(k_pt_hist2<ReadsSrc>, dim3(tiles2), dim3(1024), 0, st, src, k1, tprefix, cbase, d1, d2, hist_fine);
+      hipLaunchKernelGGL(k_pt_hist2<ReadsSrc>, dim3(tiles2), dim3(1024), 0, st, src, k1, tprefix, cbase, d1, d2, hist_fine, cap1);
       hipLaunchKernelGGL((k_pt_scatter<2, ReadsSrc>), dim3(tiles2), dim3(1024), 0, st, src, N, k1, v1, tprefix, cbase, d1, d2,
-                         hist_fine, cursor2, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(), c->pbeg.as<u32>());
+                         hist_fine, cursor2, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(), c->pbeg.as<u32>(), cap1, c->d_ctr);
     }
     HIPCHK(hipEventRecord(c->kev[40], st));
   } else {
@@ -600,6 +621,10 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   TRY(exscan_u32(c, c->ucount.as<u32>(), c->ubase.as<u32>(), (u64)n_parts + 1));
   HIPCHK(hipGetLastError());
   TRY(read_counters(c));
+  if (used_padded && c->h_ctr[CTR_SPECIAL]) {          // a coarse bin outgrew its padded room: once more, with the histogram pass
+    c->pt_padded = false;
+    return stage_count_lds(c, d_words, d_filt, N, word_nt, range_lo, range_hi, km, ordered, s, overflowed);
+  }
   if (c->h_ctr[CTR_OVERFULL]) { *overflowed = true; return HUMID_OK; }
   const u32 U = (u32)c->h_ctr[CTR_UNIQUE];
   s.usable = c->usable = c->h_ctr[CTR_USABLE];
@@ -1615,6 +1640,10 @@ int humid_ctx_set_option(humid_ctx *c, const char *key, int64_t value) {
   }
   if (strcmp(key, "coop_big") == 0) {
     c->coop_big = value != 0;
+    return HUMID_OK;
+  }
+  if (strcmp(key, "padded_partition") == 0) {
+    c->pt_padded = value != 0;
     return HUMID_OK;
   }
   if (strcmp(key, "force_comm") == 0) {

@@ -72,8 +72,10 @@ __device__ __forceinline__ void block_exscan_512(const u32 *cnt, u32 *off, u32 n
 }
 
 // tile -> (coarse bin, first record, record count): tiles never cross a coarse bin
+// cap1 > 0: the level-1 output is PADDED -- coarse bin c owns the fixed room [c * cap1, (c + 1) * cap1) and
+// holds cbase[c + 1] - cbase[c] records at its start (level 1 then needs no histogram pass of its own)
 __device__ __forceinline__ void pt_tile_of(const u32 *__restrict__ tprefix, const u32 *__restrict__ cbase, u32 nb1,
-                                           u32 tile, u32 &c, u32 &beg, u32 &cnt) {
+                                           u32 tile, u32 cap1, u32 &c, u32 &beg, u32 &cnt) {
   u32 lo = 0, hi = nb1;                    // largest c with tprefix[c] <= tile
   while (hi - lo > 1) {
     const u32 mid = (lo + hi) >> 1;
@@ -81,9 +83,9 @@ __device__ __forceinline__ void pt_tile_of(const u32 *__restrict__ tprefix, cons
   }
   c = lo;
   const u32 k = tile - tprefix[c];
-  const u32 b0 = cbase[c], b1 = cbase[c + 1];
-  beg = b0 + k * PT_TILE;
-  cnt = (beg >= b1) ? 0u : ((b1 - beg < PT_TILE) ? b1 - beg : PT_TILE);
+  const u32 n_c = cbase[c + 1] - cbase[c], done = k * PT_TILE;
+  beg = (cap1 ? c * cap1 : cbase[c]) + done;
+  cnt = (done >= n_c) ? 0u : ((n_c - done < PT_TILE) ? n_c - done : PT_TILE);
 }
 
 // ---- level 1 histogram: usable reads per coarse bin (the top d1 key bits) ----
@@ -120,11 +122,14 @@ k_pt_hist1(SRC src, u32 n_reads, u32 d1, u32 *__restrict__ hist1) {
 // EMPTY coarse bins (no tile) and the final pbeg[2^(d1+d2)] = number of records ----
 __global__ void __launch_bounds__(1024)
 k_pt_scan1(const u32 *__restrict__ hist1, u32 d1, u32 d2, u32 *__restrict__ cbase, u32 *__restrict__ tprefix,
-           u32 *__restrict__ pbeg, u32 *__restrict__ ucount_tail) {
+           u32 *__restrict__ pbeg, u32 *__restrict__ ucount_tail, u32 cap1) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u32 cnt[PT_MAXBINS], off[PT_MAXBINS + 1], wsum[8];
   const u32 nb = 1u << d1;
-  if (threadIdx.x < nb) cnt[threadIdx.x] = hist1[threadIdx.x];
+  // cap1 > 0: hist1 = the cursors of a padded level 1 (what each coarse bin received; a bin that
+  // overflowed its room is cut to it -- the run is discarded by the caller, nothing may leave its room)
+  auto count_of = [&](u32 b) { const u32 v = hist1[b]; return (cap1 && v > cap1) ? cap1 : v; };
+  if (threadIdx.x < nb) cnt[threadIdx.x] = count_of(threadIdx.x);
   __syncthreads();
   block_exscan_512(cnt, off, nb, wsum);
   if (threadIdx.x <= nb) cbase[threadIdx.x] = off[threadIdx.x];
@@ -136,7 +141,7 @@ k_pt_scan1(const u32 *__restrict__ hist1, u32 d1, u32 d2, u32 *__restrict__ cbas
       for (u32 f = 0; f < (1u << d2); f++) pbeg[(threadIdx.x << d2) | f] = off[threadIdx.x];
   }
   __syncthreads();
-  if (threadIdx.x < nb) cnt[threadIdx.x] = (hist1[threadIdx.x] + PT_TILE - 1) / PT_TILE;
+  if (threadIdx.x < nb) cnt[threadIdx.x] = (count_of(threadIdx.x) + PT_TILE - 1) / PT_TILE;
   __syncthreads();
   block_exscan_512(cnt, off, nb, wsum);
   if (threadIdx.x <= nb) tprefix[threadIdx.x] = off[threadIdx.x];
@@ -153,12 +158,12 @@ __global__ void __launch_bounds__(1024)
 k_pt_scatter(SRC src, u32 n_reads, const u64 *__restrict__ k_in, const u32 *__restrict__ v_in,
              const u32 *__restrict__ tprefix, const u32 *__restrict__ cbase, u32 d1, u32 d2,
              const u32 *__restrict__ base, u32 *cursor, u64 *__restrict__ k_out, u32 *__restrict__ v_out,
-             u32 *__restrict__ pbeg_out) {
+             u32 *__restrict__ pbeg_out, u32 cap1, ull *ctr) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u64 skey[PT_TILE];
   __shared__ u32 sval[PT_TILE];
   __shared__ unsigned short sbin[PT_TILE];
-  __shared__ u32 cnt[PT_MAXBINS], loff[PT_MAXBINS + 1], goff[PT_MAXBINS], fbase[PT_MAXBINS + 1], wsum[8];
+  __shared__ u32 cnt[PT_MAXBINS], loff[PT_MAXBINS + 1], goff[PT_MAXBINS], room[PT_MAXBINS], fbase[PT_MAXBINS + 1], wsum[8];
   __shared__ u32 s_c, s_beg, s_cnt, s_first;
   const u32 nb = 1u << (LEVEL == 1 ? d1 : d2);
   u32 t_beg, t_cnt, coarse = 0;
@@ -169,7 +174,7 @@ k_pt_scatter(SRC src, u32 n_reads, const u64 *__restrict__ k_in, const u32 *__re
     if (blockIdx.x >= tprefix[1u << d1]) return;             // beyond the last tile (uniform exit)
     if (threadIdx.x == 0) {
       u32 c, b, n;
-      pt_tile_of(tprefix, cbase, 1u << d1, blockIdx.x, c, b, n);
+      pt_tile_of(tprefix, cbase, 1u << d1, blockIdx.x, cap1, c, b, n);
       s_c = c; s_beg = b; s_cnt = n;
       s_first = (blockIdx.x == tprefix[c]) ? 1u : 0u;          // first tile of its coarse bin
     }
@@ -207,8 +212,13 @@ k_pt_scatter(SRC src, u32 n_reads, const u64 *__restrict__ k_in, const u32 *__re
   if (threadIdx.x < nb) {
     const u32 c = cnt[threadIdx.x];
     const u32 g = (LEVEL == 1) ? threadIdx.x : ((coarse << d2) | threadIdx.x);
-    const u32 b0 = (LEVEL == 1) ? base[g] : cbase[coarse] + fbase[threadIdx.x];
-    goff[threadIdx.x] = b0 + (c ? atomicAdd(&cursor[g], c) : 0u);
+    // LEVEL 1 with cap1: the bin's fixed room; what does not fit is dropped and reported (ctr[CTR_SPECIAL]):
+    // the caller repeats the partition with a histogram pass in front
+    const u32 b0 = (LEVEL == 1) ? (cap1 ? g * cap1 : base[g]) : cbase[coarse] + fbase[threadIdx.x];
+    const u32 had_before = c ? atomicAdd(&cursor[g], c) : 0u;
+    goff[threadIdx.x] = b0 + had_before;
+    room[threadIdx.x] = (LEVEL == 1 && cap1) ? (had_before >= cap1 ? 0u : cap1 - had_before) : 0xffffffffu;
+    if (LEVEL == 1 && cap1 && had_before + c > cap1) ctr[CTR_SPECIAL] = 1;
   }
 #pragma unroll
   for (u32 q = 0; q < PT_IPT; q++)
@@ -222,7 +232,9 @@ k_pt_scatter(SRC src, u32 n_reads, const u64 *__restrict__ k_in, const u32 *__re
   const u32 total = loff[nb];
   for (u32 s = threadIdx.x; s < total; s += PT_THREADS) {
     const u32 bin = sbin[s];
-    const u32 d = goff[bin] + (s - loff[bin]);
+    const u32 within = s - loff[bin];
+    if (within >= room[bin]) continue;
+    const u32 d = goff[bin] + within;
     k_out[d] = skey[s];
     v_out[d] = sval[s];
   }
@@ -232,7 +244,7 @@ k_pt_scatter(SRC src, u32 n_reads, const u64 *__restrict__ k_in, const u32 *__re
 template <class SRC>
 __global__ void __launch_bounds__(1024)
 k_pt_hist2(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ tprefix, const u32 *__restrict__ cbase, u32 d1,
-           u32 d2, u32 *__restrict__ hist_fine) {
+           u32 d2, u32 *__restrict__ hist_fine, u32 cap1) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u32 h[PT_MAXBINS];
   __shared__ u32 s_c, s_beg, s_cnt;
@@ -240,7 +252,7 @@ k_pt_hist2(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ tprefi
   const u32 nb = 1u << d2;
   if (threadIdx.x == 0) {
     u32 c, b, n;
-    pt_tile_of(tprefix, cbase, 1u << d1, blockIdx.x, c, b, n);
+    pt_tile_of(tprefix, cbase, 1u << d1, blockIdx.x, cap1, c, b, n);
     s_c = c; s_beg = b; s_cnt = n;
   }
   for (u32 b = threadIdx.x; b < nb; b += PT_THREADS) h[b] = 0;

@@ -100,6 +100,9 @@ const char *humid_last_error(const humid_ctx *ctx);   /* ctx may be NULL */
  * the hand-written LDS-staged partition (two coalesced passes each way); 0 = library radix passes
  * in front and one scattered store per read at the end (the round-1 form, also taken by itself for
  * read sets beyond ~180 M / ~67 M reads).
+ * "padded_partition": 1 (default) = the first level of the tile partition scatters into coarse bins of a
+ * fixed room and needs no histogram pass over the reads; a bin that outgrows its room (heavily duplicated
+ * words) is detected, the run repeated with the histogram pass, and the option stays 0 for this context.
  * "force_comm": 1 = humid_dedup_run_exchange goes through the humid_comm callbacks even with one rank
  * (a transport can be exercised on a one-GPU box); default 0: with one rank nothing is called or copied.
  * "bucket_walk": how many following words of its pigeonhole bucket a position is compared with by

@@ -426,6 +426,25 @@ def test_one_prefix_shared_by_200k_words(dd, d):
     check_against_oracle(dd, words, filt, 24, d, True, deep=False)
 
 
+def test_padded_partition_outgrown_by_duplicated_words(dd):
+    """the first partition level gives every coarse bin a fixed room (mean + 12.5 % + 1024 reads) and skips
+    its histogram pass; all reads of ONE word share a bin, so a word that makes up a third of the reads
+    outgrows that room: the overflow must be noticed, the run repeated with the histogram pass, and the
+    results stay those of the oracle -- also for the runs after it (the context remembers)"""
+    rng = np.random.default_rng(77)
+    words, filt = synth_words(600_000, 9, 24, p_sub=3e-3, p_n=1e-3)
+    hot = rng.random(len(words)) < 0.35
+    words = words.copy()
+    words[hot] = np.uint64(0x0123456789ab)
+    dd.set_option("padded_partition", 1)
+    for rep in range(2):
+        s = check_against_oracle(dd, words, filt, 24, 1, False, deep=(rep == 0))
+        assert s["unique"] > 100_000
+    words2, filt2 = synth_words(200_000, 10, 24, p_sub=3e-3)
+    check_against_oracle(dd, words2, filt2, 24, 1, False, deep=False)
+    dd.set_option("padded_partition", 1)
+
+
 def test_long_chain_component(dd):
     """a path-shaped component thousands of leaves deep (the reference recursion overflows here)"""
     # words 0..L-1 in unary-like Gray walk: consecutive words differ in one nucleotide
