@@ -556,12 +556,12 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
     const ReadsSrc src{in};
     // Two levels and keys that spread evenly over the coarse bins (hashed keys always do, word-ordered
     // keys were only chosen because their prefix does): level 1 scatters into PADDED coarse bins of a
-    // fixed room (mean + 12.5 % + 1024) and needs no histogram pass over the reads in front; the bins'
+    // fixed room (mean + 25 % + 1024) and needs no histogram pass over the reads in front; the bins'
     // counts are the cursors it leaves behind.  A bin that outgrows its room (heavily duplicated words:
     // all reads of a word share a bin) is reported, the run discarded, and this context goes back to the
     // histogram form (pt_padded = false).
     const bool padded = d2 > 0 && c->pt_padded;
-    const u32 cap1 = padded ? (u32)std::min<u64>(0xffffffffull / nb1, (u64)N / nb1 + (u64)N / nb1 / 8 + 1024) : 0u;
+    const u32 cap1 = padded ? (u32)std::min<u64>(0xffffffffull / nb1, (u64)N / nb1 + (u64)N / nb1 / 4 + 1024) : 0u;
     const size_t room1 = padded ? (size_t)nb1 * cap1 : (size_t)N;
     used_padded = padded;
     if (padded) {

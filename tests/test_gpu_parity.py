@@ -427,7 +427,7 @@ def test_one_prefix_shared_by_200k_words(dd, d):
 
 
 def test_padded_partition_outgrown_by_duplicated_words(dd):
-    """the first partition level gives every coarse bin a fixed room (mean + 12.5 % + 1024 reads) and skips
+    """the first partition level gives every coarse bin a fixed room (mean + 25 % + 1024 reads) and skips
     its histogram pass; all reads of ONE word share a bin, so a word that makes up a third of the reads
     outgrows that room: the overflow must be noticed, the run repeated with the histogram pass, and the
     results stay those of the oracle -- also for the runs after it (the context remembers)"""
