@@ -560,8 +560,9 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
     // counts are the cursors it leaves behind.  A bin that outgrows its room (heavily duplicated words:
     // all reads of a word share a bin) is reported, the run discarded, and this context goes back to the
     // histogram form (pt_padded = false).
+    static const u32 pad_div = getenv("HUMID_PAD_DIV") ? (u32)std::max(1, atoi(getenv("HUMID_PAD_DIV"))) : 4u;   // head room = mean / pad_div
     const bool padded = d2 > 0 && c->pt_padded;
-    const u32 cap1 = padded ? (u32)std::min<u64>(0xffffffffull / nb1, (u64)N / nb1 + (u64)N / nb1 / 4 + 1024) : 0u;
+    const u32 cap1 = padded ? (u32)std::min<u64>(0xffffffffull / nb1, (u64)N / nb1 + (u64)N / nb1 / pad_div + 1024) : 0u;
     const size_t room1 = padded ? (size_t)nb1 * cap1 : (size_t)N;
     used_padded = padded;
     if (padded) {
