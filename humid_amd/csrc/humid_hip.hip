@@ -237,7 +237,7 @@ static int read_counters(humid_ctx *c, const u32 *extra32 = nullptr) {
     u32 spins = 0;
     while (*flag != seq) {
       if ((++spins & 0xfffu) == 0) {
-        if (hipStreamQuery(c->stream) == hipSuccess) break;                    // the stream drained: the stores are done or lost
+        if (hipStreamQuery(c->stream) != hipErrorNotReady) break;              // drained (the stores are done or lost) or failed: settled below
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) break;
       }
     }
