@@ -2099,8 +2099,10 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
                          c->xr_send.as<W2>());
     d_routed = c->xr_send.as<u64>();
   }
+  u64 usable_all = 0;                                                // over all ranks: nothing travels when it is 0 (every rank knows)
+  for (size_t b = 0; b < n_bins; b++) usable_all += hist_sum[b];
   const u64 *recv_w = d_routed;                                     // one rank: what was routed is what arrives
-  if (moves) {
+  if (moves && usable_all) {
     ENSURE(c->xr_recv, n_recv * wbytes + 16);
     TRY(x_exchange(c, cm, d_routed, send_counts, false, c->xr_recv.p, recv_counts, wbytes));
     recv_w = c->xr_recv.as<u64>();
@@ -2190,8 +2192,10 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
       u64 n_got = 0;
       for (u32 q = 0; q < P; q++) { rc[q] = all_sc[(size_t)q * P + r]; n_got += rc[q]; }
       if (n_got > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "%llu unique words arrive at rank %u for one combination", (ull)n_got, r);
+      u64 items_all = 0;
+      for (u32 q = 0; q < P * P; q++) items_all += all_sc[q];
       const u64 *got = items;
-      if (moves) {
+      if (moves && items_all) {
         ENSURE(c->xr_got, n_got * ibytes + 32);
         TRY(x_exchange(c, cm, items, sc, false, c->xr_got.p, rc, ibytes));
         got = c->xr_got.as<u64>();
@@ -2208,7 +2212,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   u64 E = 0;
   for (u32 q = 0; q < P; q++) E += e_counts[q];
   const u64 *d_eall = c->xr_eloc.as<u64>();
-  if (moves) {
+  if (moves && E) {
     ENSURE(c->xr_eall, E * 16 + 16);
     ENSURE(c->xr_eloc, 16);
     TRY(x_exchange(c, cm, c->xr_eloc.p, e_counts, true, c->xr_eall.p, e_counts, 16));
@@ -2240,7 +2244,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   TRY(humid_stage_map_dense(c, l_cid, l_ismax, &packed, &n_packed));
   if (n_packed != n_recv) return fail(c, HUMID_E_INVALID, "map_dense returned %llu reads, %llu were counted", (ull)n_packed, (ull)n_recv);
   const u32 *ret = packed;
-  if (moves) {
+  if (moves && usable_all) {
     ENSURE(c->xr_ret, n_send * 4 + 8);
     TRY(x_exchange(c, cm, packed, recv_counts, false, c->xr_ret.p, send_counts, 4));
     ret = c->xr_ret.as<u32>();

@@ -79,7 +79,7 @@ def main():
         ok = np.array_equal(cid, ocid) and np.array_equal(keep, okeep) and \
             all(s[k] == osum[k] for k in ("usable", "unique", "clusters"))
         ok_x = True
-        if not desc["wide"] and desc["reads"] > 1 and not edit:
+        if desc["reads"] > 1 and not edit:                          # (two-word words too, since round 2)
             P = int(rng.integers(2, 6))
             out, offs = run_ranks(P, w, f, n, d, method, "exchange", bucket_walk=walk)
             for r in range(P):
