@@ -161,7 +161,7 @@ def load(import_torch: bool = True):
             raise HumidLibraryError("%s does not export %s" % (SO_PATH, name)) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.humid_abi_version() != 2:
+    if lib.humid_abi_version() != 3:
         raise HumidLibraryError("ABI version mismatch")
     _LIB = lib
     return lib

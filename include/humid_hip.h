@@ -42,7 +42,7 @@ extern "C" {
 #define HUMID_METHOD_DIRECTIONAL 0u  /* default; src/cluster.cc:82-87               */
 #define HUMID_METHOD_MAXIMUM     1u  /* -x;      src/cluster.cc:72-80               */
 
-#define HUMID_ABI_VERSION 2u
+#define HUMID_ABI_VERSION 3u   /* 3: humid_dedup_run_exchange, humid_comm, humid_shm_* (round 2); 2: humid_dedup_run_bases, humid_stage_route ... */
 
 typedef struct humid_ctx humid_ctx;   /* device workspace + stream; not thread-safe */
 

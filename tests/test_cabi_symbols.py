@@ -25,7 +25,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SYMBOLS) == names
-    assert lib.humid_abi_version() == 2
+    assert lib.humid_abi_version() == 3
 
 
 def test_no_cpu_fallback_without_gpu():
