@@ -64,7 +64,7 @@ def test_header_is_plain_c_and_links(tmp_path):
            "-Wl,-rpath-link,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     out = subprocess.check_output([str(exe)]).decode()
-    assert out.split()[0] == "2"
+    assert out.split()[0] == "3"
 
 
 def test_pigeonhole_plan_never_exceeds_its_tables():
