@@ -236,6 +236,9 @@ bool run_rank(Rank &k) {
   hipStream_t st = k.st;
   const uint64_t r0 = job.n_reads * r / P, r1 = job.n_reads * (r + 1) / P, n_local = r1 - r0;
 
+  // one slab for the library's buffers of this rank (about what it will count: its share of the reads; the
+  // buffers that do not fit are allocated one by one as before)
+  if (n_local) humid_ctx_reserve(k.ctx, n_local + n_local / 4, job.word_nt);
   // this rank's shard of the reads, in input order
   DevBuf d_w, d_f, d_cid, d_keep;
   const uint64_t wpr = job.word_nt > 32 ? 2 : 1;                                        // uint64 per word (include/humid_hip.h)
