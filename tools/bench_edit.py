@@ -1,5 +1,6 @@
 import sys, time
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch
 import humid_amd
 from humid_amd.synth import synth_words
@@ -9,8 +10,10 @@ for n_reads in (1_000_000, 10_000_000):
     d_w = torch.from_numpy(w.view(np.int64)).to(dev); d_f = torch.from_numpy(f).to(dev)
     d_c = torch.zeros(n_reads, dtype=torch.int32, device=dev); d_k = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
     dd = humid_amd.Dedup(device=0)
-    for d in (2, 3):
+    for d in (2, 3, 4, 5):
         for edit in (0, 1):
+            if d >= 4 and (not edit or n_reads > 1_000_000):
+                continue          # two insertion/deletion pairs: timed at 1 M reads only
             dd.set_option("edit_distance", edit)
             for _ in range(2):
                 s = dd.run_device(d_w.data_ptr(), d_f.data_ptr(), d_c.data_ptr(), d_k.data_ptr(), n_reads, 24, d, 0)
