@@ -473,8 +473,9 @@ static int stage_count_global(humid_ctx *c, const u64 *d_words, const u8 *d_filt
 
 // bucket bits of the partitioned count: 2^pb buckets of about PART_TARGET reads
 static inline u32 part_bits(u32 N) {
+  static const u64 target = getenv("HUMID_PART_TARGET") ? (u64)std::max(32, atoi(getenv("HUMID_PART_TARGET"))) : (u64)PART_TARGET;   // experiments
   u32 pb = 1;
-  while (pb < 26 && ((u64)PART_TARGET << pb) < (u64)N) pb++;
+  while (pb < 26 && (target << pb) < (u64)N) pb++;
   return pb;
 }
 
