@@ -104,6 +104,7 @@ struct humid_ctx {
        x_items, x_w, x_id, x_ids, x_ends, x_ends_s, x_head, x_hpos, x_nodes, x_cedges;   // multi-GPU exchange mode
   DBuf w_sorted, w_head, w_hpos, w_start;                                         // wide-word (sorted) counts
   DBuf pt_work, unperm_rec, route_tiles;                                                     // LDS-staged partition / un-permute (kernels_part.hip.h)
+  bool group_buckets = true;        // option "group_buckets": bucket order of stretch keys by two-level grouping instead of a library sort
   bool pt_padded = true;            // level 1 of the tile partition into padded coarse bins (no histogram pass); false after an overflow
   bool use_tile_partition = true;   // option "tile_partition": 0 = library radix passes + one-kernel un-permute (round 1)
   bool last_part_tiled = false;     // kev[39]..kev[40] bracket the second-level scatter of the last count
@@ -821,6 +822,42 @@ static int find_big_runs(humid_ctx *c, const WT *W, u32 n, WT mask, u32 walk_max
   return HUMID_OK;
 }
 
+// The same stretch keys of at most 24 bits: bucket order by GROUPING in two hand-written levels
+// (kernels_part.hip.h: the tile partition by the top d1 <= 9 key bits, k_group_fine by the rest) instead
+// of a library sort; only that equal keys end up next to each other matters.  *done = false: not this
+// shape (the caller sorts).
+static int group_words_by_stretch(humid_ctx *c, const ComboPlan &plan, u32 cb, const u64 *W, u32 n, u64 *ws, u32 *vs, bool *done) {
+  hipStream_t st = c->stream;
+  u32 bit_lo = 0, bit_n = 0;
+  bool stretch = plan.nfield[cb] >= 1;
+  for (u32 f = 0; stretch && f < plan.nfield[cb]; f++) {
+    if (f + 1 < plan.nfield[cb] && plan.shift[cb][f] != plan.shift[cb][f + 1] + plan.width[cb][f + 1]) stretch = false;
+    bit_n += plan.width[cb][f];
+    bit_lo = plan.shift[cb][f];
+  }
+  *done = stretch && c->group_buckets && bit_n >= 2 && bit_n <= 24 && bit_lo + bit_n <= 64 && n >= 4096;
+  if (!*done) return HUMID_OK;
+  const u32 d1 = bit_n >= 18 ? 9u : (bit_n + 1) / 2, d2 = bit_n - d1;          // d2 <= 15: 128 KB of LDS counters at most
+  const u32 nb1 = 1u << d1;
+  // scratch: [hist1 512 | cursor1 512] zeroed, then [cbase 513 | tprefix 513 | pbeg dummy 514]
+  ENSURE(c->pt_work, (size_t)(1024 + 513 + 513 + 516) * 4);
+  u32 *hist1 = c->pt_work.as<u32>(), *cursor1 = hist1 + 512, *cbase = cursor1 + 512, *tprefix = cbase + 513, *dummy = tprefix + 513;
+  HIPCHK(hipMemsetAsync(c->pt_work.p, 0, 1024 * 4, st));
+  ENSURE(c->seg_k0, (size_t)n * 8);
+  ENSURE(c->seg_v0, (size_t)n * 4);
+  const StretchSrc src{W, bit_lo, bit_n};
+  const u32 tiles1 = (n + PT_TILE - 1) / PT_TILE;
+  hipLaunchKernelGGL(k_pt_hist1<StretchSrc>, dim3(tiles1 < 512 ? tiles1 : 512), dim3(1024), 0, st, src, n, d1, hist1);
+  hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, (const u32 *)hist1, d1, 0u, cbase, tprefix, dummy, dummy + 513, 0u);
+  hipLaunchKernelGGL((k_pt_scatter<1, StretchSrc>), dim3(tiles1), dim3(1024), 0, st, src, n, (const u64 *)nullptr,
+                     (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr, d1, d2, (const u32 *)cbase, cursor1,
+                     c->seg_k0.as<u64>(), c->seg_v0.as<u32>(), (u32 *)nullptr, 0u, c->d_ctr);
+  hipLaunchKernelGGL(k_group_fine<StretchSrc>, dim3(nb1), dim3(GF_THREADS), 0, st, src,
+                     (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs);
+  HIPCHK(hipGetLastError());
+  return HUMID_OK;
+}
+
 // A combination whose key is ONE stretch of the word (a single segment, or neighbouring segments):
 // the words themselves are the sort keys over that bit range and come out in bucket order (ws), the
 // positions ride along as values (vs) -- no key array, and no gather of the words afterwards (44 us
@@ -963,8 +1000,10 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
         const u32 kb = plan.key_bits ? plan.key_bits : 1;
         WT *ws = c->seg_ws.as<WT>() + (size_t)(seg - 1) * U;
         bool stretch = false;
-        if (std::is_same<WT, u64>::value)
-          TRY(sort_words_by_stretch(c, plan, seg, (const u64 *)g_word, U, (u64 *)ws, vs, &stretch));
+        if (std::is_same<WT, u64>::value) {
+          TRY(group_words_by_stretch(c, plan, seg, (const u64 *)g_word, U, (u64 *)ws, vs, &stretch));
+          if (!stretch) TRY(sort_words_by_stretch(c, plan, seg, (const u64 *)g_word, U, (u64 *)ws, vs, &stretch));
+        }
         if (stretch) {
         } else {
         if (kb <= 32) {
@@ -1642,6 +1681,10 @@ int humid_ctx_set_option(humid_ctx *c, const char *key, int64_t value) {
   }
   if (strcmp(key, "coop_big") == 0) {
     c->coop_big = value != 0;
+    return HUMID_OK;
+  }
+  if (strcmp(key, "group_buckets") == 0) {
+    c->group_buckets = value != 0;
     return HUMID_OK;
   }
   if (strcmp(key, "padded_partition") == 0) {
