@@ -852,7 +852,9 @@ static int group_words_by_stretch(humid_ctx *c, const ComboPlan &plan, u32 cb, c
   hipLaunchKernelGGL((k_pt_scatter<1, StretchSrc>), dim3(tiles1), dim3(1024), 0, st, src, n, (const u64 *)nullptr,
                      (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr, d1, d2, (const u32 *)cbase, cursor1,
                      c->seg_k0.as<u64>(), c->seg_v0.as<u32>(), (u32 *)nullptr, 0u, c->d_ctr);
-  hipLaunchKernelGGL(k_group_fine<StretchSrc>, dim3(nb1), dim3(GF_THREADS), 0, st, src,
+  hipLaunchKernelGGL((k_group_fine<StretchSrc, false>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
+                     (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs);
+  hipLaunchKernelGGL((k_group_fine<StretchSrc, true>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
                      (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs);
   HIPCHK(hipGetLastError());
   return HUMID_OK;
@@ -2958,7 +2960,8 @@ int humid_stage_pairs_keyed(humid_ctx *c, const uint64_t *d_items, uint64_t n_it
                        c->x_w.as<u64>(), c->x_id.as<u32>(), c->x_cnt.as<u32>());
     const u32 kb = plan.key_bits ? plan.key_bits : 1;
     bool stretch = false;
-    TRY(sort_words_by_stretch(c, plan, combo, c->x_w.as<u64>(), n, c->seg_ws.as<u64>(), c->seg_vs.as<u32>(), &stretch));
+    TRY(group_words_by_stretch(c, plan, combo, c->x_w.as<u64>(), n, c->seg_ws.as<u64>(), c->seg_vs.as<u32>(), &stretch));
+    if (!stretch) TRY(sort_words_by_stretch(c, plan, combo, c->x_w.as<u64>(), n, c->seg_ws.as<u64>(), c->seg_vs.as<u32>(), &stretch));
     if (!stretch) {
       if (kb <= 32) {
         hipLaunchKernelGGL((k_combo_keys<u32, u64>), dim3(blocks_for(n)), dim3(256), 0, st, c->x_w.as<u64>(), n,

@@ -426,6 +426,25 @@ def test_one_prefix_shared_by_200k_words(dd, d):
     check_against_oracle(dd, words, filt, 24, d, True, deep=False)
 
 
+def test_grouping_of_a_huge_key_bucket(dd1):
+    """bucket order of the second-half combination comes from a two-level grouping (k_group_fine); 60 000
+    distinct words with the SAME last 12 nucleotides put 60 000 words into one coarse bin -- the road
+    for bins beyond 8160 words -- and into one key bucket (tiles); plus ordinary words around them"""
+    rng = np.random.default_rng(5)
+    heads = rng.choice(1 << 24, size=60_000, replace=False).astype(np.uint64)
+    block = (heads << np.uint64(24)) | np.uint64(0x6b1e57)
+    words, filt = synth_words(80_000, 21, 24, p_sub=4e-3, p_n=1e-3)
+    words = np.concatenate([words, np.repeat(block, rng.poisson(0.3, size=len(block)) + 1)])
+    filt = np.concatenate([filt, np.zeros(len(words) - len(filt), np.uint8)])
+    perm = rng.permutation(len(words))
+    words, filt = words[perm], filt[perm]
+    for d in (1, 2):
+        check_against_oracle(dd1, words, filt, 24, d, False, deep=(d == 1))
+    dd1.set_option("group_buckets", 0)                      # and the library sort gives the same
+    check_against_oracle(dd1, words, filt, 24, 1, False, deep=False)
+    dd1.set_option("group_buckets", 1)
+
+
 def test_padded_partition_outgrown_by_duplicated_words(dd):
     """the first partition level gives every coarse bin a fixed room (mean + 25 % + 1024 reads) and skips
     its histogram pass; all reads of ONE word share a bin, so a word that makes up a third of the reads
