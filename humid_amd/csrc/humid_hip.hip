@@ -852,10 +852,16 @@ static int group_words_by_stretch(humid_ctx *c, const ComboPlan &plan, u32 cb, c
   hipLaunchKernelGGL((k_pt_scatter<1, StretchSrc>), dim3(tiles1), dim3(1024), 0, st, src, n, (const u64 *)nullptr,
                      (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr, d1, d2, (const u32 *)cbase, cursor1,
                      c->seg_k0.as<u64>(), c->seg_v0.as<u32>(), (u32 *)nullptr, 0u, c->d_ctr);
-  hipLaunchKernelGGL((k_group_fine<StretchSrc, false>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
+  // three launches over the coarse bins, by bin size; which sizes cannot occur is known from n alone only
+  // roughly (the bins of a skewed key can be any size), so only the impossible ones are left out
+  hipLaunchKernelGGL((k_group_fine<StretchSrc, 0>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
                      (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs);
-  hipLaunchKernelGGL((k_group_fine<StretchSrc, true>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
-                     (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs);
+  if (n > GF_SMALL)
+    hipLaunchKernelGGL((k_group_fine<StretchSrc, 1>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
+                       (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs);
+  if (n > GF_MID)
+    hipLaunchKernelGGL((k_group_fine<StretchSrc, 2>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
+                       (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs);
   HIPCHK(hipGetLastError());
   return HUMID_OK;
 }

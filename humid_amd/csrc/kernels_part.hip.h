@@ -285,28 +285,33 @@ k_pt_hist2(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ tprefi
 // gather of the words behind them: 0.18 -> 0.05 ms at 2.7 M words and 24 key bits.
 #define GF_THREADS 1024u
 #define GF_MAXBITS 15u
-#define GF_SMALL 8160u           // a coarse bin of up to this many words takes the coalesced road
+#define GF_SMALL 8160u           // a coarse bin of up to this many words: 80 KB of LDS, two workgroups per CU
+#define GF_MID 32768u            // up to this many: 128 KB, still coalesced stores
 // BIG = false: the normal case, a few thousand words per coarse bin -- 2^15 16-bit counters and the inverse
 // permutation (output position -> input position, 16 bits each) in 80 KB of LDS, so two workgroups share a
 // CU; the stores of the last pass are coalesced and its scattered LOADS hit the lines the two passes before
 // just read.  BIG = true (a second launch that only takes the bins the first one left): 2^15 32-bit
 // counters, a bin of any size, the words placed with scattered stores.
-template <class SRC, bool BIG>
+// SIZE 0: bins of <= GF_SMALL words, SIZE 1: <= GF_MID (the same road with room for a longer permutation),
+// SIZE 2: the rest.  Three launches, each takes its own bins and leaves the others at once.
+template <class SRC, int SIZE>
 __global__ void __launch_bounds__(GF_THREADS)
 k_group_fine(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ v_in, const u32 *__restrict__ cbase, u32 d1,
              u32 d2, u64 *__restrict__ k_out, u32 *__restrict__ v_out) {
   HUMID_GUARD_LAST_VGPR();
-  __shared__ u32 gf_lds[BIG ? (1u << GF_MAXBITS) + 16 : (1u << (GF_MAXBITS - 1)) + 4096];
+  constexpr bool BIG = SIZE == 2;
+  constexpr u32 INV_WORDS = SIZE == 0 ? 4096u : (1u << (GF_MAXBITS - 1)) + 16u;       // 16-bit entries, two per word, + the wave sums
+  __shared__ u32 gf_lds[BIG ? (1u << GF_MAXBITS) + 16 : (1u << (GF_MAXBITS - 1)) + INV_WORDS];
   const u32 nb = 1u << d2, c = blockIdx.x;
   const u32 beg = cbase[c], end = cbase[c + 1];
   if (beg >= end) return;
   const u32 n = end - beg;
-  if ((n > GF_SMALL) != BIG) return;                                                  // the other launch's bin
-  u32 *wsum = BIG ? gf_lds + (1u << GF_MAXBITS) : gf_lds + (1u << (GF_MAXBITS - 1)) + 4096 - 16;
+  if ((n <= GF_SMALL ? 0 : (n <= GF_MID ? 1 : 2)) != SIZE) return;                    // another launch's bin
+  u32 *wsum = BIG ? gf_lds + (1u << GF_MAXBITS) : gf_lds + (1u << (GF_MAXBITS - 1)) + INV_WORDS - 16;
   const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   auto fine = [&](u64 w) { return (u32)(src.key(w) >> (64 - d1 - d2)) & (nb - 1); };
   if (!BIG) {
-    unsigned short *inv = (unsigned short *)(gf_lds + (1u << (GF_MAXBITS - 1)));      // 8160 entries, then the 16 wave sums
+    unsigned short *inv = (unsigned short *)(gf_lds + (1u << (GF_MAXBITS - 1)));      // GF_SMALL / GF_MID entries, then the 16 wave sums
     for (u32 b = threadIdx.x; b < (1u << (GF_MAXBITS - 1)); b += GF_THREADS) gf_lds[b] = 0;   // 2^15 16-bit counters, two per word
     __syncthreads();
     for (u32 j = threadIdx.x; j < n; j += GF_THREADS) {

@@ -426,12 +426,14 @@ def test_one_prefix_shared_by_200k_words(dd, d):
     check_against_oracle(dd, words, filt, 24, d, True, deep=False)
 
 
-def test_grouping_of_a_huge_key_bucket(dd1):
-    """bucket order of the second-half combination comes from a two-level grouping (k_group_fine); 60 000
-    distinct words with the SAME last 12 nucleotides put 60 000 words into one coarse bin -- the road
-    for bins beyond 8160 words -- and into one key bucket (tiles); plus ordinary words around them"""
+@pytest.mark.parametrize("block_words", [20_000, 60_000])
+def test_grouping_of_a_huge_key_bucket(dd1, block_words):
+    """bucket order of the second-half combination comes from a two-level grouping (k_group_fine); 20 000 /
+    60 000 distinct words with the SAME last 12 nucleotides put that many words into one coarse bin -- the
+    roads for bins of 8161 .. 32768 words and beyond -- and into one key bucket (tiles); plus ordinary
+    words around them"""
     rng = np.random.default_rng(5)
-    heads = rng.choice(1 << 24, size=60_000, replace=False).astype(np.uint64)
+    heads = rng.choice(1 << 24, size=block_words, replace=False).astype(np.uint64)
     block = (heads << np.uint64(24)) | np.uint64(0x6b1e57)
     words, filt = synth_words(80_000, 21, 24, p_sub=4e-3, p_n=1e-3)
     words = np.concatenate([words, np.repeat(block, rng.poisson(0.3, size=len(block)) + 1)])
