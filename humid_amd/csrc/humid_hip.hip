@@ -822,22 +822,18 @@ static int find_big_runs(humid_ctx *c, const WT *W, u32 n, WT mask, u32 walk_max
   return HUMID_OK;
 }
 
-// The same stretch keys of at most 24 bits: bucket order by GROUPING in two hand-written levels
+// Keys of at most 24 bits (any combination of one-word words): bucket order by GROUPING in two hand-written levels
 // (kernels_part.hip.h: the tile partition by the top d1 <= 9 key bits, k_group_fine by the rest) instead
 // of a library sort; only that equal keys end up next to each other matters.  *done = false: not this
 // shape (the caller sorts).
+static ComboFields plan_fields(const ComboPlan &plan, u32 cb);
 static int group_words_by_stretch(humid_ctx *c, const ComboPlan &plan, u32 cb, const u64 *W, u32 n, u64 *ws, u32 *vs, bool *done) {
   hipStream_t st = c->stream;
-  u32 bit_lo = 0, bit_n = 0;
-  bool stretch = plan.nfield[cb] >= 1;
-  for (u32 f = 0; stretch && f < plan.nfield[cb]; f++) {
-    if (f + 1 < plan.nfield[cb] && plan.shift[cb][f] != plan.shift[cb][f + 1] + plan.width[cb][f + 1]) stretch = false;
-    bit_n += plan.width[cb][f];
-    bit_lo = plan.shift[cb][f];
-  }
-  *done = stretch && c->group_buckets && bit_n >= 2 && bit_n <= 24 && bit_lo + bit_n <= 64 && n >= 4096;
+  u32 bit_n = 0;
+  for (u32 f = 0; f < plan.nfield[cb]; f++) bit_n += plan.width[cb][f];
+  *done = c->group_buckets && plan.nfield[cb] >= 1 && bit_n >= 2 && bit_n <= 24 && n >= 4096;
   if (!*done) return HUMID_OK;
-  const u32 d1 = bit_n >= 18 ? 9u : (bit_n + 1) / 2, d2 = bit_n - d1;          // d2 <= 15: 128 KB of LDS counters at most
+  const u32 d1 = bit_n >= 18 ? 9u : (bit_n + 1) / 2, d2 = bit_n - d1;          // d2 <= 15: 2^15 LDS counters at most
   const u32 nb1 = 1u << d1;
   // scratch: [hist1 512 | cursor1 512] zeroed, then [cbase 513 | tprefix 513 | pbeg dummy 514]
   ENSURE(c->pt_work, (size_t)(1024 + 513 + 513 + 516) * 4);
@@ -845,22 +841,22 @@ static int group_words_by_stretch(humid_ctx *c, const ComboPlan &plan, u32 cb, c
   HIPCHK(hipMemsetAsync(c->pt_work.p, 0, 1024 * 4, st));
   ENSURE(c->seg_k0, (size_t)n * 8);
   ENSURE(c->seg_v0, (size_t)n * 4);
-  const StretchSrc src{W, bit_lo, bit_n};
+  const FieldsSrc src{W, plan_fields(plan, cb), bit_n};
   const u32 tiles1 = (n + PT_TILE - 1) / PT_TILE;
-  hipLaunchKernelGGL(k_pt_hist1<StretchSrc>, dim3(tiles1 < 512 ? tiles1 : 512), dim3(1024), 0, st, src, n, d1, hist1);
+  hipLaunchKernelGGL(k_pt_hist1<FieldsSrc>, dim3(tiles1 < 512 ? tiles1 : 512), dim3(1024), 0, st, src, n, d1, hist1);
   hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, (const u32 *)hist1, d1, 0u, cbase, tprefix, dummy, dummy + 513, 0u);
-  hipLaunchKernelGGL((k_pt_scatter<1, StretchSrc>), dim3(tiles1), dim3(1024), 0, st, src, n, (const u64 *)nullptr,
+  hipLaunchKernelGGL((k_pt_scatter<1, FieldsSrc>), dim3(tiles1), dim3(1024), 0, st, src, n, (const u64 *)nullptr,
                      (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr, d1, d2, (const u32 *)cbase, cursor1,
                      c->seg_k0.as<u64>(), c->seg_v0.as<u32>(), (u32 *)nullptr, 0u, c->d_ctr);
   // three launches over the coarse bins, by bin size; which sizes cannot occur is known from n alone only
   // roughly (the bins of a skewed key can be any size), so only the impossible ones are left out
-  hipLaunchKernelGGL((k_group_fine<StretchSrc, 0>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
+  hipLaunchKernelGGL((k_group_fine<FieldsSrc, 0>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
                      (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs);
   if (n > GF_SMALL)
-    hipLaunchKernelGGL((k_group_fine<StretchSrc, 1>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
+    hipLaunchKernelGGL((k_group_fine<FieldsSrc, 1>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
                        (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs);
   if (n > GF_MID)
-    hipLaunchKernelGGL((k_group_fine<StretchSrc, 2>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
+    hipLaunchKernelGGL((k_group_fine<FieldsSrc, 2>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
                        (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs);
   HIPCHK(hipGetLastError());
   return HUMID_OK;

@@ -67,6 +67,27 @@ __global__ void k_combo_keys(const WT *__restrict__ s_word, u32 n, ComboFields c
   val[i] = i;
 }
 
+// Source of the two-level grouping (kernels_part.hip.h: tile partition + k_group_fine) for ANY combination
+// of one-word words: payload = the word, key = its combination key (fields concatenated, first field most
+// significant) moved to the top of 64 bits.
+struct FieldsSrc {
+  const u64 *words;
+  ComboFields cf;
+  u32 kb;                          // key bits, 1 .. 63
+  __device__ __forceinline__ bool load(u32 j, u64 &payload) const { payload = words[j]; return true; }
+  __device__ __forceinline__ u64 key(u64 w) const {
+    u64 k = 0;
+#pragma unroll
+    for (u32 f = 0; f < MAX_FIELDS; f++) {
+      if (f < cf.nf) {
+        const u32 wd = cf.width[f];
+        k = ((wd >= 64) ? 0ull : (k << wd)) | w_field(w, cf.shift[f], wd);
+      }
+    }
+    return k << (64 - kb);
+  }
+};
+
 // --------------------------------------------------------------------------------
 // 4. connected components (lock-free union-find, smaller index wins => root = min rank)
 // --------------------------------------------------------------------------------

@@ -48,15 +48,6 @@ struct ReadsSrc {
   __device__ __forceinline__ u64 key(u64 payload) const { return payload; }
 };
 
-// StretchSrc: the unique words of the graph stage, keyed by ONE stretch of their bits (a pigeonhole
-// combination whose segments are neighbours): payload = the word, key = the stretch moved to the top.
-struct StretchSrc {
-  const u64 *words;
-  u32 bit_lo, bit_n;             // 1 <= bit_n <= 63
-  __device__ __forceinline__ bool load(u32 j, u64 &payload) const { payload = words[j]; return true; }
-  __device__ __forceinline__ u64 key(u64 payload) const { return (payload >> bit_lo) << (64 - bit_n); }
-};
-
 // exclusive scan of cnt[0, nb) (nb <= 512) by the first 512 threads of the block -> off[0, nb],
 // off[nb] = total.  All threads of the block must call it.
 __device__ __forceinline__ void block_exscan_512(const u32 *cnt, u32 *off, u32 nb, u32 *wsum /* >= 8 */) {
@@ -277,7 +268,7 @@ k_pt_hist2(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ tprefi
 // ---- grouping by a full key: level 2 of the graph stage's bucket order ----
 // The neighbour search needs the words of equal combination key NEXT TO each other -- in any order,
 // and the buckets in any order: a grouping, not a sort.  Level 1 (k_pt_hist1 / k_pt_scan1 /
-// k_pt_scatter<1> with StretchSrc) brings the words into 2^d1 coarse bins by the top key bits; here one
+// k_pt_scatter<1> with FieldsSrc, kernels_graph.hip.h) brings the words into 2^d1 coarse bins by the top key bits; here one
 // workgroup per coarse bin groups its words by the remaining d2 <= 15 key bits: count per fine value
 // in LDS (2^d2 counters), scan, place through the running counters.  Two streaming passes over the
 // bin, so a bin of any size is handled (slowly when one key prefix holds 10^6 words).  Replaces three
