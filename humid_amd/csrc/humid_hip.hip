@@ -216,21 +216,24 @@ static int exscan_u32(humid_ctx *c, const u32 *in, u32 *out, u64 n) {
 // One tiny kernel stores the counters (and the extra value) straight into the page-locked mirror and then
 // a sequence number; the host watches that word.  Two blit copies + hipStreamSynchronize cost ~30 us of idle
 // GPU per host wait, this ~10 (three waits per single-GPU pass, eight in the multi-GPU pass).
-__global__ void k_publish_counters(const ull *__restrict__ ctr, const u32 *__restrict__ extra32, volatile ull *host, ull seq) {
+__global__ void k_publish_counters(const ull *__restrict__ ctr, const u32 *__restrict__ extra32, const u32 *__restrict__ extra32b,
+                                   volatile ull *host, ull seq) {
   HUMID_GUARD_LAST_VGPR();
   if (threadIdx.x < CTR_N) {
     ull v = ctr[threadIdx.x];
     if (threadIdx.x == CTR_N - 1 && extra32) v = (v & ~0xffffffffull) | (ull)*extra32;
+    if (threadIdx.x == CTR_N - 2 && extra32b) v = (ull)*extra32b;
     host[threadIdx.x] = v;
   }
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) { host[CTR_N] = seq; __threadfence_system(); }
 }
-static int read_counters(humid_ctx *c, const u32 *extra32 = nullptr) {
+// extra32 -> h_ctr[CTR_N - 1] (low half), extra32b -> h_ctr[CTR_N - 2]
+static int read_counters(humid_ctx *c, const u32 *extra32 = nullptr, const u32 *extra32b = nullptr) {
   if (c->h_ctr_dev && !c->no_poll) {
     const ull seq = ++c->ctr_seq;
-    hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, c->stream, (const ull *)c->d_ctr, extra32,
+    hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, c->stream, (const ull *)c->d_ctr, extra32, extra32b,
                        (volatile ull *)c->h_ctr_dev, seq);
     HIPCHK(hipGetLastError());
     volatile ull *flag = (volatile ull *)&c->h_ctr[CTR_N];
@@ -250,6 +253,11 @@ static int read_counters(humid_ctx *c, const u32 *extra32 = nullptr) {
   HIPCHK(hipMemcpyAsync(c->h_ctr, c->d_ctr, CTR_N * sizeof(ull), hipMemcpyDeviceToHost, c->stream));
   if (extra32)
     HIPCHK(hipMemcpyAsync(&c->h_ctr[CTR_N - 1], extra32, 4, hipMemcpyDeviceToHost, c->stream));
+  if (extra32b) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->h_ctr[CTR_N - 2] = 0;
+    HIPCHK(hipMemcpyAsync(&c->h_ctr[CTR_N - 2], extra32b, 4, hipMemcpyDeviceToHost, c->stream));
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
   return HUMID_OK;
 }
@@ -412,12 +420,11 @@ static int cluster_stage(humid_ctx *c, const u32 *g_cnt, u32 U, u64 M, u64 Mbig,
   return HUMID_OK;
 }
 
+static int read_counters(humid_ctx *c, const u32 *extra32, const u32 *extra32b);
 static int n_clusters_from_scan(humid_ctx *c, u32 U, u64 *out) {
-  u32 last_pos = 0, last_flag = 0;
-  HIPCHK(hipMemcpyAsync(&last_pos, c->pos.as<u32>() + (U - 1), 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(&last_flag, c->flag.as<u32>() + (U - 1), 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  *out = (u64)last_pos + last_flag;
+  // (the pass's last host wait: both values through the counters' mapped store)
+  TRY(read_counters(c, c->pos.as<u32>() + (U - 1), c->flag.as<u32>() + (U - 1)));
+  *out = (c->h_ctr[CTR_N - 1] & 0xffffffffull) + (c->h_ctr[CTR_N - 2] & 0xffffffffull);
   return HUMID_OK;
 }
 
