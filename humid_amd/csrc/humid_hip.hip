@@ -134,6 +134,7 @@ struct humid_ctx {
   DBuf deg, nbr_off, nbr_idx, seg_k0, seg_v0, seg_ks, seg_vs, seg_ws, csize, cur;
   DBuf parent, mk0, mk1, cl_of, maxleaf, cl_size, flag, pos, cid, ismax, stk, tmp, scratch;
   hipEvent_t ev[6] = {};
+  bool kev_on = false;       // option "kernel_timing": events around the single kernels beyond the count kernel's kev[0..1] (13 more records per pass: 20-45 us)
   hipEvent_t kev[44] = {};   // per-kernel timing: [0,1] insert, [2,3] cluster, [4..19] pairs fill, [20..35] pairs count
   bool have_run = false;     // a full dedup run completed (all accessors valid)
   bool have_graph = false;   // stage B completed (leaf/adjacency/cluster accessors valid)
@@ -361,7 +362,7 @@ static int cluster_stage(humid_ctx *c, const u32 *g_cnt, u32 U, u64 M, u64 Mbig,
   ENSURE(c->pos, (size_t)(U + 1) * 4);
   ENSURE(c->cid, (size_t)U * 4);
   ENSURE(c->ismax, (size_t)U);
-  HIPCHK(hipEventRecord(c->kev[2], st));
+  if (c->kev_on) HIPCHK(hipEventRecord(c->kev[2], st));
   if (method == HUMID_METHOD_MAXIMUM)
     hipLaunchKernelGGL(k_cluster_trivial<true>, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
                        c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
@@ -412,7 +413,7 @@ static int cluster_stage(humid_ctx *c, const u32 *g_cnt, u32 U, u64 M, u64 Mbig,
       }
     }
   }
-  HIPCHK(hipEventRecord(c->kev[3], st));
+  if (c->kev_on) HIPCHK(hipEventRecord(c->kev[3], st));
   hipLaunchKernelGGL(k_creator_flags, dim3(blocks_for(U)), dim3(256), 0, st, c->cl_of.as<u32>(), U,
                      c->flag.as<u32>());
   TRY(exscan_u32(c, c->flag.as<u32>(), c->pos.as<u32>(), U));
@@ -593,13 +594,13 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
     if (padded)
       hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, (const u32 *)cursor1, d1, d2, cbase, tprefix, c->pbeg.as<u32>(),
                          c->ucount.as<u32>() + n_parts, cap1);
-    HIPCHK(hipEventRecord(c->kev[39], st));
+    if (c->kev_on) HIPCHK(hipEventRecord(c->kev[39], st));
     if (d2) {
       hipLaunchKernelGGL(k_pt_hist2<ReadsSrc>, dim3(tiles2), dim3(1024), 0, st, src, k1, tprefix, cbase, d1, d2, hist_fine, cap1);
       hipLaunchKernelGGL((k_pt_scatter<2, ReadsSrc>), dim3(tiles2), dim3(1024), 0, st, src, N, k1, v1, tprefix, cbase, d1, d2,
                          hist_fine, cursor2, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(), c->pbeg.as<u32>(), cap1, c->d_ctr);
     }
-    HIPCHK(hipEventRecord(c->kev[40], st));
+    if (c->kev_on) HIPCHK(hipEventRecord(c->kev[40], st));
   } else {
     auto kin = rocprim::make_transform_iterator(d_words, PartKeyOp{ordered ? 1u : 0u, km.lo, km.scale});
     auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<u32>(0),
@@ -1000,7 +1001,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
     // phase A: bucket order per combo; degrees and component forest
     for (u32 seg = 0; seg < nseg; seg++) {
       if (seg == 0) {
-        HIPCHK(hipEventRecord(c->kev[20], st));
+        if (c->kev_on) HIPCHK(hipEventRecord(c->kev[20], st));
         hipLaunchKernelGGL((k_pairs<true, PM_COUNT, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
                            (const u32 *)nullptr, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, c->deg.as<u32>(),
                            c->parent.as<u32>(), (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
@@ -1028,14 +1029,14 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
         }
         hipLaunchKernelGGL(k_gather_bucket_words<WT>, dim3(blocks_for(U)), dim3(256), 0, st, g_word, vs, U, ws);
         }
-        if (seg < 8) HIPCHK(hipEventRecord(c->kev[20 + 2 * seg], st));
+        if (seg < 8) if (c->kev_on) HIPCHK(hipEventRecord(c->kev[20 + 2 * seg], st));
         hipLaunchKernelGGL((k_pairs<false, PM_COUNT, WT>), dim3(blocks_for(U)), dim3(256), 0, st, ws,
                            vs, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, c->deg.as<u32>(), c->parent.as<u32>(),
                            (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
                            (const u32 *)nullptr, (u64 *)nullptr, c->had.as<u32>() + (size_t)seg * U, walk_max,
                            &c->d_ctr[CTR_BIGMASK], join_cnt);
       }
-      if (seg < 8) HIPCHK(hipEventRecord(c->kev[21 + 2 * seg], st));
+      if (seg < 8) if (c->kev_on) HIPCHK(hipEventRecord(c->kev[21 + 2 * seg], st));
     }
     hipLaunchKernelGGL(k_comp_stats, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
                        c->parent.as<u32>(), U, c->csize.as<u32>());
@@ -1087,7 +1088,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
                          c->cur.as<u32>(), c->nbr_idx.as<u32>(), c->d_ctr);
     // phase B: same loops, now writing the CSR rows
     for (u32 seg = 0; !given && seg < plan.ncombo; seg++) {
-      if (seg < 8) HIPCHK(hipEventRecord(c->kev[4 + 2 * seg], st));
+      if (seg < 8) if (c->kev_on) HIPCHK(hipEventRecord(c->kev[4 + 2 * seg], st));
       if (seg == 0) {
         hipLaunchKernelGGL((k_pairs<true, PM_FILL, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word,
                            (const u32 *)nullptr, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, (u32 *)nullptr,
@@ -1104,7 +1105,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
                            walk_max);
         if (big_mask >> seg & 1) TRY(big_tiles(seg, PM_FILL));
       }
-      if (seg < 8) HIPCHK(hipEventRecord(c->kev[5 + 2 * seg], st));
+      if (seg < 8) if (c->kev_on) HIPCHK(hipEventRecord(c->kev[5 + 2 * seg], st));
     }
     hipLaunchKernelGGL(k_sort_lists, dim3(blocks_for(U)), dim3(256), 0, st, c->nbr_off.as<u32>(), U,
                        c->nbr_idx.as<u32>());
@@ -1430,7 +1431,7 @@ static int unpermute_tiled(humid_ctx *c, u32 N, bool packed, u32 *d_cid, u8 *d_k
     if (wshift == 14) hipLaunchKernelGGL((k_unperm_window<false, 14>), dim3(n_bins), dim3(512), 0, st, rec, ucur, N, d_cid, d_keep);
     else hipLaunchKernelGGL((k_unperm_window<false, 15>), dim3(n_bins), dim3(512), 0, st, rec, ucur, N, d_cid, d_keep);
   }
-  HIPCHK(hipEventRecord(c->kev[41], st));
+  if (c->kev_on) HIPCHK(hipEventRecord(c->kev[41], st));
   *done = true;
   return HUMID_OK;
 }
@@ -1463,7 +1464,7 @@ static int stage_map(humid_ctx *c, const u32 *l_cid, const u8 *l_ismax, u32 N, u
       else
         hipLaunchKernelGGL(k_read_map_part, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->pk_vals.as<u32>(),
                            c->pslot.as<u32>(), c->slot_out.as<u64>(), N, packed);
-      HIPCHK(hipEventRecord(c->kev[36], st));
+      if (c->kev_on) HIPCHK(hipEventRecord(c->kev[36], st));
       hipLaunchKernelGGL(k_split_out, dim3(grid_stride_blocks(N)), dim3(256), 0, st, packed, N, d_cid, d_keep);
     }
   } else
@@ -1540,13 +1541,14 @@ static int run_device(humid_ctx *c, const WT *d_words, const u8 *d_filt, u64 n_r
   HIPCHK(hipEventElapsedTime(&s.ms_map, c->ev[3], c->ev[4]));
   HIPCHK(hipEventElapsedTime(&s.ms_total, c->ev[0], c->ev[4]));
   HIPCHK(hipEventElapsedTime(&s.ms_k_insert, c->kev[0], c->kev[1]));
-  if (c->last_count_lds) HIPCHK(hipEventElapsedTime(&s.ms_k_map, c->ev[3], c->kev[36]));   // first map kernel alone
+  if (!c->kev_on) s.ms_k_map = s.ms_map;
+  else if (c->last_count_lds) HIPCHK(hipEventElapsedTime(&s.ms_k_map, c->ev[3], c->kev[36]));   // first map kernel alone
   else s.ms_k_map = s.ms_map;   // ev[3]..ev[4] bracket exactly the k_read_map launch
-  if (c->last_count_lds && c->last_unperm_tiled) HIPCHK(hipEventElapsedTime(&s.ms_k_unperm, c->kev[36], c->kev[41]));
-  if (c->last_count_lds && c->last_part_tiled && !c->last_count_sorted) HIPCHK(hipEventElapsedTime(&s.ms_k_part, c->kev[39], c->kev[40]));
+  if (c->kev_on && c->last_count_lds && c->last_unperm_tiled) HIPCHK(hipEventElapsedTime(&s.ms_k_unperm, c->kev[36], c->kev[41]));
+  if (c->kev_on && c->last_count_lds && c->last_part_tiled && !c->last_count_sorted) HIPCHK(hipEventElapsedTime(&s.ms_k_part, c->kev[39], c->kev[40]));
   s.count_mode_used = c->last_count_sorted ? 3u : c->last_count_lds ? (c->last_count_ordered ? 2u : 0u) : 1u;
-  HIPCHK(hipEventElapsedTime(&s.ms_k_cluster, c->kev[2], c->kev[3]));
-  for (u32 g = 0; g < n_pair_segs; g++) {
+  if (c->kev_on) HIPCHK(hipEventElapsedTime(&s.ms_k_cluster, c->kev[2], c->kev[3]));
+  for (u32 g = 0; c->kev_on && g < n_pair_segs; g++) {
     float t = 0;
     HIPCHK(hipEventElapsedTime(&t, c->kev[20 + 2 * g], c->kev[21 + 2 * g]));   // count phase
     s.ms_k_pairs += t;
@@ -1611,6 +1613,7 @@ int humid_ctx_create(humid_ctx **out, int device, void *stream) {
   for (auto &ev : c->kev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
   if (const char *m = getenv("HUMID_COUNT_MODE")) c->count_mode = (atoi(m) == 1) ? 1 : 0;
+  if (const char *m = getenv("HUMID_KERNEL_TIMING")) c->kev_on = atoi(m) != 0;
   *out = c;
   return HUMID_OK;
 }
@@ -1692,6 +1695,10 @@ int humid_ctx_set_option(humid_ctx *c, const char *key, int64_t value) {
   }
   if (strcmp(key, "coop_big") == 0) {
     c->coop_big = value != 0;
+    return HUMID_OK;
+  }
+  if (strcmp(key, "kernel_timing") == 0) {
+    c->kev_on = value != 0;
     return HUMID_OK;
   }
   if (strcmp(key, "group_buckets") == 0) {
@@ -2537,7 +2544,7 @@ int humid_stage_map_dense(humid_ctx *c, const uint32_t *d_local_cluster_id, cons
     hipLaunchKernelGGL(k_slot_results, dim3(blocks_for(U)), dim3(256), 0, st, d_local_cluster_id, d_local_is_max,
                        c->s_first.as<u32>(), c->s_slot.as<u32>(), U, c->slot_out.as<u64>());
   ENSURE(c->own_packed, ((size_t)N + 1) * 4);
-  HIPCHK(hipEventRecord(c->kev[37], st));
+  if (c->kev_on) HIPCHK(hipEventRecord(c->kev[37], st));
   bool tiled = false;
   if (c->last_count_lds) TRY(unpermute_tiled(c, N, true, c->own_packed.as<u32>(), (u8 *)nullptr, c->kev[42], &tiled));
   if (tiled) {
@@ -2554,7 +2561,7 @@ int humid_stage_map_dense(humid_ctx *c, const uint32_t *d_local_cluster_id, cons
   } else
     hipLaunchKernelGGL(k_read_map_packed, dim3(grid_stride_blocks(N)), dim3(256), 0, st, c->slot_of_read.as<u32>(),
                        c->slot_out.as<u64>(), N, c->own_packed.as<u32>());
-  HIPCHK(hipEventRecord(c->kev[38], st));
+  if (c->kev_on) HIPCHK(hipEventRecord(c->kev[38], st));
   c->stage_map_timed = true;
   HIPCHK(hipGetLastError());
   *d_packed = c->own_packed.as<u32>();     // queued on the context's stream
@@ -3146,7 +3153,7 @@ int humid_stage_kernel_ms(humid_ctx *c, float *ms_k_insert, float *ms_k_map, uin
   float a = 0, b = 0;
   if (c->N) {
     HIPCHK(hipEventElapsedTime(&a, c->kev[0], c->kev[1]));
-    HIPCHK(hipEventElapsedTime(&b, c->kev[37], c->kev[38]));
+    if (c->kev_on) HIPCHK(hipEventElapsedTime(&b, c->kev[37], c->kev[38]));
   }
   if (ms_k_insert) *ms_k_insert = a;
   if (ms_k_map) *ms_k_map = b;

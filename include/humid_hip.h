@@ -100,6 +100,9 @@ const char *humid_last_error(const humid_ctx *ctx);   /* ctx may be NULL */
  * the hand-written LDS-staged partition (two coalesced passes each way); 0 = library radix passes
  * in front and one scattered store per read at the end (the round-1 form, also taken by itself for
  * read sets beyond ~180 M / ~67 M reads).
+ * "kernel_timing": 1 = HIP events around the single kernels, so that humid_summary.ms_k_pairs / ms_k_cluster /
+ * ms_k_map / ms_k_part / ms_k_unperm are filled (default 0, also HUMID_KERNEL_TIMING: the 13 extra event
+ * records cost 20-45 us of a 1 ms pass; ms_k_insert and the stage times ms_count .. ms_map are always there).
  * "padded_partition": 1 (default) = the first level of the tile partition scatters into coarse bins of a
  * fixed room and needs no histogram pass over the reads; a bin that outgrows its room (heavily duplicated
  * words) is detected, the run repeated with the histogram pass, and the option stays 0 for this context.
