@@ -535,9 +535,12 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   ENSURE(c->ucount, (size_t)(n_parts + 1) * 4);
   ENSURE(c->pusable, (size_t)(n_parts + 1) * 4);
   ENSURE(c->ubase, (size_t)(n_parts + 1) * 4);
-  ENSURE(c->pad_word, (size_t)N * 8);
+  // pad_word / pslot double as the output of the padded first partition level (below): sized for that at
+  // once, so that they are carved from the context's slab a single time
+  const size_t room_early = (size_t)N + (size_t)N / 4 + ((size_t)1024 << ((pb + 1) / 2));
+  ENSURE(c->pad_word, room_early * 8);
   ENSURE(c->pad_cf, (size_t)N * 8);
-  ENSURE(c->pslot, (size_t)N * 4);
+  ENSURE(c->pslot, room_early * 4);
   ENSURE(c->slot_out, ((size_t)N + 1) * 8);
   ENSURE(c->uniq_slot, (size_t)N * 4 + 4);
   ENSURE(c->uniq_word, (size_t)N * 8 + 8);
@@ -1657,7 +1660,7 @@ int humid_ctx_reserve(humid_ctx *c, uint64_t n_reads, uint32_t word_nt) {
   HIPCHK(hipSetDevice(c->device));
   // what one run over n_reads reads carves (measured: 112 B per read at 24 nt, unique/reads <= 1
   // assumed worst; wide words: +24 B) plus the host entry point's staging (14 or 22 B per read)
-  const size_t per_read = (word_nt > 32 ? 200 : 168) + (word_nt > 32 ? 22 : 14);
+  const size_t per_read = (word_nt > 32 ? 200 : 180) + (word_nt > 32 ? 22 : 14);   // (168 + the padded partition level, round 2)
   size_t want = (size_t)n_reads * per_read + ((size_t)64 << 20);
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b / 2) want = free_b / 2;
