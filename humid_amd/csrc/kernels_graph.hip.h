@@ -572,6 +572,7 @@ k_comp_count(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *
   u32 m = 0, mb = 0;
   ull ds = 0;
   const u32 lane = threadIdx.x & 63;
+  u32 round = 0;
   for (u32 u0 = blockIdx.x * blockDim.x; u0 < n; u0 += gridDim.x * blockDim.x) {     // (whole waves stay in the loop: ballot below)
     const u32 u = u0 + threadIdx.x;
     bool small_root = false;
@@ -598,14 +599,17 @@ k_comp_count(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *
         base = __shfl(base, 0);
         if (small_root) lroots[base + (u32)__popcll(bm & ((1ull << lane) - 1ull))] = u;
       }
-      __syncthreads();
-      if (lroots_n > CC_ROOTS - 256u) {                  // the next round might not fit: flush (uniform decision)
+      // CC_ROOTS / 256 rounds cannot overfill the buffer: only every eighth round meets at a barrier and flushes
+      if ((++round & (CC_ROOTS / 256u - 1u)) == 0) {
+        __syncthreads();
         const u32 cntl = lroots_n;
-        if (threadIdx.x == 0) lroots_base = (u32)atomicAdd(&ctr[CTR_SMALLROOTS], (ull)cntl);
-        __syncthreads();
-        for (u32 k = threadIdx.x; k < cntl; k += blockDim.x) small_roots[lroots_base + k] = lroots[k];
-        __syncthreads();
-        if (threadIdx.x == 0) lroots_n = 0;
+        if (cntl) {                                      // (uniform: read after the barrier)
+          if (threadIdx.x == 0) lroots_base = (u32)atomicAdd(&ctr[CTR_SMALLROOTS], (ull)cntl);
+          __syncthreads();
+          for (u32 k = threadIdx.x; k < cntl; k += blockDim.x) small_roots[lroots_base + k] = lroots[k];
+          __syncthreads();
+          if (threadIdx.x == 0) lroots_n = 0;
+        }
         __syncthreads();
       }
     }
