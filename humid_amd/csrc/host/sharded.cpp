@@ -56,6 +56,7 @@ struct Group {
   unsigned P = 1;
   std::vector<int> device;                 // rank -> HIP device
   bool use_rccl = false;
+  std::atomic<bool> rccl_failed{false};   // some rank's communicator did not come up: all ranks take the peer copies
   Rccl rccl;
   ncclUniqueId nccl_id{};
   // barrier (C++17: no std::barrier) that a failed rank releases for everyone
@@ -229,7 +230,21 @@ bool run_rank(Rank &k) {
   }
   if (g.use_rccl) {
     STEP(k.together());                                           // rank 0 made the id before the threads started
-    STEP(k.nccl_ok(g.rccl.CommInitRank(&k.comm, (int)P, g.nccl_id, (int)r), "ncclCommInitRank"));
+    // a communicator that does not come up on some rank sends EVERY rank to the peer copies (the decision is
+    // taken together: nobody may wait in a group call for a rank that left)
+    const ncclResult_t ir = g.rccl.CommInitRank(&k.comm, (int)P, g.nccl_id, (int)r);
+    if (ir != ncclSuccess) {
+      std::fprintf(stderr, "humid: rank %u: ncclCommInitRank: %s\n", r, g.rccl.GetErrorString(ir));
+      k.comm = nullptr;
+      g.rccl_failed.store(true);
+    }
+    STEP(k.together());
+    if (g.rccl_failed.load()) {
+      if (k.comm) { g.rccl.CommDestroy(k.comm); k.comm = nullptr; }
+      STEP(k.together());                                         // every rank has read the flag
+      if (r == 0) { g.use_rccl = false; std::fprintf(stderr, "humid: ranks exchange through peer copies\n"); }
+      STEP(k.together());
+    }
   }
   if (!g.wait_for_job()) return g.job_state == 2 && !g.failed.load();       // no job: a clean end
   Job &job = *g.job;
@@ -353,7 +368,7 @@ ShardedSession::ShardedSession(unsigned n_ranks) : p_(new Impl) {
         g.use_rccl = false;
       }
     }
-    if (!g.use_rccl)                                   // peer copies: let the devices see each other's memory
+    // (also when RCCL is the plan: the ranks fall back to peer copies if a communicator does not come up)
       for (int a = 0; a < n_dev && a < (int)n_ranks; a++)
         for (int b = 0; b < n_dev && b < (int)n_ranks; b++)
           if (a != b && hipSetDevice(a) == hipSuccess) (void)hipDeviceEnablePeerAccess(b, 0);
