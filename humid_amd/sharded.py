@@ -593,7 +593,7 @@ class ShardedDedup:
     def __init__(self, device: int = 0, word_nt: int = 24, distance: int = 1, method: int = 0,
                  ops=None, dist=None, dense_return: bool = True, partition_search: bool = True,
                  mode: str = None, edit: bool = False):
-        # -e: distance <= 1 IS the Hamming search (equal-length words); 2 and 3 run in the all-gather
+        # -e: distance <= 1 IS the Hamming search (equal-length words); 2 to 5 run in the all-gather
         # mode, the joins of the shifted-segment search dealt out over the ranks
         self.edit = bool(edit) and distance >= 2
         # 33 <= word_nt <= 64 (two int64 per read, tensors of shape [n, 2]): the library's exchange pass only
