@@ -102,7 +102,7 @@ struct humid_ctx {
   DBuf xr_hist, xr_recv, xr_eloc, xr_got, xr_eall, xr_ret;   // humid_dedup_run_exchange: histogram, received words, pair records, received items, results
   DBuf x_slot, x_slot_s, x_cnt, x_cnts, x_rec, x_ncnt, x_route, x_creator, x_base, x_mark, x_markcr, x_scan, x_lcid, x_lismax,
        x_items, x_w, x_id, x_ids, x_ends, x_ends_s, x_head, x_hpos, x_nodes, x_cedges;   // multi-GPU exchange mode
-  DBuf w_sorted, w_head, w_hpos, w_start;                                         // wide-word (sorted) counts
+  DBuf w_sorted, w_head, w_hpos, w_start, w_heads;                                         // wide-word (sorted) counts
   DBuf pt_work, unperm_rec, route_tiles;                                                     // LDS-staged partition / un-permute (kernels_part.hip.h)
   bool group_buckets = true;        // option "group_buckets": bucket order of stretch keys by two-level grouping instead of a library sort
   bool pt_padded = true;            // level 1 of the tile partition into padded coarse bins (no histogram pass); false after an overflow
@@ -518,10 +518,14 @@ static KeyMap key_map(u32 word_nt, u64 lo, u64 hi, bool within) {
 // Partitioned variant of stage A (see section 1b of the kernels).  Returns HUMID_OK with
 // *overflowed = true when a bucket held more unique words than its LDS table (the caller then
 // runs the global-table variant; results are never taken from an overflowed run).
+// wide != null (33 <= word_nt <= 64, `ordered` only): d_words are the HEADS of the two-word words `wide`
+// (k_wide_head64); buckets are cut by the head and counted by k_dedup_lds_wide (kernels_wide.hip.h).
 static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N, u32 word_nt,
                            u64 range_lo, u64 range_hi, const KeyMap &km, bool ordered, humid_summary &s,
-                           bool *overflowed) {
+                           bool *overflowed, const W2 *wide = nullptr) {
   hipStream_t st = c->stream;
+  if (wide && !ordered) return fail(c, HUMID_E_INVALID, "wide words are counted in word-ordered buckets only");
+  const size_t wsize = wide ? sizeof(W2) : 8;
   *overflowed = false;
   c->last_count_lds = true;
   c->last_count_sorted = false;
@@ -538,7 +542,7 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   // pad_word / pslot double as the output of the padded first partition level (below): sized for that at
   // once, so that they are carved from the context's slab a single time
   const size_t room_early = (size_t)N + (size_t)N / 4 + ((size_t)1024 << ((pb + 1) / 2));
-  ENSURE(c->pad_word, room_early * 8);
+  ENSURE(c->pad_word, std::max(room_early * 8, (size_t)N * wsize));
   ENSURE(c->pad_cf, (size_t)N * 8);
   ENSURE(c->pslot, room_early * 4);
   ENSURE(c->slot_out, ((size_t)N + 1) * 8);
@@ -621,7 +625,11 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
                        pb, n_parts, c->pbeg.as<u32>(), c->ucount.as<u32>());
   }
   HIPCHK(hipEventRecord(c->kev[0], st));
-  if (ordered)
+  if (wide)
+    hipLaunchKernelGGL(k_dedup_lds_wide, dim3(n_parts), dim3(256), 0, st, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(),
+                       c->pbeg.as<u32>(), wide, 2 * (word_nt - 32), N, pb, c->pad_word.as<W2>(), c->pad_cf.as<uint2>(),
+                       c->ucount.as<u32>(), c->pusable.as<u32>(), c->pslot.as<u32>(), c->d_ctr);
+  else if (ordered)
     hipLaunchKernelGGL(k_dedup_lds<true>, dim3(n_parts), dim3(256), 0, st, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(),
                        c->pbeg.as<u32>(), N, pb, km.lo, km.scale, km.shift, c->pad_word.as<u64>(), c->pad_cf.as<uint2>(),
                        c->ucount.as<u32>(), c->pusable.as<u32>(), c->pslot.as<u32>(), c->d_ctr);
@@ -637,18 +645,23 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   TRY(read_counters(c));
   if (used_padded && c->h_ctr[CTR_SPECIAL]) {          // a coarse bin outgrew its padded room: once more, with the histogram pass
     c->pt_padded = false;
-    return stage_count_lds(c, d_words, d_filt, N, word_nt, range_lo, range_hi, km, ordered, s, overflowed);
+    return stage_count_lds(c, d_words, d_filt, N, word_nt, range_lo, range_hi, km, ordered, s, overflowed, wide);
   }
   if (c->h_ctr[CTR_OVERFULL]) { *overflowed = true; return HUMID_OK; }
   const u32 U = (u32)c->h_ctr[CTR_UNIQUE];
   s.usable = c->usable = c->h_ctr[CTR_USABLE];
   s.unique = c->U = U;
   if (U == 0) { HIPCHK(hipEventRecord(c->ev[1], st)); return HUMID_OK; }
-  ENSURE(c->s_word, (size_t)U * 8);
-  ENSURE(c->s_slot, (size_t)U * 4);
-  ENSURE(c->s_cnt, (size_t)U * 4);
-  ENSURE(c->s_first, (size_t)U * 4);
-  if (ordered) {
+  ENSURE(c->s_word, (size_t)(U + 1) * wsize);
+  ENSURE(c->s_slot, (size_t)(U + 1) * 4);
+  ENSURE(c->s_cnt, (size_t)(U + 1) * 4);
+  ENSURE(c->s_first, (size_t)(U + 1) * 4);
+  if (wide) {
+    hipLaunchKernelGGL(k_compact_padded_wide, dim3(blocks_for((u64)n_parts * 64)), dim3(256), 0, st,
+                       c->pad_word.as<W2>(), c->pad_cf.as<uint2>(), c->pbeg.as<u32>(), c->ucount.as<u32>(),
+                       c->ubase.as<u32>(), n_parts, c->s_word.as<W2>(), c->s_slot.as<u32>(),
+                       c->s_cnt.as<u32>(), c->s_first.as<u32>());
+  } else if (ordered) {
     // buckets are runs of the word order and sorted inside: squeezing out the holes IS the sort
     hipLaunchKernelGGL(k_compact_padded<true>, dim3(blocks_for((u64)n_parts * 64)), dim3(256), 0, st,
                        c->pad_word.as<u64>(), c->pad_cf.as<uint2>(), c->pbeg.as<u32>(), c->ucount.as<u32>(),
@@ -744,8 +757,27 @@ static int stage_count(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N
 // Stage A for wide words (two uint64 per read): counts by sorting, see kernels_wide.hip.h.
 // Leaves s_word (W2)/s_cnt/s_first/s_slot and, for stage C, the partition-order arrays
 // pk_vals/pslot in the context.
-static int stage_count_wide(humid_ctx *c, const W2 *d_words, const u8 *d_filt, u32 N, u32 word_nt, humid_summary &s) {
+// head_lo / head_hi (within): every word's head lies in that range (a rank's value range in the exchange pass).
+static int stage_count_wide(humid_ctx *c, const W2 *d_words, const u8 *d_filt, u32 N, u32 word_nt, humid_summary &s,
+                            u64 head_lo = 0, u64 head_hi = ~0ull, bool within = false) {
   hipStream_t st = c->stream;
+  // LDS tables over head-ordered buckets when the heads spread evenly (count_mode 0, as for one-word
+  // words; count_order 0 keeps the sort); the sort below otherwise and after an overflow
+  if (c->count_mode == 0 && c->count_order != 0 && c->use_tile_partition && (N >= 65536 || c->count_order == 1) &&
+      part_bits(N) <= 18) {
+    ENSURE(c->w_heads, (size_t)N * 8);
+    hipLaunchKernelGGL(k_wide_head64, dim3(blocks_for(N)), dim3(256), 0, st, d_words, N, 2 * (word_nt - 32), c->w_heads.as<u64>());
+    const KeyMap km = key_map(32, head_lo, head_hi, within);
+    bool ordered = c->count_order == 1;
+    if (c->count_order < 0) TRY(prefix_fits_ordered(c, c->w_heads.as<u64>(), d_filt, N, word_nt, km, &ordered));
+    if (ordered) {
+      bool overflowed = false;
+      TRY(stage_count_lds(c, c->w_heads.as<u64>(), d_filt, N, word_nt, 0ull, ~0ull, km, true, s, &overflowed, d_words));
+      if (!overflowed) return HUMID_OK;
+      c->oc_valid = true; c->oc_fits = false;
+      c->oc_n = N; c->oc_nt = word_nt; c->oc_lo = km.lo; c->oc_scale = km.scale;
+    }
+  }
   c->last_count_lds = true;          // stage C walks pk_vals/pslot (k_read_map_part)
   c->last_count_ordered = false;
   c->last_count_sorted = true;
@@ -1627,7 +1659,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->in_bases, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
-                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->big_runs, &c->small_roots, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles, &c->xr_hist, &c->xr_recv, &c->xr_eloc, &c->xr_got, &c->xr_eall, &c->xr_ret, &c->xr_heads, &c->xr_send, &c->xr_zero,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->big_runs, &c->small_roots, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_heads, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles, &c->xr_hist, &c->xr_recv, &c->xr_eloc, &c->xr_got, &c->xr_eall, &c->xr_ret, &c->xr_heads, &c->xr_send, &c->xr_zero,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->seg_ws, &c->csize, &c->cur, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -2193,7 +2225,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
       humid_summary ws;
       memset(&ws, 0, sizeof ws);
       c->N = n_recv;
-      TRY(stage_count_wide(c, (const W2 *)recv_w, c->xr_zero.as<u8>(), (u32)n_recv, n, ws));
+      TRY(stage_count_wide(c, (const W2 *)recv_w, c->xr_zero.as<u8>(), (u32)n_recv, n, ws, lo_r, hi_r, true));
       HIPCHK(hipStreamSynchronize(st));
       if (c->usable != n_recv) return fail(c, HUMID_E_INVALID, "a filtered read among the routed wide words");
     }

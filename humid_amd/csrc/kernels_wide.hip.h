@@ -108,4 +108,186 @@ __global__ void k_wide_counts(const u32 *__restrict__ start, u32 n_unique, u32 *
   if (u < n_unique) { s_cnt[u] = start[u + 1] - start[u]; s_slot[u] = u; }
 }
 
+// --------------------------------------------------------------------------------
+// Wide words in LDS tables (round 2).  The sort above moves every read through five passes of a
+// 64-bit radix sort; when the top 64 bits of the words (their "heads", k_wide_head64) spread evenly
+// -- the same test as for one-word words, prefix_fits_ordered -- the reads are bucketed by their head
+// with the two-level tile partition of kernels_part.hip.h exactly as one-word words are, and each
+// bucket is counted by one workgroup here.  A 128-bit word cannot be claimed with one LDS compare-and-
+// swap, so a table entry holds the POSITION (inside the bucket) of the read that claimed it: the
+// bucket's words are staged in LDS by position before the first insert, an entry's word is the staged
+// word of its claimer, and a probe compares against that.  Outputs and their layout are those of
+// k_dedup_lds<true> with W2 words: unique words of a bucket ascending (hi, lo) in the bucket's padded
+// room -- buckets are runs of the head order, so squeezing out the holes gives Trie::walk() order.
+// A bucket of more than WL_STAGE reads does not fit the staging array: CTR_OVERFULL, and the caller
+// counts by sorting instead.
+// --------------------------------------------------------------------------------
+#define WL_STAGE 1024u
+
+__global__ void __launch_bounds__(256)
+k_dedup_lds_wide(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u32 *__restrict__ pbeg,
+                 const W2 *__restrict__ words, u32 hbits, u32 n_reads, u32 pb, W2 *__restrict__ pad_word,
+                 uint2 *__restrict__ pad_cf, u32 *__restrict__ ucount, u32 *__restrict__ pusable,
+                 u32 *__restrict__ pslot, ull *ctr) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ W2 wk[WL_STAGE];                          // the bucket's words by position
+  __shared__ u32 ltag[LDS_SLOTS];                      // position of the claiming read, NONE32 = empty
+  __shared__ u32 lcnt[LDS_SLOTS];
+  __shared__ u32 lfirst[LDS_SLOTS];
+  __shared__ unsigned short lslot_of[LDS_SLOTS];       // unique index (claim order, then rank) -> table entry
+  __shared__ unsigned short lpos[LDS_SLOTS];           // unique index -> position of its claimer
+  __shared__ unsigned short lorder[512];
+  __shared__ u32 lcount;
+  __shared__ u32 lds[8];
+  const u32 b = blockIdx.x;
+  const u32 beg = pbeg[b], end = pbeg[b + 1];
+  if (beg >= end || end > n_reads || end - beg > WL_STAGE) {
+    if (threadIdx.x == 0) {
+      if (beg > end || end > n_reads || (beg < end && end - beg > WL_STAGE)) ctr[CTR_OVERFULL] = 1;
+      ucount[b] = 0;
+      pusable[b] = 0;
+    }
+    return;
+  }
+  const u32 len = end - beg;
+  const u64 hmask = hbits >= 64 ? ~0ull : ((1ull << hbits) - 1ull);
+  u64 kq[4];
+  u32 vq[4];
+  W2 wq[4];
+#pragma unroll
+  for (u32 q = 0; q < 4; q++) {
+    const u32 p = threadIdx.x + 256u * q;
+    vq[q] = NONE32;
+    if (p < len) { vq[q] = vals[beg + p]; kq[q] = keys[beg + p]; }
+  }
+  for (u32 s = threadIdx.x; s < LDS_SLOTS; s += 256) { ltag[s] = NONE32; lcnt[s] = 0; lfirst[s] = NONE32; }
+  if (threadIdx.x == 0) { lcount = 0; lds[0] = 0; }
+  bool overflow = false;
+#pragma unroll
+  for (u32 q = 0; q < 4; q++) {                        // the words themselves: one 16-byte gather per read
+    const u32 p = threadIdx.x + 256u * q;
+    if (p < len) {
+      W2 w{0, 0};
+      if (vq[q] < n_reads) { w = words[vq[q]]; w.hi &= hmask; }
+      wq[q] = w;
+      wk[p] = w;
+    }
+  }
+  __syncthreads();
+  const u32 hshift = 64 - pb - LDS_SLOT_BITS;
+  u32 usable = 0;
+#pragma unroll
+  for (u32 q = 0; q < 4; q++) {
+    const u32 p = threadIdx.x + 256u * q;
+    if (p >= len || overflow) continue;
+    const u32 v = vq[q];
+    if ((v & 0x7fffffffu) >= n_reads) { overflow = true; continue; }     // a malformed index is never used
+    if (v & 0x80000000u) { pslot[beg + p] = NOSLOT; continue; }
+    usable++;
+    const W2 w = wq[q];
+    u32 s = (u32)(kq[q] >> hshift) & (LDS_SLOTS - 1);
+    u32 probes = 0;
+    bool placed = false;
+    while (probes++ <= LDS_SLOTS) {
+      u32 cur = ltag[s];
+      if (cur == NONE32) cur = atomicCAS(&ltag[s], NONE32, p);
+      if (cur == NONE32 || w_eq(wk[cur & (WL_STAGE - 1)], w)) { placed = true; break; }
+      s = (s + 1) & (LDS_SLOTS - 1);
+    }
+    if (!placed) { overflow = true; continue; }
+    if (atomicAdd(&lcnt[s], 1u) == 0u) lslot_of[atomicAdd(&lcount, 1u)] = (unsigned short)s;
+    atomicMin(&lfirst[s], v);
+  }
+  if (overflow) ctr[CTR_OVERFULL] = 1;
+  {
+    u32 x = usable;
+#pragma unroll
+    for (u32 d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+    if ((threadIdx.x & 63) == 0 && x) atomicAdd(&lds[0], x);
+  }
+  __syncthreads();
+  const u32 n_uniq = lcount < LDS_SLOTS ? lcount : LDS_SLOTS;
+  for (u32 li = threadIdx.x; li < n_uniq; li += 256) lpos[li] = (unsigned short)ltag[lslot_of[li]];
+  __syncthreads();
+  if (n_uniq <= 512) {
+    // rank of an entry = number of smaller words among the bucket's unique words (all distinct)
+    for (u32 li = threadIdx.x; li < n_uniq; li += 256) {
+      const W2 w = wk[lpos[li]];
+      u32 r = 0;
+      for (u32 j = 0; j < n_uniq; j++) r += w_less(wk[lpos[j]], w) ? 1u : 0u;
+      lorder[r] = lslot_of[li];
+    }
+    __syncthreads();
+    for (u32 li = threadIdx.x; li < n_uniq; li += 256) lslot_of[li] = lorder[li];
+    __syncthreads();
+  } else {
+    // bitonic network over the claim-order list, keys through the claimer's staged word
+    u32 npow = 1;
+    while (npow < n_uniq) npow <<= 1;
+    for (u32 i = n_uniq + threadIdx.x; i < npow; i += 256) lslot_of[i] = 0xffff;      // padding: above every word
+    __syncthreads();
+    for (u32 k = 2; k <= npow; k <<= 1) {
+      for (u32 j = k >> 1; j > 0; j >>= 1) {
+        for (u32 t = threadIdx.x; t < npow; t += 256) {
+          const u32 x = t ^ j;
+          if (x > t) {
+            const u32 a = lslot_of[t], bb = lslot_of[x];
+            const bool pa = a == 0xffff, pbd = bb == 0xffff;
+            bool gt;
+            if (pa) gt = !pbd;
+            else if (pbd) gt = false;
+            else gt = w_less(wk[ltag[bb] & (WL_STAGE - 1)], wk[ltag[a] & (WL_STAGE - 1)]);
+            if (gt == ((t & k) == 0)) { lslot_of[t] = (unsigned short)bb; lslot_of[x] = (unsigned short)a; }
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  for (u32 li = threadIdx.x; li < n_uniq; li += 256) {
+    const u32 s = lslot_of[li];
+    pad_word[beg + li] = wk[ltag[s] & (WL_STAGE - 1)];
+    pad_cf[beg + li] = make_uint2(lcnt[s], lfirst[s]);
+    lfirst[s] = li;
+  }
+  if (threadIdx.x == 0) { ucount[b] = n_uniq; pusable[b] = lds[0]; }
+  __syncthreads();
+  // second pass: every position learns the padded slot of its word
+#pragma unroll
+  for (u32 q = 0; q < 4; q++) {
+    const u32 p = threadIdx.x + 256u * q;
+    if (p >= len || vq[q] >= n_reads) continue;        // excluded read (bit 31) or malformed index
+    const W2 w = wq[q];
+    u32 s = (u32)(kq[q] >> hshift) & (LDS_SLOTS - 1);
+    u32 probes = 0, li = NONE32;
+    while (probes++ <= LDS_SLOTS) {
+      const u32 t = ltag[s];
+      if (t == NONE32) break;                          // (cannot happen for a word that was inserted)
+      if (w_eq(wk[t & (WL_STAGE - 1)], w)) { li = lfirst[s]; break; }
+      s = (s + 1) & (LDS_SLOTS - 1);
+    }
+    pslot[beg + p] = (li < len) ? beg + li : NOSLOT;
+  }
+}
+
+// padded -> dense unique list of wide words, one wave per bucket (k_compact_padded<true> with W2 words)
+__global__ void __launch_bounds__(256)
+k_compact_padded_wide(const W2 *__restrict__ pad_word, const uint2 *__restrict__ pad_cf,
+                      const u32 *__restrict__ pbeg, const u32 *__restrict__ ucount,
+                      const u32 *__restrict__ ubase, u32 n_parts, W2 *__restrict__ uniq_word,
+                      u32 *__restrict__ uniq_slot, u32 *__restrict__ s_cnt, u32 *__restrict__ s_first) {
+  HUMID_GUARD_LAST_VGPR();
+  const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const u32 lane = threadIdx.x & 63;
+  if (wave >= n_parts) return;
+  const u32 beg = pbeg[wave], uc = ucount[wave], ub = ubase[wave];
+  for (u32 j = lane; j < uc; j += 64) {
+    uniq_word[ub + j] = pad_word[beg + j];
+    uniq_slot[ub + j] = beg + j;
+    const uint2 cf = pad_cf[beg + j];
+    s_cnt[ub + j] = cf.x;
+    s_first[ub + j] = cf.y;
+  }
+}
+
 #endif  // HUMID_KERNELS_WIDE_HIP_H

@@ -76,8 +76,60 @@ def test_wide_n64_extremes(dd):
 
 def test_wide_larger(dd):
     w, f = synth_wide_words(200_000, 77, 50)
-    check_against_oracle(dd, w, f, 50, 1, False, deep=False)
+    s = check_against_oracle(dd, w, f, 50, 1, False, deep=False)
+    assert s["count_mode_used"] == 2          # evenly spread heads: LDS tables over head-ordered buckets
     check_against_oracle(dd, w, f, 50, 2, False, deep=False)
+
+
+@pytest.mark.parametrize("n", [33, 40, 48, 63, 64])
+def test_wide_lds_buckets_against_the_sort(n):
+    """round 2: wide words counted in LDS tables (buckets cut by the words' top 64 bits, entries claimed by
+    position, k_dedup_lds_wide) -- against the oracle and, array for array, against the sorting count"""
+    w, f = synth_wide_words(150_000, 900 + n, n, p_sub=4e-3, p_n=1e-3)
+    a = humid_amd.Dedup()
+    s = check_against_oracle(a, w, f, n, 1, False, deep=False)
+    assert s["count_mode_used"] == 2
+    cid_a, keep_a, sa = a.run(w, f, word_nt=n, distance=2)
+    b = humid_amd.Dedup()
+    b.set_option("count_order", 0)            # keeps the sort
+    cid_b, keep_b, sb = b.run(w, f, word_nt=n, distance=2)
+    assert sa["count_mode_used"] == 2 and sb["count_mode_used"] == 3
+    assert np.array_equal(cid_a, cid_b) and np.array_equal(keep_a, keep_b)
+    for k in ("usable", "unique", "clusters", "edges"):
+        assert sa[k] == sb[k]
+    la, lb = a.leaves(), b.leaves()
+    for k in la:
+        assert np.array_equal(la[k], lb[k]), k
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("n", [33, 41, 64])
+@pytest.mark.parametrize("n_reads", [300, 3000, 40_000])
+def test_wide_lds_buckets_forced_on_small_inputs(n, n_reads):
+    dq = humid_amd.Dedup()
+    dq.set_option("count_order", 1)
+    w, f = synth_wide_words(n_reads, 7 * n + n_reads, n, p_sub=0.01, p_n=0.01)
+    for d in (0, 1, 2):
+        s = check_against_oracle(dq, w, f, n, d, d == 2)
+        assert s["count_mode_used"] == 2
+    dq.close()
+
+
+def test_wide_lds_buckets_overflow_goes_back_to_the_sort():
+    """all heads in one bucket (a constant 8-nt prefix in front of words that share 20 more nucleotides):
+    forced head-ordered buckets overflow, the run is counted by sorting and says so"""
+    rng = np.random.default_rng(5)
+    n_reads = 20_000
+    w = np.empty((n_reads, 2), dtype=np.uint64)
+    w[:, 0] = np.uint64(0x1b1b)
+    w[:, 1] = (np.uint64(0x123456789a) << np.uint64(24)) | rng.integers(0, 1 << 24, size=n_reads, dtype=np.uint64)
+    f = (rng.random(n_reads) < 0.01).astype(np.uint8)
+    dq = humid_amd.Dedup()
+    dq.set_option("count_order", 1)
+    s = check_against_oracle(dq, w, f, 40, 1, False, deep=False)
+    assert s["count_mode_used"] == 3
+    dq.close()
 
 
 @pytest.mark.parametrize("n,d,segs", [(64, 1, 3), (64, 1, 4), (48, 2, 5), (40, 1, 6), (64, 2, 3)])
