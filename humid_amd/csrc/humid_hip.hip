@@ -275,7 +275,12 @@ static u64 n_choose_k(u32 n, u32 k) {
   return r;
 }
 
-static ComboPlan make_plan(u32 n, u32 d, u64 U, u32 force_segments) {
+// short_later: the keys of the combinations after the first (the ones whose bucket order has to be MADE;
+// the first is a prefix of the sorted words) are cut to max(24, 2 * want) bits -- enough to tell U words
+// apart, and at <= 24 bits the order comes from the two-level grouping instead of a library sort over
+// every key bit (48 bits for two halves of a 48-nt word).  Only the one-GPU Hamming search asks for it:
+// the shifted joins of the edit search and the exchange pass's routing keep whole segments.
+static ComboPlan make_plan(u32 n, u32 d, u64 U, u32 force_segments, bool short_later = false) {
   ComboPlan p;
   memset(&p, 0, sizeof p);
   // d >= n: every pair is a neighbour pair.  d >= MAX_COMBOS: even the smallest plan, s = d + 1,
@@ -320,10 +325,11 @@ static ComboPlan make_plan(u32 n, u32 d, u64 U, u32 force_segments) {
     // shortened mask of some combo, so the search stays complete; it only compares a few more pairs.
     unsigned __int128 m = 0;
     u32 bits = 0, nf = 0;
-    for (u32 t = 0; t < k && bits < 64; t++) {
+    const u32 limit = (short_later && c > 0 && !force_segments) ? std::min<u32>(64u, std::max<u32>(24u, 2 * want)) : 64u;
+    for (u32 t = 0; t < k && bits < limit; t++) {
       const u32 sg = idx[t];
       u32 wd = seg_width[sg], sh = seg_shift[sg];
-      if (bits + wd > 64) { const u32 cut = bits + wd - 64; wd -= cut; sh += cut; }
+      if (bits + wd > limit) { const u32 cut = bits + wd - limit; wd -= cut; sh += cut; }
       p.shift[c][nf] = (u8)sh;
       p.width[c][nf] = (u8)wd;
       m |= ((wd >= 64) ? (unsigned __int128)~0ull : (((unsigned __int128)1 << wd) - 1)) << sh;
@@ -870,7 +876,8 @@ static int find_big_runs(humid_ctx *c, const WT *W, u32 n, WT mask, u32 walk_max
 // of a library sort; only that equal keys end up next to each other matters.  *done = false: not this
 // shape (the caller sorts).
 static ComboFields plan_fields(const ComboPlan &plan, u32 cb);
-static int group_words_by_stretch(humid_ctx *c, const ComboPlan &plan, u32 cb, const u64 *W, u32 n, u64 *ws, u32 *vs, bool *done) {
+template <class SRC, class WT>
+static int group_words_by_stretch(humid_ctx *c, const ComboPlan &plan, u32 cb, const WT *W, u32 n, u64 *ws, u32 *vs, bool *done) {
   hipStream_t st = c->stream;
   u32 bit_n = 0;
   for (u32 f = 0; f < plan.nfield[cb]; f++) bit_n += plan.width[cb][f];
@@ -884,22 +891,22 @@ static int group_words_by_stretch(humid_ctx *c, const ComboPlan &plan, u32 cb, c
   HIPCHK(hipMemsetAsync(c->pt_work.p, 0, 1024 * 4, st));
   ENSURE(c->seg_k0, (size_t)n * 8);
   ENSURE(c->seg_v0, (size_t)n * 4);
-  const FieldsSrc src{W, plan_fields(plan, cb), bit_n};
+  const SRC src{W, plan_fields(plan, cb), bit_n};
   const u32 tiles1 = (n + PT_TILE - 1) / PT_TILE;
-  hipLaunchKernelGGL(k_pt_hist1<FieldsSrc>, dim3(tiles1 < 512 ? tiles1 : 512), dim3(1024), 0, st, src, n, d1, hist1);
+  hipLaunchKernelGGL(k_pt_hist1<SRC>, dim3(tiles1 < 512 ? tiles1 : 512), dim3(1024), 0, st, src, n, d1, hist1);
   hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, (const u32 *)hist1, d1, 0u, cbase, tprefix, dummy, dummy + 513, 0u);
-  hipLaunchKernelGGL((k_pt_scatter<1, FieldsSrc>), dim3(tiles1), dim3(1024), 0, st, src, n, (const u64 *)nullptr,
+  hipLaunchKernelGGL((k_pt_scatter<1, SRC>), dim3(tiles1), dim3(1024), 0, st, src, n, (const u64 *)nullptr,
                      (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr, d1, d2, (const u32 *)cbase, cursor1,
                      c->seg_k0.as<u64>(), c->seg_v0.as<u32>(), (u32 *)nullptr, 0u, c->d_ctr);
   // three launches over the coarse bins, by bin size; which sizes cannot occur is known from n alone only
   // roughly (the bins of a skewed key can be any size), so only the impossible ones are left out
-  hipLaunchKernelGGL((k_group_fine<FieldsSrc, 0>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
+  hipLaunchKernelGGL((k_group_fine<SRC, 0>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
                      (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs);
   if (n > GF_SMALL)
-    hipLaunchKernelGGL((k_group_fine<FieldsSrc, 1>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
+    hipLaunchKernelGGL((k_group_fine<SRC, 1>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
                        (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs);
   if (n > GF_MID)
-    hipLaunchKernelGGL((k_group_fine<FieldsSrc, 2>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
+    hipLaunchKernelGGL((k_group_fine<SRC, 2>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
                        (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs);
   HIPCHK(hipGetLastError());
   return HUMID_OK;
@@ -957,7 +964,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
                      c->deg.as<u32>(), c->csize.as<u32>(), c->cur.as<u32>(), U);
   u64 E = 0, M = 0, Mbig = 0;
   u32 n_pair_segs = 0;
-  const ComboPlan plan = make_plan(word_nt, distance, U, c->force_segments);
+  const ComboPlan plan = make_plan(word_nt, distance, U, c->force_segments, true);
   EarlierMasksT<WT> d_masks;                         // masks of all combos, for the first-combo rule
   for (u32 t = 0; t < MAX_COMBOS; t++) d_masks.m[t] = w_from<WT>(plan.mask[t]);
   auto fields_of = [&](u32 cb) {
@@ -1044,12 +1051,18 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
                            &c->d_ctr[CTR_BIGMASK], join_cnt);
       } else {
         u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
-        const u32 kb = plan.key_bits ? plan.key_bits : 1;
+        u32 kb = 0;                                            // key bits of THIS combination
+        for (u32 f = 0; f < plan.nfield[seg]; f++) kb += plan.width[seg][f];
+        if (kb == 0) kb = 1;
         WT *ws = c->seg_ws.as<WT>() + (size_t)(seg - 1) * U;
         bool stretch = false;
         if (std::is_same<WT, u64>::value) {
-          TRY(group_words_by_stretch(c, plan, seg, (const u64 *)g_word, U, (u64 *)ws, vs, &stretch));
+          TRY((group_words_by_stretch<FieldsSrc, u64>(c, plan, seg, (const u64 *)g_word, U, (u64 *)ws, vs, &stretch)));
           if (!stretch) TRY(sort_words_by_stretch(c, plan, seg, (const u64 *)g_word, U, (u64 *)ws, vs, &stretch));
+        } else {
+          // two-word words: the keys are grouped (scratch), the words follow through the grouped positions
+          TRY((group_words_by_stretch<FieldsSrcW2, W2>(c, plan, seg, (const W2 *)g_word, U, c->seg_ks.as<u64>(), vs, &stretch)));
+          if (stretch) hipLaunchKernelGGL(k_gather_bucket_words<WT>, dim3(blocks_for(U)), dim3(256), 0, st, g_word, vs, U, ws);
         }
         if (stretch) {
         } else {
@@ -3011,7 +3024,7 @@ int humid_stage_pairs_keyed(humid_ctx *c, const uint64_t *d_items, uint64_t n_it
                        c->x_w.as<u64>(), c->x_id.as<u32>(), c->x_cnt.as<u32>());
     const u32 kb = plan.key_bits ? plan.key_bits : 1;
     bool stretch = false;
-    TRY(group_words_by_stretch(c, plan, combo, c->x_w.as<u64>(), n, c->seg_ws.as<u64>(), c->seg_vs.as<u32>(), &stretch));
+    TRY((group_words_by_stretch<FieldsSrc, u64>(c, plan, combo, c->x_w.as<u64>(), n, c->seg_ws.as<u64>(), c->seg_vs.as<u32>(), &stretch)));
     if (!stretch) TRY(sort_words_by_stretch(c, plan, combo, c->x_w.as<u64>(), n, c->seg_ws.as<u64>(), c->seg_vs.as<u32>(), &stretch));
     if (!stretch) {
       if (kb <= 32) {

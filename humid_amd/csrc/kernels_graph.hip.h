@@ -88,6 +88,29 @@ struct FieldsSrc {
   }
 };
 
+// The same for two-word words: a 16-byte word does not fit the 8-byte payload, so the payload IS the key
+// (computed once from the word); the grouped payloads are scratch and the words are gathered through the
+// grouped positions afterwards (k_gather_bucket_words).
+struct FieldsSrcW2 {
+  const W2 *words;
+  ComboFields cf;
+  u32 kb;
+  __device__ __forceinline__ bool load(u32 j, u64 &payload) const {
+    const W2 w = words[j];
+    u64 k = 0;
+#pragma unroll
+    for (u32 f = 0; f < MAX_FIELDS; f++) {
+      if (f < cf.nf) {
+        const u32 wd = cf.width[f];
+        k = ((wd >= 64) ? 0ull : (k << wd)) | w_field(w, cf.shift[f], wd);
+      }
+    }
+    payload = k << (64 - kb);
+    return true;
+  }
+  __device__ __forceinline__ u64 key(u64 payload) const { return payload; }
+};
+
 // --------------------------------------------------------------------------------
 // 4. connected components (lock-free union-find, smaller index wins => root = min rank)
 // --------------------------------------------------------------------------------
