@@ -2,8 +2,9 @@
 // Part of libhumid_hip.so (see humid_hip.hip for the pipeline and the C ABI).  Device code for
 // gfx950 only; included once, in this order, by humid_hip.hip.
 //
-// A 128-bit word does not fit the 64-bit LDS / HBM hash tables of kernels_count.hip.h, so the wide
-// path counts by SORTING: two stable LSD radix passes (lo, then hi with the filtered flag on top)
+// Two ways.  The default for evenly spread words is the LDS-table count at the end of this file
+// (k_dedup_lds_wide, round 2).  The general one, and its fallback: a 128-bit word does not fit the 64-bit
+// LDS / HBM hash tables of kernels_count.hip.h, so the path counts by SORTING: two stable LSD radix passes (lo, then hi with the filtered flag on top)
 // put the reads in (filtered, hi, lo, read index) order.  Runs of equal words are the leaves
 // (Trie::add, /root/reference/src/humid.cc:95), their order is Trie::walk() order, the run length
 // is the count and -- the sort being stable over ascending read indices -- the first element of a

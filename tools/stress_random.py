@@ -20,7 +20,7 @@ from test_gpu_exchange import run_ranks  # noqa: E402
 
 
 def make_case(rng):
-    wide = rng.random() < 0.15
+    wide = rng.random() < float(os.environ.get("STRESS_WIDE", "0.15"))
     n = int(rng.integers(33, 65)) if wide else int(rng.integers(2, 33))
     d = int(rng.choice([0, 1, 1, 1, 2, 2, 3]))
     method = int(rng.random() < 0.3)
@@ -74,6 +74,11 @@ def main():
         walk = int(rng.choice([1024, 1024, 1, 6, 80]))
         desc["walk"] = walk
         dd.set_option("bucket_walk", walk)
+        # the count variants: automatic, word-ordered LDS buckets forced (small inputs and two-word words
+        # included; an overflow falls back), hashed buckets / the sort
+        order = int(rng.choice([-1, -1, 1, 1, 0]))
+        desc["order"] = order
+        dd.set_option("count_order", order)
         ocid, okeep, osum, _ = orc.dedup_run(w, f, n, d, method, edit=edit)
         cid, keep, s = dd.run(w, f, word_nt=n, distance=d, method=method, edit=edit)
         ok = np.array_equal(cid, ocid) and np.array_equal(keep, okeep) and \
