@@ -631,11 +631,15 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
                        pb, n_parts, c->pbeg.as<u32>(), c->ucount.as<u32>());
   }
   HIPCHK(hipEventRecord(c->kev[0], st));
-  if (wide)
-    hipLaunchKernelGGL(k_dedup_lds_wide, dim3(n_parts), dim3(256), 0, st, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(),
+  if (wide) {
+    hipLaunchKernelGGL((k_dedup_lds_wide<9, 512, 0, WL_SMALL_LEN>), dim3(n_parts), dim3(256), 0, st, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(),
                        c->pbeg.as<u32>(), wide, 2 * (word_nt - 32), N, pb, c->pad_word.as<W2>(), c->pad_cf.as<uint2>(),
                        c->ucount.as<u32>(), c->pusable.as<u32>(), c->pslot.as<u32>(), c->d_ctr);
-  else if (ordered)
+    if (N > WL_SMALL_LEN)
+      hipLaunchKernelGGL((k_dedup_lds_wide<10, 1024, WL_SMALL_LEN, WL_STAGE>), dim3(n_parts), dim3(256), 0, st, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(),
+                         c->pbeg.as<u32>(), wide, 2 * (word_nt - 32), N, pb, c->pad_word.as<W2>(), c->pad_cf.as<uint2>(),
+                         c->ucount.as<u32>(), c->pusable.as<u32>(), c->pslot.as<u32>(), c->d_ctr);
+  } else if (ordered)
     hipLaunchKernelGGL(k_dedup_lds<true>, dim3(n_parts), dim3(256), 0, st, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(),
                        c->pbeg.as<u32>(), N, pb, km.lo, km.scale, km.shift, c->pad_word.as<u64>(), c->pad_cf.as<uint2>(),
                        c->ucount.as<u32>(), c->pusable.as<u32>(), c->pslot.as<u32>(), c->d_ctr);

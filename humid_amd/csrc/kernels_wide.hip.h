@@ -123,27 +123,36 @@ __global__ void k_wide_counts(const u32 *__restrict__ start, u32 n_unique, u32 *
 // A bucket of more than WL_STAGE reads does not fit the staging array: CTR_OVERFULL, and the caller
 // counts by sorting instead.
 // --------------------------------------------------------------------------------
-#define WL_STAGE 1024u
+#define WL_STAGE 1024u            // the longest bucket the large variant stages
+#define WL_SMALL_LEN 384u         // buckets up to this many reads: the small variant (512 entries at <= 75 % load)
 
+// Two size classes, launched one after the other over all buckets (a workgroup whose bucket belongs to the
+// other class leaves at once): SB = 9, STAGE = 512 for buckets of up to WL_SMALL_LEN reads -- nearly all of
+// them at ~300 reads per bucket -- needs 17 KB of LDS, so eight workgroups share a CU as in k_dedup_lds;
+// SB = 10, STAGE = 1024 (33 KB, four per CU) takes the rest.
+template <u32 SB, u32 STAGE, u32 LEN_MIN, u32 LEN_MAX>
 __global__ void __launch_bounds__(256)
 k_dedup_lds_wide(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u32 *__restrict__ pbeg,
                  const W2 *__restrict__ words, u32 hbits, u32 n_reads, u32 pb, W2 *__restrict__ pad_word,
                  uint2 *__restrict__ pad_cf, u32 *__restrict__ ucount, u32 *__restrict__ pusable,
                  u32 *__restrict__ pslot, ull *ctr) {
   HUMID_GUARD_LAST_VGPR();
-  __shared__ W2 wk[WL_STAGE];                          // the bucket's words by position
-  __shared__ u32 ltag[LDS_SLOTS];                      // position of the claiming read, NONE32 = empty
-  __shared__ u32 lcnt[LDS_SLOTS];
-  __shared__ u32 lfirst[LDS_SLOTS];
-  __shared__ unsigned short lslot_of[LDS_SLOTS];       // unique index (claim order, then rank) -> table entry
-  __shared__ unsigned short lpos[LDS_SLOTS];           // unique index -> position of its claimer
+  constexpr u32 SLOTS = 1u << SB, Q = STAGE / 256u;
+  static_assert(STAGE % 256u == 0 && (STAGE & (STAGE - 1)) == 0 && LEN_MAX <= STAGE && LEN_MAX <= SLOTS, "size class");
+  __shared__ W2 wk[STAGE];                             // the bucket's words by position
+  __shared__ u32 ltag[SLOTS];                          // position of the claiming read, NONE32 = empty
+  __shared__ u32 lcnt[SLOTS];
+  __shared__ u32 lfirst[SLOTS];
+  __shared__ unsigned short lslot_of[SLOTS];           // unique index (claim order, then rank) -> table entry
+  __shared__ unsigned short lpos[SLOTS];               // unique index -> position of its claimer
   __shared__ unsigned short lorder[512];
   __shared__ u32 lcount;
   __shared__ u32 lds[8];
   const u32 b = blockIdx.x;
   const u32 beg = pbeg[b], end = pbeg[b + 1];
   if (beg >= end || end > n_reads || end - beg > WL_STAGE) {
-    if (threadIdx.x == 0) {
+    // empty, malformed or too long for any class: reported once, by the class that starts at 0
+    if (LEN_MIN == 0 && threadIdx.x == 0) {
       if (beg > end || end > n_reads || (beg < end && end - beg > WL_STAGE)) ctr[CTR_OVERFULL] = 1;
       ucount[b] = 0;
       pusable[b] = 0;
@@ -151,21 +160,22 @@ k_dedup_lds_wide(const u64 *__restrict__ keys, const u32 *__restrict__ vals, con
     return;
   }
   const u32 len = end - beg;
+  if (len <= LEN_MIN || len > LEN_MAX) return;         // the other class's bucket
   const u64 hmask = hbits >= 64 ? ~0ull : ((1ull << hbits) - 1ull);
-  u64 kq[4];
-  u32 vq[4];
-  W2 wq[4];
+  u64 kq[Q];
+  u32 vq[Q];
+  W2 wq[Q];
 #pragma unroll
-  for (u32 q = 0; q < 4; q++) {
+  for (u32 q = 0; q < Q; q++) {
     const u32 p = threadIdx.x + 256u * q;
     vq[q] = NONE32;
     if (p < len) { vq[q] = vals[beg + p]; kq[q] = keys[beg + p]; }
   }
-  for (u32 s = threadIdx.x; s < LDS_SLOTS; s += 256) { ltag[s] = NONE32; lcnt[s] = 0; lfirst[s] = NONE32; }
+  for (u32 s = threadIdx.x; s < SLOTS; s += 256) { ltag[s] = NONE32; lcnt[s] = 0; lfirst[s] = NONE32; }
   if (threadIdx.x == 0) { lcount = 0; lds[0] = 0; }
   bool overflow = false;
 #pragma unroll
-  for (u32 q = 0; q < 4; q++) {                        // the words themselves: one 16-byte gather per read
+  for (u32 q = 0; q < Q; q++) {                        // the words themselves: one 16-byte gather per read
     const u32 p = threadIdx.x + 256u * q;
     if (p < len) {
       W2 w{0, 0};
@@ -175,10 +185,10 @@ k_dedup_lds_wide(const u64 *__restrict__ keys, const u32 *__restrict__ vals, con
     }
   }
   __syncthreads();
-  const u32 hshift = 64 - pb - LDS_SLOT_BITS;
+  const u32 hshift = 64 - pb - SB;
   u32 usable = 0;
 #pragma unroll
-  for (u32 q = 0; q < 4; q++) {
+  for (u32 q = 0; q < Q; q++) {
     const u32 p = threadIdx.x + 256u * q;
     if (p >= len || overflow) continue;
     const u32 v = vq[q];
@@ -186,14 +196,14 @@ k_dedup_lds_wide(const u64 *__restrict__ keys, const u32 *__restrict__ vals, con
     if (v & 0x80000000u) { pslot[beg + p] = NOSLOT; continue; }
     usable++;
     const W2 w = wq[q];
-    u32 s = (u32)(kq[q] >> hshift) & (LDS_SLOTS - 1);
+    u32 s = (u32)(kq[q] >> hshift) & (SLOTS - 1);
     u32 probes = 0;
     bool placed = false;
-    while (probes++ <= LDS_SLOTS) {
+    while (probes++ <= SLOTS) {
       u32 cur = ltag[s];
       if (cur == NONE32) cur = atomicCAS(&ltag[s], NONE32, p);
-      if (cur == NONE32 || w_eq(wk[cur & (WL_STAGE - 1)], w)) { placed = true; break; }
-      s = (s + 1) & (LDS_SLOTS - 1);
+      if (cur == NONE32 || w_eq(wk[cur & (STAGE - 1)], w)) { placed = true; break; }
+      s = (s + 1) & (SLOTS - 1);
     }
     if (!placed) { overflow = true; continue; }
     if (atomicAdd(&lcnt[s], 1u) == 0u) lslot_of[atomicAdd(&lcount, 1u)] = (unsigned short)s;
@@ -207,7 +217,7 @@ k_dedup_lds_wide(const u64 *__restrict__ keys, const u32 *__restrict__ vals, con
     if ((threadIdx.x & 63) == 0 && x) atomicAdd(&lds[0], x);
   }
   __syncthreads();
-  const u32 n_uniq = lcount < LDS_SLOTS ? lcount : LDS_SLOTS;
+  const u32 n_uniq = lcount < SLOTS ? lcount : SLOTS;
   for (u32 li = threadIdx.x; li < n_uniq; li += 256) lpos[li] = (unsigned short)ltag[lslot_of[li]];
   __syncthreads();
   if (n_uniq <= 512) {
@@ -221,7 +231,7 @@ k_dedup_lds_wide(const u64 *__restrict__ keys, const u32 *__restrict__ vals, con
     __syncthreads();
     for (u32 li = threadIdx.x; li < n_uniq; li += 256) lslot_of[li] = lorder[li];
     __syncthreads();
-  } else {
+  } else if (LEN_MAX > 512) {
     // bitonic network over the claim-order list, keys through the claimer's staged word
     u32 npow = 1;
     while (npow < n_uniq) npow <<= 1;
@@ -237,7 +247,7 @@ k_dedup_lds_wide(const u64 *__restrict__ keys, const u32 *__restrict__ vals, con
             bool gt;
             if (pa) gt = !pbd;
             else if (pbd) gt = false;
-            else gt = w_less(wk[ltag[bb] & (WL_STAGE - 1)], wk[ltag[a] & (WL_STAGE - 1)]);
+            else gt = w_less(wk[ltag[bb] & (STAGE - 1)], wk[ltag[a] & (STAGE - 1)]);
             if (gt == ((t & k) == 0)) { lslot_of[t] = (unsigned short)bb; lslot_of[x] = (unsigned short)a; }
           }
         }
@@ -247,7 +257,7 @@ k_dedup_lds_wide(const u64 *__restrict__ keys, const u32 *__restrict__ vals, con
   }
   for (u32 li = threadIdx.x; li < n_uniq; li += 256) {
     const u32 s = lslot_of[li];
-    pad_word[beg + li] = wk[ltag[s] & (WL_STAGE - 1)];
+    pad_word[beg + li] = wk[ltag[s] & (STAGE - 1)];
     pad_cf[beg + li] = make_uint2(lcnt[s], lfirst[s]);
     lfirst[s] = li;
   }
@@ -255,17 +265,17 @@ k_dedup_lds_wide(const u64 *__restrict__ keys, const u32 *__restrict__ vals, con
   __syncthreads();
   // second pass: every position learns the padded slot of its word
 #pragma unroll
-  for (u32 q = 0; q < 4; q++) {
+  for (u32 q = 0; q < Q; q++) {
     const u32 p = threadIdx.x + 256u * q;
     if (p >= len || vq[q] >= n_reads) continue;        // excluded read (bit 31) or malformed index
     const W2 w = wq[q];
-    u32 s = (u32)(kq[q] >> hshift) & (LDS_SLOTS - 1);
+    u32 s = (u32)(kq[q] >> hshift) & (SLOTS - 1);
     u32 probes = 0, li = NONE32;
-    while (probes++ <= LDS_SLOTS) {
+    while (probes++ <= SLOTS) {
       const u32 t = ltag[s];
       if (t == NONE32) break;                          // (cannot happen for a word that was inserted)
-      if (w_eq(wk[t & (WL_STAGE - 1)], w)) { li = lfirst[s]; break; }
-      s = (s + 1) & (LDS_SLOTS - 1);
+      if (w_eq(wk[t & (STAGE - 1)], w)) { li = lfirst[s]; break; }
+      s = (s + 1) & (SLOTS - 1);
     }
     pslot[beg + p] = (li < len) ? beg + li : NOSLOT;
   }
