@@ -524,13 +524,72 @@ static KeyMap key_map(u32 word_nt, u64 lo, u64 hi, bool within) {
 // Partitioned variant of stage A (see section 1b of the kernels).  Returns HUMID_OK with
 // *overflowed = true when a bucket held more unique words than its LDS table (the caller then
 // runs the global-table variant; results are never taken from an overflowed run).
-// wide != null (33 <= word_nt <= 64, `ordered` only): d_words are the HEADS of the two-word words `wide`
-// (k_wide_head64); buckets are cut by the head and counted by k_dedup_lds_wide (kernels_wide.hip.h).
+// The count stage's two-level tile partition of the reads `src` yields (kernels_part.hip.h) into pk_keys / pk_vals,
+// bucket bounds in pbeg.  SRC: ReadsSrc (one-word words) or WideReadsSrc (the heads of two-word words).
+template <class SRC>
+static int count_partition(humid_ctx *c, const SRC &src, u32 N, u32 pb, bool *used_padded) {
+  hipStream_t st = c->stream;
+  const u32 n_parts = 1u << pb;
+  // hand-written partition (kernels_part.hip.h): two levels of LDS-staged scatter; excluded reads
+  // (filtered, or outside this rank's value range) never enter it
+  const u32 d1 = (pb + 1) / 2, d2 = pb - d1;
+  const u32 nb1 = 1u << d1;
+  // pt_work, in u32: [hist1 512 | cursor1 512 | hist_fine n_parts + 1 | cursor2 n_parts] zeroed, then
+  // [cbase 513 | tprefix 513]
+  const size_t zero_words = 1024 + (size_t)n_parts + 1 + n_parts;
+  ENSURE(c->pt_work, (zero_words + 1026) * 4);
+  u32 *hist1 = c->pt_work.as<u32>(), *cursor1 = hist1 + 512, *hist_fine = cursor1 + 512,
+      *cursor2 = hist_fine + n_parts + 1, *cbase = cursor2 + n_parts, *tprefix = cbase + 513;
+  HIPCHK(hipMemsetAsync(c->pt_work.p, 0, zero_words * 4, st));
+  const u32 tiles1 = (N + PT_TILE - 1) / PT_TILE, tiles2 = tiles1 + nb1;
+  // Two levels and keys that spread evenly over the coarse bins (hashed keys always do, word-ordered
+  // keys were only chosen because their prefix does): level 1 scatters into PADDED coarse bins of a
+  // fixed room (mean + 25 % + 1024) and needs no histogram pass over the reads in front; the bins'
+  // counts are the cursors it leaves behind.  A bin that outgrows its room (heavily duplicated words:
+  // all reads of a word share a bin) is reported, the run discarded, and this context goes back to the
+  // histogram form (pt_padded = false).
+  static const u32 pad_div = getenv("HUMID_PAD_DIV") ? (u32)std::max(1, atoi(getenv("HUMID_PAD_DIV"))) : 4u;   // head room = mean / pad_div
+  const bool padded = d2 > 0 && c->pt_padded;
+  const u32 cap1 = padded ? (u32)std::min<u64>(0xffffffffull / nb1, (u64)N / nb1 + (u64)N / nb1 / pad_div + 1024) : 0u;
+  const size_t room1 = padded ? (size_t)nb1 * cap1 : (size_t)N;
+  *used_padded = padded;
+  if (padded) {
+    ENSURE(c->pad_word, room1 * 8);
+    ENSURE(c->pslot, room1 * 4);
+  }
+  // level-1 output: the final arrays when there is no second level, else scratch that is dead until
+  // k_dedup_lds writes it (pad_word, pslot)
+  u64 *k1 = d2 ? c->pad_word.as<u64>() : c->pk_keys.as<u64>();
+  u32 *v1 = d2 ? c->pslot.as<u32>() : c->pk_vals.as<u32>();
+  if (!padded) {
+    hipLaunchKernelGGL(k_pt_hist1<SRC>, dim3(tiles1 < 512 ? tiles1 : 512), dim3(1024), 0, st, src, N, d1, hist1);
+    hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, hist1, d1, d2, cbase, tprefix, c->pbeg.as<u32>(),
+                       c->ucount.as<u32>() + n_parts, 0u);
+  }
+  hipLaunchKernelGGL((k_pt_scatter<1, SRC>), dim3(tiles1), dim3(1024), 0, st, src, N, (const u64 *)nullptr,
+                     (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr, d1, d2, cbase, cursor1, k1, v1,
+                     (u32 *)nullptr, cap1, c->d_ctr);
+  if (padded)
+    hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, (const u32 *)cursor1, d1, d2, cbase, tprefix, c->pbeg.as<u32>(),
+                       c->ucount.as<u32>() + n_parts, cap1);
+  if (c->kev_on) HIPCHK(hipEventRecord(c->kev[39], st));
+  if (d2) {
+    hipLaunchKernelGGL(k_pt_hist2<SRC>, dim3(tiles2), dim3(1024), 0, st, src, k1, tprefix, cbase, d1, d2, hist_fine, cap1);
+    hipLaunchKernelGGL((k_pt_scatter<2, SRC>), dim3(tiles2), dim3(1024), 0, st, src, N, k1, v1, tprefix, cbase, d1, d2,
+                       hist_fine, cursor2, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(), c->pbeg.as<u32>(), cap1, c->d_ctr);
+  }
+  if (c->kev_on) HIPCHK(hipEventRecord(c->kev[40], st));
+  return HUMID_OK;
+}
+
+// wide != null (33 <= word_nt <= 64, `ordered` and the tile partition only; d_words unused): buckets are cut
+// by the words' heads (WideReadsSrc) and counted by k_dedup_lds_wide (kernels_wide.hip.h).
 static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N, u32 word_nt,
                            u64 range_lo, u64 range_hi, const KeyMap &km, bool ordered, humid_summary &s,
                            bool *overflowed, const W2 *wide = nullptr) {
   hipStream_t st = c->stream;
-  if (wide && !ordered) return fail(c, HUMID_E_INVALID, "wide words are counted in word-ordered buckets only");
+  if (wide && !(ordered && c->use_tile_partition && part_bits(N) <= 18))
+    return fail(c, HUMID_E_INVALID, "wide words are counted in word-ordered buckets of the tile partition only");
   const size_t wsize = wide ? sizeof(W2) : 8;
   *overflowed = false;
   c->last_count_lds = true;
@@ -560,60 +619,12 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   c->last_part_tiled = c->use_tile_partition && pb <= 2 * 9;
   bool used_padded = false;
   if (c->last_part_tiled) {
-    // hand-written partition (kernels_part.hip.h): two levels of LDS-staged scatter; excluded reads
-    // (filtered, or outside this rank's value range) never enter it
-    const u32 d1 = (pb + 1) / 2, d2 = pb - d1;
-    const u32 nb1 = 1u << d1;
-    // pt_work, in u32: [hist1 512 | cursor1 512 | hist_fine n_parts + 1 | cursor2 n_parts] zeroed, then
-    // [cbase 513 | tprefix 513]
-    const size_t zero_words = 1024 + (size_t)n_parts + 1 + n_parts;
-    ENSURE(c->pt_work, (zero_words + 1026) * 4);
-    u32 *hist1 = c->pt_work.as<u32>(), *cursor1 = hist1 + 512, *hist_fine = cursor1 + 512,
-        *cursor2 = hist_fine + n_parts + 1, *cbase = cursor2 + n_parts, *tprefix = cbase + 513;
-    HIPCHK(hipMemsetAsync(c->pt_work.p, 0, zero_words * 4, st));
     PtInput in;
     in.words = d_words; in.filtered = d_filt; in.rlo = range_lo; in.rhi = range_hi;
     in.check_range = check_range ? 1u : 0u;
     in.key = PartKeyOp{ordered ? 1u : 0u, km.lo, km.scale};
-    const u32 tiles1 = (N + PT_TILE - 1) / PT_TILE, tiles2 = tiles1 + nb1;
-    const ReadsSrc src{in};
-    // Two levels and keys that spread evenly over the coarse bins (hashed keys always do, word-ordered
-    // keys were only chosen because their prefix does): level 1 scatters into PADDED coarse bins of a
-    // fixed room (mean + 25 % + 1024) and needs no histogram pass over the reads in front; the bins'
-    // counts are the cursors it leaves behind.  A bin that outgrows its room (heavily duplicated words:
-    // all reads of a word share a bin) is reported, the run discarded, and this context goes back to the
-    // histogram form (pt_padded = false).
-    static const u32 pad_div = getenv("HUMID_PAD_DIV") ? (u32)std::max(1, atoi(getenv("HUMID_PAD_DIV"))) : 4u;   // head room = mean / pad_div
-    const bool padded = d2 > 0 && c->pt_padded;
-    const u32 cap1 = padded ? (u32)std::min<u64>(0xffffffffull / nb1, (u64)N / nb1 + (u64)N / nb1 / pad_div + 1024) : 0u;
-    const size_t room1 = padded ? (size_t)nb1 * cap1 : (size_t)N;
-    used_padded = padded;
-    if (padded) {
-      ENSURE(c->pad_word, room1 * 8);
-      ENSURE(c->pslot, room1 * 4);
-    }
-    // level-1 output: the final arrays when there is no second level, else scratch that is dead until
-    // k_dedup_lds writes it (pad_word, pslot)
-    u64 *k1 = d2 ? c->pad_word.as<u64>() : c->pk_keys.as<u64>();
-    u32 *v1 = d2 ? c->pslot.as<u32>() : c->pk_vals.as<u32>();
-    if (!padded) {
-      hipLaunchKernelGGL(k_pt_hist1<ReadsSrc>, dim3(tiles1 < 512 ? tiles1 : 512), dim3(1024), 0, st, src, N, d1, hist1);
-      hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, hist1, d1, d2, cbase, tprefix, c->pbeg.as<u32>(),
-                         c->ucount.as<u32>() + n_parts, 0u);
-    }
-    hipLaunchKernelGGL((k_pt_scatter<1, ReadsSrc>), dim3(tiles1), dim3(1024), 0, st, src, N, (const u64 *)nullptr,
-                       (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr, d1, d2, cbase, cursor1, k1, v1,
-                       (u32 *)nullptr, cap1, c->d_ctr);
-    if (padded)
-      hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, (const u32 *)cursor1, d1, d2, cbase, tprefix, c->pbeg.as<u32>(),
-                         c->ucount.as<u32>() + n_parts, cap1);
-    if (c->kev_on) HIPCHK(hipEventRecord(c->kev[39], st));
-    if (d2) {
-      hipLaunchKernelGGL(k_pt_hist2<ReadsSrc>, dim3(tiles2), dim3(1024), 0, st, src, k1, tprefix, cbase, d1, d2, hist_fine, cap1);
-      hipLaunchKernelGGL((k_pt_scatter<2, ReadsSrc>), dim3(tiles2), dim3(1024), 0, st, src, N, k1, v1, tprefix, cbase, d1, d2,
-                         hist_fine, cursor2, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(), c->pbeg.as<u32>(), cap1, c->d_ctr);
-    }
-    if (c->kev_on) HIPCHK(hipEventRecord(c->kev[40], st));
+    if (wide) TRY(count_partition(c, WideReadsSrc{wide, d_filt, 2 * (word_nt - 32), in.key}, N, pb, &used_padded));
+    else TRY(count_partition(c, ReadsSrc{in}, N, pb, &used_padded));
   } else {
     auto kin = rocprim::make_transform_iterator(d_words, PartKeyOp{ordered ? 1u : 0u, km.lo, km.scale});
     auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<u32>(0),
@@ -775,14 +786,19 @@ static int stage_count_wide(humid_ctx *c, const W2 *d_words, const u8 *d_filt, u
   // words; count_order 0 keeps the sort); the sort below otherwise and after an overflow
   if (c->count_mode == 0 && c->count_order != 0 && c->use_tile_partition && (N >= 65536 || c->count_order == 1) &&
       part_bits(N) <= 18) {
-    ENSURE(c->w_heads, (size_t)N * 8);
-    hipLaunchKernelGGL(k_wide_head64, dim3(blocks_for(N)), dim3(256), 0, st, d_words, N, 2 * (word_nt - 32), c->w_heads.as<u64>());
     const KeyMap km = key_map(32, head_lo, head_hi, within);
     bool ordered = c->count_order == 1;
-    if (c->count_order < 0) TRY(prefix_fits_ordered(c, c->w_heads.as<u64>(), d_filt, N, word_nt, km, &ordered));
+    if (c->count_order < 0) {
+      // the decision samples the first 512 K reads (and is remembered for the shape): heads of those only;
+      // the partition itself computes a word's head as it reads the word (WideReadsSrc)
+      const u32 n_sample = N < (1u << 19) ? N : (1u << 19);
+      ENSURE(c->w_heads, (size_t)n_sample * 8);
+      hipLaunchKernelGGL(k_wide_head64, dim3(blocks_for(n_sample)), dim3(256), 0, st, d_words, n_sample, 2 * (word_nt - 32), c->w_heads.as<u64>());
+      TRY(prefix_fits_ordered(c, c->w_heads.as<u64>(), d_filt, N, word_nt, km, &ordered));
+    }
     if (ordered) {
       bool overflowed = false;
-      TRY(stage_count_lds(c, c->w_heads.as<u64>(), d_filt, N, word_nt, 0ull, ~0ull, km, true, s, &overflowed, d_words));
+      TRY(stage_count_lds(c, nullptr, d_filt, N, word_nt, 0ull, ~0ull, km, true, s, &overflowed, d_words));
       if (!overflowed) return HUMID_OK;
       c->oc_valid = true; c->oc_fits = false;
       c->oc_n = N; c->oc_nt = word_nt; c->oc_lo = km.lo; c->oc_scale = km.scale;

@@ -47,6 +47,21 @@ struct ReadsSrc {
   __device__ __forceinline__ bool load(u32 j, u64 &payload) const { return pt_load(in, j, payload); }
   __device__ __forceinline__ u64 key(u64 payload) const { return payload; }
 };
+// Two-word words (33 <= n <= 64 nucleotides): the partition key is taken from the word's HEAD, the top 64
+// bits of its 2n-bit value (hbits = 2 (n - 32) of them live in .hi), computed as the word is read.
+struct WideReadsSrc {
+  const W2 *words;
+  const u8 *filtered;            // null: none filtered
+  u32 hbits;
+  PartKeyOp pkey;
+  __device__ __forceinline__ bool load(u32 j, u64 &payload) const {
+    if (filtered && filtered[j]) return false;
+    const W2 x = words[j];
+    payload = pkey(hbits >= 64 ? x.hi : ((x.hi << (64 - hbits)) | (x.lo >> hbits)));
+    return true;
+  }
+  __device__ __forceinline__ u64 key(u64 payload) const { return payload; }
+};
 
 // exclusive scan of cnt[0, nb) (nb <= 512) by the first 512 threads of the block -> off[0, nb],
 // off[nb] = total.  All threads of the block must call it.
