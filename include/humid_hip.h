@@ -68,8 +68,9 @@ typedef struct humid_summary {
   float ms_k_map;       /* first kernel of the un-permute: k_unperm_bins (or k_read_map_bucket, _part, k_read_map) */
   float ms_k_part;      /* front partition: the second-level scatter k_pt_scatter<2> (0: library radix passes) */
   float ms_k_unperm;    /* second kernel of the un-permute: k_unperm_window (0: one-kernel forms)   */
-  uint32_t count_mode_used;  /* 0 = LDS tables, hashed buckets; 2 = LDS tables, word-ordered buckets;
-                              * 1 = global HBM table (option or fallback); 3 = sorted (wide words) */
+  uint32_t count_mode_used;  /* 0 = LDS tables, hashed buckets; 2 = LDS tables, word-ordered buckets (words of
+                              * 33-64 nt: buckets on their top 64 bits); 1 = global HBM table (option or
+                              * fallback); 3 = sorted (words of 33-64 nt: small inputs, uneven top bits, fallback) */
 } humid_summary;
 
 uint32_t humid_abi_version(void);
@@ -88,7 +89,8 @@ const char *humid_last_error(const humid_ctx *ctx);   /* ctx may be NULL */
  * "count_order": LDS buckets formed on the word prefix instead of its hash, which makes the unique
  * sort unnecessary: -1 (default) = when a sampled histogram of the top word bits says the fullest
  * bucket fits its LDS table (UMI-first layouts), 0 = never, 1 = always (either way a bucket
- * overflow falls back to hashed buckets).
+ * overflow falls back to hashed buckets).  Words of 33-64 nt: the same choice between LDS tables over
+ * buckets of their top 64 bits and the sorting count (0 = always sort; "count_mode" 1 sorts too).
  * "edit_distance": 1 = neighbours under Levenshtein instead of Hamming distance (-e,
  *   findEditNeighbours src/humid.cc:140-158 / Trie::asymmetricLevenshtein) in humid_dedup_run*.
  *   Between equal-length words distance <= 1 is the Hamming search itself; 2 and 3 add the pairs that
