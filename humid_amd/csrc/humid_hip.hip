@@ -786,19 +786,22 @@ static int stage_count_wide(humid_ctx *c, const W2 *d_words, const u8 *d_filt, u
   // words; count_order 0 keeps the sort); the sort below otherwise and after an overflow
   if (c->count_mode == 0 && c->count_order != 0 && c->use_tile_partition && (N >= 65536 || c->count_order == 1) &&
       part_bits(N) <= 18) {
-    const KeyMap km = key_map(32, head_lo, head_hi, within);
+    const KeyMap km = key_map(24, head_lo >> WIDE_KEY_DROP, head_hi >> WIDE_KEY_DROP, within);   // (the keys: 48-bit numbers, see WideReadsSrc)
     bool ordered = c->count_order == 1;
     if (c->count_order < 0) {
       // the decision samples the first 512 K reads (and is remembered for the shape): heads of those only;
       // the partition itself computes a word's head as it reads the word (WideReadsSrc)
       const u32 n_sample = N < (1u << 19) ? N : (1u << 19);
       ENSURE(c->w_heads, (size_t)n_sample * 8);
-      hipLaunchKernelGGL(k_wide_head64, dim3(blocks_for(n_sample)), dim3(256), 0, st, d_words, n_sample, 2 * (word_nt - 32), c->w_heads.as<u64>());
+      hipLaunchKernelGGL(k_wide_head64, dim3(blocks_for(n_sample)), dim3(256), 0, st, d_words, n_sample, 2 * (word_nt - 32), c->w_heads.as<u64>(),
+                         WIDE_KEY_DROP);
       TRY(prefix_fits_ordered(c, c->w_heads.as<u64>(), d_filt, N, word_nt, km, &ordered));
     }
+    if (getenv("HUMID_TRACE_COUNT")) fprintf(stderr, "[wide count] N %u order %d fits %d lo %llx scale %llx shift %u\n", N, c->count_order, (int)ordered, (ull)km.lo, (ull)km.scale, km.shift);
     if (ordered) {
       bool overflowed = false;
       TRY(stage_count_lds(c, nullptr, d_filt, N, word_nt, 0ull, ~0ull, km, true, s, &overflowed, d_words));
+      if (getenv("HUMID_TRACE_COUNT")) fprintf(stderr, "[wide count] overflowed %d special %llu overfull %llu\n", (int)overflowed, (ull)c->h_ctr[CTR_SPECIAL], (ull)c->h_ctr[CTR_OVERFULL]);
       if (!overflowed) return HUMID_OK;
       c->oc_valid = true; c->oc_fits = false;
       c->oc_n = N; c->oc_nt = word_nt; c->oc_lo = km.lo; c->oc_scale = km.scale;
@@ -2166,7 +2169,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   if (wide && n_local) {
     ENSURE(c->xr_heads, (size_t)n_local * 8);
     hipLaunchKernelGGL(k_wide_head64, dim3(blocks_for(n_local)), dim3(256), 0, st, (const W2 *)d_words, (u32)n_local,
-                       2 * (word_nt - 32), c->xr_heads.as<u64>());
+                       2 * (word_nt - 32), c->xr_heads.as<u64>(), 0u);
     heads = c->xr_heads.as<u64>();
   }
   const bool moves = P > 1 || (cm && c->force_comm);                 // bytes go through the callbacks

@@ -262,12 +262,13 @@ __global__ void k_split_items_w2(const Item3 *__restrict__ items, u32 n, W2 *__r
 }
 // the top 64 bits of a wide word's 2n-bit value (hbits = 2 (n - 32) bits live in .hi): value ranges cut
 // at the bins of a <= 12-bit prefix histogram are decided by these bits alone
-__global__ void k_wide_head64(const W2 *__restrict__ w, u32 n, u32 hbits, u64 *__restrict__ out) {
+// (drop: that many low bits of the head are shifted out -- the count stage's partition keys, WideReadsSrc)
+__global__ void k_wide_head64(const W2 *__restrict__ w, u32 n, u32 hbits, u64 *__restrict__ out, u32 drop = 0) {
   HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const W2 x = w[i];
-  out[i] = hbits >= 64 ? x.hi : ((x.hi << (64 - hbits)) | (x.lo >> hbits));
+  out[i] = (hbits >= 64 ? x.hi : ((x.hi << (64 - hbits)) | (x.lo >> hbits))) >> drop;
 }
 __global__ void k_gather_w2(const W2 *__restrict__ w, const u32 *__restrict__ perm, u32 n, W2 *__restrict__ out) {
   HUMID_GUARD_LAST_VGPR();

@@ -48,7 +48,12 @@ struct ReadsSrc {
   __device__ __forceinline__ u64 key(u64 payload) const { return payload; }
 };
 // Two-word words (33 <= n <= 64 nucleotides): the partition key is taken from the word's HEAD, the top 64
-// bits of its 2n-bit value (hbits = 2 (n - 32) of them live in .hi), computed as the word is read.
+// bits of its 2n-bit value (hbits = 2 (n - 32) of them live in .hi), computed as the word is read.  Only
+// the head's top 48 bits enter the key (WIDE_KEY_DROP low bits are shifted out, "a 24-nt word"): buckets
+// and table homes need 28 bits at most, and a value range of 48-bit numbers stretches over the 64-bit key
+// space with an integer factor of ~2^16 -- a range of 64-bit heads (a rank's share on 2 GPUs: half of
+// them) would have to make do with a factor of 1 or 2 and leave up to half of the buckets empty.
+#define WIDE_KEY_DROP 16u
 struct WideReadsSrc {
   const W2 *words;
   const u8 *filtered;            // null: none filtered
@@ -57,7 +62,7 @@ struct WideReadsSrc {
   __device__ __forceinline__ bool load(u32 j, u64 &payload) const {
     if (filtered && filtered[j]) return false;
     const W2 x = words[j];
-    payload = pkey(hbits >= 64 ? x.hi : ((x.hi << (64 - hbits)) | (x.lo >> hbits)));
+    payload = pkey((hbits >= 64 ? x.hi : ((x.hi << (64 - hbits)) | (x.lo >> hbits))) >> WIDE_KEY_DROP);
     return true;
   }
   __device__ __forceinline__ u64 key(u64 payload) const { return payload; }

@@ -304,6 +304,24 @@ def test_exchange_large_buckets_go_through_the_tiles(P, walk):
             assert s["edges"] == osum["edges"] and s["clusters"] == osum["clusters"]
 
 
+@pytest.mark.parametrize("P,n", [(2, 40), (3, 64)])
+def test_exchange_wide_words_in_lds_tables(P, n):
+    """enough two-word words per rank for the LDS-table count (k_dedup_lds_wide) over a rank's own range of
+    top-64-bit values (key_map within the range, as for one-word words): every shard against the oracle"""
+    from humid_amd.synth import synth_wide_words
+    # ~385 k usable reads per rank = 2^11 buckets of ~190: well inside the LDS tables (with fewer reads the
+    # ranges' histogram looks uneven and the sort is kept; just below a power of two times 350 the decision
+    # is marginal)
+    words, filt = synth_wide_words(400_000 * P, 31 * P + n, n, p_sub=2e-3, p_n=1e-3)
+    ocid, okeep, osum, _ = orc.dedup_run(words, filt, n, 1, 0)
+    out, offs = run_ranks(P, words, filt, n, 1, 0, "exchange")
+    for r in range(P):
+        cid, keep, s, used = out[r]
+        assert used == "exchange" and s["count_mode_used"] == 2, s
+        assert np.array_equal(cid, ocid[offs[r]:offs[r + 1]]) and np.array_equal(keep, okeep[offs[r]:offs[r + 1]])
+        assert s["edges"] == osum["edges"] and s["clusters"] == osum["clusters"] and s["unique"] == osum["unique"]
+
+
 @pytest.mark.parametrize("P", [1, 2, 3])
 @pytest.mark.parametrize("n,d", [(33, 1), (40, 2), (48, 1), (64, 2)])
 def test_exchange_wide_words(P, n, d):
