@@ -24,6 +24,8 @@ CONFIGS = [
     ("C5 50M PE no-UMI d2", 50_000_000, 24, 2, "genome"),
     ("W6 10M wide 48 nt d1", 10_000_000, 48, 1, "wide"),      # two uint64 per word (sorted count stage)
     ("W7 10M wide 64 nt d2", 10_000_000, 64, 2, "wide"),
+    ("W8 50M wide 48 nt d1", 50_000_000, 48, 1, "wide"),      # 2^18 buckets: the largest LDS-table case of two-word words
+    ("W9 100M wide 48 nt d1", 100_000_000, 48, 1, "wide"),    # beyond it: counted by sorting
 ]
 
 
