@@ -128,14 +128,63 @@ def e2e_leg(n_reads, word_nt, distance):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` from a bare shell (no launcher: WORLD_SIZE/RANK unset): this process
+    becomes the launcher.  It has not imported torch and never touches the GPU; it starts N child
+    ranks of this same file (fresh interpreters, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, one GPU
+    each), relays rank 0's single JSON line and exits non-zero if any rank does."""
+    import socket
+    import subprocess
+    import tempfile
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    line_file = tempfile.NamedTemporaryFile(prefix="humid_bench_rank0_", suffix=".json", delete=False)
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HUMID_BENCH_LAUNCHER="bench.py")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=line_file if r == 0 else sys.stderr))
+    rc = 0
+    live = set(range(a.gpus))
+    while live:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            live.discard(r)
+            if c != 0 and rc == 0:
+                rc = c
+                print("bench.py: rank %d exited with %d; stopping the other ranks" % (r, c), file=sys.stderr)
+                for o in live:                       # exact PIDs of the children started above
+                    procs[o].terminate()
+        time.sleep(0.05)
+    line_file.close()
+    text = open(line_file.name).read().strip()
+    os.unlink(line_file.name)
+    if rc != 0 and not text:
+        raise SystemExit(rc)
+    try:
+        got = json.loads(text.splitlines()[-1])
+    except (ValueError, IndexError):
+        raise SystemExit("bench.py: rank 0 printed no JSON line")
+    if got.get("n_gpus") != a.gpus:
+        raise SystemExit("bench.py: rank 0 reports n_gpus %r, asked for %d: line withheld" % (got.get("n_gpus"), a.gpus))
+    print(json.dumps(got), flush=True)
+    raise SystemExit(rc)
+
+
 def main():
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        spawn_ranks(a)            # never returns
     # The contract is ONE JSON line on stdout.  Libraries print banners there (RCCL: version, host
     # name, library path; per rank), so file descriptor 1 is pointed at stderr for the whole run
     # and the JSON line goes to the saved descriptor at the end.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    a = parse()
     import torch
     import humid_amd
     from humid_amd.synth import synth_words
@@ -146,10 +195,14 @@ def main():
         local_rank = 0           # rehearsal: all ranks share the one GPU of the box (collectives over gloo)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if rank == 0 and world > 1:
-            print("warning: WORLD_SIZE %d != --gpus %d; using WORLD_SIZE" % (world, a.gpus), file=sys.stderr)
+        # a line whose n_gpus is not what was asked for would be filed under the wrong point of the curve
+        raise SystemExit("bench.py: WORLD_SIZE %d != --gpus %d (start it as `python bench.py --gpus N`, or "
+                         "under torch.distributed.run with --nproc-per-node N)" % (world, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if os.environ.get("HUMID_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d wants GPU %d, %d visible (HUMID_BENCH_BACKEND=gloo rehearses "
+                         "several ranks on one GPU)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -169,6 +222,7 @@ def main():
     # weak scaling: ONE shuffled read set of world*n_local reads, sliced by input order (rank r holds
     # reads [r*n_local, (r+1)*n_local)): families span the ranks, as a real sharded FastQ does.
     # Every rank draws the same set from the same seed and keeps its slice.
+    t_synth = time.perf_counter()
     if world == 1:
         words, filt = synth_words(n_local, seed, a.word_nt)
     else:
@@ -177,6 +231,7 @@ def main():
         filt = np.ascontiguousarray(all_f[rank * n_local:(rank + 1) * n_local])
         if rank != 0:
             del all_w, all_f
+    synth_s = time.perf_counter() - t_synth
     d_w = torch.from_numpy(words.view(np.int64)).to(dev)
     d_f = torch.from_numpy(filt).to(dev)
     d_cid = torch.zeros(n_local, dtype=torch.int32, device=dev)
@@ -273,7 +328,17 @@ def main():
 
     # ---- parity of what was just timed (outside the timed region) ----
     verified_gpu1 = None
+    verify_s = None
+    ranks_seen = None
+    if dist is not None:
+        # what the process group itself says: its size, and the device every rank computed on
+        pr = torch.cuda.get_device_properties(dev)
+        mine = {"rank": dist.get_rank(), "device": local_rank, "name": pr.name,
+                "pci_bus": getattr(pr, "pci_bus_id", None), "pid": os.getpid()}
+        ranks_seen = [None] * dist.get_world_size()
+        dist.all_gather_object(ranks_seen, mine)
     if world_sharded and (a.verify is None or a.verify):
+        t_verify = time.perf_counter()
         # every shard's results, gathered on rank 0, against ONE single-GPU pass over the whole set
         from humid_amd.sharded import _all_gather_flat
         g_cid = torch.empty(world * n_local, dtype=torch.int32, device=dev)
@@ -289,6 +354,7 @@ def main():
                                  np.array_equal(g_keep.cpu().numpy().astype(np.uint8), keep1) and
                                  all(int(last[k]) == int(s1[k]) for k in ("total", "usable", "unique", "clusters", "edges")))
         del g_cid, g_keep
+        verify_s = time.perf_counter() - t_verify
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -392,6 +458,16 @@ def main():
             out["e2e_reads_per_s"] = e2e["e2e_reads_per_s"]
     if world_sharded:
         out["shard_mode"] = sd.mode_used
+    if dist is not None:
+        out["world_size"] = dist.get_world_size()          # as the process group (RCCL) saw it
+        out["backend"] = dist.get_backend()
+        out["ranks"] = ranks_seen
+        out["launcher"] = os.environ.get("HUMID_BENCH_LAUNCHER", "external (WORLD_SIZE was set)")
+    # outside the timed region: every rank draws the whole world x reads set and keeps its slice;
+    # rank 0 re-runs the whole set on ONE GPU for verified_vs_single_gpu
+    out["synth_s"] = round(synth_s, 1)
+    if verify_s is not None:
+        out["verify_s"] = round(verify_s, 1)
     if other is not None:
         out["other_mode"] = other
     if verified_oracle is not None:

@@ -15,11 +15,6 @@
 #include <vector>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_run_length_encode.hpp>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "../../include/humid_hip.h"
 

@@ -16,8 +16,10 @@
 //   C. map            kernels_map.hip.h     per read (cluster_id, keep); replaces
 //                     trie.find()->leaf->cluster, src/humid.cc:223-231,276-277.  Also the
 //                     multi-GPU result return.
-// Sorts and scans are rocPRIM (header-only, compiled in).  No CPU fallback lives here: every
-// entry point either runs on the GPU or fails.
+// Sorts and scans are the library's own (prims.hip.h): no third-party device code is linked in, so
+// every kernel of the code object carries the last-VGPR guard (tests/test_cabi_symbols.py reads the
+// code object's kernel descriptors).  No CPU fallback lives here: every entry point either runs on
+// the GPU or fails.
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -28,6 +30,7 @@
 #include <chrono>
 
 #include "common.hip.h"
+#include "prims.hip.h"
 #include "kernels_count.hip.h"
 #include "kernels_part.hip.h"
 #include "kernels_graph.hip.h"
@@ -182,35 +185,34 @@ static inline u32 bits_for(u64 n) {  // bits needed to represent values < n
   return b ? b : 1;
 }
 
-// ---- rocPRIM wrappers (temp storage grown on demand) ---------------------------------
-// MergeSortLimit = 0: block sort up to 1024 items, Onesweep above.  The library's default takes a
-// merge sort for sub-million inputs: ~20 launches of 6 us each where Onesweep needs 4 (measured on the
-// 440 k endpoint sort of the multi-GPU path, profiles/r02c_exchange_world1.md)
-using onesweep_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                rocprim::default_config, 0>;
+// ---- sort / scan wrappers over prims.hip.h (temporary storage grown on demand) ----------
+template <class K, class V, class KIn, class VIn>
+static int sort_pairs_in(humid_ctx *c, KIn kin, K *kout, VIn vin, V *vout, u64 n, u32 b0, u32 b1) {
+  if (n == 0) return HUMID_OK;
+  if (n > 0xffffffffull) return fail(c, HUMID_E_OVERFLOW, "sort of more than 2^32-1 items");
+  ENSURE(c->tmp, (rs_temp_bytes<K, V, true>(n)));
+  HIPCHK((rs_sort<K, V, true>(c->tmp.p, kin, kout, vin, vout, n, b0, b1, c->stream)));
+  return HUMID_OK;
+}
 template <class K, class V>
 static int sort_pairs(humid_ctx *c, const K *kin, K *kout, const V *vin, V *vout, u64 n, u32 b0, u32 b1) {
-  size_t bytes = 0;
-  HIPCHK(rocprim::radix_sort_pairs<onesweep_cfg>(nullptr, bytes, kin, kout, vin, vout, (size_t)n, b0, b1, c->stream));
-  ENSURE(c->tmp, bytes);
-  HIPCHK(rocprim::radix_sort_pairs<onesweep_cfg>(c->tmp.p, bytes, kin, kout, vin, vout, (size_t)n, b0, b1, c->stream));
-  return HUMID_OK;
+  return sort_pairs_in<K, V>(c, PtrIn<K>{kin}, kout, PtrIn<V>{vin}, vout, n, b0, b1);
 }
 template <class K>
 static int sort_keys(humid_ctx *c, const K *kin, K *kout, u64 n, u32 b0, u32 b1) {
-  size_t bytes = 0;
-  HIPCHK(rocprim::radix_sort_keys<onesweep_cfg>(nullptr, bytes, kin, kout, (size_t)n, b0, b1, c->stream));
-  ENSURE(c->tmp, bytes);
-  HIPCHK(rocprim::radix_sort_keys<onesweep_cfg>(c->tmp.p, bytes, kin, kout, (size_t)n, b0, b1, c->stream));
+  if (n == 0) return HUMID_OK;
+  if (n > 0xffffffffull) return fail(c, HUMID_E_OVERFLOW, "sort of more than 2^32-1 items");
+  ENSURE(c->tmp, (rs_temp_bytes<K, u32, false>(n)));
+  HIPCHK((rs_sort<K, u32, false>(c->tmp.p, PtrIn<K>{kin}, kout, IotaIn{}, (u32 *)nullptr, n, b0, b1, c->stream)));
   return HUMID_OK;
 }
-static int exscan_u32(humid_ctx *c, const u32 *in, u32 *out, u64 n) {
-  size_t bytes = 0;
-  HIPCHK(rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, (size_t)n, rocprim::plus<u32>(), c->stream));
-  ENSURE(c->tmp, bytes);
-  HIPCHK(rocprim::exclusive_scan(c->tmp.p, bytes, in, out, 0u, (size_t)n, rocprim::plus<u32>(), c->stream));
+template <class T, class In>
+static int exscan_in(humid_ctx *c, In in, T *out, u64 n) {
+  ENSURE(c->tmp, ps_scan_scratch_items(n) * sizeof(T) + 256);
+  HIPCHK((ps_exscan<T>(in, out, n, (T *)c->tmp.p, c->stream)));
   return HUMID_OK;
 }
+static int exscan_u32(humid_ctx *c, const u32 *in, u32 *out, u64 n) { return exscan_in<u32>(c, PtrIn<u32>{in}, out, n); }
 
 // device counters -> pinned mirror, one stream sync.  extra32 (device u32, may be null) lands
 // in h_ctr[CTR_N - 1].
@@ -626,18 +628,10 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
     if (wide) TRY(count_partition(c, WideReadsSrc{wide, d_filt, 2 * (word_nt - 32), in.key}, N, pb, &used_padded));
     else TRY(count_partition(c, ReadsSrc{in}, N, pb, &used_padded));
   } else {
-    auto kin = rocprim::make_transform_iterator(d_words, PartKeyOp{ordered ? 1u : 0u, km.lo, km.scale});
-    auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<u32>(0),
-                                                ReadTagOp{check_range ? d_words : nullptr, d_filt, range_lo, range_hi});
-    // MergeSortLimit = 0: block sort up to 1024 items, Onesweep above (never the merge path)
-    using part_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                rocprim::default_config, 0>;
-    size_t bytes = 0;
-    HIPCHK(rocprim::radix_sort_pairs<part_cfg>(nullptr, bytes, kin, c->pk_keys.as<u64>(), vin,
-                                               c->pk_vals.as<u32>(), (size_t)N, 64 - pb, 64, st));
-    ENSURE(c->tmp, bytes);
-    HIPCHK(rocprim::radix_sort_pairs<part_cfg>(c->tmp.p, bytes, kin, c->pk_keys.as<u64>(), vin,
-                                               c->pk_vals.as<u32>(), (size_t)N, 64 - pb, 64, st));
+    // beyond 2^18 buckets (> ~90 M reads): radix passes over the top pb key bits (prims.hip.h)
+    ComposeIn<PartKeyOp, PtrIn<u64>> kin{PartKeyOp{ordered ? 1u : 0u, km.lo, km.scale}, PtrIn<u64>{d_words}};
+    ComposeIn<ReadTagOp, IotaIn> vin{ReadTagOp{check_range ? d_words : nullptr, d_filt, range_lo, range_hi}, IotaIn{}};
+    TRY((sort_pairs_in<u64, u32>(c, kin, c->pk_keys.as<u64>(), vin, c->pk_vals.as<u32>(), N, 64 - pb, 64)));
     hipLaunchKernelGGL(k_part_bounds, dim3(blocks_for(n_parts + 1)), dim3(256), 0, st, c->pk_keys.as<u64>(), N,
                        pb, n_parts, c->pbeg.as<u32>(), c->ucount.as<u32>());
   }
@@ -950,12 +944,7 @@ static int sort_words_by_stretch(humid_ctx *c, const ComboPlan &plan, u32 cb, co
   }
   *done = stretch && bit_n >= 1 && bit_lo + bit_n <= 64;
   if (!*done) return HUMID_OK;
-  rocprim::counting_iterator<u32> pos(0);
-  size_t bytes = 0;
-  HIPCHK(rocprim::radix_sort_pairs<onesweep_cfg>(nullptr, bytes, W, ws, pos, vs, (size_t)n, bit_lo, bit_lo + bit_n, c->stream));
-  ENSURE(c->tmp, bytes);
-  HIPCHK(rocprim::radix_sort_pairs<onesweep_cfg>(c->tmp.p, bytes, W, ws, pos, vs, (size_t)n, bit_lo, bit_lo + bit_n, c->stream));
-  return HUMID_OK;
+  return sort_pairs_in<u64, u32>(c, PtrIn<u64>{W}, ws, IotaIn{}, vs, n, bit_lo, bit_lo + bit_n);
 }
 
 // ---- stage B: neighbours + clusters over a sorted unique array ---------------------------
@@ -1957,24 +1946,25 @@ int humid_get_histogram(humid_ctx *c, uint32_t which, uint64_t *keys, uint64_t *
   u64 n = (which == 2) ? c->C : U;
   if (n == 0) return HUMID_OK;
   hipStream_t st = c->stream;
-  // layout of scratch: vals[n] | sorted[n] | uniq[n] | counts u32[n] | runs u32
-  ENSURE(c->scratch, (size_t)n * 28 + 64);
+  // layout of scratch: vals[n] | sorted[n] | uniq[n] | counts u32[n] | head u32[n + 1] | hpos u32[n + 1] | start u32[n + 1]
+  ENSURE(c->scratch, (size_t)n * 40 + 64);
   u64 *vals = c->scratch.as<u64>();
   u64 *sorted = vals + n;
   u64 *uniq = sorted + n;
   u32 *counts = (u32 *)(uniq + n);
-  u32 *runs = counts + n;
+  u32 *head = counts + n, *hpos = head + n + 1, *start = hpos + n + 1;
+  u32 *runs = hpos + n;                                      // the scan's last entry = number of runs
   if (which == 0) hipLaunchKernelGGL(k_widen32, dim3(blocks_for(U)), dim3(256), 0, st, c->g_cnt, U, vals);
   else if (which == 1) hipLaunchKernelGGL(k_widen32, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(), U, vals);
   else hipLaunchKernelGGL(k_creator_sizes, dim3(blocks_for(U)), dim3(256), 0, st, c->flag.as<u32>(),
                           c->pos.as<u32>(), c->cl_size.as<u64>(), U, vals);
   TRY(sort_keys<u64>(c, vals, sorted, n, 0, 64));
-  {
-    size_t bytes = 0;
-    HIPCHK(rocprim::run_length_encode(nullptr, bytes, sorted, (unsigned int)n, uniq, counts, runs, st));
-    ENSURE(c->tmp, bytes);
-    HIPCHK(rocprim::run_length_encode(c->tmp.p, bytes, sorted, (unsigned int)n, uniq, counts, runs, st));
-  }
+  // run-length encode: head flags, their scan, (value, first position) per run, lengths by difference
+  hipLaunchKernelGGL(k_rle_heads, dim3(blocks_for(n + 1)), dim3(256), 0, st, sorted, (u32)n, head);
+  TRY(exscan_u32(c, head, hpos, n + 1));
+  hipLaunchKernelGGL(k_rle_runs, dim3(blocks_for(n + 1)), dim3(256), 0, st, sorted, (const u32 *)head, (const u32 *)hpos, (u32)n, uniq, start);
+  hipLaunchKernelGGL(k_rle_counts, dim3(blocks_for(n)), dim3(256), 0, st, (const u32 *)start, (const u32 *)runs, counts);
+  HIPCHK(hipGetLastError());
   u32 h_runs = 0;
   HIPCHK(hipMemcpyAsync(&h_runs, runs, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -2571,12 +2561,8 @@ int humid_stage_count_dense(humid_ctx *c, const uint64_t *d_words, const uint8_t
   }
   ENSURE(c->opos, ((size_t)N + 1) * 4);
   {
-    auto fin = rocprim::make_transform_iterator(rocprim::counting_iterator<u32>(0),
-                                                OwnedRangeFlagOp{d_words, d_filtered, range_lo, range_hi, N});
-    size_t bytes = 0;
-    HIPCHK(rocprim::exclusive_scan(nullptr, bytes, fin, c->opos.as<u32>(), 0u, (size_t)N + 1, rocprim::plus<u32>(), st));
-    ENSURE(c->tmp, bytes);
-    HIPCHK(rocprim::exclusive_scan(c->tmp.p, bytes, fin, c->opos.as<u32>(), 0u, (size_t)N + 1, rocprim::plus<u32>(), st));
+    ComposeIn<OwnedRangeFlagOp, IotaIn> fin{OwnedRangeFlagOp{d_words, d_filtered, range_lo, range_hi, N}, IotaIn{}};
+    TRY(exscan_in<u32>(c, fin, c->opos.as<u32>(), (u64)N + 1));
   }
   std::vector<u32> got(n_shards + 1);
   for (u32 q = 0; q <= n_shards; q++)
@@ -2816,15 +2802,7 @@ int humid_stage_combo_route(humid_ctx *c, const uint64_t *d_word, const uint32_t
   hipLaunchKernelGGL(k_combo_owner<u64>, dim3(blocks_for(n)), dim3(256), 0, st, (const u64 *)d_word, n, plan_fields(plan, combo),
                      n_ranks, c->owner.as<u8>());
   {
-    using part_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                rocprim::default_config, 0>;   // never the merge path
-    rocprim::counting_iterator<u32> vin(0);
-    size_t bytes = 0;
-    HIPCHK(rocprim::radix_sort_pairs<part_cfg>(nullptr, bytes, c->owner.as<u8>(), c->owner_sorted.as<u8>(), vin,
-                                               c->x_ids.as<u32>(), (size_t)n, 0, 8, st));
-    ENSURE(c->tmp, bytes);
-    HIPCHK(rocprim::radix_sort_pairs<part_cfg>(c->tmp.p, bytes, c->owner.as<u8>(), c->owner_sorted.as<u8>(), vin,
-                                               c->x_ids.as<u32>(), (size_t)n, 0, 8, st));
+    TRY((sort_pairs_in<u8, u32>(c, PtrIn<u8>{c->owner.as<u8>()}, c->owner_sorted.as<u8>(), IotaIn{}, c->x_ids.as<u32>(), n, 0, 8)));
   }
   ENSURE(c->small, (size_t)(n_ranks + 2) * 4);
   hipLaunchKernelGGL(k_owner_bounds, dim3(1), dim3(256), 0, st, c->owner_sorted.as<u8>(), n, n_ranks,
@@ -2942,13 +2920,7 @@ static int combo_route_wide(humid_ctx *c, const W2 *d_word, const u32 *d_count, 
   hipLaunchKernelGGL(k_combo_owner<W2>, dim3(blocks_for(n)), dim3(256), 0, st, d_word, n, plan_fields(plan, combo), n_ranks,
                      c->owner.as<u8>());
   {
-    rocprim::counting_iterator<u32> vin(0);
-    size_t bytes = 0;
-    HIPCHK(rocprim::radix_sort_pairs<onesweep_cfg>(nullptr, bytes, c->owner.as<u8>(), c->owner_sorted.as<u8>(), vin, c->x_ids.as<u32>(),
-                                                   (size_t)n, 0, 8, st));
-    ENSURE(c->tmp, bytes);
-    HIPCHK(rocprim::radix_sort_pairs<onesweep_cfg>(c->tmp.p, bytes, c->owner.as<u8>(), c->owner_sorted.as<u8>(), vin, c->x_ids.as<u32>(),
-                                                   (size_t)n, 0, 8, st));
+    TRY((sort_pairs_in<u8, u32>(c, PtrIn<u8>{c->owner.as<u8>()}, c->owner_sorted.as<u8>(), IotaIn{}, c->x_ids.as<u32>(), n, 0, 8)));
   }
   ENSURE(c->small, (size_t)(n_ranks + 2) * 4);
   hipLaunchKernelGGL(k_owner_bounds, dim3(1), dim3(256), 0, st, c->owner_sorted.as<u8>(), n, n_ranks, c->small.as<u32>());
@@ -3117,13 +3089,7 @@ static int compact_nodes_impl(humid_ctx *c, const uint64_t *d_edges, uint64_t n_
     HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_OVERFULL], 0, sizeof(ull), st));
     hipLaunchKernelGGL(k_mark_ends, dim3(blocks_for(E)), dim3(256), 0, st, d_edges, E, record_stride, B, c->x_head.as<u8>(),
                        c->x_ends.as<u32>(), c->d_ctr);
-    {
-      auto as_u32 = rocprim::make_transform_iterator(c->x_head.as<u8>(), [] __device__(u8 v) { return (u32)v; });
-      size_t bytes = 0;
-      HIPCHK(rocprim::exclusive_scan(nullptr, bytes, as_u32, c->x_hpos.as<u32>(), 0u, (size_t)B + 1, rocprim::plus<u32>(), st));
-      ENSURE(c->tmp, bytes);
-      HIPCHK(rocprim::exclusive_scan(c->tmp.p, bytes, as_u32, c->x_hpos.as<u32>(), 0u, (size_t)B + 1, rocprim::plus<u32>(), st));
-    }
+    TRY(exscan_in<u32>(c, CastIn<u32, u8>{c->x_head.as<u8>()}, c->x_hpos.as<u32>(), (u64)B + 1));
     HIPCHK(hipGetLastError());
     TRY(read_counters(c, c->x_hpos.as<u32>() + B));
     if (c->h_ctr[CTR_OVERFULL]) return fail(c, HUMID_E_INVALID, "pair record with an index beyond the unique words");
@@ -3370,12 +3336,8 @@ int humid_stage_exchange_ids(humid_ctx *c, const uint32_t *d_nodes, const uint32
                        x_first);
   }
   {
-    auto fin = rocprim::make_transform_iterator(rocprim::counting_iterator<u32>(0),
-                                                XidFlagOp{x_mark, x_markcr, U});
-    size_t bytes = 0;
-    HIPCHK(rocprim::exclusive_scan(nullptr, bytes, fin, c->x_scan.as<u64>(), (u64)0, (size_t)U, rocprim::plus<u64>(), st));
-    ENSURE(c->tmp, bytes);
-    HIPCHK(rocprim::exclusive_scan(c->tmp.p, bytes, fin, c->x_scan.as<u64>(), (u64)0, (size_t)U, rocprim::plus<u64>(), st));
+    ComposeIn<XidFlagOp, IotaIn> fin{XidFlagOp{x_mark, x_markcr, U}, IotaIn{}};
+    TRY(exscan_in<u64>(c, fin, c->x_scan.as<u64>(), (u64)U));
   }
   hipLaunchKernelGGL(k_xid_assign, dim3(blocks_for(U)), dim3(256), 0, st, x_mark, c->x_scan.as<u64>(),
                      x_first, d_ccid, d_cismax, c->x_base.as<u32>(), Cc, goff, U, c->x_lcid.as<u32>(),
@@ -3407,12 +3369,8 @@ int humid_stage_owned_results(humid_ctx *c, const uint32_t *d_local_cluster_id, 
                        c->s_first.as<u32>(), c->s_slot.as<u32>(), U, c->slot_out.as<u64>());
   ENSURE(c->opos, ((size_t)N + 1) * 4);
   {
-    auto fin = rocprim::make_transform_iterator(rocprim::counting_iterator<u32>(0),
-                                                OwnedFlagOp{c->slot_of_read.as<u32>(), N});
-    size_t bytes = 0;
-    HIPCHK(rocprim::exclusive_scan(nullptr, bytes, fin, c->opos.as<u32>(), 0u, (size_t)N + 1, rocprim::plus<u32>(), st));
-    ENSURE(c->tmp, bytes);
-    HIPCHK(rocprim::exclusive_scan(c->tmp.p, bytes, fin, c->opos.as<u32>(), 0u, (size_t)N + 1, rocprim::plus<u32>(), st));
+    ComposeIn<OwnedFlagOp, IotaIn> fin{OwnedFlagOp{c->slot_of_read.as<u32>(), N}, IotaIn{}};
+    TRY(exscan_in<u32>(c, fin, c->opos.as<u32>(), (u64)N + 1));
   }
   // per-shard counts: opos at the shard boundaries (a handful of 4-byte copies, one sync)
   std::vector<u32> got(n_shards + 1);
@@ -3456,15 +3414,7 @@ int humid_stage_owner_perm(humid_ctx *c, const uint64_t *d_words, const uint8_t 
   hipLaunchKernelGGL(k_owner_of, dim3(blocks_for(n)), dim3(256), 0, st, d_words, d_filtered, n, rg, n_ranks,
                      c->owner.as<u8>());
   {
-    using part_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                rocprim::default_config, 0>;   // never the merge path
-    rocprim::counting_iterator<u32> vin(0);
-    size_t bytes = 0;
-    HIPCHK(rocprim::radix_sort_pairs<part_cfg>(nullptr, bytes, c->owner.as<u8>(), c->owner_sorted.as<u8>(), vin,
-                                               c->perm.as<u32>(), (size_t)n, 0, 8, st));
-    ENSURE(c->tmp, bytes);
-    HIPCHK(rocprim::radix_sort_pairs<part_cfg>(c->tmp.p, bytes, c->owner.as<u8>(), c->owner_sorted.as<u8>(), vin,
-                                               c->perm.as<u32>(), (size_t)n, 0, 8, st));
+    TRY((sort_pairs_in<u8, u32>(c, PtrIn<u8>{c->owner.as<u8>()}, c->owner_sorted.as<u8>(), IotaIn{}, c->perm.as<u32>(), n, 0, 8)));
   }
   ENSURE(c->small, (size_t)(n_ranks + 2) * 4);
   hipLaunchKernelGGL(k_owner_bounds, dim3(1), dim3(64), 0, st, c->owner_sorted.as<u8>(), n, n_ranks,

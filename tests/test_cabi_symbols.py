@@ -106,3 +106,43 @@ def test_every_kernel_guards_its_last_vector_register():
                 (os.path.basename(p), src[m.start():m.start() + 80])
             n += 1
     assert n >= 60
+
+
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def gfx950_kernel_descriptors(so_path, tmp_path):
+    """[(kernel symbol, vgpr_count, agpr_count)] of the gfx950 code object embedded in the library
+    (no GPU needed: llvm-objcopy dumps .hip_fatbin, clang-offload-bundler unbundles it, llvm-readelf
+    prints the AMDGPU metadata note)"""
+    import subprocess
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "gfx950.co")
+    subprocess.check_call([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, so_path])
+    subprocess.check_call([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+    notes = subprocess.check_output([os.path.join(LLVM_BIN, "llvm-readelf"), "--notes", co]).decode()
+    out = []
+    # one "  - .agpr_count: N" ... ".symbol: name.kd" ... ".vgpr_count: N" block per kernel
+    for blk in re.split(r"\n  - (?=\.agpr_count:)", notes)[1:]:
+        ag = int(re.search(r"\.agpr_count:\s+(\d+)", blk).group(1))
+        vg = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
+        sym = re.search(r"\.symbol:\s+'?([^\s']+)", blk).group(1)
+        out.append((sym, vg, ag))
+    return out
+
+
+def test_code_object_every_kernel_allocates_an_accumulation_register(tmp_path):
+    """The BUILT gfx950 code object, not the source text: every kernel that uses vector registers also
+    allocates accumulation registers behind them (agpr_count > 0), so the last VGPR of its allocation
+    -- the one DESIGN.md section 3a shows being overwritten -- holds nothing.  Since round 3 the
+    library links no third-party device code (rocPRIM's scans and sorts are gone: prims.hip.h), so
+    the rule holds for EVERY kernel symbol, with no allow-list."""
+    if not os.path.exists(os.path.join(LLVM_BIN, "clang-offload-bundler")):
+        pytest.skip("no LLVM binutils in this image")
+    so = build.build_hip()
+    ks = gfx950_kernel_descriptors(so, tmp_path)
+    assert len(ks) >= 100, len(ks)
+    bad = [(s, v, a) for s, v, a in ks if v > 0 and a == 0]
+    assert not bad, bad[:10]
+    foreign = [s for s, _, _ in ks if "rocprim" in s or "hipcub" in s or "thrust" in s]
+    assert not foreign, foreign[:5]
