@@ -34,6 +34,7 @@
 #include "kernels_count.hip.h"
 #include "kernels_part.hip.h"
 #include "kernels_graph.hip.h"
+#include "kernels_cgraph.hip.h"
 #include "kernels_cluster.hip.h"
 #include "kernels_map.hip.h"
 #include "kernels_wide.hip.h"
@@ -106,6 +107,14 @@ struct humid_ctx {
   DBuf x_slot, x_slot_s, x_cnt, x_cnts, x_rec, x_ncnt, x_route, x_creator, x_base, x_mark, x_markcr, x_scan, x_lcid, x_lismax,
        x_items, x_w, x_id, x_ids, x_ends, x_ends_s, x_head, x_hpos, x_nodes, x_cedges;   // multi-GPU exchange mode
   DBuf w_sorted, w_head, w_hpos, w_start, w_heads;                                         // wide-word (sorted) counts
+  // compact graph (kernels_cgraph.hip.h): pair regions + cursors, the two bitmaps with their rank blocks, per-node arrays
+  DBuf cg_edges, cg_cur, cg_far, cg_bits, cg_nbits, cg_blk, cg_nblk, cg_nodes, cg_ncnt, cg_deg, cg_off, cg_idx, cg_parent, cg_csize,
+       cg_curs, cg_cl_of, cg_maxleaf, cg_cl_size;
+  u64 cg_ecap = 0;                  // room for pairs in the append regions (remembered from pass to pass; grown on demand)
+  bool use_compact = true;          // option "compact_graph": 0 = the per-unique-word graph of rounds 1-2
+  bool cg_valid = false;            // the last graph stage left its results in the cg_* arrays ...
+  bool cg_expanded = false;         // ... and the per-unique-word view of them has been built (accessors)
+  u32 cg_M = 0, cg_nblocks = 0;
   DBuf pt_work, unperm_rec, route_tiles;                                                     // LDS-staged partition / un-permute (kernels_part.hip.h)
   bool group_buckets = true;        // option "group_buckets": bucket order of stretch keys by two-level grouping instead of a library sort
   bool pt_padded = true;            // level 1 of the tile partition into padded coarse bins (no histogram pass); false after an overflow
@@ -359,8 +368,68 @@ static ComboPlan make_plan(u32 n, u32 d, u64 U, u32 force_segments, bool short_l
 }
 
 // ---- cluster stage shared by the full pipeline and the explicit-graph entry point ------
-// needs: g_cnt[U], deg[U], nbr_off[U+1], nbr_idx, parent[U] + csize[U] (k_comp_stats done),
-// M = leaves with deg > 0, Mbig = those in components larger than SMALL_COMP.
+// The arrays a graph lives in: per unique word (legacy view: deg / nbr_off / ... of the context) or per
+// COMPACT node (cg_* buffers, kernels_cgraph.hip.h).  n nodes, cnt[n] their counts.
+struct GraphArrays {
+  u32 *deg, *parent, *csize, *off, *idx, *cl_of, *maxleaf;
+  u64 *cl_size;
+};
+static GraphArrays legacy_arrays(humid_ctx *c) {
+  return GraphArrays{c->deg.as<u32>(), c->parent.as<u32>(), c->csize.as<u32>(), c->nbr_off.as<u32>(), c->nbr_idx.as<u32>(),
+                     c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>()};
+}
+// needs: cnt[n], deg[n], off[n+1], idx, parent[n] + csize[n] (k_comp_stats done), M = nodes with deg > 0,
+// Mbig = those in components larger than SMALL_COMP; small_roots listed by k_comp_count.
+// Leaves cl_of (creator + 1) / maxleaf / cl_size (at the creators) in `g`.
+static int cluster_kernels(humid_ctx *c, const GraphArrays &g, const u32 *g_cnt, u32 U, u64 M, u64 Mbig, u32 method) {
+  hipStream_t st = c->stream;
+  if (c->kev_on) HIPCHK(hipEventRecord(c->kev[2], st));
+  if (method == HUMID_METHOD_MAXIMUM)
+    hipLaunchKernelGGL(k_cluster_trivial<true>, dim3(blocks_for(U)), dim3(256), 0, st, g.deg, g.parent, g.csize, U, g_cnt, g.off,
+                       g.idx, g.cl_of, g.maxleaf, g.cl_size);
+  else
+    hipLaunchKernelGGL(k_cluster_trivial<false>, dim3(blocks_for(U)), dim3(256), 0, st, g.deg, g.parent, g.csize, U, g_cnt, g.off,
+                       g.idx, g.cl_of, g.maxleaf, g.cl_size);
+  if (M > 0) {
+    const u64 small_cap = M / 3 + 1;                  // listed roots: components of >= 3 of the M leaves with neighbours
+    if (method == HUMID_METHOD_MAXIMUM)
+      hipLaunchKernelGGL(k_cluster_small<true>, dim3(blocks_for(small_cap, 128)), dim3(128), 0, st, c->small_roots.as<u32>(),
+                         (const ull *)c->d_ctr, g.parent, g.csize, U, g_cnt, g.off, g.idx, g.cl_of, g.maxleaf, g.cl_size);
+    else
+      hipLaunchKernelGGL(k_cluster_small<false>, dim3(blocks_for(small_cap, 128)), dim3(128), 0, st, c->small_roots.as<u32>(),
+                         (const ull *)c->d_ctr, g.parent, g.csize, U, g_cnt, g.off, g.idx, g.cl_of, g.maxleaf, g.cl_size);
+    if (Mbig > 0) {
+      ENSURE(c->mk0, (size_t)Mbig * 8);
+      ENSURE(c->mk1, (size_t)Mbig * 8);
+      ENSURE(c->stk, (size_t)Mbig * 8);
+      HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_SPECIAL], 0, sizeof(ull), st));
+      hipLaunchKernelGGL(k_member_keys, dim3(COMPACT_BLOCKS), dim3(256), 0, st, g.deg, g.parent, g.csize, U, c->mk0.as<u64>(), c->d_ctr);
+      TRY(sort_keys<u64>(c, c->mk0.as<u64>(), c->mk1.as<u64>(), Mbig, 0, 32 + bits_for(U)));
+      if (method == HUMID_METHOD_MAXIMUM) {
+        // maxLeaf ties are broken by depth-first pre-order: one lane per component
+        hipLaunchKernelGGL(k_cluster_components<true>, dim3(blocks_for(Mbig, 64)), dim3(64), 0, st,
+                           c->mk1.as<u64>(), (u32)Mbig, g_cnt, g.off, g.idx, g.cl_of, g.maxleaf, g.cl_size, c->stk.as<u32>());
+      } else if (c->coop_big) {
+        // one workgroup per component, flood as a parallel BFS
+        ENSURE(c->heads, (size_t)Mbig * 4);
+        HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_SPECIAL], 0, sizeof(ull), st));
+        hipLaunchKernelGGL(k_comp_heads, dim3(COMPACT_BLOCKS), dim3(256), 0, st, c->mk1.as<u64>(), (u32)Mbig,
+                           c->heads.as<u32>(), c->d_ctr);
+        const u32 grid = (u32)(Mbig / (SMALL_COMP + 1) + 1 < 2048 ? Mbig / (SMALL_COMP + 1) + 1 : 2048);
+        hipLaunchKernelGGL(k_cluster_big_coop, dim3(grid), dim3(256), 0, st, c->mk1.as<u64>(), (u32)Mbig,
+                           c->heads.as<u32>(), c->d_ctr, g_cnt, g.off, g.idx, g.cl_of, g.maxleaf, g.cl_size, c->stk.as<u32>());
+      } else {
+        hipLaunchKernelGGL(k_cluster_components<false>, dim3(blocks_for(Mbig, 64)), dim3(64), 0, st,
+                           c->mk1.as<u64>(), (u32)Mbig, g_cnt, g.off, g.idx, g.cl_of, g.maxleaf, g.cl_size, c->stk.as<u32>());
+      }
+    }
+  }
+  if (c->kev_on) HIPCHK(hipEventRecord(c->kev[3], st));
+  HIPCHK(hipGetLastError());
+  return HUMID_OK;
+}
+
+// the legacy view: clusters over all U unique words, then creator flags and their prefix sum
 static int cluster_stage(humid_ctx *c, const u32 *g_cnt, u32 U, u64 M, u64 Mbig, u32 method) {
   hipStream_t st = c->stream;
   ENSURE(c->cl_of, (size_t)U * 4);
@@ -370,58 +439,7 @@ static int cluster_stage(humid_ctx *c, const u32 *g_cnt, u32 U, u64 M, u64 Mbig,
   ENSURE(c->pos, (size_t)(U + 1) * 4);
   ENSURE(c->cid, (size_t)U * 4);
   ENSURE(c->ismax, (size_t)U);
-  if (c->kev_on) HIPCHK(hipEventRecord(c->kev[2], st));
-  if (method == HUMID_METHOD_MAXIMUM)
-    hipLaunchKernelGGL(k_cluster_trivial<true>, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
-                       c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
-                       c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
-  else
-    hipLaunchKernelGGL(k_cluster_trivial<false>, dim3(blocks_for(U)), dim3(256), 0, st, c->deg.as<u32>(),
-                       c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
-                       c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
-  if (M > 0) {
-    const u64 small_cap = M / 3 + 1;                  // listed roots: components of >= 3 of the M leaves with neighbours
-    if (method == HUMID_METHOD_MAXIMUM)
-      hipLaunchKernelGGL(k_cluster_small<true>, dim3(blocks_for(small_cap, 128)), dim3(128), 0, st, c->small_roots.as<u32>(),
-                         (const ull *)c->d_ctr, c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
-                         c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
-    else
-      hipLaunchKernelGGL(k_cluster_small<false>, dim3(blocks_for(small_cap, 128)), dim3(128), 0, st, c->small_roots.as<u32>(),
-                         (const ull *)c->d_ctr, c->parent.as<u32>(), c->csize.as<u32>(), U, g_cnt, c->nbr_off.as<u32>(),
-                         c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
-    if (Mbig > 0) {
-      ENSURE(c->mk0, (size_t)Mbig * 8);
-      ENSURE(c->mk1, (size_t)Mbig * 8);
-      ENSURE(c->stk, (size_t)Mbig * 8);
-      HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_SPECIAL], 0, sizeof(ull), st));
-      hipLaunchKernelGGL(k_member_keys, dim3(COMPACT_BLOCKS), dim3(256), 0, st, c->deg.as<u32>(),
-                         c->parent.as<u32>(), c->csize.as<u32>(), U, c->mk0.as<u64>(), c->d_ctr);
-      TRY(sort_keys<u64>(c, c->mk0.as<u64>(), c->mk1.as<u64>(), Mbig, 0, 32 + bits_for(U)));
-      if (method == HUMID_METHOD_MAXIMUM) {
-        // maxLeaf ties are broken by depth-first pre-order: one lane per component
-        hipLaunchKernelGGL(k_cluster_components<true>, dim3(blocks_for(Mbig, 64)), dim3(64), 0, st,
-                           c->mk1.as<u64>(), (u32)Mbig, g_cnt, c->nbr_off.as<u32>(),
-                           c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(),
-                           c->cl_size.as<u64>(), c->stk.as<u32>());
-      } else if (c->coop_big) {
-        // one workgroup per component, flood as a parallel BFS
-        ENSURE(c->heads, (size_t)Mbig * 4);
-        HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_SPECIAL], 0, sizeof(ull), st));
-        hipLaunchKernelGGL(k_comp_heads, dim3(COMPACT_BLOCKS), dim3(256), 0, st, c->mk1.as<u64>(), (u32)Mbig,
-                           c->heads.as<u32>(), c->d_ctr);
-        const u32 grid = (u32)(Mbig / (SMALL_COMP + 1) + 1 < 2048 ? Mbig / (SMALL_COMP + 1) + 1 : 2048);
-        hipLaunchKernelGGL(k_cluster_big_coop, dim3(grid), dim3(256), 0, st, c->mk1.as<u64>(), (u32)Mbig,
-                           c->heads.as<u32>(), c->d_ctr, g_cnt, c->nbr_off.as<u32>(), c->nbr_idx.as<u32>(),
-                           c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>(), c->stk.as<u32>());
-      } else {
-        hipLaunchKernelGGL(k_cluster_components<false>, dim3(blocks_for(Mbig, 64)), dim3(64), 0, st,
-                           c->mk1.as<u64>(), (u32)Mbig, g_cnt, c->nbr_off.as<u32>(),
-                           c->nbr_idx.as<u32>(), c->cl_of.as<u32>(), c->maxleaf.as<u32>(),
-                           c->cl_size.as<u64>(), c->stk.as<u32>());
-      }
-    }
-  }
-  if (c->kev_on) HIPCHK(hipEventRecord(c->kev[3], st));
+  TRY(cluster_kernels(c, legacy_arrays(c), g_cnt, U, M, Mbig, method));
   hipLaunchKernelGGL(k_creator_flags, dim3(blocks_for(U)), dim3(256), 0, st, c->cl_of.as<u32>(), U,
                      c->flag.as<u32>());
   TRY(exscan_u32(c, c->flag.as<u32>(), c->pos.as<u32>(), U));
@@ -947,6 +965,40 @@ static int sort_words_by_stretch(humid_ctx *c, const ComboPlan &plan, u32 cb, co
   return sort_pairs_in<u64, u32>(c, PtrIn<u64>{W}, ws, IotaIn{}, vs, n, bit_lo, bit_lo + bit_n);
 }
 
+// words of the unique array in bucket order of combination `seg` (> 0): ws[i] = the word walked at
+// position i, vs[i] = its walk index.  Keys of <= 24 bits: two-level grouping; one stretch of the word:
+// the words themselves as sort keys; else keys + sort + gather.  Scratch: seg_k0 / seg_v0 / seg_ks.
+template <class WT>
+static int bucket_order(humid_ctx *c, const ComboPlan &plan, u32 seg, const WT *g_word, u32 U, WT *ws, u32 *vs) {
+  hipStream_t st = c->stream;
+  u32 kb = 0;                                            // key bits of THIS combination
+  for (u32 f = 0; f < plan.nfield[seg]; f++) kb += plan.width[seg][f];
+  if (kb == 0) kb = 1;
+  bool stretch = false;
+  if (std::is_same<WT, u64>::value) {
+    TRY((group_words_by_stretch<FieldsSrc, u64>(c, plan, seg, (const u64 *)g_word, U, (u64 *)ws, vs, &stretch)));
+    if (!stretch) TRY(sort_words_by_stretch(c, plan, seg, (const u64 *)g_word, U, (u64 *)ws, vs, &stretch));
+  } else {
+    // two-word words: the keys are grouped (scratch), the words follow through the grouped positions
+    TRY((group_words_by_stretch<FieldsSrcW2, W2>(c, plan, seg, (const W2 *)g_word, U, c->seg_ks.as<u64>(), vs, &stretch)));
+    if (stretch) hipLaunchKernelGGL(k_gather_bucket_words<WT>, dim3(blocks_for(U)), dim3(256), 0, st, g_word, vs, U, ws);
+  }
+  if (stretch) return HUMID_OK;
+  const ComboFields cf = plan_fields(plan, seg);
+  if (kb <= 32) {
+    hipLaunchKernelGGL((k_combo_keys<u32, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, cf,
+                       c->seg_k0.as<u32>(), c->seg_v0.as<u32>());
+    TRY(sort_pairs<u32, u32>(c, c->seg_k0.as<u32>(), c->seg_ks.as<u32>(), c->seg_v0.as<u32>(), vs, U, 0, kb));
+  } else {
+    hipLaunchKernelGGL((k_combo_keys<u64, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, cf,
+                       c->seg_k0.as<u64>(), c->seg_v0.as<u32>());
+    TRY(sort_pairs<u64, u32>(c, c->seg_k0.as<u64>(), c->seg_ks.as<u64>(), c->seg_v0.as<u32>(), vs, U, 0, kb));
+  }
+  hipLaunchKernelGGL(k_gather_bucket_words<WT>, dim3(blocks_for(U)), dim3(256), 0, st, g_word, vs, U, ws);
+  HIPCHK(hipGetLastError());
+  return HUMID_OK;
+}
+
 // ---- stage B: neighbours + clusters over a sorted unique array ---------------------------
 // g_word[U] ascending, g_cnt[U] (device; the context's own arrays on one GPU, the gathered
 // arrays of all ranks on several).  Leaves deg/nbr_off/nbr_idx/cl_of/maxleaf/cl_size/flag/
@@ -963,6 +1015,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
   c->g_wpr = (u32)(sizeof(WT) / 8);
   c->g_cnt = g_cnt;
   c->gU = U;
+  c->cg_valid = false;
   // ---------------- 3. neighbours -----------------
   // deg has U+1 entries (last stays 0) so that one exclusive scan yields nbr_off[U] = 2E
   ENSURE(c->deg, (size_t)(U + 1) * 4);
@@ -1063,32 +1116,8 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
                            &c->d_ctr[CTR_BIGMASK], join_cnt);
       } else {
         u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
-        u32 kb = 0;                                            // key bits of THIS combination
-        for (u32 f = 0; f < plan.nfield[seg]; f++) kb += plan.width[seg][f];
-        if (kb == 0) kb = 1;
         WT *ws = c->seg_ws.as<WT>() + (size_t)(seg - 1) * U;
-        bool stretch = false;
-        if (std::is_same<WT, u64>::value) {
-          TRY((group_words_by_stretch<FieldsSrc, u64>(c, plan, seg, (const u64 *)g_word, U, (u64 *)ws, vs, &stretch)));
-          if (!stretch) TRY(sort_words_by_stretch(c, plan, seg, (const u64 *)g_word, U, (u64 *)ws, vs, &stretch));
-        } else {
-          // two-word words: the keys are grouped (scratch), the words follow through the grouped positions
-          TRY((group_words_by_stretch<FieldsSrcW2, W2>(c, plan, seg, (const W2 *)g_word, U, c->seg_ks.as<u64>(), vs, &stretch)));
-          if (stretch) hipLaunchKernelGGL(k_gather_bucket_words<WT>, dim3(blocks_for(U)), dim3(256), 0, st, g_word, vs, U, ws);
-        }
-        if (stretch) {
-        } else {
-        if (kb <= 32) {
-          hipLaunchKernelGGL((k_combo_keys<u32, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, fields_of(seg),
-                             c->seg_k0.as<u32>(), c->seg_v0.as<u32>());
-          TRY(sort_pairs<u32, u32>(c, c->seg_k0.as<u32>(), c->seg_ks.as<u32>(), c->seg_v0.as<u32>(), vs, U, 0, kb));
-        } else {
-          hipLaunchKernelGGL((k_combo_keys<u64, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word, U, fields_of(seg),
-                             c->seg_k0.as<u64>(), c->seg_v0.as<u32>());
-          TRY(sort_pairs<u64, u32>(c, c->seg_k0.as<u64>(), c->seg_ks.as<u64>(), c->seg_v0.as<u32>(), vs, U, 0, kb));
-        }
-        hipLaunchKernelGGL(k_gather_bucket_words<WT>, dim3(blocks_for(U)), dim3(256), 0, st, g_word, vs, U, ws);
-        }
+        TRY(bucket_order<WT>(c, plan, seg, g_word, U, ws, vs));
         if (seg < 8) if (c->kev_on) HIPCHK(hipEventRecord(c->kev[20 + 2 * seg], st));
         hipLaunchKernelGGL((k_pairs<false, PM_COUNT, WT>), dim3(blocks_for(U)), dim3(256), 0, st, ws,
                            vs, U, 0u, U, w_from<WT>(plan.mask[seg]), d_masks, seg, distance, c->deg.as<u32>(), c->parent.as<u32>(),
@@ -1185,6 +1214,269 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
   c->slots_done = own;
   HIPCHK(hipGetLastError());
   n_pair_segs_out = n_pair_segs;
+  return HUMID_OK;
+}
+
+
+// ---- stage B on the COMPACT graph (kernels_cgraph.hip.h): the single-GPU pipeline's form ---------
+// Same contract as stage_graph (neighbours + clusters of the ascending unique array g_word / g_cnt),
+// but every graph and cluster array lives on the M leaves that have neighbours; the per-unique-word
+// view (deg / nbr_off / nbr_idx / cl_of / ... of the context) is only built when an accessor asks for
+// it (expand_compact).  Leaves: slot_out (own = the graph is over this context's unique words) or
+// cid / ismax (own = false), c->cg_* and the cluster count on the device (n_clusters_compact).
+// ext_edges != nullptr: the pairs are GIVEN as (smaller << 32 | larger) walk indices (edit distance).
+template <class WT>
+static int stage_graph_compact(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, u32 word_nt,
+                               u32 distance, u32 method, humid_summary &s, u32 &n_pair_segs_out,
+                               const u64 *ext_edges = nullptr, u64 n_ext_edges = 0) {
+  hipStream_t st = c->stream;
+  c->g_word = g_word;
+  c->g_wpr = (u32)(sizeof(WT) / 8);
+  c->g_cnt = g_cnt;
+  c->gU = U;
+  c->cg_valid = false;
+  c->cg_expanded = false;
+  const ComboPlan plan = make_plan(word_nt, distance, U, c->force_segments, true);
+  EarlierMasksT<WT> d_masks;
+  for (u32 t = 0; t < MAX_COMBOS; t++) d_masks.m[t] = w_from<WT>(plan.mask[t]);
+  const bool given = ext_edges != nullptr;
+  const bool search = !given && distance > 0 && U > 1;
+  if (search && plan.ncombo == 1 && plan.key_bits == 0 && U > (1u << 18))
+    return fail(c, HUMID_E_OVERFLOW, "distance %u over %u-nt words compares all pairs of %u unique words: too many neighbour pairs",
+                distance, word_nt, U);
+  if (given && n_ext_edges > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "too many neighbour pairs");
+  const u32 walk_max = c->walk_max;
+  const u32 nseg = search ? plan.ncombo : 0;
+  const u32 n_words = (((U + 31) / 32) + 7) & ~7u, n_blk = n_words / 8;
+  c->cg_nblocks = n_blk;
+  ENSURE(c->cg_bits, (size_t)n_words * 4);
+  ENSURE(c->cg_nbits, (size_t)n_words * 4);
+  ENSURE(c->cg_blk, ((size_t)n_blk + 1) * 4);
+  ENSURE(c->cg_nblk, ((size_t)n_blk + 1) * 4);
+  ENSURE(c->cg_cur, (size_t)(ER_REGIONS * ER_STRIDE + 8) * 4);
+  ENSURE(c->small_roots, ((size_t)U / 3 + 2) * 4);
+  ENSURE(c->small, 64);
+  if (nseg > 1) {
+    ENSURE(c->seg_k0, (size_t)U * 8);
+    ENSURE(c->seg_v0, (size_t)U * 4);
+    ENSURE(c->seg_ks, (size_t)U * 8);
+    ENSURE(c->seg_vs, (size_t)(nseg - 1) * U * 4);
+    ENSURE(c->seg_ws, (size_t)(nseg - 1) * U * sizeof(WT));
+  }
+  u32 *bad = c->cg_cur.as<u32>() + ER_REGIONS * ER_STRIDE;       // malformed given pair
+  const u64 *far = given ? ext_edges : nullptr;
+  u64 n_far = given ? n_ext_edges : 0;
+  u64 E = 0, M = 0, Mbig = 0;
+  u32 Mb = 0;
+  EdgeRegs er;
+  // the bucket order of a combination is made ONCE: the grouping places equal keys with atomics, so a
+  // second run may order a bucket differently -- and the near / far split of a large bucket (walk
+  // distance) must be the same in the search that follows the tiles as in the one before them
+  bool ordered_seg[MAX_COMBOS] = {false};
+  for (int attempt = 0;; attempt++) {
+    if (attempt > 4) return fail(c, HUMID_E_INVALID, "internal: the pair list does not settle");
+    if (search && c->cg_ecap == 0) c->cg_ecap = std::max<u64>((u64)U / 4, 4096);
+    const u64 ecap = search ? c->cg_ecap : ER_REGIONS;
+    if (ecap / ER_REGIONS + 1 > 0xfffffff0ull) return fail(c, HUMID_E_OVERFLOW, "too many neighbour pairs");
+    er.cap_r = (u32)((ecap + ER_REGIONS - 1) / ER_REGIONS);
+    ENSURE(c->cg_edges, (size_t)ER_REGIONS * er.cap_r * 8);
+    er.e = c->cg_edges.as<u64>();
+    er.cur = c->cg_cur.as<u32>();
+    er.far = far;
+    er.n_far = (u32)n_far;
+    {
+      ZeroList z;
+      memset(&z, 0, sizeof z);
+      z.p[0] = c->cg_bits.as<u32>(); z.n[0] = n_words;
+      z.p[1] = c->cg_nbits.as<u32>(); z.n[1] = n_words;
+      z.p[2] = c->cg_cur.as<u32>(); z.n[2] = ER_REGIONS * ER_STRIDE + 8;
+      z.p[3] = (u32 *)&c->d_ctr[CTR_EDGES]; z.n[3] = 2 * (CTR_EOVER - CTR_EDGES + 1);
+      hipLaunchKernelGGL(k_zero_many, dim3(64), dim3(256), 0, st, z);
+    }
+    for (u32 seg = 0; seg < nseg; seg++) {
+      if (seg == 0) {
+        if (c->kev_on) HIPCHK(hipEventRecord(c->kev[20], st));
+        hipLaunchKernelGGL((k_pairs_append<true, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word, (const u32 *)nullptr, U,
+                           w_from<WT>(plan.mask[0]), d_masks, 0u, distance, walk_max, er, c->cg_bits.as<u32>(),
+                           &c->d_ctr[CTR_BIGMASK], (u32 *)&c->d_ctr[CTR_EOVER]);
+      } else {
+        u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
+        WT *ws = c->seg_ws.as<WT>() + (size_t)(seg - 1) * U;
+        if (!ordered_seg[seg]) TRY(bucket_order<WT>(c, plan, seg, g_word, U, ws, vs));
+        ordered_seg[seg] = true;
+        if (seg < 8 && c->kev_on) HIPCHK(hipEventRecord(c->kev[20 + 2 * seg], st));
+        hipLaunchKernelGGL((k_pairs_append<false, WT>), dim3(blocks_for(U)), dim3(256), 0, st, (const WT *)ws, (const u32 *)vs, U,
+                           w_from<WT>(plan.mask[seg]), d_masks, seg, distance, walk_max, er, c->cg_bits.as<u32>(),
+                           &c->d_ctr[CTR_BIGMASK], (u32 *)&c->d_ctr[CTR_EOVER]);
+      }
+      if (seg < 8 && c->kev_on) HIPCHK(hipEventRecord(c->kev[21 + 2 * seg], st));
+    }
+    if (n_far)
+      hipLaunchKernelGGL(k_mark_pairs, dim3(blocks_for(n_far)), dim3(256), 0, st, far, (u32)n_far, U, c->cg_bits.as<u32>(), bad);
+    // nodes <= 2 x pairs: every launch below is sized by that bound, the device knows the real numbers
+    Mb = (u32)std::min<u64>(U, 2 * (ecap + n_far));
+    ENSURE(c->cg_nodes, ((size_t)Mb + 1) * 4);
+    ENSURE(c->cg_ncnt, ((size_t)Mb + 1) * 4);
+    ENSURE(c->cg_deg, ((size_t)Mb + 2) * 4);
+    ENSURE(c->cg_off, ((size_t)Mb + 2) * 4);
+    ENSURE(c->cg_parent, ((size_t)Mb + 1) * 4);
+    ENSURE(c->cg_csize, ((size_t)Mb + 1) * 4);
+    ENSURE(c->cg_curs, ((size_t)Mb + 1) * 4);
+    hipLaunchKernelGGL(k_bits_blocks, dim3(blocks_for((u64)n_blk + 1)), dim3(256), 0, st, c->cg_bits.as<u32>(), n_blk, c->cg_blk.as<u32>());
+    TRY(exscan_u32(c, c->cg_blk.as<u32>(), c->cg_blk.as<u32>(), (u64)n_blk + 1));
+    const BitRank br{c->cg_bits.as<u32>(), c->cg_blk.as<u32>()};
+    const u32 *m_dev = c->cg_blk.as<u32>() + n_blk;
+    hipLaunchKernelGGL(k_nodes_init, dim3(blocks_for(n_words)), dim3(256), 0, st, br, n_words, g_cnt, c->cg_nodes.as<u32>(),
+                       c->cg_ncnt.as<u32>(), c->cg_deg.as<u32>(), c->cg_parent.as<u32>(), c->cg_csize.as<u32>(),
+                       c->cg_curs.as<u32>(), n_blk);
+    const u32 gx = (u32)std::min<u64>(std::max<u64>(blocks_for(std::max<u64>(er.cap_r, n_far)), 1), 4096);
+    hipLaunchKernelGGL(k_pairs_relabel, dim3(gx, ER_REGIONS + 1), dim3(256), 0, st, er, br, c->cg_ncnt.as<u32>(),
+                       c->cg_deg.as<u32>(), c->cg_parent.as<u32>(), (method & 1) == 0);
+    TRY(exscan_in<u32>(c, DegIn{c->cg_deg.as<u32>(), m_dev}, c->cg_off.as<u32>(), (u64)Mb + 1));
+    hipLaunchKernelGGL(k_comp_stats, dim3(blocks_for(Mb)), dim3(256), 0, st, c->cg_deg.as<u32>(), c->cg_parent.as<u32>(), Mb,
+                       c->cg_csize.as<u32>(), m_dev);
+    hipLaunchKernelGGL(k_comp_count, dim3(512), dim3(256), 0, st, c->cg_deg.as<u32>(), c->cg_parent.as<u32>(),
+                       c->cg_csize.as<u32>(), Mb, c->d_ctr, c->small_roots.as<u32>(), m_dev);
+    hipLaunchKernelGGL(k_regions_max, dim3(1), dim3(64), 0, st, er, c->small.as<u32>());
+    HIPCHK(hipGetLastError());
+    TRY(read_counters(c, c->cg_off.as<u32>() + Mb, c->small.as<u32>()));       // 2E, pairs the fullest region wanted
+    const u64 wanted = (c->h_ctr[CTR_N - 2] & 0xffffffffull) * ER_REGIONS;     // (as a total: every region has the same room)
+    if (c->h_ctr[CTR_EOVER] & 0xffffffffull) {          // a region was full: more room, once more
+      c->cg_ecap = wanted + wanted / 2 + ER_REGIONS * 64;
+      continue;
+    }
+    if (given) {
+      u32 h_bad = 0;
+      HIPCHK(hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      if (h_bad) return fail(c, HUMID_E_INVALID, "malformed edge list (node index out of range)");
+    }
+    if (search && c->h_ctr[CTR_BIGMASK] && !far) {
+      // some bucket is longer than k_pairs_append walks: its remaining pairs (further apart than the
+      // walk) come from the tiles, as one more region; then the search is taken again with them in place
+      const u64 big_mask = c->h_ctr[CTR_BIGMASK];
+      u64 got = 0;
+      for (int phase = 0; phase < 2; phase++) {
+        u64 at = 0;
+        for (u32 seg = 0; seg < nseg; seg++) {
+          if (!(big_mask >> seg & 1)) continue;
+          const WT *W = seg ? c->seg_ws.as<WT>() + (size_t)(seg - 1) * U : g_word;
+          const u32 *V = seg ? c->seg_vs.as<u32>() + (size_t)(seg - 1) * U : nullptr;
+          std::vector<BigRun> runs;
+          const BigRun *d_runs = nullptr;
+          TRY(find_big_runs<WT>(c, W, U, w_from<WT>(plan.mask[seg]), walk_max, seg, runs, &d_runs));
+          const ull tiles = runs.back().tile0;
+          if (!tiles) continue;
+          const u32 tgrid = (u32)std::min<ull>(tiles, 1u << 20);
+          const ull start = phase ? at : 0;
+          HIPCHK(hipMemcpyAsync(&c->d_ctr[CTR_SPECIAL], &start, sizeof(ull), hipMemcpyHostToDevice, st));
+          HIPCHK(hipStreamSynchronize(st));
+#define CG_TILES(P0, MD)                                                                                              \
+  hipLaunchKernelGGL((k_pairs_tiles<P0, MD, WT>), dim3(tgrid), dim3(PT2_THREADS), 0, st, W, V, d_runs, (u32)runs.size() - 1, \
+                     tiles, d_masks, seg, distance, walk_max, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr,       \
+                     (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, c->cg_far.as<u64>(), &c->d_ctr[CTR_SPECIAL])
+          if (phase == 0) { if (V) CG_TILES(false, PM_EMIT_COUNT); else CG_TILES(true, PM_EMIT_COUNT); }
+          else { if (V) CG_TILES(false, PM_EMIT_FILL); else CG_TILES(true, PM_EMIT_FILL); }
+#undef CG_TILES
+          HIPCHK(hipGetLastError());
+          TRY(read_counters(c));
+          if (phase == 0) got += c->h_ctr[CTR_SPECIAL]; else at = c->h_ctr[CTR_SPECIAL];
+        }
+        if (phase == 0) {
+          if (got > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "%llu neighbour pairs exceed the 32-bit adjacency offsets", (ull)got);
+          ENSURE(c->cg_far, (size_t)(got + 1) * 8);
+        }
+      }
+      far = c->cg_far.as<u64>();
+      n_far = got;
+      if (n_far) continue;                              // (nothing beyond the walk after all: the list stands)
+    }
+    const u64 twoE = c->h_ctr[CTR_N - 1] & 0xffffffffull;
+    if (c->h_ctr[CTR_EDGES] > 0xffffffffull)
+      return fail(c, HUMID_E_OVERFLOW, "%llu neighbour pairs exceed the 32-bit adjacency offsets", (ull)(c->h_ctr[CTR_EDGES] / 2));
+    E = twoE / 2;
+    M = c->h_ctr[CTR_NONSINGLE];
+    Mbig = c->h_ctr[CTR_MEMBERS];
+    if (search && wanted + wanted / 4 + ER_REGIONS * 64 < c->cg_ecap / 4) c->cg_ecap = 0;   // far too roomy for this input: re-sized next time
+    break;
+  }
+  s.edges = c->E = E;
+  s.nonsingle = c->M = M;
+  c->cg_M = (u32)M;
+  ENSURE(c->cg_idx, (size_t)(2 * E + 1) * 4);
+  ENSURE(c->cg_cl_of, ((size_t)M + 1) * 4);
+  ENSURE(c->cg_maxleaf, ((size_t)M + 1) * 4);
+  ENSURE(c->cg_cl_size, ((size_t)M + 1) * 8);
+  const GraphArrays g{c->cg_deg.as<u32>(), c->cg_parent.as<u32>(), c->cg_csize.as<u32>(), c->cg_off.as<u32>(), c->cg_idx.as<u32>(),
+                      c->cg_cl_of.as<u32>(), c->cg_maxleaf.as<u32>(), c->cg_cl_size.as<u64>()};
+  if (E > 0) {
+    const u32 gx = (u32)std::min<u64>(std::max<u64>(blocks_for(std::max<u64>(er.cap_r, n_far)), 1), 4096);
+    hipLaunchKernelGGL(k_pairs_fill, dim3(gx, ER_REGIONS + 1), dim3(256), 0, st, er, (const u32 *)g.off, c->cg_curs.as<u32>(), g.idx);
+    hipLaunchKernelGGL(k_sort_lists, dim3(blocks_for(M)), dim3(256), 0, st, (const u32 *)g.off, (u32)M, g.idx);
+  }
+  HIPCHK(hipEventRecord(c->ev[2], st));
+  if (M > 0) TRY(cluster_kernels(c, g, c->cg_ncnt.as<u32>(), (u32)M, M, Mbig, method));
+  else { if (c->kev_on) { HIPCHK(hipEventRecord(c->kev[2], st)); HIPCHK(hipEventRecord(c->kev[3], st)); } }
+  if (M > 0)
+    hipLaunchKernelGGL(k_noncreator_bits, dim3(blocks_for(M)), dim3(256), 0, st, (const u32 *)g.cl_of, c->cg_nodes.as<u32>(), (u32)M,
+                       c->cg_nbits.as<u32>());
+  hipLaunchKernelGGL(k_bits_blocks, dim3(blocks_for((u64)n_blk + 1)), dim3(256), 0, st, c->cg_nbits.as<u32>(), n_blk, c->cg_nblk.as<u32>());
+  TRY(exscan_u32(c, c->cg_nblk.as<u32>(), c->cg_nblk.as<u32>(), (u64)n_blk + 1));
+  const bool own = ((const void *)g_word == c->s_word.p) && U == (u32)c->U;
+  if (!own) { ENSURE(c->cid, (size_t)U * 4); ENSURE(c->ismax, (size_t)U); }
+  hipLaunchKernelGGL(k_finalize_leaves, dim3(blocks_for(U)), dim3(256), 0, st, BitRank{c->cg_bits.as<u32>(), c->cg_blk.as<u32>()},
+                     BitRank{c->cg_nbits.as<u32>(), c->cg_nblk.as<u32>()}, c->cg_nodes.as<u32>(), (const u32 *)g.cl_of,
+                     (const u32 *)g.maxleaf, U, own ? c->s_first.as<u32>() : (const u32 *)nullptr,
+                     own ? c->s_slot.as<u32>() : (const u32 *)nullptr, own ? c->slot_out.as<u64>() : (u64 *)nullptr,
+                     own ? (u32 *)nullptr : c->cid.as<u32>(), own ? (u8 *)nullptr : c->ismax.as<u8>());
+  c->slots_done = own;
+  c->cg_valid = true;
+  HIPCHK(hipGetLastError());
+  n_pair_segs_out = nseg < 8 ? nseg : 8;
+  return HUMID_OK;
+}
+
+// clusters = unique words - graph nodes that created no cluster (the pass's last host wait)
+static int n_clusters_compact(humid_ctx *c, u32 U, u64 *out) {
+  TRY(read_counters(c, c->cg_nblk.as<u32>() + c->cg_nblocks));
+  *out = (u64)U - (c->h_ctr[CTR_N - 1] & 0xffffffffull);
+  return HUMID_OK;
+}
+
+// The per-unique-word view of a compact graph stage, for the accessors (humid_get_leaves / _adjacency /
+// _clusters / _histogram): degrees, CSR rows in walk indices, cluster arrays, creator prefix sum, ids.
+static int expand_compact(humid_ctx *c) {
+  if (!c->cg_valid || c->cg_expanded) return HUMID_OK;
+  hipStream_t st = c->stream;
+  const u32 U = c->gU, M = c->cg_M;
+  const u64 E = c->E;
+  if (U == 0) { c->cg_expanded = true; return HUMID_OK; }
+  ENSURE(c->deg, ((size_t)U + 1) * 4);
+  ENSURE(c->nbr_off, ((size_t)U + 1) * 4);
+  ENSURE(c->nbr_idx, (size_t)(2 * E + 1) * 4);
+  ENSURE(c->cl_of, (size_t)U * 4);
+  ENSURE(c->maxleaf, (size_t)U * 4);
+  ENSURE(c->cl_size, (size_t)U * 8);
+  ENSURE(c->flag, (size_t)U * 4);
+  ENSURE(c->pos, ((size_t)U + 1) * 4);
+  ENSURE(c->cid, (size_t)U * 4);
+  ENSURE(c->ismax, (size_t)U);
+  const BitRank br{c->cg_bits.as<u32>(), c->cg_blk.as<u32>()};
+  hipLaunchKernelGGL(k_expand_leaves, dim3(blocks_for((u64)U + 1)), dim3(256), 0, st, br, c->cg_nodes.as<u32>(), c->cg_deg.as<u32>(),
+                     c->cg_cl_of.as<u32>(), c->cg_maxleaf.as<u32>(), c->cg_cl_size.as<u64>(), c->g_cnt, U, c->deg.as<u32>(),
+                     c->cl_of.as<u32>(), c->maxleaf.as<u32>(), c->cl_size.as<u64>());
+  TRY(exscan_u32(c, c->deg.as<u32>(), c->nbr_off.as<u32>(), (u64)U + 1));
+  if (M)
+    hipLaunchKernelGGL(k_expand_rows, dim3(blocks_for(M)), dim3(256), 0, st, c->cg_nodes.as<u32>(), c->cg_off.as<u32>(),
+                       c->cg_idx.as<u32>(), M, c->nbr_off.as<u32>(), c->nbr_idx.as<u32>());
+  hipLaunchKernelGGL(k_creator_flags, dim3(blocks_for(U)), dim3(256), 0, st, c->cl_of.as<u32>(), U, c->flag.as<u32>());
+  TRY(exscan_u32(c, c->flag.as<u32>(), c->pos.as<u32>(), U));
+  hipLaunchKernelGGL(k_finalize_nodes, dim3(blocks_for(U)), dim3(256), 0, st, c->cl_of.as<u32>(), c->pos.as<u32>(),
+                     c->maxleaf.as<u32>(), U, c->cid.as<u32>(), c->ismax.as<u8>(), (const u32 *)nullptr, (const u32 *)nullptr,
+                     (u64 *)nullptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  c->cg_expanded = true;
   return HUMID_OK;
 }
 
@@ -1587,12 +1879,19 @@ static int run_device(humid_ctx *c, const WT *d_words, const u8 *d_filt, u64 n_r
     u64 E = 0;
     TRY(edit_edges<WT>(c, c->s_word.as<WT>(), U, word_nt, distance, &E));
     static const u64 no_edges = 0;
-    TRY(stage_graph<WT>(c, c->s_word.as<WT>(), c->s_cnt.as<u32>(), U, word_nt, distance, method, s, n_pair_segs,
-                        E ? c->e_edges.as<u64>() : &no_edges, E));
-  } else
+    if (c->use_compact)
+      TRY(stage_graph_compact<WT>(c, c->s_word.as<WT>(), c->s_cnt.as<u32>(), U, word_nt, distance, method, s, n_pair_segs,
+                                  E ? c->e_edges.as<u64>() : &no_edges, E));
+    else
+      TRY(stage_graph<WT>(c, c->s_word.as<WT>(), c->s_cnt.as<u32>(), U, word_nt, distance, method, s, n_pair_segs,
+                          E ? c->e_edges.as<u64>() : &no_edges, E));
+  } else if (c->use_compact)
+    TRY(stage_graph_compact<WT>(c, c->s_word.as<WT>(), c->s_cnt.as<u32>(), U, word_nt, distance, method, s, n_pair_segs));
+  else
     TRY(stage_graph<WT>(c, c->s_word.as<WT>(), c->s_cnt.as<u32>(), U, word_nt, distance, method, s, n_pair_segs));
   TRY(stage_map(c, c->cid.as<u32>(), c->ismax.as<u8>(), N, d_cid, d_keep));
-  TRY(n_clusters_from_scan(c, U, &c->C));
+  if (c->cg_valid) TRY(n_clusters_compact(c, U, &c->C));
+  else TRY(n_clusters_from_scan(c, U, &c->C));
   s.clusters = c->C;
   const u64 E = c->E, M = c->M;
   HIPCHK(hipEventElapsedTime(&s.ms_count, c->ev[0], c->ev[1]));
@@ -1612,7 +1911,7 @@ static int run_device(humid_ctx *c, const WT *d_words, const u8 *d_filt, u64 n_r
     float t = 0;
     HIPCHK(hipEventElapsedTime(&t, c->kev[20 + 2 * g], c->kev[21 + 2 * g]));   // count phase
     s.ms_k_pairs += t;
-    if (E > 0) {
+    if (E > 0 && !c->cg_valid) {
       HIPCHK(hipEventElapsedTime(&t, c->kev[4 + 2 * g], c->kev[5 + 2 * g]));   // fill phase
       s.ms_k_pairs += t;
     }
@@ -1685,6 +1984,8 @@ void humid_ctx_destroy(humid_ctx *c) {
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->in_bases, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
                   &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->big_runs, &c->small_roots, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_heads, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles, &c->xr_hist, &c->xr_recv, &c->xr_eloc, &c->xr_got, &c->xr_eall, &c->xr_ret, &c->xr_heads, &c->xr_send, &c->xr_zero,
+                  &c->cg_edges, &c->cg_cur, &c->cg_far, &c->cg_bits, &c->cg_nbits, &c->cg_blk, &c->cg_nblk, &c->cg_nodes, &c->cg_ncnt, &c->cg_deg,
+                  &c->cg_off, &c->cg_idx, &c->cg_parent, &c->cg_csize, &c->cg_curs, &c->cg_cl_of, &c->cg_maxleaf, &c->cg_cl_size,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
                   &c->seg_v0, &c->seg_vs, &c->seg_ws, &c->csize, &c->cur, &c->parent, &c->mk0, &c->mk1, &c->cl_of,
@@ -1759,6 +2060,10 @@ int humid_ctx_set_option(humid_ctx *c, const char *key, int64_t value) {
   }
   if (strcmp(key, "kernel_timing") == 0) {
     c->kev_on = value != 0;
+    return HUMID_OK;
+  }
+  if (strcmp(key, "compact_graph") == 0) {
+    c->use_compact = value != 0;
     return HUMID_OK;
   }
   if (strcmp(key, "group_buckets") == 0) {
@@ -1883,6 +2188,7 @@ int humid_get_packed_words(humid_ctx *c, uint64_t *words, uint8_t *filtered) {
     if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");                             \
     if (!c->have_graph || c->graph_mode) return fail(c, HUMID_E_STATE, "no completed dedup run / graph stage in this context"); \
     HIPCHK(hipSetDevice(c->device));                                                          \
+    TRY(expand_compact(c));                                                                   \
   } while (0)
 
 #define D2H(dst, src, bytes)                                                                  \
@@ -2001,6 +2307,7 @@ int humid_cluster_graph(humid_ctx *c, const uint32_t *count, const uint32_t *nbr
   c->have_run = false;
   c->have_graph = false;
   c->graph_mode = true;
+  c->cg_valid = false;
   ENSURE(c->s_cnt, (size_t)U * 4);
   c->g_cnt = c->s_cnt.as<u32>();
   c->gU = U;

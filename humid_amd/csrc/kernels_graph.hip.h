@@ -570,9 +570,11 @@ k_sort_lists(const u32 *__restrict__ off, u32 n, u32 *idx) {
 #define SMALL_COMP 32u      // components up to this many leaves are clustered by one lane, in registers
 
 // flatten the forest and count the leaves of every component at its root
-__global__ void k_comp_stats(const u32 *__restrict__ deg, u32 *P, u32 n, u32 *csize) {
+// n_dev (may be null): the number of nodes as the device knows it, when the launch is sized by a bound
+__global__ void k_comp_stats(const u32 *__restrict__ deg, u32 *P, u32 n, u32 *csize, const u32 *__restrict__ n_dev = nullptr) {
   HUMID_GUARD_LAST_VGPR();
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev && *n_dev < n) n = *n_dev;
   if (u >= n || deg[u] == 0) return;
   const u32 root = uf_find(P, u);
   P[u] = root;
@@ -585,8 +587,9 @@ __global__ void k_comp_stats(const u32 *__restrict__ deg, u32 *P, u32 n, u32 *cs
 #define CC_ROOTS 2048u      // listed roots a workgroup of k_comp_count holds before it flushes them
 __global__ void __launch_bounds__(256)
 k_comp_count(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *__restrict__ csize, u32 n,
-             ull *ctr, u32 *__restrict__ small_roots) {
+             ull *ctr, u32 *__restrict__ small_roots, const u32 *__restrict__ n_dev = nullptr) {
   HUMID_GUARD_LAST_VGPR();
+  if (n_dev && *n_dev < n) n = *n_dev;
   __shared__ u32 lds[4];
   __shared__ ull ldeg;
   __shared__ u32 lroots[CC_ROOTS], lroots_n, lroots_base;
