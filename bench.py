@@ -368,12 +368,15 @@ def main():
     # candidates: the N-proportional single-launch kernels (13 B/read x N is their unit)
     mode_used = int(last.get("count_mode_used", 0))
     lds = mode_used in (0, 2) and (not world_sharded or getattr(sd, "mode_used", "") == "exchange")
-    kern = {("k_dedup_lds" if lds else "k_hash_insert"): ks["ms_k_insert"],
-            ("k_unpermute_bins" if ks["ms_k_unperm"] > 0 else ("k_read_map_bucket" if lds else "k_read_map")): ks["ms_k_map"]}
+    # (names: the word-ordered count runs on 8-byte records since round 3 -- k_dedup_rec, k_p8_scatter2,
+    # k_unperm_bins8; hashed buckets and the fall-backs keep k_dedup_lds / k_pt_scatter<2> / k_unperm_bins)
+    rec8 = mode_used == 2
+    kern = {(("k_dedup_rec" if rec8 else "k_dedup_lds") if lds else "k_hash_insert"): ks["ms_k_insert"],
+            (("k_unperm_bins8" if rec8 else "k_unperm_bins") if ks["ms_k_unperm"] > 0 else ("k_read_map_bucket" if lds else "k_read_map")): ks["ms_k_map"]}
     if ks["ms_k_part"] > 0:
-        kern["k_partition_fine"] = ks["ms_k_part"]
+        kern["k_p8_scatter2" if rec8 else "k_pt_scatter<2>"] = ks["ms_k_part"]
     if ks["ms_k_unperm"] > 0:
-        kern["k_unpermute_window"] = ks["ms_k_unperm"]
+        kern["k_unperm_window"] = ks["ms_k_unperm"]
     dom = max(kern, key=lambda k: kern[k])
     dom_ms = kern[dom]
     achieved = (BYTES_PER_READ * n_local / (dom_ms * 1e-3)) / 1e9 if dom_ms > 0 else 0.0
@@ -383,7 +386,7 @@ def main():
         tr = json.load(open(tj))
         traffic = tr.get(dom)
         if traffic is None:                       # template instantiations: k_dedup_lds<true>
-            traffic = next((v for k, v in tr.items() if k.split("<")[0] == dom), None)
+            traffic = next((v for k, v in tr.items() if k.split("<")[0] == dom.split("<")[0]), None)
     roofline = {"bound": "hbm", "kernel": dom, "kernel_ms": round(dom_ms, 4),
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,

@@ -33,6 +33,7 @@
 #include "prims.hip.h"
 #include "kernels_count.hip.h"
 #include "kernels_part.hip.h"
+#include "kernels_part8.hip.h"
 #include "kernels_graph.hip.h"
 #include "kernels_cgraph.hip.h"
 #include "kernels_cluster.hip.h"
@@ -115,6 +116,10 @@ struct humid_ctx {
   bool cg_valid = false;            // the last graph stage left its results in the cg_* arrays ...
   bool cg_expanded = false;         // ... and the per-unique-word view of them has been built (accessors)
   u32 cg_M = 0, cg_nblocks = 0;
+  DBuf p8_a, p8_b, p8_cur;               // 8-byte records of the count stage: level-1 output, level-2 output (kernels_part8.hip.h)
+  bool use_rec8 = true;             // option "records8": 0 = always the 12-byte (key, read) pairs of kernels_part.hip.h
+  bool last_rec8 = false;           // the last count ran on records: positions are (bucket << 9 | j), the un-permute reads p8_b
+  const u32 *rec_cursor2 = nullptr; // reads per bucket of that count
   DBuf pt_work, unperm_rec, route_tiles;                                                     // LDS-staged partition / un-permute (kernels_part.hip.h)
   bool group_buckets = true;        // option "group_buckets": bucket order of stretch keys by two-level grouping instead of a library sort
   bool pt_padded = true;            // level 1 of the tile partition into padded coarse bins (no histogram pass); false after an overflow
@@ -464,6 +469,7 @@ static int stage_count_global(humid_ctx *c, const u64 *d_words, const u8 *d_filt
   hipStream_t st = c->stream;
   c->last_count_lds = false;
   c->last_count_sorted = false;
+  c->last_rec8 = false;
   if (expected_reads == 0 || expected_reads > N) expected_reads = N;
   u32 cap_log2 = 10;
   while (((u64)1 << cap_log2) < expected_reads + expected_reads / 2) cap_log2++;
@@ -614,6 +620,7 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   *overflowed = false;
   c->last_count_lds = true;
   c->last_count_sorted = false;
+  c->last_rec8 = false;
   c->last_count_ordered = ordered;
   const u32 pb = part_bits(N);
   const u32 n_parts = 1u << pb;
@@ -715,6 +722,99 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   return HUMID_OK;
 }
 
+// Stage A on 8-byte records (kernels_part8.hip.h): word-ordered buckets only, both partition levels padded.
+// *done = false: not this shape (the record would not fit 64 bits, too few / too many buckets, the read
+// set too large for the tiled un-permute) or a bin outgrew its room -- the caller takes stage_count_lds.
+static int stage_count_rec(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N, u32 word_nt, u64 range_lo, u64 range_hi,
+                           const KeyMap &km, humid_summary &s, bool *done) {
+  hipStream_t st = c->stream;
+  *done = false;
+  if (!c->use_rec8 || !c->use_tile_partition || !c->pt_padded) return HUMID_OK;
+  const u32 pb = part_bits(N);
+  if (pb < 6 || pb > 18) return HUMID_OK;
+  if ((((u64)N + (1u << UW_MAXSHIFT) - 1) >> UW_MAXSHIFT) > UW_MAXBINS) return HUMID_OK;
+  const u32 d1 = (pb + 1) / 2, d2 = pb - d1, nb1 = 1u << d1, n_parts = 1u << pb;
+  RecKey rk;
+  rk.lo = km.lo; rk.scale = km.scale;
+  rk.pow2 = km.shift < 64 ? 1u : 0u;
+  rk.z = rk.pow2 ? km.shift : 63u - (u32)__builtin_clzll(km.scale);
+  rk.kbits = 64 - rk.z;
+  const u32 ibits = bits_for(N);
+  if (rk.kbits < pb + 1 || rk.kbits - d1 + ibits > 64) return HUMID_OK;
+  static const u32 pad_div = getenv("HUMID_PAD_DIV") ? (u32)std::max(1, atoi(getenv("HUMID_PAD_DIV"))) : 4u;
+  const u32 cap1 = (u32)std::min<u64>(0xffffffffull / nb1, (u64)N / nb1 + (u64)N / nb1 / pad_div + 1024);
+  const size_t room1 = (size_t)nb1 * cap1, room2 = (size_t)n_parts << P8_CAP2_LOG;
+  ENSURE(c->p8_a, room1 * 8);
+  ENSURE(c->p8_b, room2 * 8);
+  ENSURE(c->pad_word, room2 * 8);
+  ENSURE(c->pad_cf, room2 * 8);
+  ENSURE(c->slot_out, (room2 + 1) * 8);
+  ENSURE(c->pbeg, (size_t)(n_parts + 1) * 4);
+  ENSURE(c->ucount, (size_t)(n_parts + 1) * 4);
+  ENSURE(c->pusable, (size_t)(n_parts + 1) * 4);
+  ENSURE(c->ubase, (size_t)(n_parts + 1) * 4);
+  // p8_cur, in u32: [cursor1 512 | cursor2 n_parts] zeroed, then [cbase 513 | tprefix 513].  (Not pt_work: the
+  // reads per bucket, cursor2, are read again by the un-permute at the end of the pass, and the graph
+  // stage's grouping uses pt_work in between.)
+  ENSURE(c->p8_cur, ((size_t)512 + n_parts + 1026) * 4);
+  u32 *cursor1 = c->p8_cur.as<u32>(), *cursor2 = cursor1 + 512, *cbase = cursor2 + n_parts, *tprefix = cbase + 513;
+  HIPCHK(hipEventRecord(c->ev[0], st));
+  {
+    ZeroList z;
+    memset(&z, 0, sizeof z);
+    z.p[0] = cursor1; z.n[0] = 512 + n_parts;
+    z.p[1] = (u32 *)c->d_ctr; z.n[1] = 2 * CTR_N;
+    hipLaunchKernelGGL(k_zero_many, dim3(32), dim3(256), 0, st, z);
+  }
+  const bool check_range = !(range_lo == 0 && range_hi == ~0ull);
+  const Reads8 src{d_words, d_filt, range_lo, range_hi, check_range ? 1u : 0u, rk};
+  const u32 tiles1 = (N + PT_TILE - 1) / PT_TILE, tiles2 = tiles1 + nb1;
+  hipLaunchKernelGGL(k_p8_scatter1<Reads8>, dim3(tiles1), dim3(1024), 0, st, src, N, rk.kbits, d1, ibits, cap1, cursor1,
+                     c->p8_a.as<u64>(), c->d_ctr);
+  hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, (const u32 *)cursor1, d1, d2, cbase, tprefix, c->pbeg.as<u32>(),
+                     c->ucount.as<u32>() + n_parts, cap1);
+  if (c->kev_on) HIPCHK(hipEventRecord(c->kev[39], st));
+  hipLaunchKernelGGL(k_p8_scatter2, dim3(tiles2), dim3(1024), 0, st, (const u64 *)c->p8_a.as<u64>(), (const u32 *)tprefix,
+                     (const u32 *)cbase, rk.kbits, d1, d2, ibits, cap1, cursor2, c->p8_b.as<u64>(), c->d_ctr);
+  if (c->kev_on) HIPCHK(hipEventRecord(c->kev[40], st));
+  HIPCHK(hipEventRecord(c->kev[0], st));
+  hipLaunchKernelGGL(k_dedup_rec, dim3(n_parts), dim3(256), 0, st, c->p8_b.as<u64>(), (const u32 *)cursor2, N, pb, d1, ibits, rk,
+                     c->pad_word.as<u64>(), c->pad_cf.as<uint2>(), c->ucount.as<u32>(), c->pusable.as<u32>(), c->d_ctr);
+  HIPCHK(hipEventRecord(c->kev[1], st));
+  hipLaunchKernelGGL(k_part_totals, dim3(n_parts >= 16384 ? 64 : 4), dim3(256), 0, st, c->ucount.as<u32>(),
+                     c->pusable.as<u32>(), n_parts, c->d_ctr);
+  TRY(exscan_u32(c, c->ucount.as<u32>(), c->ubase.as<u32>(), (u64)n_parts + 1));
+  HIPCHK(hipGetLastError());
+  TRY(read_counters(c));
+  if (getenv("HUMID_TRACE_COUNT"))
+    fprintf(stderr, "[rec count] N %u pb %u kbits %u ibits %u cap1 %u special %llu overfull %llu unique %llu usable %llu\n", N, pb, rk.kbits,
+            ibits, cap1, (ull)c->h_ctr[CTR_SPECIAL], (ull)c->h_ctr[CTR_OVERFULL], (ull)c->h_ctr[CTR_UNIQUE], (ull)c->h_ctr[CTR_USABLE]);
+  if (c->h_ctr[CTR_SPECIAL]) { c->pt_padded = false; return HUMID_OK; }     // a bin outgrew its room: the exact kernels from now on
+  if (c->h_ctr[CTR_OVERFULL]) return HUMID_OK;
+  c->last_count_lds = true;
+  c->last_count_sorted = false;
+  c->last_count_ordered = true;
+  c->last_part_tiled = true;
+  c->last_rec8 = true;
+  c->rec_cursor2 = cursor2;
+  c->n_parts = n_parts;
+  const u32 U = (u32)c->h_ctr[CTR_UNIQUE];
+  s.usable = c->usable = c->h_ctr[CTR_USABLE];
+  s.unique = c->U = U;
+  *done = true;
+  if (U == 0) { HIPCHK(hipEventRecord(c->ev[1], st)); return HUMID_OK; }
+  ENSURE(c->s_word, (size_t)(U + 1) * 8);
+  ENSURE(c->s_slot, (size_t)(U + 1) * 4);
+  ENSURE(c->s_cnt, (size_t)(U + 1) * 4);
+  ENSURE(c->s_first, (size_t)(U + 1) * 4);
+  hipLaunchKernelGGL(k_compact_padded8, dim3(blocks_for((u64)n_parts * 64)), dim3(256), 0, st, c->pad_word.as<u64>(),
+                     c->pad_cf.as<uint2>(), c->ucount.as<u32>(), c->ubase.as<u32>(), n_parts, c->s_word.as<u64>(),
+                     c->s_slot.as<u32>(), c->s_cnt.as<u32>(), c->s_first.as<u32>());
+  HIPCHK(hipEventRecord(c->ev[1], st));
+  HIPCHK(hipGetLastError());
+  return HUMID_OK;
+}
+
 // Would word-ordered buckets fit their LDS tables?  Histogram of the top (up to 12) word bits over
 // a sample of the reads, folded / scaled to the 2^pb buckets the partition will use: the fullest
 // bucket, with a 1.5x margin, must stay below the table's fill limit (a bucket's unique words
@@ -774,7 +874,11 @@ static int stage_count(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u32 N
     bool overflowed = false;
     bool ordered = c->count_order == 1;
     if (c->count_order < 0) TRY(prefix_fits_ordered(c, d_words, d_filt, N, word_nt, km, &ordered));
+    c->last_rec8 = false;
     if (ordered) {
+      bool done = false;
+      TRY(stage_count_rec(c, d_words, d_filt, N, word_nt, range_lo, range_hi, km, s, &done));
+      if (done) return HUMID_OK;
       TRY(stage_count_lds(c, d_words, d_filt, N, word_nt, range_lo, range_hi, km, true, s, &overflowed));
       if (!overflowed) return HUMID_OK;
       // these words do not fit word-ordered buckets after all: remember that for this shape
@@ -822,6 +926,7 @@ static int stage_count_wide(humid_ctx *c, const W2 *d_words, const u8 *d_filt, u
   c->last_count_lds = true;          // stage C walks pk_vals/pslot (k_read_map_part)
   c->last_count_ordered = false;
   c->last_count_sorted = true;
+  c->last_rec8 = false;
   c->n_parts = 0;
   const u32 hbits = 2 * (word_nt - 32);
   const u32 grid = grid_stride_blocks(N);
@@ -1773,6 +1878,19 @@ static int unpermute_tiled(humid_ctx *c, u32 N, bool packed, u32 *d_cid, u8 *d_k
   // positions in use: all N for the sorted (wide-word) count, else up to pbeg[n_parts] (on the device)
   const bool bucketed = c->n_parts && !c->last_count_sorted;
   const u32 *n_pos_dev = bucketed ? c->pbeg.as<u32>() + c->n_parts : (const u32 *)nullptr;
+  if (c->last_rec8) {
+    // buckets per workgroup: about 7/8 of a tile's worth of records (reads per bucket: usable / buckets)
+    const u64 mean = std::max<u64>(1, c->usable / c->n_parts);
+    const u32 B = (u32)std::min<u64>(64, std::max<u64>(1, (PT_TILE - PT_TILE / 8) / mean));
+    const u32 grid = (c->n_parts + B - 1) / B;
+    if (n_bins <= 1024)
+      hipLaunchKernelGGL(k_unperm_bins8<1024>, dim3(grid), dim3(1024), 0, st, (const u64 *)c->p8_b.as<u64>(), c->rec_cursor2,
+                         (const u64 *)c->slot_out.as<u64>(), c->n_parts, B, N, wshift, n_bins, ucur, rec);
+    else
+      hipLaunchKernelGGL(k_unperm_bins8<2048>, dim3(grid), dim3(1024), 0, st, (const u64 *)c->p8_b.as<u64>(), c->rec_cursor2,
+                         (const u64 *)c->slot_out.as<u64>(), c->n_parts, B, N, wshift, n_bins, ucur, rec);
+  }
+  else
   hipLaunchKernelGGL(k_unperm_bins, dim3((N + PT_TILE - 1) / PT_TILE), dim3(1024), 0, st, c->pk_vals.as<u32>(),
                      c->pslot.as<u32>(), c->slot_out.as<u64>(), n_pos_dev, N, N, wshift, n_bins, ucur, rec);
   HIPCHK(hipEventRecord(ev_mid, st));
@@ -1894,6 +2012,9 @@ static int run_device(humid_ctx *c, const WT *d_words, const u8 *d_filt, u64 n_r
   else TRY(n_clusters_from_scan(c, U, &c->C));
   s.clusters = c->C;
   const u64 E = c->E, M = c->M;
+  // (the last host wait watches a mapped flag, not the stream: the runtime may not have seen the last
+  // event's signal yet -- "device not ready" from hipEventElapsedTime once in ~10^3 runs)
+  HIPCHK(hipEventSynchronize(c->ev[4]));
   HIPCHK(hipEventElapsedTime(&s.ms_count, c->ev[0], c->ev[1]));
   HIPCHK(hipEventElapsedTime(&s.ms_neighbours, c->ev[1], c->ev[2]));
   HIPCHK(hipEventElapsedTime(&s.ms_cluster, c->ev[2], c->ev[3]));
@@ -1984,7 +2105,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->in_bases, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
                   &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->big_runs, &c->small_roots, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_heads, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles, &c->xr_hist, &c->xr_recv, &c->xr_eloc, &c->xr_got, &c->xr_eall, &c->xr_ret, &c->xr_heads, &c->xr_send, &c->xr_zero,
-                  &c->cg_edges, &c->cg_cur, &c->cg_far, &c->cg_bits, &c->cg_nbits, &c->cg_blk, &c->cg_nblk, &c->cg_nodes, &c->cg_ncnt, &c->cg_deg,
+                  &c->p8_a, &c->p8_b, &c->p8_cur, &c->cg_edges, &c->cg_cur, &c->cg_far, &c->cg_bits, &c->cg_nbits, &c->cg_blk, &c->cg_nblk, &c->cg_nodes, &c->cg_ncnt, &c->cg_deg,
                   &c->cg_off, &c->cg_idx, &c->cg_parent, &c->cg_csize, &c->cg_curs, &c->cg_cl_of, &c->cg_maxleaf, &c->cg_cl_size,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
@@ -2060,6 +2181,10 @@ int humid_ctx_set_option(humid_ctx *c, const char *key, int64_t value) {
   }
   if (strcmp(key, "kernel_timing") == 0) {
     c->kev_on = value != 0;
+    return HUMID_OK;
+  }
+  if (strcmp(key, "records8") == 0) {
+    c->use_rec8 = value != 0;
     return HUMID_OK;
   }
   if (strcmp(key, "compact_graph") == 0) {

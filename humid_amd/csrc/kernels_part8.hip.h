@@ -1,0 +1,394 @@
+// kernels_part8.hip.h -- the count stage's partition and LDS count on 8-BYTE records (round 3)
+// Part of libhumid_hip.so (see humid_hip.hip for the pipeline and the C ABI).  Device code for
+// gfx950 only; included once, in this order, by humid_hip.hip.
+//
+// kernels_part.hip.h moves a (64-bit key, 32-bit read index) pair per read through both partition levels:
+// 12 bytes, in two arrays.  A word-ordered key of an n-nucleotide word has only 2n significant bits, and
+// once a record sits in coarse bin c its top d1 key bits are known from WHERE it is -- so
+//     record = (key bits below the top d1) << ibits | read index,        ibits = bits of the read count
+// fits ONE 64-bit word whenever 2n - d1 + ibits <= 64 (the metric workload: 48 - 8 + 24 = 64).  What this
+// buys: 8 instead of 12 bytes per read and level through HBM, and a tile of 8192 records in 64 KB of
+// LDS instead of 112 KB, so that TWO workgroups of the scatter share a CU.  Both levels scatter into
+// PADDED bins of fixed room (keys that were checked to spread evenly: no histogram pass in front of
+// either level, the bins' counts are the cursors left behind); any bin that outgrows its room is
+// reported and the caller takes the exact, histogram-based kernels of kernels_part.hip.h instead.
+#ifndef HUMID_KERNELS_PART8_HIP_H
+#define HUMID_KERNELS_PART8_HIP_H
+
+#include "common.hip.h"
+#include "kernels_count.hip.h"
+#include "kernels_part.hip.h"
+
+// room of a fine bucket: the mean is <= PART_TARGET = 350 reads, but reads come in FAMILIES of equal words,
+// so the spread is that of a compound distribution -- sigma ~ sqrt(mean x E[k^2]/E[k]) for family sizes k
+// (46 for the benchmark's families of 4 on average, 110 for families of 20): 1024 leaves 6 sigma even then.
+#define P8_CAP2_LOG 10u
+#define P8_CAP2 (1u << P8_CAP2_LOG)
+#define P8_RPT (P8_CAP2 / 256u)              // records per thread of k_dedup_rec
+
+// word -> key' : the word-ordered partition key with its insignificant low bits dropped.
+// key = (w - lo) * scale stretches the value range [lo, hi] over 64 bits (PartKeyOp); z = floor(log2 scale)
+// of its low bits carry no information (distinct words stay distinct after >> z), kbits = 64 - z remain.
+// scale = 2^z (always on one GPU): key' = w - lo.
+struct RecKey {
+  u64 lo, scale;
+  u32 z, kbits;
+  u32 pow2;
+  __host__ __device__ __forceinline__ u64 operator()(u64 w) const { return ((w - lo) * scale) >> z; }
+  // key' -> word
+  __device__ __forceinline__ u64 word(u64 k) const {
+    if (pow2) return lo + k;
+    const u64 x = k << z, q = x / scale;
+    return lo + q + ((x - q * scale) ? 1u : 0u);               // the smallest v with v * scale >= k 2^z
+  }
+};
+
+// the reads of the count stage as a source of (key', index)
+struct Reads8 {
+  const u64 *words;
+  const u8 *filtered;            // null: none filtered
+  u64 rlo, rhi;                  // value range this rank counts (multi-GPU); check_range = 0: everything
+  u32 check_range;
+  RecKey key;
+  __device__ __forceinline__ bool load(u32 j, u64 &k) const {
+    if (filtered && filtered[j]) return false;
+    const u64 w = words[j];
+    if (check_range && (w < rlo || w > rhi)) return false;
+    k = key(w);
+    return true;
+  }
+};
+
+// a tile's records, sorted by bin in LDS (srec, loff), written out bin by bin: a group of G lanes (a power of
+// two, 8 .. 64, about the mean number of records per bin and tile) takes one bin at a time, so that every
+// store instruction of a wave writes 64 / G contiguous runs.  dst(bin, k): where record k of the bin goes
+// (~0: dropped -- the bin's room is used up).
+template <class Dst>
+__device__ __forceinline__ void p8_write_bins(const u64 *srec, const u32 *loff, u32 nb, u32 G, u64 *__restrict__ out, Dst dst) {
+  const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  const u32 per_wave = 64 / G, sub = lane / G, gl = lane % G;
+  for (u32 b0 = wv * per_wave; b0 < nb; b0 += n_waves * per_wave) {
+    const u32 bin = b0 + sub;
+    if (bin >= nb) continue;
+    const u32 beg = loff[bin], n = loff[bin + 1] - beg;
+    for (u32 k = gl; k < n; k += G) {
+      const u64 d = dst(bin, k);
+      if (d != ~0ull) out[d] = srec[beg + k];
+    }
+  }
+}
+__device__ __forceinline__ u32 p8_group(u32 records, u32 nb) {
+  u32 g = 8;
+  while (g < 64 && g * nb < records) g <<= 1;
+  return g;
+}
+
+// ---- level 1: reads -> padded coarse bins (top d1 key bits), records as described above ----
+template <class SRC>
+__global__ void __launch_bounds__(1024, 8)
+k_p8_scatter1(SRC src, u32 n_reads, u32 kbits, u32 d1, u32 ibits, u32 cap1, u32 *cursor, u64 *__restrict__ out, ull *ctr) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ u64 srec[PT_TILE];
+  __shared__ u32 cnt[PT_MAXBINS], loff[PT_MAXBINS + 1], goff[PT_MAXBINS], room[PT_MAXBINS], wsum[8];
+  const u32 nb = 1u << d1;
+  const u32 t_beg = blockIdx.x * PT_TILE;
+  const u32 t_cnt = (t_beg >= n_reads) ? 0u : ((n_reads - t_beg < PT_TILE) ? n_reads - t_beg : PT_TILE);
+  for (u32 b = threadIdx.x; b < nb; b += PT_THREADS) cnt[b] = 0;
+  __syncthreads();
+  const u32 rbits = kbits - d1;                               // key bits a record keeps
+  u64 rec[PT_IPT];
+  u32 binrank[PT_IPT];                                        // bin << 16 | rank inside (tile, bin); ~0: none
+#pragma unroll
+  for (u32 q = 0; q < PT_IPT; q++) {
+    const u32 j = threadIdx.x + q * PT_THREADS;
+    binrank[q] = NONE32;
+    u64 k;
+    if (j < t_cnt && src.load(t_beg + j, k)) {
+      const u32 bin = (u32)(k >> rbits);
+      rec[q] = ((k & ((1ull << rbits) - 1ull)) << ibits) | (u64)(t_beg + j);
+      binrank[q] = bin << 16 | atomicAdd(&cnt[bin], 1u);
+    }
+  }
+  __syncthreads();
+  block_exscan_512(cnt, loff, nb, wsum);
+  if (threadIdx.x < nb) {
+    const u32 c = cnt[threadIdx.x];
+    const u32 had = c ? atomicAdd(&cursor[threadIdx.x], c) : 0u;
+    goff[threadIdx.x] = threadIdx.x * cap1 + had;
+    room[threadIdx.x] = had >= cap1 ? 0u : cap1 - had;
+    if (had + c > cap1) ctr[CTR_SPECIAL] = 1;                 // the bin outgrew its room: the caller repartitions
+  }
+#pragma unroll
+  for (u32 q = 0; q < PT_IPT; q++)
+    if (binrank[q] != NONE32) srec[loff[binrank[q] >> 16] + (binrank[q] & 0xffffu)] = rec[q];
+  __syncthreads();
+  p8_write_bins(srec, loff, nb, p8_group(loff[nb], nb), out,
+                [&](u32 bin, u32 k) -> u64 { return k < room[bin] ? (u64)goff[bin] + k : ~0ull; });
+}
+
+// ---- level 2: one tile of one coarse bin -> padded fine buckets (the next d2 key bits) ----
+// bucket g = c << d2 | f owns the positions [g << P8_CAP2_LOG, (g + 1) << P8_CAP2_LOG); cursor2[g] = its reads
+__global__ void __launch_bounds__(1024, 8)
+k_p8_scatter2(const u64 *__restrict__ in, const u32 *__restrict__ tprefix, const u32 *__restrict__ cbase, u32 kbits, u32 d1,
+              u32 d2, u32 ibits, u32 cap1, u32 *cursor2, u64 *__restrict__ out, ull *ctr) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ u64 srec[PT_TILE];
+  __shared__ u32 cnt[PT_MAXBINS], loff[PT_MAXBINS + 1], goff[PT_MAXBINS], room[PT_MAXBINS], wsum[8];
+  __shared__ u32 s_c, s_beg, s_cnt;
+  if (blockIdx.x >= tprefix[1u << d1]) return;                // beyond the last tile (uniform exit)
+  const u32 nb = 1u << d2;
+  if (threadIdx.x == 0) {
+    u32 c, b, n;
+    pt_tile_of(tprefix, cbase, 1u << d1, blockIdx.x, cap1, c, b, n);
+    s_c = c; s_beg = b; s_cnt = n;
+  }
+  for (u32 b = threadIdx.x; b < nb; b += PT_THREADS) cnt[b] = 0;
+  __syncthreads();
+  const u32 coarse = s_c, t_beg = s_beg, t_cnt = s_cnt;
+  const u32 fshift = ibits + kbits - d1 - d2;                 // where a record keeps the fine bits
+  u64 rec[PT_IPT];
+  u32 binrank[PT_IPT];
+#pragma unroll
+  for (u32 q = 0; q < PT_IPT; q++) {
+    const u32 j = threadIdx.x + q * PT_THREADS;
+    binrank[q] = NONE32;
+    if (j < t_cnt) rec[q] = in[t_beg + j];
+  }
+#pragma unroll
+  for (u32 q = 0; q < PT_IPT; q++) {
+    const u32 j = threadIdx.x + q * PT_THREADS;
+    if (j < t_cnt) {
+      const u32 bin = (u32)(rec[q] >> fshift) & (nb - 1);
+      binrank[q] = bin << 16 | atomicAdd(&cnt[bin], 1u);
+    }
+  }
+  __syncthreads();
+  block_exscan_512(cnt, loff, nb, wsum);
+  if (threadIdx.x < nb) {
+    const u32 c = cnt[threadIdx.x];
+    const u32 g = (coarse << d2) | threadIdx.x;
+    const u32 had = c ? atomicAdd(&cursor2[g], c) : 0u;
+    goff[threadIdx.x] = had;
+    room[threadIdx.x] = had >= P8_CAP2 ? 0u : P8_CAP2 - had;
+    if (had + c > P8_CAP2) ctr[CTR_SPECIAL] = 1;
+  }
+#pragma unroll
+  for (u32 q = 0; q < PT_IPT; q++)
+    if (binrank[q] != NONE32) srec[loff[binrank[q] >> 16] + (binrank[q] & 0xffffu)] = rec[q];
+  __syncthreads();
+  const u64 gbase = (u64)(coarse << d2) << P8_CAP2_LOG;
+  p8_write_bins(srec, loff, nb, p8_group(loff[nb], nb), out, [&](u32 bin, u32 k) -> u64 {
+    return k < room[bin] ? gbase + ((u64)bin << P8_CAP2_LOG) + goff[bin] + k : ~0ull;
+  });
+}
+
+// ---- the LDS count of one bucket, on records (k_dedup_lds<true> of kernels_count.hip.h) ----
+// Bucket g reads its n = cursor2[g] <= P8_CAP2 records at g << P8_CAP2_LOG; key' = the bucket's top d1 bits | the record's
+// key bits.  Outputs as k_dedup_lds: pad_word / pad_cf at [g << 9, + unique words) in word order, ucount[g],
+// pusable[g]; and, IN PLACE of every record, (padded slot of its word << 32 | read index) -- what the
+// un-permute wants of a position (k_unperm_bins8), so that no separate slot array is written.
+__global__ void __launch_bounds__(256)
+k_dedup_rec(u64 *recs, const u32 *__restrict__ cursor2, u32 n_reads, u32 pb, u32 d1, u32 ibits, RecKey rk,
+            u64 *__restrict__ pad_word, uint2 *__restrict__ pad_cf, u32 *__restrict__ ucount, u32 *__restrict__ pusable, ull *ctr) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ u64 lkey[LDS_SLOTS];
+  __shared__ u32 lcnt[LDS_SLOTS];
+  __shared__ u32 lfirst[LDS_SLOTS];
+  __shared__ unsigned short lslot_of[LDS_SLOTS];       // unique index (claim order, then rank) -> table entry
+  __shared__ unsigned short lorder[P8_CAP2];
+  __shared__ u32 lcount;
+  const u32 g = blockIdx.x;
+  u32 n = cursor2[g];
+  if (n > P8_CAP2) n = P8_CAP2;                        // (an overfull bucket was reported by the scatter: the run is discarded)
+  if (n == 0) {
+    if (threadIdx.x == 0) { ucount[g] = 0; pusable[g] = 0; }
+    return;
+  }
+  const size_t beg = (size_t)g << P8_CAP2_LOG;
+  u64 rq[P8_RPT];
+#pragma unroll
+  for (u32 q = 0; q < P8_RPT; q++) {
+    const u32 i = threadIdx.x + 256u * q;
+    if (i < n) rq[q] = recs[beg + i];
+  }
+  for (u32 s = threadIdx.x; s < LDS_SLOTS; s += 256) { lkey[s] = EMPTY_KEY; lcnt[s] = 0; lfirst[s] = NONE32; }
+  if (threadIdx.x == 0) lcount = 0;
+  __syncthreads();
+  const u32 rbits = rk.kbits - d1, d2 = pb - d1;
+  const u64 top = (u64)(g >> d2) << rbits;             // the coarse bin: the key's top d1 bits
+  const u64 imask = (1ull << ibits) - 1ull;
+  // table home = the key bits just below the bucket bits (fewer than LDS_SLOT_BITS of them left: all of them)
+  const int hs = (int)rk.kbits - (int)pb - (int)LDS_SLOT_BITS;
+  auto home = [&](u64 k) -> u32 { return hs >= 0 ? (u32)(k >> hs) & (LDS_SLOTS - 1) : (u32)k & ((1u << (rk.kbits - pb)) - 1u); };
+  bool bad = false;
+#pragma unroll
+  for (u32 q = 0; q < P8_RPT; q++) {
+    const u32 i = threadIdx.x + 256u * q;
+    if (i >= n) continue;
+    const u64 k = top | (rq[q] >> ibits);
+    const u32 v = (u32)(rq[q] & imask);
+    if (v >= n_reads) { bad = true; continue; }        // a malformed index is never used
+    u32 s = home(k), probes = 0;
+    while (true) {
+      u64 cur = lkey[s];
+      if (cur == EMPTY_KEY) cur = atomicCAS((ull *)&lkey[s], EMPTY_KEY, (ull)k);
+      if (cur == EMPTY_KEY || cur == k) break;
+      s = (s + 1) & (LDS_SLOTS - 1);
+      if (++probes >= LDS_SLOTS) { bad = true; break; }
+    }
+    if (bad) continue;
+    if (atomicAdd(&lcnt[s], 1u) == 0u) lslot_of[atomicAdd(&lcount, 1u)] = (unsigned short)s;
+    atomicMin(&lfirst[s], v);
+  }
+  if (bad) ctr[CTR_OVERFULL] = 1;
+  __syncthreads();
+  const u32 n_uniq = lcount;                           // <= n <= P8_CAP2 = the table's entries
+  // rank of an entry = number of smaller keys (keys are distinct: the ranks are a permutation)
+  for (u32 li = threadIdx.x; li < n_uniq; li += 256) {
+    const u32 s = lslot_of[li];
+    const u64 k = lkey[s];
+    u32 r = 0;
+    for (u32 j = 0; j < n_uniq; j++) r += (lkey[lslot_of[j]] < k) ? 1u : 0u;
+    lorder[r] = (unsigned short)s;
+  }
+  __syncthreads();
+  for (u32 li = threadIdx.x; li < n_uniq; li += 256) {
+    const u32 s = lorder[li];
+    pad_word[beg + li] = rk.word(lkey[s]);
+    pad_cf[beg + li] = make_uint2(lcnt[s], lfirst[s]);
+    lfirst[s] = li;                                    // entry -> rank
+  }
+  if (threadIdx.x == 0) { ucount[g] = n_uniq; pusable[g] = n; }
+  __syncthreads();
+#pragma unroll
+  for (u32 q = 0; q < P8_RPT; q++) {
+    const u32 i = threadIdx.x + 256u * q;
+    if (i >= n) continue;
+    const u64 k = top | (rq[q] >> ibits);
+    const u32 v = (u32)(rq[q] & imask);
+    u32 s = home(k), probes = 0;
+    while (lkey[s] != k && probes++ < LDS_SLOTS) s = (s + 1) & (LDS_SLOTS - 1);
+    const u32 li = lfirst[s];
+    recs[beg + i] = ((u64)(li < n ? (u32)beg + li : NOSLOT) << 32) | v;
+  }
+}
+
+// padded (fixed room per bucket) -> dense unique arrays in walk order, one wave per bucket
+__global__ void __launch_bounds__(256)
+k_compact_padded8(const u64 *__restrict__ pad_word, const uint2 *__restrict__ pad_cf, const u32 *__restrict__ ucount,
+                  const u32 *__restrict__ ubase, u32 n_parts, u64 *__restrict__ s_word, u32 *__restrict__ s_slot,
+                  u32 *__restrict__ s_cnt, u32 *__restrict__ s_first) {
+  HUMID_GUARD_LAST_VGPR();
+  const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const u32 lane = threadIdx.x & 63;
+  if (wave >= n_parts) return;
+  const u32 beg = wave << P8_CAP2_LOG, uc = ucount[wave], ub = ubase[wave];
+  for (u32 j = lane; j < uc; j += 64) {
+    s_word[ub + j] = pad_word[beg + j];
+    s_slot[ub + j] = beg + j;
+    const uint2 cf = pad_cf[beg + j];
+    s_cnt[ub + j] = cf.x;
+    s_first[ub + j] = cf.y;
+  }
+}
+
+// ---- un-permute, pass 1, from the in-place records of k_dedup_rec ----
+// A workgroup takes B consecutive buckets (about a tile's worth of records: the positions in use are the
+// first cursor2[g] of every bucket's room, the holes behind them are never read); record = (padded slot <<
+// 32 | read).  Otherwise as k_unperm_bins (kernels_part.hip.h): the packed result travels as (result << 32
+// | read) into bin read >> wshift, a tile's records leave bin by bin as contiguous runs.  NBMAX = 1024 (read
+// sets up to 16 M reads): 77 KB of LDS, two workgroups per CU.
+template <u32 NBMAX>
+__global__ void __launch_bounds__(1024, NBMAX <= 1024 ? 8 : 4)
+k_unperm_bins8(const u64 *__restrict__ recs, const u32 *__restrict__ cursor2, const u64 *__restrict__ slot_out, u32 n_parts,
+               u32 B, u32 n_reads, u32 wshift, u32 n_bins, u32 *ucur, u64 *__restrict__ rec) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ u64 srec[PT_TILE];
+  __shared__ u32 cnt[NBMAX], loff[NBMAX + 1], goff[NBMAX], wsum[16];
+  __shared__ u32 bpre[65];                                    // records before bucket g0 + b in this workgroup's stretch
+  const u32 g0 = blockIdx.x * B;
+  if (g0 >= n_parts) return;
+  const u32 nbk = (n_parts - g0 < B) ? n_parts - g0 : B;      // <= 64
+  if (threadIdx.x < 64) {
+    u32 c = threadIdx.x < nbk ? cursor2[g0 + threadIdx.x] : 0u;
+    if (c > P8_CAP2) c = P8_CAP2;
+    u32 incl = c;
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+      const u32 y = __shfl_up(incl, d);
+      if (threadIdx.x >= d) incl += y;
+    }
+    bpre[threadIdx.x + 1] = incl;
+    if (threadIdx.x == 0) bpre[0] = 0;
+  }
+  __syncthreads();
+  const u32 T = bpre[nbk];
+  for (u32 c0 = 0; c0 < T; c0 += PT_TILE) {
+    for (u32 b = threadIdx.x; b < n_bins; b += PT_THREADS) cnt[b] = 0;
+    __syncthreads();
+    u64 in[PT_IPT], r64[PT_IPT];
+    u32 binrank[PT_IPT];                                      // bin << 16 | rank inside (tile, bin); ~0: none
+#pragma unroll
+    for (u32 q = 0; q < PT_IPT; q++) {                        // all loads of the thread in flight together
+      const u32 r = c0 + threadIdx.x + q * PT_THREADS;
+      binrank[q] = NONE32;
+      if (r < T) {
+        u32 lo = 0, hi = nbk;                                 // the bucket holding record r: bpre[lo] <= r < bpre[lo + 1]
+        while (hi - lo > 1) {
+          const u32 mid = (lo + hi) >> 1;
+          if (bpre[mid] <= r) lo = mid; else hi = mid;
+        }
+        in[q] = recs[((size_t)(g0 + lo) << P8_CAP2_LOG) + (r - bpre[lo])];
+        binrank[q] = 0;
+      }
+    }
+#pragma unroll
+    for (u32 q = 0; q < PT_IPT; q++) {
+      if (binrank[q] == NONE32) continue;
+      const u32 r = (u32)in[q], sl = (u32)(in[q] >> 32);
+      binrank[q] = NONE32;
+      if (r < n_reads && sl != NOSLOT) {
+        const u64 o = slot_out[sl];
+        const u32 c = (u32)o | (((u32)(o >> 32) == r) ? 0x80000000u : 0u);
+        r64[q] = ((u64)c << 32) | r;
+        const u32 bin = r >> wshift;
+        binrank[q] = bin << 16 | atomicAdd(&cnt[bin], 1u);    // (bin < 2048, rank < 8192)
+      }
+    }
+    __syncthreads();
+    {
+      const u32 a = 2 * threadIdx.x, b = a + 1;               // exclusive scan of up to 2048 counters: two per thread
+      const u32 ca = a < n_bins ? cnt[a] : 0u, cb = b < n_bins ? cnt[b] : 0u;
+      const u32 s = ca + cb;
+      const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      u32 incl = s;
+#pragma unroll
+      for (u32 d = 1; d < 64; d <<= 1) {
+        const u32 y = __shfl_up(incl, d);
+        if (lane >= d) incl += y;
+      }
+      if (lane == 63) wsum[wv] = incl;
+      __syncthreads();
+      u32 before = 0;
+      for (u32 k = 0; k < wv; k++) before += wsum[k];
+      const u32 ex = before + incl - s;
+      if (a < n_bins) loff[a] = ex;
+      if (b < n_bins) loff[b] = ex + ca;
+      if (threadIdx.x == 1023) loff[n_bins] = before + incl;
+    }
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < n_bins; b += PT_THREADS) {
+      const u32 c = cnt[b];
+      goff[b] = (b << wshift) + (c ? atomicAdd(&ucur[b], c) : 0u);
+    }
+#pragma unroll
+    for (u32 q = 0; q < PT_IPT; q++)
+      if (binrank[q] != NONE32) srec[loff[binrank[q] >> 16] + (binrank[q] & 0xffffu)] = r64[q];
+    __syncthreads();
+    p8_write_bins(srec, loff, n_bins, p8_group(loff[n_bins], n_bins), rec,
+                  [&](u32 bin, u32 k) -> u64 { return (u64)goff[bin] + k; });
+    __syncthreads();
+  }
+}
+
+#endif  // HUMID_KERNELS_PART8_HIP_H

@@ -41,7 +41,7 @@ def main(fetch_csv, write_csv, out_json):
         print("| `%s` | %d | %.1f | %.1f | %.3e |" % (k[:70], n, a, b, t))
     # whole pass: every launch of every kernel, divided by the passes of the run (the torch fill kernels
     # of the bench's own buffers run once, not per pass: left out)
-    passes = max(nf.get(k, 0) for k in nf if k.startswith("k_dedup_lds"))
+    passes = max([nf.get(k, 0) for k in nf if k.startswith(("k_dedup_lds", "k_dedup_rec"))] or [1])
     own = [(k, n, a, b) for k, n, a, b, _ in rows if not k.startswith("at::")]
     rd = sum(2.0 * a * 1024.0 * n for _, n, a, _ in own) / passes
     wr = sum(b * 1024.0 * n for _, n, _, b in own) / passes
