@@ -370,7 +370,7 @@ def main():
     lds = mode_used in (0, 2) and (not world_sharded or getattr(sd, "mode_used", "") == "exchange")
     # (names: the word-ordered count runs on 8-byte records since round 3 -- k_dedup_rec, k_p8_scatter2,
     # k_unperm_bins8; hashed buckets and the fall-backs keep k_dedup_lds / k_pt_scatter<2> / k_unperm_bins)
-    rec8 = mode_used == 2
+    rec8 = bool(last.get("records8", False))
     kern = {(("k_dedup_rec" if rec8 else "k_dedup_lds") if lds else "k_hash_insert"): ks["ms_k_insert"],
             (("k_unperm_bins8" if rec8 else "k_unperm_bins") if ks["ms_k_unperm"] > 0 else ("k_read_map_bucket" if lds else "k_read_map")): ks["ms_k_map"]}
     if ks["ms_k_part"] > 0:

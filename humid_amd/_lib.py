@@ -26,7 +26,11 @@ class HumidSummary(C.Structure):
                 ("ms_k_unperm", C.c_float), ("count_mode_used", C.c_uint32)]
 
     def asdict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        # bit 8 of count_mode_used: the word-ordered count ran on 8-byte records (kernels_part8.hip.h)
+        d["records8"] = bool(d["count_mode_used"] >> 8)
+        d["count_mode_used"] &= 0xff
+        return d
 
 
 HOST_ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)

@@ -35,8 +35,8 @@
 #include "kernels_part.hip.h"
 #include "kernels_part8.hip.h"
 #include "kernels_graph.hip.h"
-#include "kernels_cgraph.hip.h"
 #include "kernels_cluster.hip.h"
+#include "kernels_cgraph.hip.h"
 #include "kernels_map.hip.h"
 #include "kernels_wide.hip.h"
 
@@ -116,7 +116,7 @@ struct humid_ctx {
   bool cg_valid = false;            // the last graph stage left its results in the cg_* arrays ...
   bool cg_expanded = false;         // ... and the per-unique-word view of them has been built (accessors)
   u32 cg_M = 0, cg_nblocks = 0;
-  DBuf p8_a, p8_b, p8_cur;               // 8-byte records of the count stage: level-1 output, level-2 output (kernels_part8.hip.h)
+  DBuf p8_a, p8_b, p8_cur, p8_status;               // 8-byte records of the count stage: level-1 output, level-2 output (kernels_part8.hip.h)
   bool use_rec8 = true;             // option "records8": 0 = always the 12-byte (key, read) pairs of kernels_part.hip.h
   bool last_rec8 = false;           // the last count ran on records: positions are (bucket << 9 | j), the un-permute reads p8_b
   const u32 *rec_cursor2 = nullptr; // reads per bucket of that count
@@ -234,24 +234,25 @@ static int exscan_u32(humid_ctx *c, const u32 *in, u32 *out, u64 n) { return exs
 // a sequence number; the host watches that word.  Two blit copies + hipStreamSynchronize cost ~30 us of idle
 // GPU per host wait, this ~10 (three waits per single-GPU pass, eight in the multi-GPU pass).
 __global__ void k_publish_counters(const ull *__restrict__ ctr, const u32 *__restrict__ extra32, const u32 *__restrict__ extra32b,
-                                   volatile ull *host, ull seq) {
+                                   volatile ull *host, ull seq, const u32 *__restrict__ extra32c = nullptr) {
   HUMID_GUARD_LAST_VGPR();
   if (threadIdx.x < CTR_N) {
     ull v = ctr[threadIdx.x];
     if (threadIdx.x == CTR_N - 1 && extra32) v = (v & ~0xffffffffull) | (ull)*extra32;
     if (threadIdx.x == CTR_N - 2 && extra32b) v = (ull)*extra32b;
+    if (threadIdx.x == CTR_N - 3 && extra32c) v = (ull)*extra32c;
     host[threadIdx.x] = v;
   }
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) { host[CTR_N] = seq; __threadfence_system(); }
 }
-// extra32 -> h_ctr[CTR_N - 1] (low half), extra32b -> h_ctr[CTR_N - 2]
-static int read_counters(humid_ctx *c, const u32 *extra32 = nullptr, const u32 *extra32b = nullptr) {
+// extra32 -> h_ctr[CTR_N - 1] (low half), extra32b -> h_ctr[CTR_N - 2], extra32c -> h_ctr[CTR_N - 3]
+static int read_counters(humid_ctx *c, const u32 *extra32 = nullptr, const u32 *extra32b = nullptr, const u32 *extra32c = nullptr) {
   if (c->h_ctr_dev && !c->no_poll) {
     const ull seq = ++c->ctr_seq;
     hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, c->stream, (const ull *)c->d_ctr, extra32, extra32b,
-                       (volatile ull *)c->h_ctr_dev, seq);
+                       (volatile ull *)c->h_ctr_dev, seq, extra32c);
     HIPCHK(hipGetLastError());
     volatile ull *flag = (volatile ull *)&c->h_ctr[CTR_N];
     const auto t0 = std::chrono::steady_clock::now();
@@ -270,10 +271,10 @@ static int read_counters(humid_ctx *c, const u32 *extra32 = nullptr, const u32 *
   HIPCHK(hipMemcpyAsync(c->h_ctr, c->d_ctr, CTR_N * sizeof(ull), hipMemcpyDeviceToHost, c->stream));
   if (extra32)
     HIPCHK(hipMemcpyAsync(&c->h_ctr[CTR_N - 1], extra32, 4, hipMemcpyDeviceToHost, c->stream));
-  if (extra32b) {
+  if (extra32b || extra32c) {
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->h_ctr[CTR_N - 2] = 0;
-    HIPCHK(hipMemcpyAsync(&c->h_ctr[CTR_N - 2], extra32b, 4, hipMemcpyDeviceToHost, c->stream));
+    if (extra32b) { c->h_ctr[CTR_N - 2] = 0; HIPCHK(hipMemcpyAsync(&c->h_ctr[CTR_N - 2], extra32b, 4, hipMemcpyDeviceToHost, c->stream)); }
+    if (extra32c) { c->h_ctr[CTR_N - 3] = 0; HIPCHK(hipMemcpyAsync(&c->h_ctr[CTR_N - 3], extra32c, 4, hipMemcpyDeviceToHost, c->stream)); }
   }
   HIPCHK(hipStreamSynchronize(c->stream));
   return HUMID_OK;
@@ -386,10 +387,13 @@ static GraphArrays legacy_arrays(humid_ctx *c) {
 // needs: cnt[n], deg[n], off[n+1], idx, parent[n] + csize[n] (k_comp_stats done), M = nodes with deg > 0,
 // Mbig = those in components larger than SMALL_COMP; small_roots listed by k_comp_count.
 // Leaves cl_of (creator + 1) / maxleaf / cl_size (at the creators) in `g`.
-static int cluster_kernels(humid_ctx *c, const GraphArrays &g, const u32 *g_cnt, u32 U, u64 M, u64 Mbig, u32 method) {
+// trivial_done: the components of one and two nodes are done and the roots listed (k_cg_trivial)
+static int cluster_kernels(humid_ctx *c, const GraphArrays &g, const u32 *g_cnt, u32 U, u64 M, u64 Mbig, u32 method,
+                           bool trivial_done = false) {
   hipStream_t st = c->stream;
-  if (c->kev_on) HIPCHK(hipEventRecord(c->kev[2], st));
-  if (method == HUMID_METHOD_MAXIMUM)
+  if (!trivial_done && c->kev_on) HIPCHK(hipEventRecord(c->kev[2], st));
+  if (trivial_done) {
+  } else if (method == HUMID_METHOD_MAXIMUM)
     hipLaunchKernelGGL(k_cluster_trivial<true>, dim3(blocks_for(U)), dim3(256), 0, st, g.deg, g.parent, g.csize, U, g_cnt, g.off,
                        g.idx, g.cl_of, g.maxleaf, g.cl_size);
   else
@@ -398,10 +402,10 @@ static int cluster_kernels(humid_ctx *c, const GraphArrays &g, const u32 *g_cnt,
   if (M > 0) {
     const u64 small_cap = M / 3 + 1;                  // listed roots: components of >= 3 of the M leaves with neighbours
     if (method == HUMID_METHOD_MAXIMUM)
-      hipLaunchKernelGGL(k_cluster_small<true>, dim3(blocks_for(small_cap, 128)), dim3(128), 0, st, c->small_roots.as<u32>(),
+      hipLaunchKernelGGL(k_cluster_small_lds<true>, dim3(blocks_for(small_cap, 64)), dim3(64), 0, st, c->small_roots.as<u32>(),
                          (const ull *)c->d_ctr, g.parent, g.csize, U, g_cnt, g.off, g.idx, g.cl_of, g.maxleaf, g.cl_size);
     else
-      hipLaunchKernelGGL(k_cluster_small<false>, dim3(blocks_for(small_cap, 128)), dim3(128), 0, st, c->small_roots.as<u32>(),
+      hipLaunchKernelGGL(k_cluster_small_lds<false>, dim3(blocks_for(small_cap, 64)), dim3(64), 0, st, c->small_roots.as<u32>(),
                          (const ull *)c->d_ctr, g.parent, g.csize, U, g_cnt, g.off, g.idx, g.cl_of, g.maxleaf, g.cl_size);
     if (Mbig > 0) {
       ENSURE(c->mk0, (size_t)Mbig * 8);
@@ -452,7 +456,6 @@ static int cluster_stage(humid_ctx *c, const u32 *g_cnt, u32 U, u64 M, u64 Mbig,
   return HUMID_OK;
 }
 
-static int read_counters(humid_ctx *c, const u32 *extra32, const u32 *extra32b);
 static int n_clusters_from_scan(humid_ctx *c, u32 U, u64 *out) {
   // (the pass's last host wait: both values through the counters' mapped store)
   TRY(read_counters(c, c->pos.as<u32>() + (U - 1), c->flag.as<u32>() + (U - 1)));
@@ -751,8 +754,9 @@ static int stage_count_rec(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   ENSURE(c->slot_out, (room2 + 1) * 8);
   ENSURE(c->pbeg, (size_t)(n_parts + 1) * 4);
   ENSURE(c->ucount, (size_t)(n_parts + 1) * 4);
-  ENSURE(c->pusable, (size_t)(n_parts + 1) * 4);
-  ENSURE(c->ubase, (size_t)(n_parts + 1) * 4);
+  // per bucket (reads << 32 | unique words) and its exclusive scan; entry n_parts = the scan's sentinel -> the totals
+  ENSURE(c->p8_status, ((size_t)n_parts + 1) * 16);
+  u64 *agg = c->p8_status.as<u64>(), *abase = agg + n_parts + 1;
   // p8_cur, in u32: [cursor1 512 | cursor2 n_parts] zeroed, then [cbase 513 | tprefix 513].  (Not pt_work: the
   // reads per bucket, cursor2, are read again by the un-permute at the end of the pass, and the graph
   // stage's grouping uses pt_work in between.)
@@ -764,6 +768,7 @@ static int stage_count_rec(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
     memset(&z, 0, sizeof z);
     z.p[0] = cursor1; z.n[0] = 512 + n_parts;
     z.p[1] = (u32 *)c->d_ctr; z.n[1] = 2 * CTR_N;
+    z.p[2] = (u32 *)(agg + n_parts); z.n[2] = 2;
     hipLaunchKernelGGL(k_zero_many, dim3(32), dim3(256), 0, st, z);
   }
   const bool check_range = !(range_lo == 0 && range_hi == ~0ull);
@@ -779,16 +784,14 @@ static int stage_count_rec(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   if (c->kev_on) HIPCHK(hipEventRecord(c->kev[40], st));
   HIPCHK(hipEventRecord(c->kev[0], st));
   hipLaunchKernelGGL(k_dedup_rec, dim3(n_parts), dim3(256), 0, st, c->p8_b.as<u64>(), (const u32 *)cursor2, N, pb, d1, ibits, rk,
-                     c->pad_word.as<u64>(), c->pad_cf.as<uint2>(), c->ucount.as<u32>(), c->pusable.as<u32>(), c->d_ctr);
+                     c->pad_word.as<u64>(), c->pad_cf.as<uint2>(), agg, c->d_ctr);
   HIPCHK(hipEventRecord(c->kev[1], st));
-  hipLaunchKernelGGL(k_part_totals, dim3(n_parts >= 16384 ? 64 : 4), dim3(256), 0, st, c->ucount.as<u32>(),
-                     c->pusable.as<u32>(), n_parts, c->d_ctr);
-  TRY(exscan_u32(c, c->ucount.as<u32>(), c->ubase.as<u32>(), (u64)n_parts + 1));
+  TRY(exscan_in<u64>(c, PtrIn<u64>{agg}, abase, (u64)n_parts + 1));
   HIPCHK(hipGetLastError());
-  TRY(read_counters(c));
+  TRY(read_counters(c, (const u32 *)(abase + n_parts), (const u32 *)(abase + n_parts) + 1));   // U, usable
   if (getenv("HUMID_TRACE_COUNT"))
     fprintf(stderr, "[rec count] N %u pb %u kbits %u ibits %u cap1 %u special %llu overfull %llu unique %llu usable %llu\n", N, pb, rk.kbits,
-            ibits, cap1, (ull)c->h_ctr[CTR_SPECIAL], (ull)c->h_ctr[CTR_OVERFULL], (ull)c->h_ctr[CTR_UNIQUE], (ull)c->h_ctr[CTR_USABLE]);
+            ibits, cap1, (ull)c->h_ctr[CTR_SPECIAL], (ull)c->h_ctr[CTR_OVERFULL], (ull)(c->h_ctr[CTR_N - 1] & 0xffffffffull), (ull)(c->h_ctr[CTR_N - 2] & 0xffffffffull));
   if (c->h_ctr[CTR_SPECIAL]) { c->pt_padded = false; return HUMID_OK; }     // a bin outgrew its room: the exact kernels from now on
   if (c->h_ctr[CTR_OVERFULL]) return HUMID_OK;
   c->last_count_lds = true;
@@ -798,8 +801,8 @@ static int stage_count_rec(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   c->last_rec8 = true;
   c->rec_cursor2 = cursor2;
   c->n_parts = n_parts;
-  const u32 U = (u32)c->h_ctr[CTR_UNIQUE];
-  s.usable = c->usable = c->h_ctr[CTR_USABLE];
+  const u32 U = (u32)(c->h_ctr[CTR_N - 1] & 0xffffffffull);
+  s.usable = c->usable = c->h_ctr[CTR_N - 2] & 0xffffffffull;
   s.unique = c->U = U;
   *done = true;
   if (U == 0) { HIPCHK(hipEventRecord(c->ev[1], st)); return HUMID_OK; }
@@ -808,7 +811,7 @@ static int stage_count_rec(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   ENSURE(c->s_cnt, (size_t)(U + 1) * 4);
   ENSURE(c->s_first, (size_t)(U + 1) * 4);
   hipLaunchKernelGGL(k_compact_padded8, dim3(blocks_for((u64)n_parts * 64)), dim3(256), 0, st, c->pad_word.as<u64>(),
-                     c->pad_cf.as<uint2>(), c->ucount.as<u32>(), c->ubase.as<u32>(), n_parts, c->s_word.as<u64>(),
+                     c->pad_cf.as<uint2>(), (const u64 *)agg, (const u64 *)abase, n_parts, c->s_word.as<u64>(),
                      c->s_slot.as<u32>(), c->s_cnt.as<u32>(), c->s_first.as<u32>());
   HIPCHK(hipEventRecord(c->ev[1], st));
   HIPCHK(hipGetLastError());
@@ -1323,6 +1326,112 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
 }
 
 
+// ---- the compact graph from marked ids + pairs (kernels_cgraph.hip.h): shared by the single-GPU search
+// (pairs appended into regions, counts by id) and the multi-GPU pass (pair records in global ids) ----
+struct CgSource {
+  EdgeRegs er;                 // pairs in id space: regions + far list (recs == null); set to the compact pairs on return
+  const ulonglong2 *recs;      // or: pair records {a << 32 | b, count a | count b << 32}
+  u32 n_recs;
+  const u32 *cnt_by_id;        // counts by id (with plain pairs)
+  u32 n_ids;                   // id space = bits of the bitmap c->cg_bits (zeroed, then marked, by the caller)
+  u64 pairs_bound;             // no more pairs than this can be in the source
+};
+struct CgStatus {
+  bool overflow = false;       // an append region was full: `wanted` says how much room the search wants in all
+  u64 wanted = 0, big_mask = 0, E = 0, M = 0, Mbig = 0;
+};
+static GraphArrays cg_arrays(humid_ctx *c) {
+  return GraphArrays{c->cg_deg.as<u32>(), c->cg_parent.as<u32>(), c->cg_csize.as<u32>(), c->cg_off.as<u32>(), c->cg_idx.as<u32>(),
+                     c->cg_cl_of.as<u32>(), c->cg_maxleaf.as<u32>(), c->cg_cl_size.as<u64>()};
+}
+// rank structure, nodes, compact pairs, degrees, forest, CSR rows (ascending), component sizes, the trivial
+// components; ONE host wait at the end (every launch before it is sized by bounds: nodes <= 2 x pairs).
+static int cg_build(humid_ctx *c, CgSource &src, u32 method, CgStatus &out) {
+  hipStream_t st = c->stream;
+  const u32 n_words = (((src.n_ids + 31) / 32) + 7) & ~7u, n_blk = n_words / 8;
+  const u64 pb = std::max<u64>(src.pairs_bound, 1);
+  if (2 * pb + 2 > 0xffffffffull) return fail(c, HUMID_E_OVERFLOW, "too many neighbour pairs");
+  const u32 Mb = (u32)std::min<u64>(src.n_ids, 2 * pb);
+  ENSURE(c->cg_blk, ((size_t)n_blk + 1) * 4);
+  ENSURE(c->cg_nodes, ((size_t)Mb + 1) * 4);
+  ENSURE(c->cg_ncnt, ((size_t)Mb + 1) * 4);
+  ENSURE(c->cg_deg, ((size_t)Mb + 2) * 4);
+  ENSURE(c->cg_off, ((size_t)Mb + 2) * 4);
+  ENSURE(c->cg_parent, ((size_t)Mb + 1) * 4);
+  ENSURE(c->cg_csize, ((size_t)Mb + 1) * 4);
+  ENSURE(c->cg_curs, ((size_t)Mb + 1) * 4);
+  ENSURE(c->cg_idx, (size_t)(2 * pb + 1) * 4);
+  ENSURE(c->cg_cl_of, ((size_t)Mb + 1) * 4);
+  ENSURE(c->cg_maxleaf, ((size_t)Mb + 1) * 4);
+  ENSURE(c->cg_cl_size, ((size_t)Mb + 1) * 8);
+  ENSURE(c->small_roots, ((size_t)Mb / 3 + 2) * 4);
+  ENSURE(c->small, 64);
+  hipLaunchKernelGGL(k_bits_blocks, dim3(blocks_for((u64)n_blk + 1)), dim3(256), 0, st, c->cg_bits.as<u32>(), n_blk, c->cg_blk.as<u32>());
+  TRY(exscan_u32(c, c->cg_blk.as<u32>(), c->cg_blk.as<u32>(), (u64)n_blk + 1));
+  const BitRank br{c->cg_bits.as<u32>(), c->cg_blk.as<u32>()};
+  const u32 *m_dev = c->cg_blk.as<u32>() + n_blk;
+  const GraphArrays g = cg_arrays(c);
+  hipLaunchKernelGGL(k_nodes_init, dim3(blocks_for(n_words)), dim3(256), 0, st, br, n_words, src.cnt_by_id, c->cg_nodes.as<u32>(),
+                     c->cg_ncnt.as<u32>(), g.deg, g.parent, g.csize, c->cg_curs.as<u32>(), n_blk);
+  const bool by_count = (method & 1) == 0;
+  if (src.recs) {
+    ENSURE(c->cg_far, ((size_t)src.n_recs + 1) * 8);
+    if (src.n_recs)
+      hipLaunchKernelGGL(k_records_relabel, dim3(blocks_for(src.n_recs)), dim3(256), 0, st, src.recs, src.n_recs, src.n_ids, br,
+                         c->cg_far.as<u64>(), c->cg_ncnt.as<u32>(), g.deg, g.parent, by_count);
+    src.er.far = c->cg_far.as<u64>();
+    src.er.n_far = src.n_recs;
+  } else {
+    const u32 gx = (u32)std::min<u64>(std::max<u64>(blocks_for(std::max<u64>(src.er.cap_r, src.er.n_far)), 1), 4096);
+    hipLaunchKernelGGL(k_pairs_relabel, dim3(gx, ER_REGIONS + 1), dim3(256), 0, st, src.er, br, (const u32 *)c->cg_ncnt.as<u32>(),
+                       g.deg, g.parent, by_count);
+  }
+  TRY(exscan_in<u32>(c, DegIn{g.deg, m_dev}, g.off, (u64)Mb + 1));
+  hipLaunchKernelGGL(k_comp_stats, dim3(blocks_for(Mb)), dim3(256), 0, st, g.deg, g.parent, Mb, g.csize, m_dev);
+  {
+    const u32 gx = (u32)std::min<u64>(std::max<u64>(blocks_for(std::max<u64>(src.er.cap_r, src.er.n_far)), 1), 4096);
+    hipLaunchKernelGGL(k_pairs_fill, dim3(gx, ER_REGIONS + 1), dim3(256), 0, st, src.er, (const u32 *)g.off, c->cg_curs.as<u32>(), g.idx);
+  }
+  hipLaunchKernelGGL(k_sort_lists, dim3(blocks_for(Mb)), dim3(256), 0, st, (const u32 *)g.off, Mb, g.idx);
+  if (c->kev_on) HIPCHK(hipEventRecord(c->kev[2], st));
+  const u32 tg = (u32)std::min<u64>(std::max<u64>(blocks_for(Mb), 1), 512);
+  if (method == HUMID_METHOD_MAXIMUM)
+    hipLaunchKernelGGL(k_cg_trivial<true>, dim3(tg), dim3(256), 0, st, (const u32 *)g.parent, (const u32 *)g.csize, m_dev,
+                       (const u32 *)c->cg_ncnt.as<u32>(), (const u32 *)g.off, (const u32 *)g.idx, g.cl_of, g.maxleaf, g.cl_size, c->d_ctr,
+                       c->small_roots.as<u32>());
+  else
+    hipLaunchKernelGGL(k_cg_trivial<false>, dim3(tg), dim3(256), 0, st, (const u32 *)g.parent, (const u32 *)g.csize, m_dev,
+                       (const u32 *)c->cg_ncnt.as<u32>(), (const u32 *)g.off, (const u32 *)g.idx, g.cl_of, g.maxleaf, g.cl_size, c->d_ctr,
+                       c->small_roots.as<u32>());
+  hipLaunchKernelGGL(k_regions_max, dim3(1), dim3(64), 0, st, src.er, c->small.as<u32>());
+  HIPCHK(hipGetLastError());
+  TRY(read_counters(c, g.off + Mb, c->small.as<u32>(), m_dev));              // 2E, pairs the fullest region wanted, M
+  out.wanted = (c->h_ctr[CTR_N - 2] & 0xffffffffull) * ER_REGIONS;            // (as a total: every region has the same room)
+  out.overflow = (c->h_ctr[CTR_EOVER] & 0xffffffffull) != 0;
+  out.big_mask = c->h_ctr[CTR_BIGMASK];
+  out.E = (c->h_ctr[CTR_N - 1] & 0xffffffffull) / 2;
+  out.M = c->h_ctr[CTR_N - 3] & 0xffffffffull;
+  out.Mbig = c->h_ctr[CTR_MEMBERS];
+  return HUMID_OK;
+}
+// the components of 3 and more nodes, then the nodes that created no cluster as a bitmap over the ids with
+// its rank structure (c->cg_nbits zeroed by the caller; cg_nblk)
+static int cg_cluster_rest(humid_ctx *c, u32 n_ids, u64 M, u64 Mbig, u32 method) {
+  hipStream_t st = c->stream;
+  const u32 n_words = (((n_ids + 31) / 32) + 7) & ~7u, n_blk = n_words / 8;
+  const GraphArrays g = cg_arrays(c);
+  ENSURE(c->cg_nblk, ((size_t)n_blk + 1) * 4);
+  if (M > 0) TRY(cluster_kernels(c, g, c->cg_ncnt.as<u32>(), (u32)M, M, Mbig, method, true));
+  else if (c->kev_on) HIPCHK(hipEventRecord(c->kev[3], st));
+  if (M > 0)
+    hipLaunchKernelGGL(k_noncreator_bits, dim3(blocks_for(M)), dim3(256), 0, st, (const u32 *)g.cl_of, c->cg_nodes.as<u32>(), (u32)M,
+                       c->cg_nbits.as<u32>());
+  hipLaunchKernelGGL(k_bits_blocks, dim3(blocks_for((u64)n_blk + 1)), dim3(256), 0, st, c->cg_nbits.as<u32>(), n_blk, c->cg_nblk.as<u32>());
+  TRY(exscan_u32(c, c->cg_nblk.as<u32>(), c->cg_nblk.as<u32>(), (u64)n_blk + 1));
+  HIPCHK(hipGetLastError());
+  return HUMID_OK;
+}
+
 // ---- stage B on the COMPACT graph (kernels_cgraph.hip.h): the single-GPU pipeline's form ---------
 // Same contract as stage_graph (neighbours + clusters of the ascending unique array g_word / g_cnt),
 // but every graph and cluster array lives on the M leaves that have neighbours; the per-unique-word
@@ -1372,7 +1481,7 @@ static int stage_graph_compact(humid_ctx *c, const WT *g_word, const u32 *g_cnt,
   const u64 *far = given ? ext_edges : nullptr;
   u64 n_far = given ? n_ext_edges : 0;
   u64 E = 0, M = 0, Mbig = 0;
-  u32 Mb = 0;
+  CgStatus cgs;
   EdgeRegs er;
   // the bucket order of a combination is made ONCE: the grouping places equal keys with atomics, so a
   // second run may order a bucket differently -- and the near / far split of a large bucket (walk
@@ -1418,36 +1527,13 @@ static int stage_graph_compact(humid_ctx *c, const WT *g_word, const u32 *g_cnt,
     }
     if (n_far)
       hipLaunchKernelGGL(k_mark_pairs, dim3(blocks_for(n_far)), dim3(256), 0, st, far, (u32)n_far, U, c->cg_bits.as<u32>(), bad);
-    // nodes <= 2 x pairs: every launch below is sized by that bound, the device knows the real numbers
-    Mb = (u32)std::min<u64>(U, 2 * (ecap + n_far));
-    ENSURE(c->cg_nodes, ((size_t)Mb + 1) * 4);
-    ENSURE(c->cg_ncnt, ((size_t)Mb + 1) * 4);
-    ENSURE(c->cg_deg, ((size_t)Mb + 2) * 4);
-    ENSURE(c->cg_off, ((size_t)Mb + 2) * 4);
-    ENSURE(c->cg_parent, ((size_t)Mb + 1) * 4);
-    ENSURE(c->cg_csize, ((size_t)Mb + 1) * 4);
-    ENSURE(c->cg_curs, ((size_t)Mb + 1) * 4);
-    hipLaunchKernelGGL(k_bits_blocks, dim3(blocks_for((u64)n_blk + 1)), dim3(256), 0, st, c->cg_bits.as<u32>(), n_blk, c->cg_blk.as<u32>());
-    TRY(exscan_u32(c, c->cg_blk.as<u32>(), c->cg_blk.as<u32>(), (u64)n_blk + 1));
-    const BitRank br{c->cg_bits.as<u32>(), c->cg_blk.as<u32>()};
-    const u32 *m_dev = c->cg_blk.as<u32>() + n_blk;
-    hipLaunchKernelGGL(k_nodes_init, dim3(blocks_for(n_words)), dim3(256), 0, st, br, n_words, g_cnt, c->cg_nodes.as<u32>(),
-                       c->cg_ncnt.as<u32>(), c->cg_deg.as<u32>(), c->cg_parent.as<u32>(), c->cg_csize.as<u32>(),
-                       c->cg_curs.as<u32>(), n_blk);
-    const u32 gx = (u32)std::min<u64>(std::max<u64>(blocks_for(std::max<u64>(er.cap_r, n_far)), 1), 4096);
-    hipLaunchKernelGGL(k_pairs_relabel, dim3(gx, ER_REGIONS + 1), dim3(256), 0, st, er, br, c->cg_ncnt.as<u32>(),
-                       c->cg_deg.as<u32>(), c->cg_parent.as<u32>(), (method & 1) == 0);
-    TRY(exscan_in<u32>(c, DegIn{c->cg_deg.as<u32>(), m_dev}, c->cg_off.as<u32>(), (u64)Mb + 1));
-    hipLaunchKernelGGL(k_comp_stats, dim3(blocks_for(Mb)), dim3(256), 0, st, c->cg_deg.as<u32>(), c->cg_parent.as<u32>(), Mb,
-                       c->cg_csize.as<u32>(), m_dev);
-    hipLaunchKernelGGL(k_comp_count, dim3(512), dim3(256), 0, st, c->cg_deg.as<u32>(), c->cg_parent.as<u32>(),
-                       c->cg_csize.as<u32>(), Mb, c->d_ctr, c->small_roots.as<u32>(), m_dev);
-    hipLaunchKernelGGL(k_regions_max, dim3(1), dim3(64), 0, st, er, c->small.as<u32>());
-    HIPCHK(hipGetLastError());
-    TRY(read_counters(c, c->cg_off.as<u32>() + Mb, c->small.as<u32>()));       // 2E, pairs the fullest region wanted
-    const u64 wanted = (c->h_ctr[CTR_N - 2] & 0xffffffffull) * ER_REGIONS;     // (as a total: every region has the same room)
-    if (c->h_ctr[CTR_EOVER] & 0xffffffffull) {          // a region was full: more room, once more
-      c->cg_ecap = wanted + wanted / 2 + ER_REGIONS * 64;
+    CgSource src;
+    src.er = er; src.recs = nullptr; src.n_recs = 0; src.cnt_by_id = g_cnt; src.n_ids = U;
+    src.pairs_bound = ecap + n_far;
+    TRY(cg_build(c, src, method, cgs));
+    er = src.er;
+    if (cgs.overflow) {                                  // a region was full: more room, once more
+      c->cg_ecap = cgs.wanted + cgs.wanted / 2 + ER_REGIONS * 64;
       continue;
     }
     if (given) {
@@ -1456,10 +1542,10 @@ static int stage_graph_compact(humid_ctx *c, const WT *g_word, const u32 *g_cnt,
       HIPCHK(hipStreamSynchronize(st));
       if (h_bad) return fail(c, HUMID_E_INVALID, "malformed edge list (node index out of range)");
     }
-    if (search && c->h_ctr[CTR_BIGMASK] && !far) {
+    if (search && cgs.big_mask && !far) {
       // some bucket is longer than k_pairs_append walks: its remaining pairs (further apart than the
       // walk) come from the tiles, as one more region; then the search is taken again with them in place
-      const u64 big_mask = c->h_ctr[CTR_BIGMASK];
+      const u64 big_mask = cgs.big_mask;
       u64 got = 0;
       for (int phase = 0; phase < 2; phase++) {
         u64 at = 0;
@@ -1496,37 +1582,17 @@ static int stage_graph_compact(humid_ctx *c, const WT *g_word, const u32 *g_cnt,
       n_far = got;
       if (n_far) continue;                              // (nothing beyond the walk after all: the list stands)
     }
-    const u64 twoE = c->h_ctr[CTR_N - 1] & 0xffffffffull;
-    if (c->h_ctr[CTR_EDGES] > 0xffffffffull)
-      return fail(c, HUMID_E_OVERFLOW, "%llu neighbour pairs exceed the 32-bit adjacency offsets", (ull)(c->h_ctr[CTR_EDGES] / 2));
-    E = twoE / 2;
-    M = c->h_ctr[CTR_NONSINGLE];
-    Mbig = c->h_ctr[CTR_MEMBERS];
-    if (search && wanted + wanted / 4 + ER_REGIONS * 64 < c->cg_ecap / 4) c->cg_ecap = 0;   // far too roomy for this input: re-sized next time
+    E = cgs.E; M = cgs.M; Mbig = cgs.Mbig;
+    // far too roomy for this input: the next pass gets what this one wanted + a quarter (launches are sized by it)
+    if (search && 2 * (cgs.wanted + cgs.wanted / 4 + ER_REGIONS * 64) < c->cg_ecap) c->cg_ecap = cgs.wanted + cgs.wanted / 4 + ER_REGIONS * 64;
     break;
   }
   s.edges = c->E = E;
   s.nonsingle = c->M = M;
   c->cg_M = (u32)M;
-  ENSURE(c->cg_idx, (size_t)(2 * E + 1) * 4);
-  ENSURE(c->cg_cl_of, ((size_t)M + 1) * 4);
-  ENSURE(c->cg_maxleaf, ((size_t)M + 1) * 4);
-  ENSURE(c->cg_cl_size, ((size_t)M + 1) * 8);
-  const GraphArrays g{c->cg_deg.as<u32>(), c->cg_parent.as<u32>(), c->cg_csize.as<u32>(), c->cg_off.as<u32>(), c->cg_idx.as<u32>(),
-                      c->cg_cl_of.as<u32>(), c->cg_maxleaf.as<u32>(), c->cg_cl_size.as<u64>()};
-  if (E > 0) {
-    const u32 gx = (u32)std::min<u64>(std::max<u64>(blocks_for(std::max<u64>(er.cap_r, n_far)), 1), 4096);
-    hipLaunchKernelGGL(k_pairs_fill, dim3(gx, ER_REGIONS + 1), dim3(256), 0, st, er, (const u32 *)g.off, c->cg_curs.as<u32>(), g.idx);
-    hipLaunchKernelGGL(k_sort_lists, dim3(blocks_for(M)), dim3(256), 0, st, (const u32 *)g.off, (u32)M, g.idx);
-  }
   HIPCHK(hipEventRecord(c->ev[2], st));
-  if (M > 0) TRY(cluster_kernels(c, g, c->cg_ncnt.as<u32>(), (u32)M, M, Mbig, method));
-  else { if (c->kev_on) { HIPCHK(hipEventRecord(c->kev[2], st)); HIPCHK(hipEventRecord(c->kev[3], st)); } }
-  if (M > 0)
-    hipLaunchKernelGGL(k_noncreator_bits, dim3(blocks_for(M)), dim3(256), 0, st, (const u32 *)g.cl_of, c->cg_nodes.as<u32>(), (u32)M,
-                       c->cg_nbits.as<u32>());
-  hipLaunchKernelGGL(k_bits_blocks, dim3(blocks_for((u64)n_blk + 1)), dim3(256), 0, st, c->cg_nbits.as<u32>(), n_blk, c->cg_nblk.as<u32>());
-  TRY(exscan_u32(c, c->cg_nblk.as<u32>(), c->cg_nblk.as<u32>(), (u64)n_blk + 1));
+  TRY(cg_cluster_rest(c, U, M, Mbig, method));
+  const GraphArrays g = cg_arrays(c);
   const bool own = ((const void *)g_word == c->s_word.p) && U == (u32)c->U;
   if (!own) { ENSURE(c->cid, (size_t)U * 4); ENSURE(c->ismax, (size_t)U); }
   hipLaunchKernelGGL(k_finalize_leaves, dim3(blocks_for(U)), dim3(256), 0, st, BitRank{c->cg_bits.as<u32>(), c->cg_blk.as<u32>()},
@@ -2026,7 +2092,7 @@ static int run_device(humid_ctx *c, const WT *d_words, const u8 *d_filt, u64 n_r
   else s.ms_k_map = s.ms_map;   // ev[3]..ev[4] bracket exactly the k_read_map launch
   if (c->kev_on && c->last_count_lds && c->last_unperm_tiled) HIPCHK(hipEventElapsedTime(&s.ms_k_unperm, c->kev[36], c->kev[41]));
   if (c->kev_on && c->last_count_lds && c->last_part_tiled && !c->last_count_sorted) HIPCHK(hipEventElapsedTime(&s.ms_k_part, c->kev[39], c->kev[40]));
-  s.count_mode_used = c->last_count_sorted ? 3u : c->last_count_lds ? (c->last_count_ordered ? 2u : 0u) : 1u;
+  s.count_mode_used = (c->last_count_sorted ? 3u : c->last_count_lds ? (c->last_count_ordered ? 2u : 0u) : 1u) | (c->last_rec8 ? 0x100u : 0u);
   if (c->kev_on) HIPCHK(hipEventElapsedTime(&s.ms_k_cluster, c->kev[2], c->kev[3]));
   for (u32 g = 0; c->kev_on && g < n_pair_segs; g++) {
     float t = 0;
@@ -2105,7 +2171,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->in_bases, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
                   &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->big_runs, &c->small_roots, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_heads, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles, &c->xr_hist, &c->xr_recv, &c->xr_eloc, &c->xr_got, &c->xr_eall, &c->xr_ret, &c->xr_heads, &c->xr_send, &c->xr_zero,
-                  &c->p8_a, &c->p8_b, &c->p8_cur, &c->cg_edges, &c->cg_cur, &c->cg_far, &c->cg_bits, &c->cg_nbits, &c->cg_blk, &c->cg_nblk, &c->cg_nodes, &c->cg_ncnt, &c->cg_deg,
+                  &c->p8_a, &c->p8_b, &c->p8_cur, &c->p8_status, &c->cg_edges, &c->cg_cur, &c->cg_far, &c->cg_bits, &c->cg_nbits, &c->cg_blk, &c->cg_nblk, &c->cg_nodes, &c->cg_ncnt, &c->cg_deg,
                   &c->cg_off, &c->cg_idx, &c->cg_parent, &c->cg_csize, &c->cg_curs, &c->cg_cl_of, &c->cg_maxleaf, &c->cg_cl_size,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
@@ -3626,7 +3692,7 @@ int humid_stage_kernel_ms(humid_ctx *c, float *ms_k_insert, float *ms_k_map, uin
   }
   if (ms_k_insert) *ms_k_insert = a;
   if (ms_k_map) *ms_k_map = b;
-  if (count_mode_used) *count_mode_used = c->last_count_sorted ? 3u : c->last_count_lds ? (c->last_count_ordered ? 2u : 0u) : 1u;
+  if (count_mode_used) *count_mode_used = (c->last_count_sorted ? 3u : c->last_count_lds ? (c->last_count_ordered ? 2u : 0u) : 1u) | (c->last_rec8 ? 0x100u : 0u);
   return HUMID_OK;
 }
 

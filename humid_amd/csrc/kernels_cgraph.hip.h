@@ -19,6 +19,7 @@
 
 #include "common.hip.h"
 #include "kernels_graph.hip.h"
+#include "kernels_cluster.hip.h"
 
 // ---- append regions of the pair list ------------------------------------------------------------
 #define ER_REGIONS 64u
@@ -204,7 +205,7 @@ k_nodes_init(BitRank br, u32 n_words, const u32 *__restrict__ s_cnt, u32 *__rest
     x &= x - 1u;
     const u32 u = (w << 5) | bit;
     nodes[c] = u;
-    ncnt[c] = s_cnt[u];
+    if (s_cnt) ncnt[c] = s_cnt[u];                     // (null: the counts come with pair records, k_records_relabel)
     deg[c] = 0; parent[c] = c; csize[c] = 0; cur[c] = 0;
     c++;
   }
@@ -256,6 +257,123 @@ __global__ void k_regions_max(EdgeRegs er, u32 *__restrict__ out) {
 #pragma unroll
   for (u32 d = 32; d >= 1; d >>= 1) { const u32 y = __shfl_xor(c, d); c = y > c ? y : c; }
   if (threadIdx.x == 0) out[0] = c;
+}
+
+// ---- pair RECORDS as the source (multi-GPU: pairs in global unique indices with both ends' counts) ----
+// record = {smaller id << 32 | larger id, count(smaller) | count(larger) << 32}
+__global__ void __launch_bounds__(256)
+k_mark_records(const ulonglong2 *__restrict__ recs, u32 n_recs, u32 n_ids, u32 *bits, u32 *bad) {
+  HUMID_GUARD_LAST_VGPR();
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_recs) return;
+  const u64 e = recs[k].x;
+  const u32 a = (u32)(e >> 32), b = (u32)e;
+  if (a >= n_ids || b >= n_ids || a == b) { *bad = 1; return; }
+  atomicOr(&bits[a >> 5], 1u << (a & 31));
+  atomicOr(&bits[b >> 5], 1u << (b & 31));
+}
+// records -> compact pairs (a dense list: the `far` region of an EdgeRegs), the nodes' counts (all records
+// of a node carry the same count: equal values race freely), degrees, component forest
+__global__ void __launch_bounds__(256)
+k_records_relabel(const ulonglong2 *__restrict__ recs, u32 n_recs, u32 n_ids, BitRank br, u64 *__restrict__ cpairs,
+                  u32 *__restrict__ ncnt, u32 *deg, u32 *parent, bool join_by_count) {
+  HUMID_GUARD_LAST_VGPR();
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_recs) return;
+  const ulonglong2 r = recs[k];
+  const u32 ia = (u32)(r.x >> 32), ib = (u32)r.x;
+  if (ia >= n_ids || ib >= n_ids || ia == ib) { cpairs[k] = 0; return; }      // (reported by k_mark_records)
+  const u32 a = br_rank(br, ia), b = br_rank(br, ib);
+  const u32 ca = (u32)r.y, cb = (u32)(r.y >> 32);
+  cpairs[k] = ((u64)a << 32) | b;
+  ncnt[a] = ca;
+  ncnt[b] = cb;
+  atomicAdd(&deg[a], 1u);
+  atomicAdd(&deg[b], 1u);
+  if (!join_by_count || at_least_double(ca, cb) || at_least_double(cb, ca)) uf_union(parent, a, b);
+}
+
+// ---- the trivial components, and the lists the other cluster kernels work from ----------------------
+// k_cluster_trivial (kernels_cluster.hip.h) for a compact graph (every node has neighbours; the number of
+// nodes is read on the device: the launch is sized by a bound) which ALSO does what k_comp_count did in a
+// pass of its own: the roots of the components of 3 .. SMALL_COMP nodes as a dense list (collected per
+// workgroup in LDS, one global atomic per flush) and the number of nodes in larger components.
+template <bool MAXIMUM>
+__global__ void __launch_bounds__(256)
+k_cg_trivial(const u32 *__restrict__ P, const u32 *__restrict__ csize, const u32 *__restrict__ m_dev, const u32 *__restrict__ cnt,
+             const u32 *__restrict__ off, const u32 *__restrict__ idx, u32 *cl_of, u32 *maxleaf, u64 *cl_size, ull *ctr,
+             u32 *__restrict__ small_roots) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ u32 lds[4];
+  __shared__ u32 lroots[CC_ROOTS], lroots_n, lroots_base;
+  if (threadIdx.x == 0) lroots_n = 0;
+  __syncthreads();
+  const u32 n = *m_dev;
+  const u32 lane = threadIdx.x & 63;
+  u32 mb = 0, round = 0;
+  for (u32 a0 = blockIdx.x * blockDim.x; a0 < n; a0 += gridDim.x * blockDim.x) {     // (whole waves stay in the loop: ballot below)
+    const u32 a = a0 + threadIdx.x;
+    bool small_root = false;
+    if (a < n) {
+      const u32 root = P[a];                         // flattened by k_comp_stats
+      const u32 members = csize[root];
+      if (members > SMALL_COMP) { mb++; cl_of[a] = 0; }
+      else if (members > 2) { small_root = root == a; cl_of[a] = 0; }
+      else if (members == 1) { cl_of[a] = a + 1; maxleaf[a] = a; cl_size[a] = cnt[a]; }
+      else if (root == a) {                          // two nodes a < b: closed form, done by a's lane
+        u32 b = a;
+        for (u32 k = off[a]; k < off[a + 1]; k++) {
+          const u32 nb = idx[k];
+          if (P[nb] == root) { b = nb; break; }
+        }
+        const u64 ca = cnt[a], cb = cnt[b];
+        if (MAXIMUM) {
+          cl_of[a] = a + 1; cl_of[b] = a + 1;
+          maxleaf[a] = (cb > ca) ? b : a;
+          cl_size[a] = ca + cb;
+        } else if (at_least_double(cb, ca)) {        // a climbs to b, b floods back to a
+          cl_of[a] = a + 1; cl_of[b] = a + 1;
+          maxleaf[a] = b;
+          cl_size[a] = ca + cb;
+        } else if (at_least_double(ca, cb)) {        // a stays, absorbs b
+          cl_of[a] = a + 1; cl_of[b] = a + 1;
+          maxleaf[a] = a;
+          cl_size[a] = ca + cb;
+        } else {                                     // two clusters; b finds a already assigned
+          cl_of[a] = a + 1; maxleaf[a] = a; cl_size[a] = ca;
+          cl_of[b] = b + 1; maxleaf[b] = b; cl_size[b] = cb;
+        }
+      }
+    }
+    const u64 bm = __ballot(small_root);
+    if (bm) {
+      u32 base = 0;
+      if (lane == 0) base = atomicAdd(&lroots_n, (u32)__popcll(bm));
+      base = __shfl(base, 0);
+      if (small_root) lroots[base + (u32)__popcll(bm & ((1ull << lane) - 1ull))] = a;
+    }
+    if ((++round & (CC_ROOTS / 256u - 1u)) == 0) {   // every eighth round: flush (the buffer cannot overfill in between)
+      __syncthreads();
+      const u32 cntl = lroots_n;
+      if (cntl) {
+        if (threadIdx.x == 0) lroots_base = (u32)atomicAdd(&ctr[CTR_SMALLROOTS], (ull)cntl);
+        __syncthreads();
+        for (u32 k = threadIdx.x; k < cntl; k += blockDim.x) small_roots[lroots_base + k] = lroots[k];
+        __syncthreads();
+        if (threadIdx.x == 0) lroots_n = 0;
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  const u32 cntl = lroots_n;
+  if (cntl) {
+    if (threadIdx.x == 0) lroots_base = (u32)atomicAdd(&ctr[CTR_SMALLROOTS], (ull)cntl);
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < cntl; k += blockDim.x) small_roots[lroots_base + k] = lroots[k];
+  }
+  const u32 tb = block_sum(mb, lds);
+  if (threadIdx.x == 0 && tb) atomicAdd(&ctr[CTR_MEMBERS], (ull)tb);
 }
 
 // ---- results -------------------------------------------------------------------------------------------

@@ -21,12 +21,13 @@
 //   assignMaxCluster             src/cluster.cc:72-80
 // A cluster is named by its creating leaf (cl_of = creator rank + 1); ids come later from a
 // prefix sum over creators, which reproduces `id++` in walk order.  `st` holds 2 words per member.
-template <bool MAXIMUM, class MemberAt>
+// St: anything indexable as st[i] -> u32& (a pointer into scratch, or a strided view of LDS)
+template <bool MAXIMUM, class MemberAt, class St>
 __device__ __forceinline__ void cluster_one_component(MemberAt member_at, u32 n_members,
                                                       const u32 *__restrict__ cnt,
                                                       const u32 *__restrict__ off,
                                                       const u32 *__restrict__ idx, u32 *cl_of,
-                                                      u32 *maxleaf, u64 *cl_size, u32 *st) {
+                                                      u32 *maxleaf, u64 *cl_size, St st) {
   for (u32 m = 0; m < n_members; m++) {
     const u32 u = member_at(m);
     if (cl_of[u] != 0) continue;                  // src/humid.cc:179
@@ -318,6 +319,48 @@ k_cluster_small(const u32 *__restrict__ roots, const ull *__restrict__ ctr, cons
   }
   for (u32 k = 1; k < nm; k++) {              // ascending = walk order inside the component
     u32 x = mem[k];
+    u32 m = k;
+    while (m > 0 && mem[m - 1] > x) { mem[m] = mem[m - 1]; m--; }
+    mem[m] = x;
+  }
+  cluster_one_component<MAXIMUM>([&](u32 m) { return mem[m]; }, nm, cnt, off, idx, cl_of, maxleaf, cl_size, st);
+}
+
+// The same with the member list and the stack in LDS instead of private (scratch) memory: column
+// `lane` of two [depth][64] tables, so that the lanes of a wave hit 64 different banks.  64 threads per
+// workgroup, 24 KB of LDS.
+struct LdsColumn {
+  u32 *base;                                            // &table[0][lane]
+  __device__ __forceinline__ u32 &operator[](u32 i) const { return base[i * 64u]; }
+};
+template <bool MAXIMUM>
+__global__ void __launch_bounds__(64)
+k_cluster_small_lds(const u32 *__restrict__ roots, const ull *__restrict__ ctr, const u32 *__restrict__ P,
+                    const u32 *__restrict__ csize, u32 n, const u32 *__restrict__ cnt, const u32 *__restrict__ off,
+                    const u32 *__restrict__ idx, u32 *cl_of, u32 *maxleaf, u64 *cl_size) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ u32 lmem[SMALL_COMP][64];
+  __shared__ u32 lst[2 * SMALL_COMP][64];
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (u32)ctr[CTR_SMALLROOTS]) return;
+  const u32 u = roots[t];
+  if (u >= n) return;
+  const u32 target = csize[u];
+  if (target > SMALL_COMP || target <= 2) return;
+  const LdsColumn mem{&lmem[0][threadIdx.x]}, st{&lst[0][threadIdx.x]};
+  u32 nm = 1;
+  mem[0] = u;
+  for (u32 q = 0; q < nm && nm < target; q++) {
+    const u32 v = mem[q];
+    for (u32 k = off[v]; k < off[v + 1] && nm < target; k++) {
+      const u32 nb = idx[k];
+      bool seen = P[nb] != u;                         // a neighbour outside this component (joins_for_clustering)
+      for (u32 j = 0; j < nm; j++) seen |= (mem[j] == nb);
+      if (!seen) { mem[nm] = nb; nm++; }
+    }
+  }
+  for (u32 k = 1; k < nm; k++) {              // ascending = walk order inside the component
+    const u32 x = mem[k];
     u32 m = k;
     while (m > 0 && mem[m - 1] > x) { mem[m] = mem[m - 1]; m--; }
     mem[m] = x;

@@ -184,12 +184,12 @@ k_p8_scatter2(const u64 *__restrict__ in, const u32 *__restrict__ tprefix, const
 
 // ---- the LDS count of one bucket, on records (k_dedup_lds<true> of kernels_count.hip.h) ----
 // Bucket g reads its n = cursor2[g] <= P8_CAP2 records at g << P8_CAP2_LOG; key' = the bucket's top d1 bits | the record's
-// key bits.  Outputs as k_dedup_lds: pad_word / pad_cf at [g << 9, + unique words) in word order, ucount[g],
-// pusable[g]; and, IN PLACE of every record, (padded slot of its word << 32 | read index) -- what the
+// key bits.  Outputs as k_dedup_lds: pad_word / pad_cf at [g << P8_CAP2_LOG, + unique words) in word order,
+// agg[g] = reads << 32 | unique words; and, IN PLACE of every record, (padded slot of its word << 32 | read index) -- what the
 // un-permute wants of a position (k_unperm_bins8), so that no separate slot array is written.
 __global__ void __launch_bounds__(256)
 k_dedup_rec(u64 *recs, const u32 *__restrict__ cursor2, u32 n_reads, u32 pb, u32 d1, u32 ibits, RecKey rk,
-            u64 *__restrict__ pad_word, uint2 *__restrict__ pad_cf, u32 *__restrict__ ucount, u32 *__restrict__ pusable, ull *ctr) {
+            u64 *__restrict__ pad_word, uint2 *__restrict__ pad_cf, u64 *__restrict__ agg, ull *ctr) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u64 lkey[LDS_SLOTS];
   __shared__ u32 lcnt[LDS_SLOTS];
@@ -201,7 +201,7 @@ k_dedup_rec(u64 *recs, const u32 *__restrict__ cursor2, u32 n_reads, u32 pb, u32
   u32 n = cursor2[g];
   if (n > P8_CAP2) n = P8_CAP2;                        // (an overfull bucket was reported by the scatter: the run is discarded)
   if (n == 0) {
-    if (threadIdx.x == 0) { ucount[g] = 0; pusable[g] = 0; }
+    if (threadIdx.x == 0) agg[g] = 0;
     return;
   }
   const size_t beg = (size_t)g << P8_CAP2_LOG;
@@ -258,7 +258,7 @@ k_dedup_rec(u64 *recs, const u32 *__restrict__ cursor2, u32 n_reads, u32 pb, u32
     pad_cf[beg + li] = make_uint2(lcnt[s], lfirst[s]);
     lfirst[s] = li;                                    // entry -> rank
   }
-  if (threadIdx.x == 0) { ucount[g] = n_uniq; pusable[g] = n; }
+  if (threadIdx.x == 0) agg[g] = ((u64)n << 32) | n_uniq;     // one scan of these gives both prefixes and both totals
   __syncthreads();
 #pragma unroll
   for (u32 q = 0; q < P8_RPT; q++) {
@@ -275,14 +275,14 @@ k_dedup_rec(u64 *recs, const u32 *__restrict__ cursor2, u32 n_reads, u32 pb, u32
 
 // padded (fixed room per bucket) -> dense unique arrays in walk order, one wave per bucket
 __global__ void __launch_bounds__(256)
-k_compact_padded8(const u64 *__restrict__ pad_word, const uint2 *__restrict__ pad_cf, const u32 *__restrict__ ucount,
-                  const u32 *__restrict__ ubase, u32 n_parts, u64 *__restrict__ s_word, u32 *__restrict__ s_slot,
+k_compact_padded8(const u64 *__restrict__ pad_word, const uint2 *__restrict__ pad_cf, const u64 *__restrict__ agg,
+                  const u64 *__restrict__ abase, u32 n_parts, u64 *__restrict__ s_word, u32 *__restrict__ s_slot,
                   u32 *__restrict__ s_cnt, u32 *__restrict__ s_first) {
   HUMID_GUARD_LAST_VGPR();
   const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const u32 lane = threadIdx.x & 63;
   if (wave >= n_parts) return;
-  const u32 beg = wave << P8_CAP2_LOG, uc = ucount[wave], ub = ubase[wave];
+  const u32 beg = wave << P8_CAP2_LOG, uc = (u32)agg[wave], ub = (u32)abase[wave];
   for (u32 j = lane; j < uc; j += 64) {
     s_word[ub + j] = pad_word[beg + j];
     s_slot[ub + j] = beg + j;

@@ -178,6 +178,30 @@ k_ps_down(In in, u64 n, const T *__restrict__ tile_base, T *out) {
   }
 }
 
+// one workgroup, n <= PS_TINY_MAX: thread t owns the items [t * per, (t + 1) * per) straight from memory
+// (a few dozen KB: the rank blocks of a bitmap, bucket counts), ONE block scan
+#define PS_TINY_MAX 16384u
+template <class T, class In>
+__global__ void __launch_bounds__(PS_SMALL_THREADS)
+// (out may be the array `in` reads: a thread reads its items before it writes them)
+k_ps_scan_tiny(In in, u32 n, T *out) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ T lds[PS_SMALL_THREADS / 64 + 1];
+  constexpr u32 PER = PS_TINY_MAX / PS_SMALL_THREADS;        // 16
+  const u32 lo = threadIdx.x * PER;
+  T v[PER];
+  T s = 0;
+#pragma unroll
+  for (u32 k = 0; k < PER; k++) { v[k] = lo + k < n ? in(lo + k) : (T)0; s += v[k]; }
+  T tot;
+  T run = ps_block_exscan<T, PS_SMALL_THREADS>(s, lds, &tot);
+#pragma unroll
+  for (u32 k = 0; k < PER; k++) {
+    if (lo + k < n) out[lo + k] = run;
+    run += v[k];
+  }
+}
+
 // scratch (in T) the scan of n items needs
 static inline size_t ps_scan_scratch_items(u64 n) { return n <= PS_SMALL_MAX ? 0 : (size_t)((n + PS_TILE - 1) / PS_TILE); }
 
@@ -185,6 +209,10 @@ static inline size_t ps_scan_scratch_items(u64 n) { return n <= PS_SMALL_MAX ? 0
 template <class T, class In>
 static inline hipError_t ps_exscan(In in, T *out, u64 n, T *scratch, hipStream_t st) {
   if (n == 0) return hipSuccess;
+  if (n <= PS_TINY_MAX) {
+    hipLaunchKernelGGL((k_ps_scan_tiny<T, In>), dim3(1), dim3(PS_SMALL_THREADS), 0, st, in, (u32)n, out);
+    return hipGetLastError();
+  }
   if (n <= PS_SMALL_MAX) {
     hipLaunchKernelGGL((k_ps_scan_small<T, In>), dim3(1), dim3(PS_SMALL_THREADS), 0, st, in, (u32)n, out);
     return hipGetLastError();

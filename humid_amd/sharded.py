@@ -294,7 +294,7 @@ class HipStageOps(Context):
         """HIP-event ms of the dominant kernels of the last count_dense / map_dense pair"""
         a, b, m = C.c_float(), C.c_float(), C.c_uint32()
         self._call(self._lib.humid_stage_kernel_ms, C.byref(a), C.byref(b), C.byref(m))
-        return dict(ms_k_insert=a.value, ms_k_map=b.value, count_mode_used=m.value)
+        return dict(ms_k_insert=a.value, ms_k_map=b.value, count_mode_used=m.value & 0xff, records8=bool(m.value >> 8))
 
     def run_exchange(self, dist, d_w, d_f, d_cid, d_keep, word_nt, distance, method):
         """the whole exchange-mode pass in ONE library call (humid_dedup_run_exchange): the stage sequence

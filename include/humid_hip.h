@@ -70,7 +70,8 @@ typedef struct humid_summary {
   float ms_k_unperm;    /* second kernel of the un-permute: k_unperm_window (0: one-kernel forms)   */
   uint32_t count_mode_used;  /* 0 = LDS tables, hashed buckets; 2 = LDS tables, word-ordered buckets (words of
                               * 33-64 nt: buckets on their top 64 bits); 1 = global HBM table (option or
-                              * fallback); 3 = sorted (words of 33-64 nt: small inputs, uneven top bits, fallback) */
+                              * fallback); 3 = sorted (words of 33-64 nt: small inputs, uneven top bits, fallback).
+                              * Bit 8 (0x100) is set on top of 2 when the count ran on 8-byte records (round 3). */
 } humid_summary;
 
 uint32_t humid_abi_version(void);
