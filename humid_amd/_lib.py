@@ -45,7 +45,7 @@ class HumidComm(C.Structure):
 
 class HumidExchangeInfo(C.Structure):
     _fields_ = [("unique_local", C.c_uint64), ("id_base", C.c_uint64), ("n_nodes", C.c_uint64),
-                ("n_pairs", C.c_uint64), ("d_unique_count", C.c_void_p), ("d_compact_edges", C.c_void_p)]
+                ("n_pairs", C.c_uint64), ("d_unique_count", C.c_void_p), ("d_unique_degree", C.c_void_p)]
 
 
 # every symbol include/humid_hip.h declares: (restype, argtypes)
@@ -165,7 +165,7 @@ def load(import_torch: bool = True):
             raise HumidLibraryError("%s does not export %s" % (SO_PATH, name)) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.humid_abi_version() != 3:
+    if lib.humid_abi_version() != 4:
         raise HumidLibraryError("ABI version mismatch")
     _LIB = lib
     return lib

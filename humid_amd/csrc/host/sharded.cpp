@@ -305,17 +305,14 @@ bool run_rank(Rank &k) {
       std::lock_guard<std::mutex> lk(g.mu);
       for (auto &kv : m) g.hist_counts[kv.first] += kv.second;
     }
-    if (r == 0) {                                                                       // neigh.dat: degree of every leaf
-      std::vector<uint32_t> deg(info.n_nodes, 0);
-      if (info.n_pairs) {
-        std::vector<uint64_t> he(info.n_pairs);
-        STEP(k.hip_ok(hipMemcpyAsync(he.data(), info.d_compact_edges, info.n_pairs * 8, hipMemcpyDeviceToHost, st), "hipMemcpy (edges)"));
-        STEP(k.hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"));
-        for (uint64_t e : he) { deg[e >> 32]++; deg[e & 0xffffffffull]++; }
-      }
+    if (info.unique_local) {                                                            // neigh.dat: degree of every own leaf
+      std::vector<uint32_t> dg(info.unique_local);
+      STEP(k.hip_ok(hipMemcpyAsync(dg.data(), info.d_unique_degree, info.unique_local * 4, hipMemcpyDeviceToHost, st), "hipMemcpy (degrees)"));
+      STEP(k.hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"));
+      std::map<uint64_t, uint64_t> m;
+      for (uint32_t v : dg) m[v]++;
       std::lock_guard<std::mutex> lk(g.mu);
-      for (uint32_t v : deg) g.hist_neigh[v]++;
-      if (sum.unique > info.n_nodes) g.hist_neigh[0] += sum.unique - info.n_nodes;
+      for (auto &kv : m) g.hist_neigh[kv.first] += kv.second;
     }
   }
   STEP(k.hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"));

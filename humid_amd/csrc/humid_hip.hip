@@ -38,6 +38,7 @@
 #include "kernels_cluster.hip.h"
 #include "kernels_cgraph.hip.h"
 #include "kernels_map.hip.h"
+#include "kernels_xchg.hip.h"
 #include "kernels_wide.hip.h"
 
 // --------------------------------------------------------------------------------
@@ -116,6 +117,9 @@ struct humid_ctx {
   bool cg_valid = false;            // the last graph stage left its results in the cg_* arrays ...
   bool cg_expanded = false;         // ... and the per-unique-word view of them has been built (accessors)
   u32 cg_M = 0, cg_nblocks = 0;
+  // owner-local clustering of the exchange pass (kernels_xchg.hip.h): records by destination, interior / crossing /
+  // flagged-interior records, the forest over own leaves, crossing-creator bitmap and ids, own results
+  DBuf xo_send, xo_int, xo_cross, xo_sel, xo_selall, xo_parent, xo_flag, xo_xroot, xo_xcbits, xo_xcblk, xo_xcid, xo_xcall, xo_ldeg, xo_cnt;
   DBuf p8_a, p8_b, p8_cur, p8_status;               // 8-byte records of the count stage: level-1 output, level-2 output (kernels_part8.hip.h)
   bool use_rec8 = true;             // option "records8": 0 = always the 12-byte (key, read) pairs of kernels_part.hip.h
   bool last_rec8 = false;           // the last count ran on records: positions are (bucket << 9 | j), the un-permute reads p8_b
@@ -1332,6 +1336,7 @@ struct CgSource {
   EdgeRegs er;                 // pairs in id space: regions + far list (recs == null); set to the compact pairs on return
   const ulonglong2 *recs;      // or: pair records {a << 32 | b, count a | count b << 32}
   u32 n_recs;
+  const RecSegs *segs = nullptr;   // or: several record arrays (the multi-GPU pass: interior, crossing, flagged-interior of the others)
   const u32 *cnt_by_id;        // counts by id (with plain pairs)
   u32 n_ids;                   // id space = bits of the bitmap c->cg_bits (zeroed, then marked, by the caller)
   u64 pairs_bound;             // no more pairs than this can be in the source
@@ -1374,7 +1379,16 @@ static int cg_build(humid_ctx *c, CgSource &src, u32 method, CgStatus &out) {
   hipLaunchKernelGGL(k_nodes_init, dim3(blocks_for(n_words)), dim3(256), 0, st, br, n_words, src.cnt_by_id, c->cg_nodes.as<u32>(),
                      c->cg_ncnt.as<u32>(), g.deg, g.parent, g.csize, c->cg_curs.as<u32>(), n_blk);
   const bool by_count = (method & 1) == 0;
-  if (src.recs) {
+  if (src.segs) {
+    const u32 n_all = src.segs->first[REC_SEGS];
+    u32 n_max = 1;
+    for (u32 q = 0; q < REC_SEGS; q++) n_max = std::max(n_max, src.segs->n[q]);
+    ENSURE(c->cg_far, ((size_t)n_all + 1) * 8);
+    hipLaunchKernelGGL(k_segs_relabel, dim3(std::min<u32>(blocks_for(n_max), 4096), REC_SEGS), dim3(256), 0, st, *src.segs, src.n_ids, br,
+                       c->cg_far.as<u64>(), c->cg_ncnt.as<u32>(), g.deg, g.parent, by_count);
+    src.er.far = c->cg_far.as<u64>();
+    src.er.n_far = n_all;
+  } else if (src.recs) {
     ENSURE(c->cg_far, ((size_t)src.n_recs + 1) * 8);
     if (src.n_recs)
       hipLaunchKernelGGL(k_records_relabel, dim3(blocks_for(src.n_recs)), dim3(256), 0, st, src.recs, src.n_recs, src.n_ids, br,
@@ -2171,7 +2185,8 @@ void humid_ctx_destroy(humid_ctx *c) {
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->in_bases, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
                   &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->big_runs, &c->small_roots, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_heads, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles, &c->xr_hist, &c->xr_recv, &c->xr_eloc, &c->xr_got, &c->xr_eall, &c->xr_ret, &c->xr_heads, &c->xr_send, &c->xr_zero,
-                  &c->p8_a, &c->p8_b, &c->p8_cur, &c->p8_status, &c->cg_edges, &c->cg_cur, &c->cg_far, &c->cg_bits, &c->cg_nbits, &c->cg_blk, &c->cg_nblk, &c->cg_nodes, &c->cg_ncnt, &c->cg_deg,
+                  &c->xo_send, &c->xo_int, &c->xo_cross, &c->xo_sel, &c->xo_selall, &c->xo_parent, &c->xo_flag, &c->xo_xroot, &c->xo_xcbits, &c->xo_xcblk,
+                  &c->xo_xcid, &c->xo_xcall, &c->xo_ldeg, &c->xo_cnt, &c->p8_a, &c->p8_b, &c->p8_cur, &c->p8_status, &c->cg_edges, &c->cg_cur, &c->cg_far, &c->cg_bits, &c->cg_nbits, &c->cg_blk, &c->cg_nblk, &c->cg_nodes, &c->cg_ncnt, &c->cg_deg,
                   &c->cg_off, &c->cg_idx, &c->cg_parent, &c->cg_csize, &c->cg_curs, &c->cg_cl_of, &c->cg_maxleaf, &c->cg_cl_size,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
@@ -2828,36 +2843,237 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
       }
     }
   }
-  u64 e_counts[MAX_RANKS];
-  TRY(x_host_gather(c, cm, &e_mine, 8, e_counts));
-  u64 E = 0;
-  for (u32 q = 0; q < P; q++) E += e_counts[q];
-  const u64 *d_eall = c->xr_eloc.as<u64>();
-  if (moves && E) {
-    ENSURE(c->xr_eall, E * 16 + 16);
-    ENSURE(c->xr_eloc, 16);
-    TRY(x_exchange(c, cm, c->xr_eloc.p, e_counts, true, c->xr_eall.p, e_counts, 16));
-    d_eall = c->xr_eall.as<u64>();
+  // ---- 5. every pair to the owner of its ends; pairs with two owners, and the components they touch, to everybody ----
+  const bool by_count = (method & 1) == 0;
+  if (u_total + 8 > 0xffffffffull) return fail(c, HUMID_E_OVERFLOW, "more than 2^32-10 unique words in total");
+  if (e_mine > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "%llu neighbour pairs found by one rank", (ull)e_mine);
+  IdRanges idr;
+  {
+    u64 at = 0;
+    for (u32 q = 0; q <= MAX_RANKS; q++) { idr.b[q] = (u32)at; if (q < P) at += metas[3 * q]; }
+  }
+  ENSURE(c->cg_cur, (size_t)(ER_REGIONS * ER_STRIDE + 8) * 4);
+  ENSURE(c->xo_cnt, 64 * 4);
+  u32 *dcnt = c->xo_cnt.as<u32>();                                  // [0, P]: records per destination; [32, 32 + P]: scatter cursors
+  u32 *x_bad = c->cg_cur.as<u32>() + ER_REGIONS * ER_STRIDE;
+  {
+    ZeroList z;
+    memset(&z, 0, sizeof z);
+    z.p[0] = c->cg_cur.as<u32>(); z.n[0] = ER_REGIONS * ER_STRIDE + 8;
+    z.p[1] = dcnt; z.n[1] = 64;
+    hipLaunchKernelGGL(k_zero_many, dim3(8), dim3(256), 0, st, z);
+  }
+  RecRegs mine;                                                      // this rank's discoveries: one dense list
+  mine.e = nullptr; mine.cap_r = 0; mine.cur = c->cg_cur.as<u32>();
+  mine.far = (const ulonglong2 *)c->xr_eloc.p; mine.n_far = (u32)e_mine;
+  u64 dest_cnt[MAX_RANKS + 1] = {0};
+  const u32 cgx = (u32)std::min<u64>(std::max<u64>(blocks_for(e_mine), 1), 2048);
+  if (P == 1) dest_cnt[0] = e_mine;
+  else if (e_mine) {
+    std::vector<u32> h(P + 1);
+    hipLaunchKernelGGL(k_rec_dest_count, dim3(cgx, ER_REGIONS + 1), dim3(256), 0, st, mine, idr, P, dcnt);
+    HIPCHK(hipMemcpyAsync(h.data(), dcnt, (P + 1) * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (u32 q = 0; q <= P; q++) dest_cnt[q] = h[q];
+  }
+  u64 all_dest[MAX_RANKS * (MAX_RANKS + 1)];
+  TRY(x_host_gather(c, cm, dest_cnt, (P + 1) * 8, all_dest));
+  u64 E = 0, X_total = 0, n_int = 0, int_from[MAX_RANKS], cross_from[MAX_RANKS], int_to[MAX_RANKS];
+  for (u32 q = 0; q < P; q++) {
+    for (u32 dd = 0; dd <= P; dd++) E += all_dest[(size_t)q * (P + 1) + dd];
+    int_from[q] = all_dest[(size_t)q * (P + 1) + r];
+    cross_from[q] = all_dest[(size_t)q * (P + 1) + P];
+    int_to[q] = dest_cnt[q];
+    n_int += int_from[q];
+    X_total += cross_from[q];
+  }
+  if (n_int > 0x7fffffffull || X_total > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "too many neighbour pairs for one rank");
+  // destination-major copy of this rank's records (one rank: the list as it stands)
+  const ulonglong2 *sendbuf = (const ulonglong2 *)c->xr_eloc.p;
+  u64 send_base[MAX_RANKS + 2] = {0};
+  for (u32 q = 0; q <= P; q++) send_base[q + 1] = send_base[q] + dest_cnt[q];
+  if (P > 1 && e_mine) {
+    ENSURE(c->xo_send, e_mine * 16 + 16);
+    IdRanges base;
+    for (u32 q = 0; q <= MAX_RANKS; q++) base.b[q] = (u32)send_base[q <= P ? q : P + 1];
+    hipLaunchKernelGGL(k_rec_dest_scatter, dim3(cgx, ER_REGIONS + 1), dim3(256), 0, st, mine, idr, P, base, dcnt + 32,
+                       c->xo_send.as<ulonglong2>());
+    sendbuf = c->xo_send.as<ulonglong2>();
+  }
+  const ulonglong2 *d_int = sendbuf, *d_cross = nullptr;             // interior records of this rank, crossing records of all
+  if (moves) {
+    ENSURE(c->xo_int, n_int * 16 + 16);
+    ENSURE(c->xo_cross, X_total * 16 + 16);
+    if (E - X_total) TRY(x_exchange(c, cm, sendbuf, int_to, false, c->xo_int.p, int_from, 16));
+    d_int = c->xo_int.as<ulonglong2>();
+    if (X_total) {
+      u64 xs[MAX_RANKS];
+      for (u32 q = 0; q < P; q++) xs[q] = dest_cnt[P];
+      TRY(x_exchange(c, cm, sendbuf + send_base[P], xs, true, c->xo_cross.p, cross_from, 16));
+      d_cross = c->xo_cross.as<ulonglong2>();
+    }
+  }
+  // the interior pairs of the components a crossing pair touches: to everybody as well
+  u64 k_mine = 0, k_from[MAX_RANKS] = {0}, K_total = 0;
+  const ulonglong2 *d_kall = nullptr;
+  if (X_total) {
+    if (u_local) {
+      ENSURE(c->xo_parent, (size_t)u_local * 4);
+      ENSURE(c->xo_flag, (size_t)u_local + 16);
+      ENSURE(c->xo_sel, n_int * 16 + 16);
+      hipLaunchKernelGGL(k_iota, dim3(blocks_for(u_local)), dim3(256), 0, st, c->xo_parent.as<u32>(), (u32)u_local);
+      HIPCHK(hipMemsetAsync(c->xo_flag.p, 0, (size_t)u_local, st));
+      if (n_int)
+        hipLaunchKernelGGL(k_union_records, dim3(blocks_for(n_int)), dim3(256), 0, st, d_int, (u32)n_int, (u32)goff, (u32)u_local,
+                           c->xo_parent.as<u32>(), by_count, x_bad);
+      hipLaunchKernelGGL(k_flag_crossing, dim3(blocks_for(X_total)), dim3(256), 0, st, d_cross, (u32)X_total, (u32)goff, (u32)u_local,
+                         (const u32 *)c->xo_parent.as<u32>(), c->xo_flag.as<u8>(), by_count);
+      if (n_int) {
+        hipLaunchKernelGGL(k_select_flagged<false>, dim3(std::min<u32>(blocks_for(n_int), 1024)), dim3(256), 0, st, d_int, (u32)n_int,
+                           (u32)goff, (const u32 *)c->xo_parent.as<u32>(), (const u8 *)c->xo_flag.as<u8>(), dcnt + 48,
+                           c->xo_sel.as<ulonglong2>());
+        u32 h = 0;
+        HIPCHK(hipMemcpyAsync(&h, dcnt + 48, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        k_mine = h;
+      }
+    }
+    TRY(x_host_gather(c, cm, &k_mine, 8, k_from));
+    for (u32 q = 0; q < P; q++) K_total += k_from[q];
+    if (K_total > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "too many neighbour pairs for one rank");
+    if (K_total) {
+      ENSURE(c->xo_selall, K_total * 16 + 16);
+      ENSURE(c->xo_sel, 16);
+      u64 ks[MAX_RANKS];
+      for (u32 q = 0; q < P; q++) ks[q] = k_mine;
+      TRY(x_exchange(c, cm, c->xo_sel.p, ks, true, c->xo_selall.p, k_from, 16));
+      d_kall = c->xo_selall.as<ulonglong2>();
+    }
   }
 
-  // ---- 5. compact graph over the pairs' endpoints (replicated); ids by closed-form prefix counts ----
-  const u32 *nodes = nullptr, *node_cnt = nullptr, *ccid = nullptr;
-  const u64 *cedges = nullptr;
-  const u8 *cismax = nullptr;
-  u64 M = 0, C_c = 0;
+  // ---- 5b. ONE compact graph over global unique indices: own pairs + crossing pairs + the others' flagged pairs ----
+  RecSegs segs;
+  memset(&segs, 0, sizeof segs);
+  {
+    u64 kb = 0;                                                      // records of the lower ranks in the gathered flagged list
+    for (u32 q = 0; q < r; q++) kb += k_from[q];
+    segs.p[0] = d_int; segs.n[0] = (u32)n_int;
+    segs.p[1] = d_cross; segs.n[1] = (u32)X_total;
+    segs.p[2] = d_kall; segs.n[2] = (u32)kb;
+    segs.p[3] = d_kall ? d_kall + kb + k_mine : nullptr; segs.n[3] = (u32)(K_total - kb - k_mine);
+    for (u32 q = 0; q < REC_SEGS; q++) segs.first[q + 1] = segs.first[q] + segs.n[q];
+  }
+  const u64 n_recs_all = segs.first[REC_SEGS];
+  const u32 n_ids = (u32)u_total;
+  const u32 nw = (((n_ids + 31) / 32) + 7) & ~7u, nblk = nw / 8;
+  c->cg_valid = false;
+  c->cg_nblocks = nblk;
+  ENSURE(c->cg_bits, (size_t)nw * 4);
+  ENSURE(c->cg_nbits, (size_t)nw * 4);
+  ENSURE(c->xo_xcbits, (size_t)nw * 4);
+  ENSURE(c->xo_xcblk, ((size_t)nblk + 1) * 4);
+  {
+    ZeroList z;
+    memset(&z, 0, sizeof z);
+    z.p[0] = c->cg_bits.as<u32>(); z.n[0] = nw;
+    z.p[1] = c->cg_nbits.as<u32>(); z.n[1] = nw;
+    z.p[2] = X_total ? c->xo_xcbits.as<u32>() : nullptr; z.n[2] = X_total ? nw : 0;
+    z.p[3] = (u32 *)&c->d_ctr[CTR_EDGES]; z.n[3] = 2 * (CTR_EOVER - CTR_EDGES + 1);
+    z.p[4] = c->cg_cur.as<u32>(); z.n[4] = ER_REGIONS * ER_STRIDE;   // (not the bad flag behind them)
+    hipLaunchKernelGGL(k_zero_many, dim3(64), dim3(256), 0, st, z);
+  }
   humid_summary gs;
   memset(&gs, 0, sizeof gs);
-  if (E) {
-    TRY(compact_nodes_impl(c, d_eall, E, 2, u_total, &nodes, &M, &cedges, &node_cnt));
-    // (the graph runs over the compact node list: its "words" are only carried for the accessors)
-    TRY(humid_stage_graph_edges(c, (const u64 *)nodes, node_cnt, M, cedges, E, head_nt, d, method, &ccid, &cismax, &gs));   // (the pairs are given: the word length only labels the context)
-    C_c = gs.clusters;
+  CgStatus cgs;
+  u64 M_mine = 0;
+  if (n_recs_all) {
+    u32 n_max = 1;
+    for (u32 q = 0; q < REC_SEGS; q++) n_max = std::max(n_max, segs.n[q]);
+    hipLaunchKernelGGL(k_mark_segs, dim3(std::min<u32>(blocks_for(n_max), 4096), REC_SEGS), dim3(256), 0, st, segs, n_ids,
+                       c->cg_bits.as<u32>(), x_bad);
+    CgSource src;
+    src.er.e = nullptr; src.er.cap_r = 0; src.er.cur = c->cg_cur.as<u32>(); src.er.far = nullptr; src.er.n_far = 0;
+    src.recs = nullptr; src.n_recs = 0; src.segs = &segs; src.cnt_by_id = nullptr; src.n_ids = n_ids;
+    src.pairs_bound = n_recs_all;
+    HIPCHK(hipEventRecord(c->ev[2], st));
+    TRY(cg_build(c, src, method, cgs));
+    {
+      u32 h_bad = 0;
+      HIPCHK(hipMemcpyAsync(&h_bad, x_bad, 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      if (h_bad) return fail(c, HUMID_E_INVALID, "a pair record with an index outside the unique words");
+    }
+    M_mine = cgs.M;
+    TRY(cg_cluster_rest(c, n_ids, cgs.M, cgs.Mbig, method));
+  } else {
+    ENSURE(c->cg_blk, ((size_t)nblk + 1) * 4);
+    ENSURE(c->cg_nblk, ((size_t)nblk + 1) * 4);
+    HIPCHK(hipMemsetAsync(c->cg_blk.p, 0, ((size_t)nblk + 1) * 4, st));
+    HIPCHK(hipMemsetAsync(c->cg_nblk.p, 0, ((size_t)nblk + 1) * 4, st));
   }
-  const u64 clusters = u_total - M + C_c;
+  const GraphArrays cg = cg_arrays(c);
+  const BitRank br_in{c->cg_bits.as<u32>(), c->cg_blk.as<u32>()}, br_nc{c->cg_nbits.as<u32>(), c->cg_nblk.as<u32>()};
+  BitRank br_xc{c->xo_xcbits.as<u32>(), c->xo_xcblk.as<u32>()};
+
+  // ---- 5c. cluster ids: creators before a leaf = the lower ranks' creators + its owner's creators before it ----
+  u64 C_x = 0;
+  if (X_total && M_mine) {
+    ENSURE(c->xo_xroot, (size_t)M_mine + 16);
+    HIPCHK(hipMemsetAsync(c->xo_xroot.p, 0, (size_t)M_mine, st));
+    hipLaunchKernelGGL(k_flag_xroots, dim3(std::min<u32>(blocks_for(X_total), 4096)), dim3(256), 0, st, segs, 1u, n_ids, br_in,
+                       (const u32 *)cg.parent, c->xo_xroot.as<u8>(), by_count);
+    hipLaunchKernelGGL(k_xcreator_bits, dim3(blocks_for(M_mine)), dim3(256), 0, st, (const u32 *)cg.cl_of, (const u32 *)cg.parent,
+                       (const u8 *)c->xo_xroot.as<u8>(), (const u32 *)c->cg_nodes.as<u32>(), (u32)M_mine, c->xo_xcbits.as<u32>());
+  }
+  if (X_total) {
+    hipLaunchKernelGGL(k_bits_blocks, dim3(blocks_for((u64)nblk + 1)), dim3(256), 0, st, c->xo_xcbits.as<u32>(), nblk, c->xo_xcblk.as<u32>());
+    TRY(exscan_u32(c, c->xo_xcblk.as<u32>(), c->xo_xcblk.as<u32>(), (u64)nblk + 1));
+  }
+  hipLaunchKernelGGL(k_own_totals, dim3(1), dim3(64), 0, st, br_nc, br_in, (u32)goff, (u32)u_local, dcnt + 56);
+  HIPCHK(hipGetLastError());
+  TRY(read_counters(c, dcnt + 56, dcnt + 57, X_total ? c->xo_xcblk.as<u32>() + nblk : nullptr));
+  u64 tot_mine[4] = {c->h_ctr[CTR_N - 1] & 0xffffffffull, c->h_ctr[CTR_N - 2] & 0xffffffffull,
+                     X_total ? (c->h_ctr[CTR_N - 3] & 0xffffffffull) : 0ull, u_local};   // non-creators, nodes, crossing creators, leaves
+  u64 tot_all[4 * MAX_RANKS];
+  TRY(x_host_gather(c, cm, tot_mine, sizeof tot_mine, tot_all));
+  u64 creators_before = 0, clusters = 0, M = 0;
+  C_x = tot_mine[2];
+  for (u32 q = 0; q < P; q++) {
+    const u64 cr = tot_all[4 * q + 3] - tot_all[4 * q];
+    if (q < r) creators_before += cr;
+    clusters += cr;
+    M += tot_all[4 * q + 1];
+    if (tot_all[4 * q + 2] != C_x) return fail(c, HUMID_E_INVALID, "internal: the ranks disagree on the crossing clusters (%llu vs %llu)", (ull)tot_all[4 * q + 2], (ull)C_x);
+  }
   if (clusters >= (1ull << 31)) return fail(c, HUMID_E_OVERFLOW, "cluster ids exceed 31 bits");
+  const u32 *xcid_all = nullptr;
+  if (C_x) {
+    ENSURE(c->xo_xcid, C_x * 4 + 16);
+    hipLaunchKernelGGL(k_xcreator_ids, dim3(blocks_for(nw)), dim3(256), 0, st, br_xc, nw, (u32)goff, (u32)u_local, (u32)creators_before,
+                       br_nc, c->xo_xcid.as<u32>());
+    xcid_all = c->xo_xcid.as<u32>();
+    if (moves) {
+      ENSURE(c->xo_xcall, (size_t)P * C_x * 4 + 16);
+      u64 cs[MAX_RANKS];
+      for (u32 q = 0; q < P; q++) cs[q] = C_x;
+      TRY(x_exchange(c, cm, c->xo_xcid.p, cs, true, c->xo_xcall.p, cs, 4));
+      hipLaunchKernelGGL(k_max_rows, dim3(blocks_for(C_x)), dim3(256), 0, st, (const u32 *)c->xo_xcall.as<u32>(), P, (u32)C_x,
+                         c->xo_xcid.as<u32>());
+    }
+  }
   const u32 *l_cid = nullptr;
   const u8 *l_ismax = nullptr;
-  TRY(humid_stage_exchange_ids(c, nodes, ccid, cismax, M, C_c, goff, u_local, &l_cid, &l_ismax));
+  if (u_local) {
+    ENSURE(c->x_lcid, (size_t)u_local * 4);
+    ENSURE(c->x_lismax, (size_t)u_local);
+    ENSURE(c->xo_ldeg, (size_t)u_local * 4);
+    hipLaunchKernelGGL(k_own_results, dim3(blocks_for(u_local)), dim3(256), 0, st, br_in, br_nc, br_xc, xcid_all,
+                       (const u32 *)c->cg_nodes.as<u32>(), (const u32 *)cg.cl_of, (const u32 *)cg.maxleaf, (const u32 *)cg.deg, (u32)goff,
+                       (u32)u_local, (u32)creators_before, c->x_lcid.as<u32>(), c->x_lismax.as<u8>(), c->xo_ldeg.as<u32>());
+    HIPCHK(hipGetLastError());
+    l_cid = c->x_lcid.as<u32>();
+    l_ismax = c->x_lismax.as<u8>();
+  }
 
   // ---- 6. per-read results at the owner, back to the home shards ----
   const u32 *packed = nullptr;
@@ -2888,7 +3104,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
     info->n_nodes = M;
     info->n_pairs = E;
     info->d_unique_count = lc;
-    info->d_compact_edges = cedges;
+    info->d_unique_degree = u_local ? c->xo_ldeg.as<u32>() : nullptr;
   }
   return HUMID_OK;
 }

@@ -42,7 +42,7 @@ extern "C" {
 #define HUMID_METHOD_DIRECTIONAL 0u  /* default; src/cluster.cc:82-87               */
 #define HUMID_METHOD_MAXIMUM     1u  /* -x;      src/cluster.cc:72-80               */
 
-#define HUMID_ABI_VERSION 3u   /* 3: humid_dedup_run_exchange, humid_comm, humid_shm_* (round 2); 2: humid_dedup_run_bases, humid_stage_route ... */
+#define HUMID_ABI_VERSION 4u   /* 4: humid_exchange_info.d_unique_degree replaces d_compact_edges (owner-local clustering, round 3); 3: humid_dedup_run_exchange, humid_comm, humid_shm_* (round 2); 2: humid_dedup_run_bases, humid_stage_route ... */
 
 typedef struct humid_ctx humid_ctx;   /* device workspace + stream; not thread-safe */
 
@@ -393,10 +393,11 @@ typedef struct humid_comm {
 typedef struct humid_exchange_info {
   uint64_t unique_local;             /* unique words this rank owns (its value range)             */
   uint64_t id_base;                  /* walk index of the first of them                           */
-  uint64_t n_nodes;                  /* unique words with neighbours, all ranks (compact graph)   */
+  uint64_t n_nodes;                  /* unique words with neighbours, all ranks                   */
   uint64_t n_pairs;                  /* neighbour pairs, all ranks                                */
   const uint32_t *d_unique_count;    /* device: counts of this rank's unique words (counts.dat)   */
-  const uint64_t *d_compact_edges;   /* device: the pairs over compact node indices (a << 32 | b) */
+  const uint32_t *d_unique_degree;   /* device: neighbours of every one of them (neigh.dat); since ABI 4: every rank clusters
+                                      * its own components (+ the replicated ones that cross value ranges), no rank holds all pairs */
 } humid_exchange_info;
 int humid_dedup_run_exchange(humid_ctx *ctx, const humid_comm *comm, const uint64_t *d_words,
                              const uint8_t *d_filtered, uint64_t n_local, uint32_t word_nt,

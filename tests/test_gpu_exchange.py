@@ -337,3 +337,38 @@ def test_exchange_wide_words(P, n, d):
         assert used == "exchange"
         assert np.array_equal(cid, ocid[offs[r]:offs[r + 1]]) and np.array_equal(keep, okeep[offs[r]:offs[r + 1]])
         assert s["edges"] == osum["edges"] and s["clusters"] == osum["clusters"] and s["unique"] == osum["unique"]
+
+
+@pytest.mark.parametrize("P,method", [(4, 0), (4, 1), (8, 0), (3, 0)])
+def test_exchange_components_spanning_three_and_more_ranges(P, method):
+    """owner-local clustering (round 3): clusters whose leaves lie in three and four value ranges -- families whose
+    members differ in the FIRST nucleotides, the ones that decide the owner -- with count ladders the
+    directional method climbs and floods along (64 > 24 > 9 > 3), flat ones it does not cross, and chains
+    through the second nucleotide; ids, keep flags and all summary counts against the oracle"""
+    rng = np.random.default_rng(100 + P)
+    n_fam = 3000
+    base = rng.integers(0, 1 << 48, size=n_fam, dtype=np.uint64)
+    words = []
+    for f in range(n_fam):
+        ladder = (64, 24, 9, 3) if f % 3 else (10, 10, 10, 10)
+        for k in range(4):                                   # the first nucleotide: A C G T -> four quarters of the walk
+            w = (int(base[f]) & ~(3 << 46)) | (k << 46)
+            words += [w] * ladder[k]
+            if f % 5 == 0 and k == 3:                        # a tail through the second nucleotide
+                w2 = w ^ (1 << 44)
+                words += [w2]
+    words = np.array(words, dtype=np.uint64)
+    words = words[rng.permutation(len(words))]
+    filt = (rng.random(len(words)) < 0.002).astype(np.uint8)
+    # the oracle's clusters really do span the ranges
+    p = orc.Pipeline(24)
+    p.read_data(words, filt)
+    p.find_hamming_neighbours(1)
+    p.find_clusters(bool(method))
+    lv = p.leaves()
+    first_nt = (lv["word"] >> np.uint64(46)).astype(np.int64)
+    spans = {}
+    for cid_, nt in zip(lv["cluster_id"].tolist(), first_nt.tolist()):
+        spans.setdefault(cid_, set()).add(nt)
+    assert sum(1 for v in spans.values() if len(v) >= 3) >= 500
+    check(P, words, filt, 24, 1, method)
