@@ -119,6 +119,8 @@ struct humid_ctx {
   u32 cg_M = 0, cg_nblocks = 0;
   // owner-local clustering of the exchange pass (kernels_xchg.hip.h): records by destination, interior / crossing /
   // flagged-interior records, the forest over own leaves, crossing-creator bitmap and ids, own results
+  DBuf xo_regs, xo_inv;             // record regions of the pair search; routed position of every read
+  u64 xr_ecap = 0;                  // room for pair records in the regions (remembered from pass to pass)
   DBuf xo_send, xo_int, xo_cross, xo_sel, xo_selall, xo_parent, xo_flag, xo_xroot, xo_xcbits, xo_xcblk, xo_xcid, xo_xcall, xo_ldeg, xo_cnt;
   DBuf p8_a, p8_b, p8_cur, p8_status;               // 8-byte records of the count stage: level-1 output, level-2 output (kernels_part8.hip.h)
   bool use_rec8 = true;             // option "records8": 0 = always the 12-byte (key, read) pairs of kernels_part.hip.h
@@ -2185,7 +2187,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->in_bases, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
                   &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->big_runs, &c->small_roots, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_heads, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles, &c->xr_hist, &c->xr_recv, &c->xr_eloc, &c->xr_got, &c->xr_eall, &c->xr_ret, &c->xr_heads, &c->xr_send, &c->xr_zero,
-                  &c->xo_send, &c->xo_int, &c->xo_cross, &c->xo_sel, &c->xo_selall, &c->xo_parent, &c->xo_flag, &c->xo_xroot, &c->xo_xcbits, &c->xo_xcblk,
+                  &c->xo_regs, &c->xo_inv, &c->xo_send, &c->xo_int, &c->xo_cross, &c->xo_sel, &c->xo_selall, &c->xo_parent, &c->xo_flag, &c->xo_xroot, &c->xo_xcbits, &c->xo_xcblk,
                   &c->xo_xcid, &c->xo_xcall, &c->xo_ldeg, &c->xo_cnt, &c->p8_a, &c->p8_b, &c->p8_cur, &c->p8_status, &c->cg_edges, &c->cg_cur, &c->cg_far, &c->cg_bits, &c->cg_nbits, &c->cg_blk, &c->cg_nblk, &c->cg_nodes, &c->cg_ncnt, &c->cg_deg,
                   &c->cg_off, &c->cg_idx, &c->cg_parent, &c->cg_csize, &c->cg_curs, &c->cg_cl_of, &c->cg_maxleaf, &c->cg_cl_size,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
@@ -2803,24 +2805,101 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
     e_mine += n_rec;
     return HUMID_OK;
   };
-  if (d > 0 && u_total > 1) {
-    u32 n_combos = 0, pb2 = 0;
-    TRY(humid_stage_plan_info(c, n, d, u_total, &n_combos, &pb2));
-    const ComboPlan wplan = make_plan(n, d, u_total, c->force_segments);      // (the wide helpers take the plan itself)
-    const u64 ibytes = wide ? sizeof(Item3) : 16;
-    const u64 *rec = nullptr;
-    u64 n_rec = 0;
-    if (u_local > 1) {
-      if (wide) TRY(pairs_keyed_wide(c, lw, (u32)u_local, false, goff, lc, wplan, 0, d, &rec, &n_rec));
-      else TRY(humid_stage_pairs_keyed(c, lw, u_local, 0, goff, lc, n, d, u_total, 0, &rec, &n_rec));
-      TRY(append_pairs(rec, n_rec));
+  // (rounds 1-2: count, scan, host wait, fill, records, copy -- per combination.  Kept as the road for inputs with
+  // large buckets and for a pass whose record regions overflowed.)
+  auto discover_dense = [&]() -> int {
+    if (d > 0 && u_total > 1) {
+      u32 n_combos = 0, pb2 = 0;
+      TRY(humid_stage_plan_info(c, n, d, u_total, &n_combos, &pb2));
+      const ComboPlan wplan = make_plan(n, d, u_total, c->force_segments);      // (the wide helpers take the plan itself)
+      const u64 ibytes = wide ? sizeof(Item3) : 16;
+      const u64 *rec = nullptr;
+      u64 n_rec = 0;
+      if (u_local > 1) {
+        if (wide) TRY(pairs_keyed_wide(c, lw, (u32)u_local, false, goff, lc, wplan, 0, d, &rec, &n_rec));
+        else TRY(humid_stage_pairs_keyed(c, lw, u_local, 0, goff, lc, n, d, u_total, 0, &rec, &n_rec));
+        TRY(append_pairs(rec, n_rec));
+      }
+      for (u32 cb = 1; cb < n_combos; cb++) {
+        const u64 *items = nullptr;
+        u64 sc[MAX_RANKS] = {0}, all_sc[MAX_RANKS * MAX_RANKS], rc[MAX_RANKS];
+        if (wide) {
+          const Item3 *it3 = nullptr;
+          TRY(combo_route_wide(c, (const W2 *)lw, lc, (u32)u_local, goff, wplan, cb, P, &it3, sc));
+          items = (const u64 *)it3;
+        } else
+          TRY(humid_stage_combo_route(c, lw, lc, u_local, goff, n, d, u_total, cb, P, &items, sc));
+        TRY(x_host_gather(c, cm, sc, P * 8, all_sc));
+        u64 n_got = 0;
+        for (u32 q = 0; q < P; q++) { rc[q] = all_sc[(size_t)q * P + r]; n_got += rc[q]; }
+        if (n_got > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "%llu unique words arrive at rank %u for one combination", (ull)n_got, r);
+        u64 items_all = 0;
+        for (u32 q = 0; q < P * P; q++) items_all += all_sc[q];
+        const u64 *got = items;
+        if (moves && items_all) {
+          ENSURE(c->xr_got, n_got * ibytes + 32);
+          TRY(x_exchange(c, cm, items, sc, false, c->xr_got.p, rc, ibytes));
+          got = c->xr_got.as<u64>();
+        }
+        if (n_got > 1) {
+          if (wide) TRY(pairs_keyed_wide(c, got, (u32)n_got, true, 0, nullptr, wplan, cb, d, &rec, &n_rec));
+          else TRY(humid_stage_pairs_keyed(c, got, n_got, 1, 0, nullptr, n, d, u_total, cb, &rec, &n_rec));
+          TRY(append_pairs(rec, n_rec));
+        }
+      }
     }
-    for (u32 cb = 1; cb < n_combos; cb++) {
+    return HUMID_OK;
+  };
+  // Round 3: the search APPENDS its pairs as records (k_pairs_records: one walk per position, one global atomic
+  // per workgroup, 64 append regions) -- no count / scan / fill phases and no host wait per combination.
+  const bool by_count = (method & 1) == 0;
+  RecRegs mine;                                                      // this rank's discoveries
+  mine.e = nullptr; mine.cap_r = 0; mine.cur = nullptr; mine.far = nullptr; mine.n_far = 0;
+  ENSURE(c->cg_cur, (size_t)(ER_REGIONS * ER_STRIDE + 8) * 4);
+  ENSURE(c->xo_cnt, 64 * 4);
+  ENSURE(c->small, 64);
+  u32 *dcnt = c->xo_cnt.as<u32>();                                  // [0, P]: records per destination; [32, 32 + P]: scatter cursors; 48: flagged; 56..: totals
+  bool use_regions = !c->edit && d > 0 && u_total > 1 && c->walk_max > 0;
+  bool flagged_mine = false;                                         // a region overflowed / a bucket beyond the walk: this pass takes the dense road
+  auto zero_discovery = [&]() -> int {
+    ZeroList z;
+    memset(&z, 0, sizeof z);
+    z.p[0] = c->cg_cur.as<u32>(); z.n[0] = ER_REGIONS * ER_STRIDE + 8;
+    z.p[1] = dcnt; z.n[1] = 64;
+    z.p[2] = (u32 *)&c->d_ctr[CTR_EDGES]; z.n[2] = 2 * (CTR_EOVER - CTR_EDGES + 1);
+    hipLaunchKernelGGL(k_zero_many, dim3(8), dim3(256), 0, st, z);
+    return HUMID_OK;
+  };
+  TRY(zero_discovery());
+  if (use_regions) {
+    if (c->xr_ecap == 0) c->xr_ecap = std::max<u64>(u_local / 4, 4096);
+    mine.cap_r = (u32)std::min<u64>((c->xr_ecap + ER_REGIONS - 1) / ER_REGIONS, 0x7fffffffull / ER_REGIONS);
+    ENSURE(c->xo_regs, (size_t)ER_REGIONS * mine.cap_r * 16);
+    mine.e = c->xo_regs.as<ulonglong2>();
+    mine.cur = c->cg_cur.as<u32>();
+    const ComboPlan plan = make_plan(n, d, u_total, c->force_segments);
+    const u64 ibytes = wide ? sizeof(Item3) : 16;
+    ull *big = &c->d_ctr[CTR_BIGMASK];
+    u32 *over = (u32 *)&c->d_ctr[CTR_EOVER];
+#define PAIRS_RECORDS(WT, P0, W, V, NN, CB, IDOF, IDBASE, CNTOF)                                                              \
+  do {                                                                                                                        \
+    EarlierMasksT<WT> em_;                                                                                                    \
+    for (u32 t_ = 0; t_ < MAX_COMBOS; t_++) em_.m[t_] = w_from<WT>(plan.mask[t_]);                                            \
+    hipLaunchKernelGGL((k_pairs_records<P0, WT>), dim3(blocks_for(NN)), dim3(256), 0, st, (const WT *)(W), (const u32 *)(V), \
+                       (u32)(NN), w_from<WT>(plan.mask[CB]), em_, (u32)(CB), d, c->walk_max, (const u32 *)(IDOF), (u32)(IDBASE), \
+                       (const u32 *)(CNTOF), mine, big, over);                                                                \
+  } while (0)
+    if (u_local > 1) {
+      if (wide) PAIRS_RECORDS(W2, true, lw, nullptr, u_local, 0, nullptr, goff, lc);
+      else PAIRS_RECORDS(u64, true, lw, nullptr, u_local, 0, nullptr, goff, lc);
+    }
+    for (u32 cb = 1; cb < plan.ncombo; cb++) {
       const u64 *items = nullptr;
       u64 sc[MAX_RANKS] = {0}, all_sc[MAX_RANKS * MAX_RANKS], rc[MAX_RANKS];
-      if (wide) {
+      if (!moves) sc[0] = u_local;                       // (one rank: no item list is made, see below)
+      else if (wide) {
         const Item3 *it3 = nullptr;
-        TRY(combo_route_wide(c, (const W2 *)lw, lc, (u32)u_local, goff, wplan, cb, P, &it3, sc));
+        TRY(combo_route_wide(c, (const W2 *)lw, lc, (u32)u_local, goff, plan, cb, P, &it3, sc));
         items = (const u64 *)it3;
       } else
         TRY(humid_stage_combo_route(c, lw, lc, u_local, goff, n, d, u_total, cb, P, &items, sc));
@@ -2836,53 +2915,107 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
         TRY(x_exchange(c, cm, items, sc, false, c->xr_got.p, rc, ibytes));
         got = c->xr_got.as<u64>();
       }
-      if (n_got > 1) {
-        if (wide) TRY(pairs_keyed_wide(c, got, (u32)n_got, true, 0, nullptr, wplan, cb, d, &rec, &n_rec));
-        else TRY(humid_stage_pairs_keyed(c, got, n_got, 1, 0, nullptr, n, d, u_total, cb, &rec, &n_rec));
-        TRY(append_pairs(rec, n_rec));
+      if (n_got > 1 && !moves) {
+        // one rank, nothing travels: the unique array itself is the item list (ids goff + position, counts lc)
+        const u32 ng = (u32)u_local;
+        ENSURE(c->seg_k0, (size_t)ng * 8);
+        ENSURE(c->seg_v0, (size_t)ng * 4);
+        ENSURE(c->seg_ks, (size_t)ng * 8);
+        ENSURE(c->seg_vs, (size_t)ng * 4);
+        ENSURE(c->seg_ws, (size_t)ng * (wide ? 16 : 8));
+        if (wide) {
+          TRY(bucket_order<W2>(c, plan, cb, (const W2 *)lw, ng, c->seg_ws.as<W2>(), c->seg_vs.as<u32>()));
+          PAIRS_RECORDS(W2, false, c->seg_ws.p, c->seg_vs.p, ng, cb, nullptr, goff, lc);
+        } else {
+          TRY(bucket_order<u64>(c, plan, cb, lw, ng, c->seg_ws.as<u64>(), c->seg_vs.as<u32>()));
+          PAIRS_RECORDS(u64, false, c->seg_ws.p, c->seg_vs.p, ng, cb, nullptr, goff, lc);
+        }
+      } else if (n_got > 1) {
+        const u32 ng = (u32)n_got;
+        ENSURE(c->x_w, (size_t)ng * (wide ? 16 : 8));
+        ENSURE(c->x_id, (size_t)ng * 4);
+        ENSURE(c->x_cnt, (size_t)ng * 4);
+        ENSURE(c->seg_k0, (size_t)ng * 8);
+        ENSURE(c->seg_v0, (size_t)ng * 4);
+        ENSURE(c->seg_ks, (size_t)ng * 8);
+        ENSURE(c->seg_vs, (size_t)ng * 4);
+        ENSURE(c->seg_ws, (size_t)ng * (wide ? 16 : 8));
+        if (wide) {
+          hipLaunchKernelGGL(k_split_items_w2, dim3(blocks_for(ng)), dim3(256), 0, st, (const Item3 *)got, ng, c->x_w.as<W2>(),
+                             c->x_id.as<u32>(), c->x_cnt.as<u32>());
+          TRY(bucket_order<W2>(c, plan, cb, c->x_w.as<W2>(), ng, c->seg_ws.as<W2>(), c->seg_vs.as<u32>()));
+          PAIRS_RECORDS(W2, false, c->seg_ws.p, c->seg_vs.p, ng, cb, c->x_id.p, 0, c->x_cnt.p);
+        } else {
+          hipLaunchKernelGGL(k_split_items, dim3(blocks_for(ng)), dim3(256), 0, st, (const ulonglong2 *)got, ng, c->x_w.as<u64>(),
+                             c->x_id.as<u32>(), c->x_cnt.as<u32>());
+          TRY(bucket_order<u64>(c, plan, cb, c->x_w.as<u64>(), ng, c->seg_ws.as<u64>(), c->seg_vs.as<u32>()));
+          PAIRS_RECORDS(u64, false, c->seg_ws.p, c->seg_vs.p, ng, cb, c->x_id.p, 0, c->x_cnt.p);
+        }
       }
     }
+#undef PAIRS_RECORDS
+    hipLaunchKernelGGL(k_rec_regions_max, dim3(1), dim3(64), 0, st, mine, c->small.as<u32>());
+    HIPCHK(hipGetLastError());
+    TRY(read_counters(c, c->small.as<u32>(), c->small.as<u32>() + 1));     // fullest region's demand, records held
+    const u64 want_r = c->h_ctr[CTR_N - 1] & 0xffffffffull;
+    e_mine = c->h_ctr[CTR_N - 2] & 0xffffffffull;
+    flagged_mine = (c->h_ctr[CTR_EOVER] & 0xffffffffull) != 0 || c->h_ctr[CTR_BIGMASK] != 0;
+    const u64 wanted = want_r * ER_REGIONS;
+    if (c->h_ctr[CTR_EOVER] & 0xffffffffull) c->xr_ecap = wanted + wanted / 2 + ER_REGIONS * 64;
+    else if (2 * (wanted + wanted / 4 + ER_REGIONS * 64) < c->xr_ecap) c->xr_ecap = wanted + wanted / 4 + ER_REGIONS * 64;
+  } else {
+    TRY(discover_dense());
+    mine.cur = c->cg_cur.as<u32>();
+    mine.far = (const ulonglong2 *)c->xr_eloc.p;
+    mine.n_far = (u32)e_mine;
   }
+
   // ---- 5. every pair to the owner of its ends; pairs with two owners, and the components they touch, to everybody ----
-  const bool by_count = (method & 1) == 0;
   if (u_total + 8 > 0xffffffffull) return fail(c, HUMID_E_OVERFLOW, "more than 2^32-10 unique words in total");
-  if (e_mine > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "%llu neighbour pairs found by one rank", (ull)e_mine);
   IdRanges idr;
   {
     u64 at = 0;
     for (u32 q = 0; q <= MAX_RANKS; q++) { idr.b[q] = (u32)at; if (q < P) at += metas[3 * q]; }
   }
-  ENSURE(c->cg_cur, (size_t)(ER_REGIONS * ER_STRIDE + 8) * 4);
-  ENSURE(c->xo_cnt, 64 * 4);
-  u32 *dcnt = c->xo_cnt.as<u32>();                                  // [0, P]: records per destination; [32, 32 + P]: scatter cursors
-  u32 *x_bad = c->cg_cur.as<u32>() + ER_REGIONS * ER_STRIDE;
-  {
-    ZeroList z;
-    memset(&z, 0, sizeof z);
-    z.p[0] = c->cg_cur.as<u32>(); z.n[0] = ER_REGIONS * ER_STRIDE + 8;
-    z.p[1] = dcnt; z.n[1] = 64;
-    hipLaunchKernelGGL(k_zero_many, dim3(8), dim3(256), 0, st, z);
+  u32 *x_bad = (u32 *)&c->d_ctr[CTR_OVERFULL];                       // a malformed record (read at the graph's host wait)
+  u64 dest_cnt[MAX_RANKS + 2] = {0};                                 // [P + 1]: this rank asks everybody for the dense road
+  u64 all_dest[MAX_RANKS * (MAX_RANKS + 2)];
+  u32 cgx = 1;
+  for (int round = 0;; round++) {
+    if (e_mine > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "%llu neighbour pairs found by one rank", (ull)e_mine);
+    cgx = (u32)std::min<u64>(std::max<u64>(blocks_for(std::max<u64>(mine.cap_r, mine.n_far)), 1), 1024);
+    for (u32 q = 0; q <= P + 1; q++) dest_cnt[q] = 0;
+    dest_cnt[P + 1] = flagged_mine ? 1 : 0;
+    if (flagged_mine) {
+    } else if (P == 1) dest_cnt[0] = e_mine;
+    else if (e_mine) {
+      std::vector<u32> h(P + 1);
+      hipLaunchKernelGGL(k_rec_dest_count, dim3(cgx, ER_REGIONS + 1), dim3(256), 0, st, mine, idr, P, dcnt);
+      HIPCHK(hipMemcpyAsync(h.data(), dcnt, (P + 1) * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      for (u32 q = 0; q <= P; q++) dest_cnt[q] = h[q];
+    }
+    TRY(x_host_gather(c, cm, dest_cnt, (P + 2) * 8, all_dest));
+    bool anybody = false;
+    for (u32 q = 0; q < P; q++) anybody = anybody || all_dest[(size_t)q * (P + 2) + P + 1] != 0;
+    if (!anybody) break;
+    if (round) return fail(c, HUMID_E_INVALID, "internal: the dense pair search asked for itself");
+    // some rank's regions overflowed or met a bucket beyond the walk: EVERY rank repeats the search on the dense
+    // road (its exchanges are collective), this pass only
+    e_mine = 0;
+    TRY(zero_discovery());
+    TRY(discover_dense());
+    mine.e = nullptr; mine.cap_r = 0; mine.cur = c->cg_cur.as<u32>();
+    mine.far = (const ulonglong2 *)c->xr_eloc.p;
+    mine.n_far = (u32)e_mine;
+    flagged_mine = false;
+    use_regions = false;
   }
-  RecRegs mine;                                                      // this rank's discoveries: one dense list
-  mine.e = nullptr; mine.cap_r = 0; mine.cur = c->cg_cur.as<u32>();
-  mine.far = (const ulonglong2 *)c->xr_eloc.p; mine.n_far = (u32)e_mine;
-  u64 dest_cnt[MAX_RANKS + 1] = {0};
-  const u32 cgx = (u32)std::min<u64>(std::max<u64>(blocks_for(e_mine), 1), 2048);
-  if (P == 1) dest_cnt[0] = e_mine;
-  else if (e_mine) {
-    std::vector<u32> h(P + 1);
-    hipLaunchKernelGGL(k_rec_dest_count, dim3(cgx, ER_REGIONS + 1), dim3(256), 0, st, mine, idr, P, dcnt);
-    HIPCHK(hipMemcpyAsync(h.data(), dcnt, (P + 1) * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    for (u32 q = 0; q <= P; q++) dest_cnt[q] = h[q];
-  }
-  u64 all_dest[MAX_RANKS * (MAX_RANKS + 1)];
-  TRY(x_host_gather(c, cm, dest_cnt, (P + 1) * 8, all_dest));
   u64 E = 0, X_total = 0, n_int = 0, int_from[MAX_RANKS], cross_from[MAX_RANKS], int_to[MAX_RANKS];
   for (u32 q = 0; q < P; q++) {
-    for (u32 dd = 0; dd <= P; dd++) E += all_dest[(size_t)q * (P + 1) + dd];
-    int_from[q] = all_dest[(size_t)q * (P + 1) + r];
-    cross_from[q] = all_dest[(size_t)q * (P + 1) + P];
+    for (u32 dd = 0; dd <= P; dd++) E += all_dest[(size_t)q * (P + 2) + dd];
+    int_from[q] = all_dest[(size_t)q * (P + 2) + r];
+    cross_from[q] = all_dest[(size_t)q * (P + 2) + P];
     int_to[q] = dest_cnt[q];
     n_int += int_from[q];
     X_total += cross_from[q];
@@ -2892,7 +3025,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   const ulonglong2 *sendbuf = (const ulonglong2 *)c->xr_eloc.p;
   u64 send_base[MAX_RANKS + 2] = {0};
   for (u32 q = 0; q <= P; q++) send_base[q + 1] = send_base[q] + dest_cnt[q];
-  if (P > 1 && e_mine) {
+  if ((P > 1 || use_regions) && e_mine) {                            // (regions: also what makes one dense list of them)
     ENSURE(c->xo_send, e_mine * 16 + 16);
     IdRanges base;
     for (u32 q = 0; q <= MAX_RANKS; q++) base.b[q] = (u32)send_base[q <= P ? q : P + 1];
@@ -2997,12 +3130,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
     src.pairs_bound = n_recs_all;
     HIPCHK(hipEventRecord(c->ev[2], st));
     TRY(cg_build(c, src, method, cgs));
-    {
-      u32 h_bad = 0;
-      HIPCHK(hipMemcpyAsync(&h_bad, x_bad, 4, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
-      if (h_bad) return fail(c, HUMID_E_INVALID, "a pair record with an index outside the unique words");
-    }
+    if (c->h_ctr[CTR_OVERFULL]) return fail(c, HUMID_E_INVALID, "a pair record with an index outside the unique words");
     M_mine = cgs.M;
     TRY(cg_cluster_rest(c, n_ids, cgs.M, cgs.Mbig, method));
   } else {
@@ -3069,7 +3197,9 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
     ENSURE(c->xo_ldeg, (size_t)u_local * 4);
     hipLaunchKernelGGL(k_own_results, dim3(blocks_for(u_local)), dim3(256), 0, st, br_in, br_nc, br_xc, xcid_all,
                        (const u32 *)c->cg_nodes.as<u32>(), (const u32 *)cg.cl_of, (const u32 *)cg.maxleaf, (const u32 *)cg.deg, (u32)goff,
-                       (u32)u_local, (u32)creators_before, c->x_lcid.as<u32>(), c->x_lismax.as<u8>(), c->xo_ldeg.as<u32>());
+                       (u32)u_local, (u32)creators_before, c->x_lcid.as<u32>(), c->x_lismax.as<u8>(), c->xo_ldeg.as<u32>(),
+                       (const u32 *)c->s_first.as<u32>(), (const u32 *)c->s_slot.as<u32>(), c->slot_out.as<u64>());
+    c->slots_done = true;                                            // (humid_stage_map_dense skips k_slot_results)
     HIPCHK(hipGetLastError());
     l_cid = c->x_lcid.as<u32>();
     l_ismax = c->x_lismax.as<u8>();
@@ -3086,7 +3216,11 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
     TRY(x_exchange(c, cm, packed, recv_counts, false, c->xr_ret.p, send_counts, 4));
     ret = c->xr_ret.as<u32>();
   }
-  TRY(humid_stage_scatter(c, d_perm, ret, n_send, n_local, d_cluster_id, d_keep));
+  // per read: its routed position -> its result (coalesced stores; filtered reads: cluster 0, not kept)
+  if (n_local)
+    hipLaunchKernelGGL(k_gather_results, dim3(grid_stride_blocks(n_local)), dim3(256), 0, st, (const u32 *)c->xo_inv.as<u32>(), ret,
+                       (u32)n_send, (u32)n_local, d_cluster_id, d_keep);
+  HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));
   if (summary) {
     *summary = gs;                                                   // the kernel times of the graph stage
@@ -3311,9 +3445,10 @@ int humid_stage_map_dense(humid_ctx *c, const uint32_t *d_local_cluster_id, cons
   *n_packed = N;
   if (N == 0) return HUMID_OK;
   if (U && (!d_local_cluster_id || !d_local_is_max)) return fail(c, HUMID_E_INVALID, "null buffer");
-  if (U > 0)
+  if (U > 0 && !c->slots_done)                         // (slots_done: the caller's id kernel wrote the slot results itself)
     hipLaunchKernelGGL(k_slot_results, dim3(blocks_for(U)), dim3(256), 0, st, d_local_cluster_id, d_local_is_max,
                        c->s_first.as<u32>(), c->s_slot.as<u32>(), U, c->slot_out.as<u64>());
+  c->slots_done = false;
   ENSURE(c->own_packed, ((size_t)N + 1) * 4);
   if (c->kev_on) HIPCHK(hipEventRecord(c->kev[37], st));
   bool tiled = false;
@@ -3962,6 +4097,7 @@ int humid_stage_route(humid_ctx *c, const uint64_t *d_words, const uint8_t *d_fi
   const u32 n_tiles = (n + ROUTE_TILE - 1) / ROUTE_TILE;
   ENSURE(c->route_tiles, ((size_t)n_tiles * MAX_RANKS + 16) * 4 + ROUTE_BINS);   // tile counts | bad flag | owner table
   ENSURE(c->perm, (size_t)n * 4);
+  ENSURE(c->xo_inv, (size_t)n * 4);
   ENSURE(c->x_route, (size_t)(tot ? tot : 1) * 8);
   u32 *tile_cnt = c->route_tiles.as<u32>(), *bad = tile_cnt + (size_t)n_tiles * MAX_RANKS;
   // ranges cut at the bins of a prefix histogram (every boundary a multiple of 2^shift, at most
@@ -3985,10 +4121,10 @@ int humid_stage_route(humid_ctx *c, const uint64_t *d_words, const uint8_t *d_fi
   hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(1024), 0, st, tile_cnt, n_tiles, ob, bad);
   if (table)
     hipLaunchKernelGGL(k_route_scatter<true>, dim3(n_tiles), dim3(1024), 0, st, d_words, d_filtered, n, rg, n_ranks, shift,
-                       (const u8 *)d_table, (const u32 *)tile_cnt, c->x_route.as<u64>(), c->perm.as<u32>());
+                       (const u8 *)d_table, (const u32 *)tile_cnt, c->x_route.as<u64>(), c->perm.as<u32>(), c->xo_inv.as<u32>());
   else
     hipLaunchKernelGGL(k_route_scatter<false>, dim3(n_tiles), dim3(1024), 0, st, d_words, d_filtered, n, rg, n_ranks, shift,
-                       (const u8 *)d_table, (const u32 *)tile_cnt, c->x_route.as<u64>(), c->perm.as<u32>());
+                       (const u8 *)d_table, (const u32 *)tile_cnt, c->x_route.as<u64>(), c->perm.as<u32>(), c->xo_inv.as<u32>());
   HIPCHK(hipGetLastError());
   c->route_checked = false;
   c->route_bad = bad;

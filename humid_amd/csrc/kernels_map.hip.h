@@ -525,7 +525,7 @@ template <bool TABLE>
 __global__ void __launch_bounds__(1024)
 k_route_scatter(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n, OwnerRanges rg,
                 u32 n_ranks, u32 shift, const u8 *__restrict__ table, const u32 *__restrict__ tile_off,
-                u64 *__restrict__ routed, u32 *__restrict__ perm) {
+                u64 *__restrict__ routed, u32 *__restrict__ perm, u32 *__restrict__ inv = nullptr) {
   HUMID_GUARD_LAST_VGPR();
   constexpr u32 R = ROUTE_TILE / 1024;
   __shared__ u32 wcnt[R][16][MAX_RANKS];   // reads of every owner per round and wave -> their offsets
@@ -564,13 +564,31 @@ k_route_scatter(const u64 *__restrict__ words, const u8 *__restrict__ filtered, 
       }
   }
   __syncthreads();
+  // inv (may be null): routed position of every read (~0: filtered / nobody's) -- the result return then
+  // GATHERS per read with coalesced stores (k_gather_results) instead of two memsets and a scatter
 #pragma unroll
-  for (u32 k = 0; k < R; k++)
+  for (u32 k = 0; k < R; k++) {
+    const u32 j = beg + k * 1024 + threadIdx.x;
     if (o[k] < n_ranks) {
       const u32 pos = wcnt[k][wave][o[k]] + rk[k];
       routed[pos] = w[k];
-      perm[pos] = beg + k * 1024 + threadIdx.x;
-    }
+      perm[pos] = j;
+      if (inv) inv[j] = pos;
+    } else if (inv && j < n) inv[j] = NONE32;
+  }
+}
+
+// this shard's outputs from the received dense stream through the routed position of every read
+__global__ void __launch_bounds__(256)
+k_gather_results(const u32 *__restrict__ inv, const u32 *__restrict__ packed, u32 n_recv, u32 n_reads,
+                 u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
+  HUMID_GUARD_LAST_VGPR();
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_reads; i += gridDim.x * blockDim.x) {
+    const u32 p = inv[i];
+    const u32 t = p < n_recv ? packed[p] : 0u;
+    cluster_id[i] = t & 0x7fffffffu;
+    keep[i] = (u8)(t >> 31);
+  }
 }
 
 // ---- cluster ids of one rank's unique words from the replicated compact graph ----

@@ -110,13 +110,14 @@ k_pairs_records(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, WT m
   }
 }
 
-// the fullest region's cursor -> out[0]
+// the fullest region's cursor -> out[0], the records in all regions (cursors cut to the room) -> out[1]
 __global__ void k_rec_regions_max(RecRegs rr, u32 *__restrict__ out) {
   HUMID_GUARD_LAST_VGPR();
   u32 c = rr.cur[threadIdx.x * ER_STRIDE];
+  u32 t = c < rr.cap_r ? c : rr.cap_r;
 #pragma unroll
-  for (u32 d = 32; d >= 1; d >>= 1) { const u32 y = __shfl_xor(c, d); c = y > c ? y : c; }
-  if (threadIdx.x == 0) out[0] = c;
+  for (u32 d = 32; d >= 1; d >>= 1) { const u32 y = __shfl_xor(c, d); c = y > c ? y : c; t += __shfl_xor(t, d); }
+  if (threadIdx.x == 0) { out[0] = c; out[1] = t; }
 }
 
 // ---- where a record goes ---------------------------------------------------------------------------
@@ -339,7 +340,8 @@ __global__ void k_max_rows(const u32 *__restrict__ rows, u32 n_rows, u32 n, u32 
 __global__ void __launch_bounds__(256)
 k_own_results(BitRank in_graph, BitRank noncreator, BitRank xc, const u32 *__restrict__ xcid_all, const u32 *__restrict__ nodes,
               const u32 *__restrict__ cl_of, const u32 *__restrict__ maxleaf, const u32 *__restrict__ deg, u32 id0, u32 n_local,
-              u32 creators_before_rank, u32 *__restrict__ l_cid, u8 *__restrict__ l_ismax, u32 *__restrict__ l_deg) {
+              u32 creators_before_rank, u32 *__restrict__ l_cid, u8 *__restrict__ l_ismax, u32 *__restrict__ l_deg,
+              const u32 *__restrict__ s_first, const u32 *__restrict__ s_slot, u64 *__restrict__ slot_out) {
   HUMID_GUARD_LAST_VGPR();
   const u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n_local) return;
@@ -359,6 +361,7 @@ k_own_results(BitRank in_graph, BitRank noncreator, BitRank xc, const u32 *__res
   l_cid[u] = id;
   l_ismax[u] = mx ? 1 : 0;
   if (l_deg) l_deg[u] = dg;
+  if (slot_out) slot_out[s_slot[u]] = ((u64)(mx ? s_first[u] : NONE32) << 32) | id;   // (k_slot_results of the result return, done here)
 }
 // non-creators and nodes among this rank's own leaves [id0, id0 + n_local): out[0], out[1]
 __global__ void k_own_totals(BitRank noncreator, BitRank in_graph, u32 id0, u32 n_local, u32 *__restrict__ out) {

@@ -76,30 +76,33 @@ __global__ void __launch_bounds__(PS_SMALL_THREADS)
 // (out may be the array `in` reads: a chunk is staged before it is written)
 k_ps_scan_small(In in, u32 n, T *out) {
   HUMID_GUARD_LAST_VGPR();
-  __shared__ T stage[PS_SMALL_THREADS * PS_SMALL_ITEMS];
+  // (one pad per PS_SMALL_ITEMS entries: thread t's items start at entry 9 t, so the lanes of a wave spread
+  // over the banks when each reads ITS items -- unpadded, a stride of 8 entries put every fourth lane on one bank)
+  __shared__ T stage[PS_SMALL_THREADS * (PS_SMALL_ITEMS + 1)];
   __shared__ T lds[PS_SMALL_THREADS / 64 + 1];
+  auto at = [](u32 j) { return j + j / PS_SMALL_ITEMS; };
   T carry = 0;
   for (u32 c0 = 0; c0 < n; c0 += PS_SMALL_THREADS * PS_SMALL_ITEMS) {
 #pragma unroll
     for (u32 k = 0; k < PS_SMALL_ITEMS; k++) {
       const u32 i = c0 + k * PS_SMALL_THREADS + threadIdx.x;
-      stage[k * PS_SMALL_THREADS + threadIdx.x] = i < n ? in(i) : (T)0;
+      stage[at(k * PS_SMALL_THREADS + threadIdx.x)] = i < n ? in(i) : (T)0;
     }
     __syncthreads();
     T v[PS_SMALL_ITEMS];
     T s = 0;
 #pragma unroll
-    for (u32 k = 0; k < PS_SMALL_ITEMS; k++) { v[k] = stage[threadIdx.x * PS_SMALL_ITEMS + k]; s += v[k]; }
+    for (u32 k = 0; k < PS_SMALL_ITEMS; k++) { v[k] = stage[at(threadIdx.x * PS_SMALL_ITEMS + k)]; s += v[k]; }
     T tot;
     T run = carry + ps_block_exscan<T, PS_SMALL_THREADS>(s, lds, &tot);
 #pragma unroll
-    for (u32 k = 0; k < PS_SMALL_ITEMS; k++) { stage[threadIdx.x * PS_SMALL_ITEMS + k] = run; run += v[k]; }
+    for (u32 k = 0; k < PS_SMALL_ITEMS; k++) { stage[at(threadIdx.x * PS_SMALL_ITEMS + k)] = run; run += v[k]; }
     carry += tot;
     __syncthreads();
 #pragma unroll
     for (u32 k = 0; k < PS_SMALL_ITEMS; k++) {
       const u32 i = c0 + k * PS_SMALL_THREADS + threadIdx.x;
-      if (i < n) out[i] = stage[k * PS_SMALL_THREADS + threadIdx.x];
+      if (i < n) out[i] = stage[at(k * PS_SMALL_THREADS + threadIdx.x)];
     }
     __syncthreads();
   }
@@ -153,33 +156,35 @@ __global__ void __launch_bounds__(PS_THREADS)
 // (in place allowed: a tile is staged before it is written)
 k_ps_down(In in, u64 n, const T *__restrict__ tile_base, T *out) {
   HUMID_GUARD_LAST_VGPR();
-  __shared__ T stage[PS_TILE];
+  __shared__ T stage[PS_TILE + PS_THREADS];               // (padded as in k_ps_scan_small)
   __shared__ T lds[PS_THREADS / 64 + 1];
+  auto at = [](u32 j) { return j + j / PS_ITEMS; };
   const u64 base = (u64)blockIdx.x * PS_TILE;
 #pragma unroll
   for (u32 k = 0; k < PS_ITEMS; k++) {
     const u64 i = base + k * PS_THREADS + threadIdx.x;
-    stage[k * PS_THREADS + threadIdx.x] = i < n ? in(i) : (T)0;
+    stage[at(k * PS_THREADS + threadIdx.x)] = i < n ? in(i) : (T)0;
   }
   __syncthreads();
   T v[PS_ITEMS];
   T s = 0;
 #pragma unroll
-  for (u32 k = 0; k < PS_ITEMS; k++) { v[k] = stage[threadIdx.x * PS_ITEMS + k]; s += v[k]; }
+  for (u32 k = 0; k < PS_ITEMS; k++) { v[k] = stage[at(threadIdx.x * PS_ITEMS + k)]; s += v[k]; }
   T tot;
   T run = tile_base[blockIdx.x] + ps_block_exscan<T, PS_THREADS>(s, lds, &tot);
 #pragma unroll
-  for (u32 k = 0; k < PS_ITEMS; k++) { stage[threadIdx.x * PS_ITEMS + k] = run; run += v[k]; }
+  for (u32 k = 0; k < PS_ITEMS; k++) { stage[at(threadIdx.x * PS_ITEMS + k)] = run; run += v[k]; }
   __syncthreads();
 #pragma unroll
   for (u32 k = 0; k < PS_ITEMS; k++) {
     const u64 i = base + k * PS_THREADS + threadIdx.x;
-    if (i < n) out[i] = stage[k * PS_THREADS + threadIdx.x];
+    if (i < n) out[i] = stage[at(k * PS_THREADS + threadIdx.x)];
   }
 }
 
 // one workgroup, n <= PS_TINY_MAX: thread t owns the items [t * per, (t + 1) * per) straight from memory
-// (a few dozen KB: the rank blocks of a bitmap, bucket counts), ONE block scan
+// (a few hundred KB at most: the rank blocks of a bitmap, bucket counts), ONE block scan; the items are read
+// twice (they stay in the cache)
 #define PS_TINY_MAX 16384u
 template <class T, class In>
 __global__ void __launch_bounds__(PS_SMALL_THREADS)
@@ -187,18 +192,19 @@ __global__ void __launch_bounds__(PS_SMALL_THREADS)
 k_ps_scan_tiny(In in, u32 n, T *out) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ T lds[PS_SMALL_THREADS / 64 + 1];
-  constexpr u32 PER = PS_TINY_MAX / PS_SMALL_THREADS;        // 16
-  const u32 lo = threadIdx.x * PER;
-  T v[PER];
+  const u32 per = (n + PS_SMALL_THREADS - 1) / PS_SMALL_THREADS;
+  const u32 lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
   T s = 0;
-#pragma unroll
-  for (u32 k = 0; k < PER; k++) { v[k] = lo + k < n ? in(lo + k) : (T)0; s += v[k]; }
+  for (u32 i = lo; i < hi; i += 4) {                         // four independent loads in flight
+    T v0 = in(i), v1 = i + 1 < hi ? in(i + 1) : (T)0, v2 = i + 2 < hi ? in(i + 2) : (T)0, v3 = i + 3 < hi ? in(i + 3) : (T)0;
+    s += v0 + v1 + v2 + v3;
+  }
   T tot;
   T run = ps_block_exscan<T, PS_SMALL_THREADS>(s, lds, &tot);
-#pragma unroll
-  for (u32 k = 0; k < PER; k++) {
-    if (lo + k < n) out[lo + k] = run;
-    run += v[k];
+  for (u32 i = lo; i < hi; i++) {
+    const T v = in(i);
+    out[i] = run;
+    run += v;
   }
 }
 
