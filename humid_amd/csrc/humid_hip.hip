@@ -2665,6 +2665,20 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   HIPCHK(hipSetDevice(c->device));
   hipStream_t st = c->stream;
   const auto t_begin = std::chrono::steady_clock::now();
+  // HUMID_XTRACE=1: host time of every phase of the pass on stderr (each mark waits for the stream: for
+  // measurements with the ranks taking turns on one GPU, tools/exchange_phase_cost.py -- never in a timed run)
+  static const bool xtrace = getenv("HUMID_XTRACE") != nullptr;
+  auto xt_last = t_begin;
+  std::string xt_line;
+  auto XT = [&](const char *name) {
+    if (!xtrace) return;
+    (void)hipStreamSynchronize(st);
+    const auto now = std::chrono::steady_clock::now();
+    char buf[64];
+    snprintf(buf, sizeof buf, " %s %.3f", name, std::chrono::duration<double, std::milli>(now - xt_last).count());
+    xt_line += buf;
+    xt_last = std::chrono::steady_clock::now();
+  };
   // 33 <= word_nt <= 64: two uint64 per read.  Value ranges are decided by the top 64 bits of the word
   // (its "head"): histogram, splitters and routing run on an array of heads exactly as they do on
   // one-word words of 32 nucleotides; what travels and what is counted are the two-word words.
@@ -2725,6 +2739,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   c->count_mode = 0;
   struct Restore { humid_ctx *c; int o, m; ~Restore() { c->count_order = o; c->count_mode = m; } } restore{c, saved_order, saved_mode};
 
+  XT("hist+ranges");
   // ---- 2. usable words -> owner of their range (stable: input order inside every block) ----
   const u64 *d_routed = nullptr;
   const u32 *d_perm = nullptr;
@@ -2746,6 +2761,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
     recv_w = c->xr_recv.as<u64>();
   }
 
+  XT("route+exchange");
   // ---- 3. exact counts of the received words (all usable, all in this rank's range) ----
   const u64 shard_begin[2] = {0, n_recv};
   u64 cnt_one = 0, u_local = 0, usable_local = 0;
@@ -2789,6 +2805,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   const u32 *lc = nullptr, *lfirst = nullptr;
   if (u_local) TRY(humid_stage_unique(c, &lw, &lc, &lfirst));
 
+  XT("count");
   // ---- 4. neighbour pairs in global unique indices, each with the counts of its endpoints ----
   u64 e_mine = 0;                                                    // 16-byte records in xr_eloc
   auto append_pairs = [&](const u64 *rec, u64 n_rec) -> int {
@@ -2970,6 +2987,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
     mine.n_far = (u32)e_mine;
   }
 
+  XT("pairs");
   // ---- 5. every pair to the owner of its ends; pairs with two owners, and the components they touch, to everybody ----
   if (u_total + 8 > 0xffffffffull) return fail(c, HUMID_E_OVERFLOW, "more than 2^32-10 unique words in total");
   IdRanges idr;
@@ -3046,6 +3064,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
       d_cross = c->xo_cross.as<ulonglong2>();
     }
   }
+  XT("classify+exchange");
   // the interior pairs of the components a crossing pair touches: to everybody as well
   u64 k_mine = 0, k_from[MAX_RANKS] = {0}, K_total = 0;
   const ulonglong2 *d_kall = nullptr;
@@ -3084,6 +3103,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
     }
   }
 
+  XT("flagged");
   // ---- 5b. ONE compact graph over global unique indices: own pairs + crossing pairs + the others' flagged pairs ----
   RecSegs segs;
   memset(&segs, 0, sizeof segs);
@@ -3143,6 +3163,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
   const BitRank br_in{c->cg_bits.as<u32>(), c->cg_blk.as<u32>()}, br_nc{c->cg_nbits.as<u32>(), c->cg_nblk.as<u32>()};
   BitRank br_xc{c->xo_xcbits.as<u32>(), c->xo_xcblk.as<u32>()};
 
+  XT("graph");
   // ---- 5c. cluster ids: creators before a leaf = the lower ranks' creators + its owner's creators before it ----
   u64 C_x = 0;
   if (X_total && M_mine) {
@@ -3205,6 +3226,7 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
     l_ismax = c->x_lismax.as<u8>();
   }
 
+  XT("ids");
   // ---- 6. per-read results at the owner, back to the home shards ----
   const u32 *packed = nullptr;
   u64 n_packed = 0;
@@ -3222,6 +3244,10 @@ int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t 
                        (u32)n_send, (u32)n_local, d_cluster_id, d_keep);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));
+  XT("return");
+  if (xtrace)
+    fprintf(stderr, "[xtrace] rank %u/%u reads %llu pairs: mine %llu interior %llu crossing %llu flagged %llu (all ranks) graph %llu nodes |%s\n", r, P,
+            (ull)n_local, (ull)e_mine, (ull)n_int, (ull)X_total, (ull)K_total, (ull)M_mine, xt_line.c_str());
   if (summary) {
     *summary = gs;                                                   // the kernel times of the graph stage
     summary->total = total;
