@@ -129,6 +129,7 @@ SYMBOLS = {
                                            C.POINTER(HumidSummary), C.POINTER(HumidExchangeInfo)]),
     "humid_shm_open": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64]),
     "humid_shm_all_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "humid_shm_abort": (None, [C.c_void_p]),
     "humid_shm_close": (None, [C.c_void_p]),
     "humid_at_least_double": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_int)]),
 }

@@ -19,6 +19,7 @@
 #include "../../include/humid_hip.h"
 
 typedef uint64_t u64;
+typedef int64_t i64;
 typedef uint32_t u32;
 typedef uint8_t u8;
 typedef unsigned long long ull;

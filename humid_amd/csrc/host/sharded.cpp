@@ -29,6 +29,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;      // optional: ends the collectives a failed pass left in flight
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -42,6 +43,7 @@ struct Rccl {
     GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
     CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
     CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+    CommAbort = (decltype(CommAbort))sym("ncclCommAbort");
     GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
     GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
     Send = (decltype(Send))sym("ncclSend");
@@ -67,6 +69,17 @@ struct Group {
   std::atomic<bool> failed{false};
   int fail_code = HUMID_OK;
   std::string fail_text;
+  // every rank's communicator (null until it is up), so that a rank that fails can abort them ALL: a peer that
+  // already waits in hipStreamSynchronize for an RCCL kernel would wait for ever
+  std::vector<std::atomic<ncclComm_t>> comms;
+  std::atomic<bool> aborted{false};
+  void abort_comms() {
+    if (!use_rccl || !rccl.CommAbort || aborted.exchange(true)) return;
+    for (auto &cm : comms) {
+      ncclComm_t x = cm.exchange(nullptr);
+      if (x) (void)rccl.CommAbort(x);
+    }
+  }
   // host numbers: slot[r] = what rank r published for the current step
   std::vector<std::vector<uint8_t>> slot;
   // device buffers published for a peer-copy exchange
@@ -90,9 +103,12 @@ struct Group {
   }
 
   void fail(int code, const std::string &text) {
-    std::lock_guard<std::mutex> lk(mu);
-    if (!failed.load()) { fail_code = code; fail_text = text; failed.store(true); }
-    cv.notify_all();
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!failed.load()) { fail_code = code; fail_text = text; failed.store(true); }
+      cv.notify_all();
+    }
+    abort_comms();
   }
   // false: some rank failed (nobody waits any longer)
   bool barrier() {
@@ -131,7 +147,8 @@ struct Rank {
 
   Rank(Group &grp, unsigned rank) : g(grp), r(rank) {}
   ~Rank() {
-    if (comm) g.rccl.CommDestroy(comm);
+    // (an aborted communicator was taken out of g.comms by abort_comms and is gone already)
+    if (comm && r < g.comms.size() && g.comms[r].exchange(nullptr) == comm) g.rccl.CommDestroy(comm);
     if (ctx) humid_ctx_destroy(ctx);
     if (st) (void)hipStreamDestroy(st);
   }
@@ -175,17 +192,23 @@ struct Rank {
     if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) return false;   // queued stage work (route) done
     if (g.use_rccl) {
       if (!together()) return false;      // every rank is alive and about to enter the same group call
-      if (!nccl_ok(g.rccl.GroupStart(), "ncclGroupStart")) return false;
-      for (unsigned q = 0; q < g.P; q++) {
-        if (send_cnt[q] &&
-            !nccl_ok(g.rccl.Send((const uint8_t *)send + send_off[q], send_cnt[q], ncclUint8, (int)q, comm, st), "ncclSend"))
-          return false;
-        if (recv_cnt[q] &&
-            !nccl_ok(g.rccl.Recv((uint8_t *)recv + recv_off[q], recv_cnt[q], ncclUint8, (int)q, comm, st), "ncclRecv"))
-          return false;
+      if (!nccl_ok(g.rccl.GroupStart(), "ncclGroupStart")) { g.fail(code, "rank " + std::to_string(r) + ": " + err); return false; }
+      bool ok = true;
+      for (unsigned q = 0; q < g.P && ok; q++) {
+        if (send_cnt[q])
+          ok = nccl_ok(g.rccl.Send((const uint8_t *)send + send_off[q], send_cnt[q], ncclUint8, (int)q, comm, st), "ncclSend");
+        if (ok && recv_cnt[q])
+          ok = nccl_ok(g.rccl.Recv((uint8_t *)recv + recv_off[q], recv_cnt[q], ncclUint8, (int)q, comm, st), "ncclRecv");
       }
-      if (!nccl_ok(g.rccl.GroupEnd(), "ncclGroupEnd")) return false;
-      return hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize (exchange)");
+      // the group is ALWAYS closed (an open group would swallow every later call of this thread); a failed
+      // send / receive then makes the whole group fail: all communicators are aborted, so that no peer keeps
+      // waiting in its stream for this rank's half of the exchange
+      const ncclResult_t ge = g.rccl.GroupEnd();
+      if (ok) ok = nccl_ok(ge, "ncclGroupEnd");
+      if (!ok) { g.fail(code, "rank " + std::to_string(r) + ": " + err); return false; }
+      if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize (exchange)")) { g.fail(code, "rank " + std::to_string(r) + ": " + err); return false; }
+      if (g.failed.load()) { if (code == HUMID_OK) { code = g.fail_code; err = g.fail_text; } return false; }
+      return true;
     }
     Group::Pub &mine = g.pub[r];
     mine.ptr = (const uint8_t *)send;
@@ -237,10 +260,11 @@ bool run_rank(Rank &k) {
       std::fprintf(stderr, "humid: rank %u: ncclCommInitRank: %s\n", r, g.rccl.GetErrorString(ir));
       k.comm = nullptr;
       g.rccl_failed.store(true);
-    }
+    } else
+      g.comms[r].store(k.comm);
     STEP(k.together());
     if (g.rccl_failed.load()) {
-      if (k.comm) { g.rccl.CommDestroy(k.comm); k.comm = nullptr; }
+      if (k.comm) { g.comms[r].store(nullptr); g.rccl.CommDestroy(k.comm); k.comm = nullptr; }
       STEP(k.together());                                         // every rank has read the flag
       if (r == 0) { g.use_rccl = false; std::fprintf(stderr, "humid: ranks exchange through peer copies\n"); }
       STEP(k.together());
@@ -328,6 +352,7 @@ struct ShardedSession::Impl {
   std::thread starter;
   std::string early_error;
   int early_code = HUMID_OK;
+  bool ran = false;
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   double ms_init = 0;
   std::atomic<unsigned> ready{0};
@@ -345,6 +370,8 @@ ShardedSession::ShardedSession(unsigned n_ranks) : p_(new Impl) {
   g.device.resize(n_ranks);
   g.slot.resize(n_ranks);
   g.pub.resize(n_ranks);
+  g.comms = std::vector<std::atomic<ncclComm_t>>(n_ranks);
+  for (auto &cm : g.comms) cm.store(nullptr);
   // everything that touches the HIP runtime happens on the starter thread: the caller goes on parsing
   m.starter = std::thread([&m, n_ranks] {
     Group &g = m.g;
@@ -393,6 +420,8 @@ int ShardedSession::run(const uint64_t *words, const uint8_t *filtered, uint64_t
   Impl &m = *p_;
   Group &g = m.g;
   if (m.early_code != HUMID_OK) { out.error = m.early_error; return m.early_code; }
+  if (m.ran) { out.error = "-g: a sharded session runs one job"; return HUMID_E_INVALID; }     // (its rank threads end with the job)
+  m.ran = true;
   if (word_nt == 0 || word_nt > 64) { out.error = "-g: word length 1 .. 64"; return HUMID_E_UNSUPPORTED; }
   if (n_reads >= 0x7fffffffull * g.P) { out.error = "-g: more than 2^31-1 reads per rank"; return HUMID_E_OVERFLOW; }
   if (m.starter.joinable()) m.starter.join();
@@ -400,7 +429,7 @@ int ShardedSession::run(const uint64_t *words, const uint8_t *filtered, uint64_t
   Job job{words, filtered, n_reads, word_nt, distance, method, want_hist, cluster_id, keep, {}};
   const auto t1 = std::chrono::steady_clock::now();
   g.post_job(&job);
-  for (auto &t : m.threads) t.join();
+  for (auto &t : m.threads) if (t.joinable()) t.join();
   out.ms_run = ms_since(t1);
   out.comm = g.use_rccl ? "rccl" : "copy";
   if (g.failed.load()) {

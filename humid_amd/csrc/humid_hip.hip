@@ -131,6 +131,8 @@ struct humid_ctx {
   bool pt_padded = true;            // level 1 of the tile partition into padded coarse bins (no histogram pass); false after an overflow
   bool use_tile_partition = true;   // option "tile_partition": 0 = library radix passes + one-kernel un-permute (round 1)
   bool last_part_tiled = false;     // kev[39]..kev[40] bracket the second-level scatter of the last count
+  int x_test_fail_after = -1, x_gathers = 0;   // option "test_fail_before_gather": this rank leaves the pass with an error in the compute phase before its k-th gather (tests)
+  bool x_hist_done = false, x_peer_failed = false;   // humid_dedup_run_exchange: the pass's first gather is done; a peer's failure was seen
   bool route_checked = true;        // no humid_stage_route since the last humid_stage_route_check
   const u32 *route_bad = nullptr;   // device flag of the last humid_stage_route
   bool last_unperm_tiled = false;   // kev[36]..kev[41] bracket k_unperm_window of the last map
@@ -2266,6 +2268,10 @@ int humid_ctx_set_option(humid_ctx *c, const char *key, int64_t value) {
     c->kev_on = value != 0;
     return HUMID_OK;
   }
+  if (strcmp(key, "test_fail_before_gather") == 0) {
+    c->x_test_fail_after = (int)value;
+    return HUMID_OK;
+  }
   if (strcmp(key, "records8") == 0) {
     c->use_rec8 = value != 0;
     return HUMID_OK;
@@ -2626,10 +2632,55 @@ int x_order_hint(const std::vector<u64> &hist, const XRange &rg, u32 word_nt, u3
 }  // namespace
 
 // host numbers of all ranks
+// Failure is COLLECTIVE: every gather carries a status word per rank, and all gathers of a pass but
+// the first (the histograms) have ONE size, X_SLOT -- so a rank that fails between two gathers can still join the
+// next one its peers reach (run_exchange's wrapper does that for it, x_announce_failure) and every rank returns
+// an error from the same gather instead of waiting for a peer that has left.  (What this covers: a failure in a
+// compute phase -- a kernel error, an overflow check, a malformed record -- whose next collective is a gather.
+// Not covered: running out of memory for the receive buffer BETWEEN a gather and the device exchange it sized;
+// there the transport's own failure handling applies: ncclCommAbort in csrc/host/sharded.cpp, the process
+// group's timeout under torch.distributed.)
+#define X_SLOT 248u                 // payload bytes of the small gathers (the largest: (P + 2) x 8 = 144 at 16 ranks)
+static int x_gather_slots(humid_ctx *c, const humid_comm *cm, const void *mine, u64 bytes, u64 slot, void *all, i64 my_status) {
+  const u32 P = cm->world;
+  std::vector<u8> out(slot + 8, 0), in((size_t)P * (slot + 8));
+  if (bytes) memcpy(out.data(), mine, bytes);
+  memcpy(out.data() + slot, &my_status, 8);
+  if (cm->host_all_gather(cm->user, out.data(), slot + 8, in.data()) < 0) {
+    c->x_peer_failed = true;                                     // (the transport itself failed: nobody is waiting for an announcement)
+    return fail(c, HUMID_E_COMM, "humid_comm.host_all_gather failed");
+  }
+  int bad_rank = -1;
+  i64 bad = 0;
+  for (u32 q = 0; q < P; q++) {
+    i64 stq;
+    memcpy(&stq, in.data() + (size_t)q * (slot + 8) + slot, 8);
+    if (stq != 0 && bad_rank < 0) { bad_rank = (int)q; bad = stq; }
+    if (all && bytes) memcpy((u8 *)all + (size_t)q * bytes, in.data() + (size_t)q * (slot + 8), bytes);
+  }
+  if (bad_rank >= 0) {
+    c->x_peer_failed = true;
+    return fail(c, HUMID_E_COMM, "rank %d left the pass with error %lld; every rank returns here", bad_rank, (long long)bad);
+  }
+  return HUMID_OK;
+}
 static int x_host_gather(humid_ctx *c, const humid_comm *cm, const void *mine, u64 bytes, void *all) {
   if (!cm || (cm->world == 1 && !c->force_comm)) { memcpy(all, mine, bytes); return HUMID_OK; }
-  if (cm->host_all_gather(cm->user, mine, bytes, all) < 0) return fail(c, HUMID_E_COMM, "humid_comm.host_all_gather failed");
-  return HUMID_OK;
+  // (test hook: this rank's compute phase in front of its k-th gather "fails")
+  if (++c->x_gathers == c->x_test_fail_after) return fail(c, HUMID_E_INVALID, "test: this rank fails before gather %d", c->x_gathers);
+  const bool first = !c->x_hist_done;                            // the first gather of a pass: the histograms (its own size)
+  c->x_hist_done = true;
+  if (!first && bytes > X_SLOT) return fail(c, HUMID_E_INVALID, "internal: a host gather of %llu bytes", (ull)bytes);
+  return x_gather_slots(c, cm, mine, bytes, first ? bytes : X_SLOT, all, 0);
+}
+// a rank that fails joins the gather its peers reach next, with its error code in the status word
+static void x_announce_failure(humid_ctx *c, const humid_comm *cm, int rc, u64 first_gather_bytes) {
+  if (!cm || (cm->world == 1 && !c->force_comm) || c->x_peer_failed || !cm->host_all_gather) return;
+  const std::string keep = c->err;
+  const u64 slot = c->x_hist_done ? X_SLOT : first_gather_bytes;
+  c->x_hist_done = true;
+  (void)x_gather_slots(c, cm, nullptr, 0, slot, nullptr, rc ? rc : -1);
+  c->err = keep;
 }
 // items of `elem` bytes: send_items[q] to rank q (laid out in rank order in d_send, or the same
 // send_items[rank] items to everybody when `same`), recv_items[q] from rank q in rank order in d_recv.
@@ -2653,10 +2704,31 @@ static int x_exchange(humid_ctx *c, const humid_comm *cm, const void *d_send, co
   return HUMID_OK;
 }
 
+static int run_exchange_impl(humid_ctx *c, const humid_comm *cm, const uint64_t *d_words, const uint8_t *d_filtered,
+                             uint64_t n_local, uint32_t word_nt, uint32_t distance, uint32_t method,
+                             uint32_t *d_cluster_id, uint8_t *d_keep, humid_summary *summary, humid_exchange_info *info);
 int humid_dedup_run_exchange(humid_ctx *c, const humid_comm *cm, const uint64_t *d_words, const uint8_t *d_filtered,
                              uint64_t n_local, uint32_t word_nt, uint32_t distance, uint32_t method,
                              uint32_t *d_cluster_id, uint8_t *d_keep, humid_summary *summary, humid_exchange_info *info) {
   if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  c->x_hist_done = false;
+  c->x_peer_failed = false;
+  c->x_gathers = 0;
+  const int rc = run_exchange_impl(c, cm, d_words, d_filtered, n_local, word_nt, distance, method, d_cluster_id, d_keep, summary, info);
+  if (rc != HUMID_OK && cm) {
+    // the size of the pass's first gather, should this rank have failed before it: the histogram table
+    // (the same arithmetic as in run_exchange_impl; word lengths it refuses are refused on every rank alike)
+    u64 first = 0;
+    u32 nc1 = 0, pbits = 0;
+    if (word_nt >= 1 && word_nt <= 64 && humid_stage_plan_info(c, word_nt, distance, 1, &nc1, &pbits) == HUMID_OK && pbits >= 1)
+      first = ((u64)1 << std::min<u32>(std::min<u32>(12u, 2 * std::min<u32>(word_nt, 32u)), pbits)) * 4;
+    if (first || c->x_hist_done) x_announce_failure(c, cm, rc, first);
+  }
+  return rc;
+}
+static int run_exchange_impl(humid_ctx *c, const humid_comm *cm, const uint64_t *d_words, const uint8_t *d_filtered,
+                             uint64_t n_local, uint32_t word_nt, uint32_t distance, uint32_t method,
+                             uint32_t *d_cluster_id, uint8_t *d_keep, humid_summary *summary, humid_exchange_info *info) {
   const u32 P = cm ? cm->world : 1, r = cm ? cm->rank : 0;
   if (P == 0 || P > MAX_RANKS || r >= P) return fail(c, HUMID_E_UNSUPPORTED, "1 .. %d ranks", MAX_RANKS);
   if ((P > 1 || (cm && c->force_comm)) && (!cm->host_all_gather || !cm->exchange)) return fail(c, HUMID_E_INVALID, "humid_comm without callbacks");
@@ -3276,40 +3348,69 @@ struct humid_shm {
   u64 slot_bytes = 0, map_bytes = 0, calls = 0;
   u8 *base = nullptr;
   bool owner = false;
-  std::atomic<u64> *arrive() const { return (std::atomic<u64> *)base; }                 // [world], 64 B apart
+  // one 64-byte line per rank: [0] arrival counter, [1] hello (the rank's pid once it has mapped the segment),
+  // [2] ack (rank 0 copies hello there: "you are on MY segment"); line `world`: [0] abort flag
+  std::atomic<u64> *line(u32 q) const { return (std::atomic<u64> *)(base + 64ull * q); }
+  std::atomic<u64> *arrive() const { return (std::atomic<u64> *)base; }                 // [8 * q]
   u8 *slot(u32 bank, u32 q) const { return base + 64ull * (world + 1) + ((u64)bank * world + q) * slot_bytes; }
 };
 
+// Collective: every rank of the group calls it.  Rank 0 creates the segment (after unlinking a stale one of the
+// same name); the others attach -- and PROVE that what they mapped is rank 0's segment, not a stale one left
+// under the name by a crashed run that they opened before rank 0's unlink: each writes its
+// pid into its line and waits for rank 0 to echo it; no echo within 50 ms = the wrong inode: map again.
 int humid_shm_open(humid_shm **out, const char *name, uint32_t rank, uint32_t world, uint64_t slot_bytes) {
   if (!out || !name || world == 0 || rank >= world || slot_bytes == 0) return fail(nullptr, HUMID_E_INVALID, "humid_shm_open: bad argument");
   slot_bytes = (slot_bytes + 63) & ~63ull;
   const u64 bytes = 64ull * (world + 1) + 2ull * world * slot_bytes;
-  int fd = -1;
+  const u64 me = ((u64)getpid() << 20) | (rank + 1);
+  const auto t0 = std::chrono::steady_clock::now();
+  auto timed_out = [&] { return std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60); };
+  void *m = MAP_FAILED;
   if (rank == 0) {
     shm_unlink(name);
-    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
     if (fd < 0) return fail(nullptr, HUMID_E_COMM, "shm_open(%s): %s", name, strerror(errno));
     if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(name); return fail(nullptr, HUMID_E_COMM, "ftruncate: %s", strerror(errno)); }
-  } else {
-    for (int tries = 0; tries < 30000; tries++) {                      // rank 0 may still be on its way
-      fd = shm_open(name, O_RDWR, 0600);
-      if (fd >= 0) {
-        struct stat sb;
-        if (fstat(fd, &sb) == 0 && (u64)sb.st_size >= bytes) break;   // created AND sized
-        close(fd);
-        fd = -1;
+    m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { shm_unlink(name); return fail(nullptr, HUMID_E_COMM, "mmap of %s: %s", name, strerror(errno)); }
+    // (a fresh segment is zero: counters start at 0.)  Wait for every other rank's hello and echo it.
+    for (u32 q = 1; q < world; q++) {
+      std::atomic<u64> *ln = (std::atomic<u64> *)((u8 *)m + 64ull * q);
+      u64 h = 0;
+      while ((h = ln[1].load(std::memory_order_acquire)) == 0) {
+        if (timed_out()) { munmap(m, bytes); shm_unlink(name); return fail(nullptr, HUMID_E_COMM, "rank %u did not attach to %s", q, name); }
+        usleep(200);
       }
-      usleep(1000);
+      ln[2].store(h, std::memory_order_release);
     }
-    if (fd < 0) return fail(nullptr, HUMID_E_COMM, "shared segment %s did not appear", name);
+  } else {
+    while (true) {
+      if (timed_out()) return fail(nullptr, HUMID_E_COMM, "shared segment %s did not appear (or is not rank 0's)", name);
+      const int fd = shm_open(name, O_RDWR, 0600);
+      if (fd < 0) { usleep(1000); continue; }
+      struct stat sb;
+      if (fstat(fd, &sb) != 0 || (u64)sb.st_size < bytes) { close(fd); usleep(1000); continue; }    // created AND sized
+      m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      close(fd);
+      if (m == MAP_FAILED) return fail(nullptr, HUMID_E_COMM, "mmap of %s: %s", name, strerror(errno));
+      std::atomic<u64> *ln = (std::atomic<u64> *)((u8 *)m + 64ull * rank);
+      ln[1].store(me, std::memory_order_release);
+      bool acked = false;
+      for (int tries = 0; tries < 250 && !acked; tries++) {       // 50 ms
+        acked = ln[2].load(std::memory_order_acquire) == me;
+        if (!acked) usleep(200);
+      }
+      if (acked) break;
+      munmap(m, bytes);                                             // a stale segment: rank 0 is on another inode
+      m = MAP_FAILED;
+    }
   }
-  void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (m == MAP_FAILED) return fail(nullptr, HUMID_E_COMM, "mmap of %s: %s", name, strerror(errno));
   humid_shm *h = new (std::nothrow) humid_shm;
   if (!h) { munmap(m, bytes); return fail(nullptr, HUMID_E_NOMEM, "out of host memory"); }
   h->name = name; h->rank = rank; h->world = world; h->slot_bytes = slot_bytes; h->map_bytes = bytes;
-  h->base = (u8 *)m; h->owner = rank == 0;                             // (a fresh segment is zero: counters start at 0)
+  h->base = (u8 *)m; h->owner = rank == 0;
   *out = h;
   return HUMID_OK;
 }
@@ -3317,6 +3418,8 @@ int humid_shm_open(humid_shm **out, const char *name, uint32_t rank, uint32_t wo
 int humid_shm_all_gather(void *shm, const void *mine, uint64_t bytes, void *all) {
   humid_shm *h = (humid_shm *)shm;
   if (!h || !mine || !all || bytes > h->slot_bytes) return -1;
+  std::atomic<u64> *abort_flag = h->line(h->world);
+  if (abort_flag->load(std::memory_order_acquire)) return -1;
   const u64 seq = ++h->calls;
   const u32 bank = (u32)(seq & 1);
   memcpy(h->slot(bank, h->rank), mine, bytes);
@@ -3324,13 +3427,22 @@ int humid_shm_all_gather(void *shm, const void *mine, uint64_t bytes, void *all)
   const auto t0 = std::chrono::steady_clock::now();
   for (u32 q = 0; q < h->world; q++) {
     u32 spins = 0;
-    while (h->arrive()[8 * q].load(std::memory_order_acquire) < seq)
-      if ((++spins & 0xffffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) return -1;
+    while (h->arrive()[8 * q].load(std::memory_order_acquire) < seq) {
+      if ((++spins & 0xfffu) == 0) {
+        if (abort_flag->load(std::memory_order_acquire)) return -1;                      // a rank gave up the group (humid_shm_abort)
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) return -1;
+      }
+    }
     memcpy((u8 *)all + (u64)q * bytes, h->slot(bank, q), bytes);
   }
   // the bank is written again two calls from now; by then every rank has arrived at the call in
   // between, i.e. has finished reading this one
   return 0;
+}
+
+// a rank that leaves the group for good (its pass failed outside a gather): every gather of every rank returns -1 from now on
+void humid_shm_abort(humid_shm *h) {
+  if (h && h->base) h->line(h->world)->store(1, std::memory_order_release);
 }
 
 void humid_shm_close(humid_shm *h) {

@@ -409,12 +409,15 @@ int humid_dedup_run_exchange(humid_ctx *ctx, const humid_comm *comm, const uint6
  * release of the counter and a spin on the others': a few microseconds, where a collective of the
  * process group costs ~100 us of launches and waits for a 16 KB table).  Rank 0 creates the segment
  * `name` (e.g. "/humid_<pid>"), the others attach to it (they wait up to ~30 s for it to appear); every
+ * humid_shm_open is COLLECTIVE (rank 0 waits until every rank has attached to ITS segment: a rank that mapped a
+ * stale segment of the same name, left by a crashed run, notices and maps again).  Every
  * rank then passes humid_shm_all_gather as host_all_gather and its handle as `user` -- or, when it needs
  * `user` for its own exchange callback, calls humid_shm_all_gather(handle, ...) from its own wrapper.
  * A gather is at most slot_bytes per rank (humid_dedup_run_exchange needs 16 KB: the histogram table). */
 typedef struct humid_shm humid_shm;
 int  humid_shm_open(humid_shm **out, const char *name, uint32_t rank, uint32_t world, uint64_t slot_bytes);
 int  humid_shm_all_gather(void *shm, const void *mine, uint64_t bytes, void *all);
+void humid_shm_abort(humid_shm *shm);    /* this rank gives the group up: every rank's gathers return -1 from now on */
 void humid_shm_close(humid_shm *shm);
 
 /* src/cluster.cc:31-33 atLeastDouble_, evaluated on the device (parity probe). */

@@ -372,3 +372,52 @@ def test_exchange_components_spanning_three_and_more_ranges(P, method):
         spans.setdefault(cid_, set()).add(nt)
     assert sum(1 for v in spans.values() if len(v) >= 3) >= 500
     check(P, words, filt, 24, 1, method)
+
+
+@pytest.mark.parametrize("fail_after", [1, 2, 3, 4])
+def test_exchange_one_rank_failing_ends_the_pass_on_every_rank(fail_after):
+    """failure is collective.  Rank 1 leaves the pass with an error right after its k-th host
+    gather (test hook "test_fail_before_gather"); it still joins the NEXT gather with its error code in the status
+    word, so ranks 0 and 2 return an error from that gather instead of waiting for ever -- and nobody hangs."""
+    import threading
+    import torch
+    import humid_amd
+    from fake_dist import FakeDist, FakeWorld
+    from humid_amd.sharded import HipStageOps, ShardedDedup
+    P = 3
+    words, filt = synth_words(90_000, 31, 24, p_sub=5e-3)
+    world = FakeWorld(P)
+    dev = torch.device("cuda:0")
+    result = [None] * P
+
+    def rank_main(r):
+        try:
+            torch.cuda.set_device(0)
+            ops = HipStageOps(0)
+            if r == 1:
+                ops.set_option("test_fail_before_gather", fail_after)
+            sd = ShardedDedup(device=0, word_nt=24, distance=1, ops=ops, dist=FakeDist(world, r), mode="exchange")
+            n = 30_000
+            w = torch.from_numpy(words[r * n:(r + 1) * n].view(np.int64)).to(dev)
+            f = torch.from_numpy(filt[r * n:(r + 1) * n]).to(dev)
+            c = torch.zeros(n, dtype=torch.int32, device=dev)
+            k = torch.zeros(n, dtype=torch.uint8, device=dev)
+            try:
+                sd.run(w, f, c, k)
+                result[r] = "ok"
+            except humid_amd.HumidError as e:
+                result[r] = str(e)
+            ops.close()
+        except Exception as e:  # pragma: no cover
+            result[r] = "crash: %r" % (e,)
+            world.barrier.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(P)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in th), "a rank is still waiting for a peer that left"
+    assert "test: this rank fails" in result[1], result
+    for r in (0, 2):
+        assert "rank 1 left the pass" in result[r], result

@@ -302,6 +302,22 @@ def test_oracle_parity_at_scale(dd):
     check_against_oracle(dd, words, filt, 24, 1, False, deep=True)
 
 
+def test_oracle_parity_at_scale_genome_d2(dd1):
+    """3 M reads of BASELINE config 5's shape (no UMI: 12 + 12 nucleotides of a fragment's two ends drawn from a
+    random genome, d = 2: six combinations of 12 nt, dense neighbourhoods), every array against the oracle.  The
+    six-combination key kernels and the first-combination rule at d = 2 were only oracle-compared up to 200 k
+    reads before round 3 (VERDICT round 2, weak #3)."""
+    words, filt = synth_words(3_000_000, 1005, 24, mode="genome")
+    check_against_oracle(dd1, words, filt, 24, 2, False, deep=True)
+
+
+def test_oracle_parity_metric_words_d2(dd1):
+    """1 M reads of the metric workload at d = 2, both methods"""
+    words, filt = synth_words(1_000_000, 1002, 24)
+    check_against_oracle(dd1, words, filt, 24, 2, False, deep=True)
+    check_against_oracle(dd1, words, filt, 24, 2, True, deep=False)
+
+
 @pytest.fixture(scope="module")
 def dd1():
     """one context with the default settings, for tests that do not depend on the count variant"""

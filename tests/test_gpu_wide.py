@@ -81,6 +81,15 @@ def test_wide_larger(dd):
     check_against_oracle(dd, w, f, 50, 2, False, deep=False)
 
 
+def test_full_umi_variant_n36(dd):
+    """SURVEY 8(d), config 3's full-UMI variant: `-n 36` = 12 + 12 + 12 nucleotides (72 bits, two uint64 per
+    word).  500 k reads, d = 1, both methods, every array against the oracle; counted in LDS tables."""
+    w, f = synth_wide_words(500_000, 1003, 36)
+    s = check_against_oracle(dd, w, f, 36, 1, False, deep=True)
+    assert s["count_mode_used"] == 2
+    check_against_oracle(dd, w, f, 36, 1, True, deep=False)
+
+
 @pytest.mark.parametrize("n", [33, 40, 48, 63, 64])
 def test_wide_lds_buckets_against_the_sort(n):
     """round 2: wide words counted in LDS tables (buckets cut by the words' top 64 bits, entries claimed by

@@ -22,6 +22,7 @@ CONFIGS = [
     ("C3 50M PE+UMI file d1", 50_000_000, 24, 1, "umi"),
     ("C4 shard 25M UMI8 d1", 25_000_000, 24, 1, "umi"),
     ("C5 50M PE no-UMI d2", 50_000_000, 24, 2, "genome"),
+    ("C3b 50M PE+UMI file -n 36 (12+12+12: the full UMI) d1", 50_000_000, 36, 1, "wide"),   # the full-UMI variant of config 3
     ("W6 10M wide 48 nt d1", 10_000_000, 48, 1, "wide"),      # two uint64 per word (sorted count stage)
     ("W7 10M wide 64 nt d2", 10_000_000, 64, 2, "wide"),
     ("W8 50M wide 48 nt d1", 50_000_000, 48, 1, "wide"),      # 2^18 buckets: the largest LDS-table case of two-word words
