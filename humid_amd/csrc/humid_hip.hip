@@ -103,6 +103,7 @@ struct humid_ctx {
   DBuf big_runs;            // k_big_runs: (start, length, first tile) of the buckets beyond k_pairs' walk, per combination
   DBuf had;                 // k_pairs: per combination and position, pairs found in the first phase (<< 24) | distance to the first one
   DBuf e_kx, e_vx, e_ky, e_vy, e_raw, e_sorted, e_edges, e_head, e_hpos;   // edit-distance neighbour search
+  DBuf e_runlo, e_nch, e_choff, e_pc2, e_poff2;                            // ... its long runs in pieces
   bool edit = false;         // option "edit_distance": Levenshtein instead of Hamming neighbours (-e)
   DBuf xr_heads, xr_send, xr_zero;                             // the same for two-word words: heads, routed words, an all-usable flag array
   DBuf xr_hist, xr_recv, xr_eloc, xr_got, xr_eall, xr_ret;   // humid_dedup_run_exchange: histogram, received words, pair records, received items, results
@@ -994,10 +995,12 @@ static int stage_count_wide(humid_ctx *c, const W2 *d_words, const u8 *d_filt, u
 // buckets longer than k_pairs' bounded walk, over the walked order W[0, n) of one combination: device list at
 // c->big_runs + slot * cap (start, length, first tile), host copy in `runs` with the total as a last entry
 template <class WT>
+// cap_n (0: n): the array length the slots of the device list are sized by -- one value for all combinations of a
+// caller that keeps several lists at once
 static int find_big_runs(humid_ctx *c, const WT *W, u32 n, WT mask, u32 walk_max, u32 slot, std::vector<BigRun> &runs,
-                         const BigRun **d_runs_out) {
+                         const BigRun **d_runs_out, u32 cap_n = 0) {
   hipStream_t st = c->stream;
-  const u32 cap = n / (walk_max + 2) + 1;                         // runs are disjoint and longer than walk_max + 1
+  const u32 cap = (cap_n ? cap_n : n) / (walk_max + 2) + 1;       // runs are disjoint and longer than walk_max + 1
   ENSURE(c->big_runs, (size_t)MAX_COMBOS * cap * sizeof(BigRun) + 16);
   u32 *d_n = (u32 *)((char *)c->big_runs.p + (size_t)MAX_COMBOS * cap * sizeof(BigRun));
   BigRun *d_runs = c->big_runs.as<BigRun>() + (size_t)slot * cap;
@@ -1772,9 +1775,15 @@ static int edit_edges(humid_ctx *c, const WT *g_word, u32 U, u32 word_nt, u32 di
           vy = c->e_vy.as<u32>();
         }
         HIPCHK(hipMemsetAsync(c->pc.as<u32>() + U, 0, 4, st));
+        HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_BIGMASK], 0, sizeof(ull), st));
+        const u32 jwalk = c->walk_max;                         // candidates one lane verifies for one entry (0: all)
 #define EDIT_JOIN(FILL, KT, BAND, PC, POFF, OUT)                                                              \
   hipLaunchKernelGGL((k_edit_join<FILL, KT, WT, BAND>), dim3(blocks_for(U)), dim3(256), 0, st, c->e_kx.as<KT>(), \
-                     c->e_vx.as<u32>(), (const KT *)ky, vy, U, g_word, word_nt, distance, PC, POFF, OUT)
+                     c->e_vx.as<u32>(), (const KT *)ky, vy, U, g_word, word_nt, distance, PC, POFF, OUT, jwalk, &c->d_ctr[CTR_BIGMASK])
+#define EDIT_CHUNKS(FILL, KT, BAND, NP, PC, POFF, OUT)                                                                    \
+  hipLaunchKernelGGL((k_edit_join_chunks<FILL, KT, WT, BAND>), dim3(blocks_for(NP)), dim3(256), 0, st, c->e_kx.as<KT>(),  \
+                     c->e_vx.as<u32>(), (const KT *)ky, vy, U, (const u32 *)c->e_runlo.as<u32>(), (const u32 *)c->e_choff.as<u32>(), \
+                     (u32)(NP), jwalk, g_word, word_nt, distance, PC, POFF, OUT)
         if (k32) { if (D <= 1) EDIT_JOIN(false, u32, 1, c->pc.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr);
                    else EDIT_JOIN(false, u32, 2, c->pc.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr); }
         else { if (D <= 1) EDIT_JOIN(false, u64, 1, c->pc.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr);
@@ -1782,7 +1791,34 @@ static int edit_edges(humid_ctx *c, const WT *g_word, u32 U, u32 word_nt, u32 di
         TRY(exscan_u32(c, c->pc.as<u32>(), c->poff.as<u32>(), (u64)U + 1));
         HIPCHK(hipGetLastError());
         TRY(read_counters(c, c->poff.as<u32>() + U));
-        const u64 found = c->h_ctr[CTR_N - 1] & 0xffffffffull;
+        u64 found = c->h_ctr[CTR_N - 1] & 0xffffffffull;
+        u64 n_pieces = 0;                                       // > 0: this join goes through the pieces
+        if (c->h_ctr[CTR_BIGMASK]) {
+          // some run of equal keys is longer than one lane walks: every run in pieces of jwalk candidates
+          ENSURE(c->e_runlo, ((size_t)U + 1) * 4);
+          ENSURE(c->e_nch, ((size_t)U + 1) * 4);
+          ENSURE(c->e_choff, ((size_t)U + 1) * 4);
+          if (k32) hipLaunchKernelGGL(k_edit_chunks<u32>, dim3(blocks_for((u64)U + 1)), dim3(256), 0, st, c->e_kx.as<u32>(), (const u32 *)ky, U,
+                                      jwalk, c->e_runlo.as<u32>(), c->e_nch.as<u32>());
+          else hipLaunchKernelGGL(k_edit_chunks<u64>, dim3(blocks_for((u64)U + 1)), dim3(256), 0, st, c->e_kx.as<u64>(), (const u64 *)ky, U,
+                                  jwalk, c->e_runlo.as<u32>(), c->e_nch.as<u32>());
+          TRY(exscan_u32(c, c->e_nch.as<u32>(), c->e_choff.as<u32>(), (u64)U + 1));
+          HIPCHK(hipGetLastError());
+          TRY(read_counters(c, c->e_choff.as<u32>() + U));
+          n_pieces = c->h_ctr[CTR_N - 1] & 0xffffffffull;
+          if (n_pieces >= 0xfffffff0ull) return fail(c, HUMID_E_OVERFLOW, "too many candidate pieces in the edit-distance search");
+          ENSURE(c->e_pc2, ((size_t)n_pieces + 1) * 4);
+          ENSURE(c->e_poff2, ((size_t)n_pieces + 1) * 4);
+          HIPCHK(hipMemsetAsync(c->e_pc2.as<u32>() + n_pieces, 0, 4, st));
+          if (k32) { if (D <= 1) EDIT_CHUNKS(false, u32, 1, n_pieces, c->e_pc2.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr);
+                     else EDIT_CHUNKS(false, u32, 2, n_pieces, c->e_pc2.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr); }
+          else { if (D <= 1) EDIT_CHUNKS(false, u64, 1, n_pieces, c->e_pc2.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr);
+                 else EDIT_CHUNKS(false, u64, 2, n_pieces, c->e_pc2.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr); }
+          TRY(exscan_u32(c, c->e_pc2.as<u32>(), c->e_poff2.as<u32>(), n_pieces + 1));
+          HIPCHK(hipGetLastError());
+          TRY(read_counters(c, c->e_poff2.as<u32>() + n_pieces));
+          found = c->h_ctr[CTR_N - 1] & 0xffffffffull;
+        }
         if (found == 0) continue;
         if (raw + found >= 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "too many candidate pairs in the edit-distance search");
         if ((raw + found) * 8 > c->e_raw.cap) {               // grow, keeping what is there
@@ -1793,10 +1829,17 @@ static int edit_edges(humid_ctx *c, const WT *g_word, u32 U, u32 word_nt, u32 di
           c->e_raw.release();
           c->e_raw = bigger;
         }
+        if (n_pieces) {
+          if (k32) { if (D <= 1) EDIT_CHUNKS(true, u32, 1, n_pieces, (u32 *)nullptr, (const u32 *)c->e_poff2.as<u32>(), c->e_raw.as<u64>() + raw);
+                     else EDIT_CHUNKS(true, u32, 2, n_pieces, (u32 *)nullptr, (const u32 *)c->e_poff2.as<u32>(), c->e_raw.as<u64>() + raw); }
+          else { if (D <= 1) EDIT_CHUNKS(true, u64, 1, n_pieces, (u32 *)nullptr, (const u32 *)c->e_poff2.as<u32>(), c->e_raw.as<u64>() + raw);
+                 else EDIT_CHUNKS(true, u64, 2, n_pieces, (u32 *)nullptr, (const u32 *)c->e_poff2.as<u32>(), c->e_raw.as<u64>() + raw); }
+        } else
         if (k32) { if (D <= 1) EDIT_JOIN(true, u32, 1, (u32 *)nullptr, c->poff.as<u32>(), c->e_raw.as<u64>() + raw);
                    else EDIT_JOIN(true, u32, 2, (u32 *)nullptr, c->poff.as<u32>(), c->e_raw.as<u64>() + raw); }
         else { if (D <= 1) EDIT_JOIN(true, u64, 1, (u32 *)nullptr, c->poff.as<u32>(), c->e_raw.as<u64>() + raw);
                else EDIT_JOIN(true, u64, 2, (u32 *)nullptr, c->poff.as<u32>(), c->e_raw.as<u64>() + raw); }
+#undef EDIT_CHUNKS
 #undef EDIT_JOIN
         raw += found;
       }
@@ -1902,6 +1945,36 @@ static int stage_pairs_share(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt
   ENSURE(c->pc, (size_t)(T + 1) * 4);
   ENSURE(c->poff, (size_t)(T + 1) * 4);
   HIPCHK(hipMemsetAsync(c->pc.as<u32>() + T, 0, 4, st));
+  HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_BIGMASK], 0, sizeof(ull), st));
+  // the walk of a position is bounded as on one GPU (round 3: a bucket of 10^5 words made a lane walk it all);
+  // what lies beyond it inside large buckets is finished by the tiles below
+  const u32 walk_max = c->walk_max;
+  u64 E_near = 0, E_far = 0;
+  std::vector<std::vector<BigRun>> runs(nseg);
+  std::vector<const BigRun *> d_runs(nseg, nullptr);
+  u64 big_mask = 0;
+  // what the tiles of combination `seg` walk: the whole array, first positions in this rank's slice (prefix
+  // combination), or this rank's selected words (the others)
+  auto tile_launch = [&](u32 seg, int mode) -> int {
+    const ull tiles = runs[seg].back().tile0;
+    if (!tiles) return HUMID_OK;
+    const u32 tgrid = (u32)std::min<ull>(tiles, 1u << 20);
+    const u32 *vs = seg ? c->seg_vs.as<u32>() + (size_t)(seg - 1) * U : nullptr;
+    const u64 *ws = seg ? c->seg_ws.as<u64>() + (size_t)(seg - 1) * U : g_word;
+    const u32 lo = seg ? 0u : p_lo, hi = seg ? 0xffffffffu : p_hi;
+#define SHARE_TILES(P0, MD)                                                                                                     \
+  hipLaunchKernelGGL((k_pairs_tiles<P0, MD, u64>), dim3(tgrid), dim3(PT2_THREADS), 0, st, ws, vs, d_runs[seg],                    \
+                     (u32)runs[seg].size() - 1, tiles, d_masks, seg, distance, walk_max, (u32 *)nullptr, (u32 *)nullptr,          \
+                     (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr, c->share_edges.as<u64>(),       \
+                     &c->d_ctr[CTR_SPECIAL], lo, hi)
+    if (seg == 0 && mode == PM_EMIT_COUNT) SHARE_TILES(true, PM_EMIT_COUNT);
+    else if (seg == 0) SHARE_TILES(true, PM_EMIT_FILL);
+    else if (mode == PM_EMIT_COUNT) SHARE_TILES(false, PM_EMIT_COUNT);
+    else SHARE_TILES(false, PM_EMIT_FILL);
+#undef SHARE_TILES
+    HIPCHK(hipGetLastError());
+    return HUMID_OK;
+  };
   for (int phase = 0; phase < 2; phase++) {
     for (u32 seg = 0; seg < nseg; seg++) {
       if (n_sel[seg] == 0) continue;
@@ -1914,29 +1987,51 @@ static int stage_pairs_share(humid_ctx *c, const u64 *g_word, u32 U, u32 word_nt
       if (seg == 0 && phase == 0)
         hipLaunchKernelGGL((k_pairs<true, PM_EMIT_COUNT, u64>), grid, blk, 0, st, g_word, vs, U, p_lo, n_sel[0], plan.mask[0].lo,
                            d_masks, 0u, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr,
-                           (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u32 *)nullptr);
+                           (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u32 *)nullptr, walk_max, &c->d_ctr[CTR_BIGMASK]);
       else if (seg == 0)
         hipLaunchKernelGGL((k_pairs<true, PM_EMIT_FILL, u64>), grid, blk, 0, st, g_word, vs, U, p_lo, n_sel[0], plan.mask[0].lo,
                            d_masks, 0u, distance, (u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr,
-                           (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u32 *)nullptr);
+                           (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u32 *)nullptr, walk_max);
       else if (phase == 0)
         hipLaunchKernelGGL((k_pairs<false, PM_EMIT_COUNT, u64>), grid, blk, 0, st, ws, vs, n_sel[seg], 0u, n_sel[seg],
                            plan.mask[seg].lo, d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
-                           (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u32 *)nullptr);
+                           (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u32 *)nullptr, walk_max,
+                           &c->d_ctr[CTR_BIGMASK]);
       else
         hipLaunchKernelGGL((k_pairs<false, PM_EMIT_FILL, u64>), grid, blk, 0, st, ws, vs, n_sel[seg], 0u, n_sel[seg],
                            plan.mask[seg].lo, d_masks, seg, distance, (u32 *)nullptr, (u32 *)nullptr,
-                           (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u32 *)nullptr);
+                           (const u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, pcs, pos, ed, (u32 *)nullptr, walk_max);
     }
     if (phase == 0) {
       TRY(exscan_u32(c, c->pc.as<u32>(), c->poff.as<u32>(), T + 1));
       HIPCHK(hipGetLastError());
       TRY(read_counters(c, c->poff.as<u32>() + T));
-      const u64 E = c->h_ctr[CTR_N - 1] & 0xffffffffull;
-      *n_edges_out = E;
-      if (E == 0) return HUMID_OK;
-      ENSURE(c->share_edges, (size_t)E * 8);
+      E_near = c->h_ctr[CTR_N - 1] & 0xffffffffull;
+      big_mask = c->h_ctr[CTR_BIGMASK];
+      if (big_mask) {
+        HIPCHK(hipMemsetAsync(&c->d_ctr[CTR_SPECIAL], 0, sizeof(ull), st));
+        for (u32 seg = 0; seg < nseg; seg++) {
+          if (!(big_mask >> seg & 1) || n_sel[seg] == 0) continue;
+          const u64 *ws = seg ? c->seg_ws.as<u64>() + (size_t)(seg - 1) * U : g_word;
+          TRY(find_big_runs<u64>(c, ws, seg ? n_sel[seg] : U, plan.mask[seg].lo, walk_max, seg, runs[seg], &d_runs[seg], U));
+          TRY(tile_launch(seg, PM_EMIT_COUNT));
+        }
+        TRY(read_counters(c));
+        E_far = c->h_ctr[CTR_SPECIAL];
+      }
+      if (E_near + E_far > 0xffffffffull) return fail(c, HUMID_E_OVERFLOW, "%llu neighbour pairs in one share", (ull)(E_near + E_far));
+      *n_edges_out = E_near + E_far;
+      if (E_near + E_far == 0) return HUMID_OK;
+      ENSURE(c->share_edges, (size_t)(E_near + E_far) * 8);
+      if (E_near == 0) break;                          // (only far pairs: no fill launches of k_pairs)
     }
+  }
+  if (E_far) {
+    const ull at = E_near;                             // the tiles append behind k_pairs' pairs
+    HIPCHK(hipMemcpyAsync(&c->d_ctr[CTR_SPECIAL], &at, sizeof(ull), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));                  // (`at` is a host temporary)
+    for (u32 seg = 0; seg < nseg; seg++)
+      if ((big_mask >> seg & 1) && n_sel[seg] && runs[seg].size() > 1) TRY(tile_launch(seg, PM_EMIT_FILL));
   }
   HIPCHK(hipGetLastError());
   return HUMID_OK;
@@ -2188,7 +2283,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->in_bases, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
-                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->big_runs, &c->small_roots, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_heads, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles, &c->xr_hist, &c->xr_recv, &c->xr_eloc, &c->xr_got, &c->xr_eall, &c->xr_ret, &c->xr_heads, &c->xr_send, &c->xr_zero,
+                  &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->big_runs, &c->small_roots, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->e_runlo, &c->e_nch, &c->e_choff, &c->e_pc2, &c->e_poff2, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_heads, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles, &c->xr_hist, &c->xr_recv, &c->xr_eloc, &c->xr_got, &c->xr_eall, &c->xr_ret, &c->xr_heads, &c->xr_send, &c->xr_zero,
                   &c->xo_regs, &c->xo_inv, &c->xo_send, &c->xo_int, &c->xo_cross, &c->xo_sel, &c->xo_selall, &c->xo_parent, &c->xo_flag, &c->xo_xroot, &c->xo_xcbits, &c->xo_xcblk,
                   &c->xo_xcid, &c->xo_xcall, &c->xo_ldeg, &c->xo_cnt, &c->p8_a, &c->p8_b, &c->p8_cur, &c->p8_status, &c->cg_edges, &c->cg_cur, &c->cg_far, &c->cg_bits, &c->cg_nbits, &c->cg_blk, &c->cg_nblk, &c->cg_nodes, &c->cg_ncnt, &c->cg_deg,
                   &c->cg_off, &c->cg_idx, &c->cg_parent, &c->cg_csize, &c->cg_curs, &c->cg_cl_of, &c->cg_maxleaf, &c->cg_cl_size,

@@ -266,8 +266,10 @@ __global__ void __launch_bounds__(PT2_THREADS)
 k_pairs_tiles(const WT *__restrict__ W, const u32 *__restrict__ V, const BigRun *__restrict__ runs, u32 n_runs,
               ull total_tiles, EarlierMasksT<WT> em, u32 cb, u32 distance, u32 walk_max, u32 *deg, u32 *parent,
               const u32 *__restrict__ nbr_off, u32 *cur, u32 *nbr_idx, const u32 *__restrict__ cnt,
-              u64 *__restrict__ edges = nullptr, ull *ecount = nullptr) {
+              u64 *__restrict__ edges = nullptr, ull *ecount = nullptr, u32 i_lo = 0, u32 i_hi = 0xffffffffu) {
   HUMID_GUARD_LAST_VGPR();
+  // [i_lo, i_hi): only pairs whose FIRST position lies in that range (a rank's share of the positions in the
+  // all-gather mode's pair search); the default is every pair
   // PM_EMIT_COUNT: *ecount += pairs found (one add per wave and square); PM_EMIT_FILL: the pairs are
   // appended to edges[] at *ecount (which the caller set to the pairs already there)
   __shared__ WT sb[PT2_TILE];
@@ -311,6 +313,7 @@ k_pairs_tiles(const WT *__restrict__ W, const u32 *__restrict__ V, const BigRun 
           first = first && !(qq < cb && !w_hits(x, em.m[qq]));
         if (!first) continue;
         const u32 i = lim[k] - walk_max;
+        if (i < i_lo || i >= i_hi) continue;
         const u32 ri = PASS0 ? i : V[i], rj = PASS0 ? j : V[j];
         if (MODE == PM_FILL) {
           nbr_idx[nbr_off[ri] + atomicAdd(&cur[ri], 1u)] = rj;
@@ -475,11 +478,15 @@ __device__ __forceinline__ u32 lev_band(WT x, WT y, u32 n) {
 // programme.  COUNT: pc[t] = pairs found; FILL: (smaller rank << 32 | larger rank) from poff[t].
 // A pair may come out several times (both roles, several combinations): the list is made unique
 // afterwards.
+// walk (0: no bound) / big: a run of equal keys in Y longer than `walk` is not walked by one lane -- the COUNT pass
+// stops there and raises *big; the caller then takes this join through k_edit_chunks / k_edit_join_chunks, which
+// cut every long run into pieces of `walk` candidates (round 3: a 10^5-word bucket made every one of its 10^5 lanes
+// verify 10^5 candidates)
 template <bool FILL, class KeyT, class WT, u32 BAND>
 __global__ void __launch_bounds__(256)
 k_edit_join(const KeyT *__restrict__ KX, const u32 *__restrict__ VX, const KeyT *__restrict__ KY,
             const u32 *__restrict__ VY, u32 n, const WT *__restrict__ words, u32 word_nt, u32 distance,
-            u32 *__restrict__ pc, const u32 *__restrict__ poff, u64 *__restrict__ edges) {
+            u32 *__restrict__ pc, const u32 *__restrict__ poff, u64 *__restrict__ edges, u32 walk = 0, ull *big = nullptr) {
   HUMID_GUARD_LAST_VGPR();
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
@@ -493,6 +500,7 @@ k_edit_join(const KeyT *__restrict__ KX, const u32 *__restrict__ VX, const KeyT 
   }
   u32 found = 0;
   u64 e = FILL ? (u64)poff[t] : 0;
+  if (!FILL && walk && big && lo + walk < n && KY[lo + walk] == key) { atomicOr(big, 1ull); pc[t] = 0; return; }
   for (u32 j = lo; j < n && KY[j] == key; j++) {
     const u32 ry = VY[j];
     if (ry == rx) continue;
@@ -501,6 +509,64 @@ k_edit_join(const KeyT *__restrict__ KX, const u32 *__restrict__ VX, const KeyT 
     else found++;
   }
   if (!FILL) pc[t] = found;
+}
+
+// ---- the same join with every run of equal keys cut into pieces of `walk` candidates ----
+// per X entry: start of its run in Y and the number of pieces (>= 1: the scan's input)
+template <class KeyT>
+__global__ void __launch_bounds__(256)
+k_edit_chunks(const KeyT *__restrict__ KX, const KeyT *__restrict__ KY, u32 n, u32 walk, u32 *__restrict__ run_lo,
+              u32 *__restrict__ n_chunks) {
+  HUMID_GUARD_LAST_VGPR();
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > n) return;
+  if (t == n) { n_chunks[n] = 0; return; }             // scan sentinel
+  const KeyT key = KX[t];
+  u32 lo = 0, hi = n;
+  while (lo < hi) {
+    const u32 mid = lo + ((hi - lo) >> 1);
+    if (KY[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  const u32 first = lo;
+  hi = n;
+  while (lo < hi) {                                    // first j with KY[j] > key
+    const u32 mid = lo + ((hi - lo) >> 1);
+    if (KY[mid] <= key) lo = mid + 1; else hi = mid;
+  }
+  const u32 len = lo - first;
+  run_lo[t] = first;
+  n_chunks[t] = len ? (len + walk - 1) / walk : 1u;
+}
+// one thread per piece: chunk_off = exclusive scan of n_chunks (n + 1 entries)
+template <bool FILL, class KeyT, class WT, u32 BAND>
+__global__ void __launch_bounds__(256)
+k_edit_join_chunks(const KeyT *__restrict__ KX, const u32 *__restrict__ VX, const KeyT *__restrict__ KY,
+                   const u32 *__restrict__ VY, u32 n, const u32 *__restrict__ run_lo, const u32 *__restrict__ chunk_off,
+                   u32 n_pieces, u32 walk, const WT *__restrict__ words, u32 word_nt, u32 distance, u32 *__restrict__ pc,
+                   const u32 *__restrict__ poff, u64 *__restrict__ edges) {
+  HUMID_GUARD_LAST_VGPR();
+  const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pieces) return;
+  u32 lo = 0, hi = n;                                  // the X entry of this piece: largest t with chunk_off[t] <= p
+  while (hi - lo > 1) {
+    const u32 mid = lo + ((hi - lo) >> 1);
+    if (chunk_off[mid] <= p) lo = mid; else hi = mid;
+  }
+  const u32 t = lo;
+  const KeyT key = KX[t];
+  const u32 rx = VX[t];
+  const WT wx = words[rx];
+  const u32 j0 = run_lo[t] + (p - chunk_off[t]) * walk;
+  u32 found = 0;
+  u64 e = FILL ? (u64)poff[p] : 0;
+  for (u32 j = j0; j < n && j - j0 < walk && KY[j] == key; j++) {
+    const u32 ry = VY[j];
+    if (ry == rx) continue;
+    if (lev_band<BAND>(wx, words[ry], word_nt) > distance) continue;
+    if (FILL) edges[e++] = rx < ry ? (((u64)rx << 32) | ry) : (((u64)ry << 32) | rx);
+    else found++;
+  }
+  if (!FILL) pc[p] = found;
 }
 
 // head[i] = 1 where a new value starts in the sorted 64-bit array; head[n] = 0 (scan sentinel)

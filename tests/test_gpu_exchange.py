@@ -304,6 +304,30 @@ def test_exchange_large_buckets_go_through_the_tiles(P, walk):
             assert s["edges"] == osum["edges"] and s["clusters"] == osum["clusters"]
 
 
+@pytest.mark.parametrize("walk", [None, 50])
+def test_allgather_mode_large_buckets_go_through_the_tiles(walk):
+    """round 3: the position shares of the all-gather mode (humid_stage_pairs) walk
+    bounded too; a 30 000-word bucket is finished by k_pairs_tiles restricted to the rank's own first
+    positions.  2 virtual ranks, d = 1 and 2, against the oracle."""
+    rng = np.random.default_rng(23)
+    tails = rng.choice(1 << 24, size=30_000, replace=False).astype(np.uint64)
+    uniq = (np.uint64(0x3c5a96) << np.uint64(24)) | tails
+    words = np.repeat(uniq, rng.poisson(0.4, size=len(uniq)) + 1)
+    extra, ef = synth_words(40_000, 5, 24, p_sub=4e-3, p_n=1e-3)
+    words = np.concatenate([words, extra])
+    filt = np.concatenate([np.zeros(len(words) - len(extra), np.uint8), ef])
+    perm = rng.permutation(len(words))
+    words, filt = words[perm], filt[perm]
+    for d in (1, 2):
+        ocid, okeep, osum, _ = orc.dedup_run(words, filt, 24, d, 0)
+        out, offs = run_ranks(2, words, filt, 24, d, 0, "allgather", bucket_walk=walk)
+        for r in range(2):
+            cid, keep, s, used = out[r]
+            assert used == "allgather"
+            assert np.array_equal(cid, ocid[offs[r]:offs[r + 1]]) and np.array_equal(keep, okeep[offs[r]:offs[r + 1]])
+            assert s["edges"] == osum["edges"] and s["clusters"] == osum["clusters"]
+
+
 @pytest.mark.parametrize("P,n", [(2, 40), (3, 64)])
 def test_exchange_wide_words_in_lds_tables(P, n):
     """enough two-word words per rank for the LDS-table count (k_dedup_lds_wide) over a rank's own range of
