@@ -218,10 +218,6 @@ int main(int argc, char **argv) {
     std::fprintf(stderr, "humid: -g takes 1 .. 16 GPUs\n");
     return 2;
   }
-  if (a.gpus > 1 && a.edit && a.distance > 1) {
-    std::fprintf(stderr, "humid: -g %u: edit distances beyond 1 run on one GPU only\n", a.gpus);
-    return 2;
-  }
   // HUMID_FORCE_SHARDED=1: the rank orchestration also for -g 1 (one rank; exercises the transport)
   const bool sharded = a.gpus > 1 || getenv("HUMID_FORCE_SHARDED") != nullptr;
   std::ofstream log(a.log_name.c_str(), std::ios::out | std::ios::binary);
@@ -430,8 +426,8 @@ int main(int argc, char **argv) {
   int rc;
   if (sharded) {
     // the read set in input-order shards, one rank (thread + context + GPU) per shard: sharded.cpp
-    rc = ranks->run(run_words, run_filt, N, (uint32_t)a.word_length, a.edit ? (uint32_t)std::min<size_t>(a.distance, 1) : (uint32_t)a.distance,
-                    method, a.stats, cluster_id, keep, shr);
+    rc = ranks->run(run_words, run_filt, N, (uint32_t)a.word_length, (uint32_t)a.distance, method, a.stats, cluster_id, keep, shr,
+                    a.edit);
     sum = shr.sum;
     if (rc == HUMID_OK && getenv("HUMID_TIMING"))
       std::fprintf(stderr, "[humid]   %u ranks, bulk data by %s: set-up %.1f ms, ranks %.1f ms\n", a.gpus,

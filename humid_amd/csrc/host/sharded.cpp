@@ -234,6 +234,7 @@ struct Job {
   uint64_t n_reads;
   uint32_t word_nt, distance, method;
   bool want_hist;
+  bool edit;
   uint32_t *cluster_id;
   uint8_t *keep;
   humid_summary sum{};                     // written by rank 0
@@ -290,6 +291,7 @@ bool run_rank(Rank &k) {
     STEP(k.hip_ok(hipMemcpyAsync(d_f.p, job.filtered + r0, n_local, hipMemcpyHostToDevice, st), "hipMemcpyAsync (flags)"));
   }
   // the pass itself is the library's (humid_dedup_run_exchange); this file moves the bytes
+  if (job.edit) humid_ctx_set_option(k.ctx, "edit_distance", 1);
   if (P == 1) humid_ctx_set_option(k.ctx, "force_comm", 1);    // (HUMID_FORCE_SHARDED: the point is to run the transport)
   humid_comm cm;
   cm.user = &k;
@@ -416,7 +418,7 @@ ShardedSession::~ShardedSession() {
 
 int ShardedSession::run(const uint64_t *words, const uint8_t *filtered, uint64_t n_reads, uint32_t word_nt,
                         uint32_t distance, uint32_t method, bool want_hist, uint32_t *cluster_id, uint8_t *keep,
-                        ShardedResult &out) {
+                        ShardedResult &out, bool edit) {
   Impl &m = *p_;
   Group &g = m.g;
   if (m.early_code != HUMID_OK) { out.error = m.early_error; return m.early_code; }
@@ -426,7 +428,7 @@ int ShardedSession::run(const uint64_t *words, const uint8_t *filtered, uint64_t
   if (n_reads >= 0x7fffffffull * g.P) { out.error = "-g: more than 2^31-1 reads per rank"; return HUMID_E_OVERFLOW; }
   if (m.starter.joinable()) m.starter.join();
   out.ms_init = m.ms_init;
-  Job job{words, filtered, n_reads, word_nt, distance, method, want_hist, cluster_id, keep, {}};
+  Job job{words, filtered, n_reads, word_nt, distance, method, want_hist, edit, cluster_id, keep, {}};
   const auto t1 = std::chrono::steady_clock::now();
   g.post_job(&job);
   for (auto &t : m.threads) if (t.joinable()) t.join();

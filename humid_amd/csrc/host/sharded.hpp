@@ -44,10 +44,11 @@ class ShardedSession {
   ShardedSession(const ShardedSession &) = delete;
   ShardedSession &operator=(const ShardedSession &) = delete;
   // words[n_reads] packed (two uint64 per read for word_nt > 32), filtered[n_reads]; cluster_id / keep: host outputs.
+  // edit: Levenshtein instead of Hamming neighbours (-e; distances 2..5 all-gather the unique words inside the pass).
   // want_hist: fill ShardedResult::hist.  Returns HUMID_OK or a HUMID_E_* code with
   // ShardedResult::error set.  Once per session.
   int run(const uint64_t *words, const uint8_t *filtered, uint64_t n_reads, uint32_t word_nt, uint32_t distance,
-          uint32_t method, bool want_hist, uint32_t *cluster_id, uint8_t *keep, ShardedResult &out);
+          uint32_t method, bool want_hist, uint32_t *cluster_id, uint8_t *keep, ShardedResult &out, bool edit = false);
 
  private:
   struct Impl;

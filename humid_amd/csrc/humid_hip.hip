@@ -120,6 +120,7 @@ struct humid_ctx {
   u32 cg_M = 0, cg_nblocks = 0;
   // owner-local clustering of the exchange pass (kernels_xchg.hip.h): records by destination, interior / crossing /
   // flagged-interior records, the forest over own leaves, crossing-creator bitmap and ids, own results
+  DBuf xo_gw, xo_gc;                // the edit-distance road: unique words / counts of all ranks
   DBuf xo_regs, xo_inv;             // record regions of the pair search; routed position of every read
   u64 xr_ecap = 0;                  // room for pair records in the regions (remembered from pass to pass)
   DBuf xo_send, xo_int, xo_cross, xo_sel, xo_selall, xo_parent, xo_flag, xo_xroot, xo_xcbits, xo_xcblk, xo_xcid, xo_xcall, xo_ldeg, xo_cnt;
@@ -2284,7 +2285,7 @@ void humid_ctx_destroy(humid_ctx *c) {
   DBuf *bufs[] = {&c->in_words, &c->in_filt, &c->in_bases, &c->out_cid, &c->out_keep, &c->table, &c->pk_keys, &c->pk_vals,
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
                   &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->big_runs, &c->small_roots, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->e_runlo, &c->e_nch, &c->e_choff, &c->e_pc2, &c->e_poff2, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_heads, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles, &c->xr_hist, &c->xr_recv, &c->xr_eloc, &c->xr_got, &c->xr_eall, &c->xr_ret, &c->xr_heads, &c->xr_send, &c->xr_zero,
-                  &c->xo_regs, &c->xo_inv, &c->xo_send, &c->xo_int, &c->xo_cross, &c->xo_sel, &c->xo_selall, &c->xo_parent, &c->xo_flag, &c->xo_xroot, &c->xo_xcbits, &c->xo_xcblk,
+                  &c->xo_gw, &c->xo_gc, &c->xo_regs, &c->xo_inv, &c->xo_send, &c->xo_int, &c->xo_cross, &c->xo_sel, &c->xo_selall, &c->xo_parent, &c->xo_flag, &c->xo_xroot, &c->xo_xcbits, &c->xo_xcblk,
                   &c->xo_xcid, &c->xo_xcall, &c->xo_ldeg, &c->xo_cnt, &c->p8_a, &c->p8_b, &c->p8_cur, &c->p8_status, &c->cg_edges, &c->cg_cur, &c->cg_far, &c->cg_bits, &c->cg_nbits, &c->cg_blk, &c->cg_nblk, &c->cg_nodes, &c->cg_ncnt, &c->cg_deg,
                   &c->cg_off, &c->cg_idx, &c->cg_parent, &c->cg_csize, &c->cg_curs, &c->cg_cl_of, &c->cg_maxleaf, &c->cg_cl_size,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
@@ -2973,6 +2974,144 @@ static int run_exchange_impl(humid_ctx *c, const humid_comm *cm, const uint64_t 
   if (u_local) TRY(humid_stage_unique(c, &lw, &lc, &lfirst));
 
   XT("count");
+  if (c->edit && d >= 2) {
+    // ---- the edit-distance road (-e -m 2..5, src/humid.cc:140-158): the unique words of all ranks are all-gathered
+    // (they are slices of the walk order: rank order = walk order), every rank runs every P-th shifted-segment join
+    // over the whole array (edit_edges), the shares are gathered and made unique, and every rank clusters the WHOLE
+    // graph -- no owner-local split: the joins, not the clustering, are what this mode spends its time on ----
+    if (d > 5) return fail(c, HUMID_E_UNSUPPORTED, "edit distance %u > 5 is not supported", d);
+    if (u_total + 8 > 0xffffffffull) return fail(c, HUMID_E_OVERFLOW, "more than 2^32-10 unique words in total");
+    const u64 wb = wide ? 16 : 8;
+    u64 ucnt[MAX_RANKS];
+    for (u32 q = 0; q < P; q++) ucnt[q] = metas[3 * q];
+    const void *gw = lw;
+    const u32 *gc = lc;
+    if (moves && u_total) {
+      ENSURE(c->xo_gw, u_total * wb + 16);
+      ENSURE(c->xo_gc, u_total * 4 + 16);
+      ENSURE(c->s_word, 16);
+      ENSURE(c->s_cnt, 16);
+      TRY(x_exchange(c, cm, c->s_word.p, ucnt, true, c->xo_gw.p, ucnt, wb));
+      TRY(x_exchange(c, cm, c->s_cnt.p, ucnt, true, c->xo_gc.p, ucnt, 4));
+      gw = c->xo_gw.p;
+      gc = c->xo_gc.as<u32>();
+    }
+    u64 e_raw = 0;
+    if (u_total > 1) {
+      if (wide) TRY(edit_edges<W2>(c, (const W2 *)gw, (u32)u_total, n, d, &e_raw, r, P, false));
+      else TRY(edit_edges<u64>(c, (const u64 *)gw, (u32)u_total, n, d, &e_raw, r, P, false));
+    }
+    u64 raw_from[MAX_RANKS], raw_all = 0;
+    TRY(x_host_gather(c, cm, &e_raw, 8, raw_from));
+    for (u32 q = 0; q < P; q++) raw_all += raw_from[q];
+    if (raw_all >= 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "too many candidate pairs in the edit-distance search");
+    const u64 *all_raw = c->e_raw.as<u64>();
+    if (moves && raw_all) {
+      ENSURE(c->xo_cross, raw_all * 8 + 16);
+      ENSURE(c->e_raw, 16);
+      u64 rs[MAX_RANKS];
+      for (u32 q = 0; q < P; q++) rs[q] = e_raw;
+      TRY(x_exchange(c, cm, c->e_raw.p, rs, true, c->xo_cross.p, raw_from, 8));
+      all_raw = c->xo_cross.as<u64>();
+    }
+    u64 E_e = 0;
+    if (raw_all) TRY(unique_edges(c, all_raw, raw_all, (u32)u_total, &E_e));
+    XT("edit joins");
+    const u32 n_ids = (u32)u_total;
+    const u32 nw = (((n_ids + 31) / 32) + 7) & ~7u, nblk = nw / 8;
+    c->cg_valid = false;
+    c->cg_nblocks = nblk;
+    ENSURE(c->cg_bits, (size_t)nw * 4);
+    ENSURE(c->cg_nbits, (size_t)nw * 4);
+    ENSURE(c->cg_cur, (size_t)(ER_REGIONS * ER_STRIDE + 8) * 4);
+    ENSURE(c->xo_cnt, 64 * 4);
+    {
+      ZeroList z;
+      memset(&z, 0, sizeof z);
+      z.p[0] = c->cg_bits.as<u32>(); z.n[0] = nw;
+      z.p[1] = c->cg_nbits.as<u32>(); z.n[1] = nw;
+      z.p[2] = (u32 *)&c->d_ctr[CTR_EDGES]; z.n[2] = 2 * (CTR_EOVER - CTR_EDGES + 1);
+      z.p[3] = c->cg_cur.as<u32>(); z.n[3] = ER_REGIONS * ER_STRIDE + 8;
+      hipLaunchKernelGGL(k_zero_many, dim3(64), dim3(256), 0, st, z);
+    }
+    CgStatus cgs;
+    u64 M_e = 0;
+    if (E_e) {
+      hipLaunchKernelGGL(k_mark_pairs, dim3(blocks_for(E_e)), dim3(256), 0, st, (const u64 *)c->e_edges.as<u64>(), (u32)E_e, n_ids,
+                         c->cg_bits.as<u32>(), (u32 *)&c->d_ctr[CTR_OVERFULL]);
+      CgSource src;
+      src.er.e = nullptr; src.er.cap_r = 0; src.er.cur = c->cg_cur.as<u32>(); src.er.far = c->e_edges.as<u64>(); src.er.n_far = (u32)E_e;
+      src.recs = nullptr; src.n_recs = 0; src.segs = nullptr; src.cnt_by_id = gc; src.n_ids = n_ids;
+      src.pairs_bound = E_e;
+      HIPCHK(hipEventRecord(c->ev[2], st));
+      TRY(cg_build(c, src, method, cgs));
+      if (c->h_ctr[CTR_OVERFULL]) return fail(c, HUMID_E_INVALID, "internal: an edit-distance pair outside the unique words");
+      M_e = cgs.M;
+      TRY(cg_cluster_rest(c, n_ids, cgs.M, cgs.Mbig, method));
+    } else {
+      ENSURE(c->cg_blk, ((size_t)nblk + 1) * 4);
+      ENSURE(c->cg_nblk, ((size_t)nblk + 1) * 4);
+      HIPCHK(hipMemsetAsync(c->cg_blk.p, 0, ((size_t)nblk + 1) * 4, st));
+      HIPCHK(hipMemsetAsync(c->cg_nblk.p, 0, ((size_t)nblk + 1) * 4, st));
+    }
+    const GraphArrays cg = cg_arrays(c);
+    const BitRank br_in{c->cg_bits.as<u32>(), c->cg_blk.as<u32>()}, br_nc{c->cg_nbits.as<u32>(), c->cg_nblk.as<u32>()};
+    const u32 *l_cid = nullptr;
+    const u8 *l_ismax = nullptr;
+    if (u_local) {
+      ENSURE(c->x_lcid, (size_t)u_local * 4);
+      ENSURE(c->x_lismax, (size_t)u_local);
+      ENSURE(c->xo_ldeg, (size_t)u_local * 4);
+      hipLaunchKernelGGL(k_own_results, dim3(blocks_for(u_local)), dim3(256), 0, st, br_in, br_nc, br_nc, (const u32 *)nullptr,
+                         (const u32 *)c->cg_nodes.as<u32>(), (const u32 *)cg.cl_of, (const u32 *)cg.maxleaf, (const u32 *)cg.deg, (u32)goff,
+                         (u32)u_local, 0u, c->x_lcid.as<u32>(), c->x_lismax.as<u8>(), c->xo_ldeg.as<u32>(),
+                         (const u32 *)c->s_first.as<u32>(), (const u32 *)c->s_slot.as<u32>(), c->slot_out.as<u64>(), true);
+      c->slots_done = true;
+      l_cid = c->x_lcid.as<u32>();
+      l_ismax = c->x_lismax.as<u8>();
+    }
+    HIPCHK(hipGetLastError());
+    TRY(read_counters(c, c->cg_nblk.as<u32>() + nblk));                 // nodes that created no cluster, all ranks
+    const u64 clusters_e = u_total - (c->h_ctr[CTR_N - 1] & 0xffffffffull);
+    if (clusters_e >= (1ull << 31)) return fail(c, HUMID_E_OVERFLOW, "cluster ids exceed 31 bits");
+    XT("graph+ids");
+    const u32 *packed = nullptr;
+    u64 n_packed = 0;
+    TRY(humid_stage_map_dense(c, l_cid, l_ismax, &packed, &n_packed));
+    if (n_packed != n_recv) return fail(c, HUMID_E_INVALID, "map_dense returned %llu reads, %llu were counted", (ull)n_packed, (ull)n_recv);
+    const u32 *ret = packed;
+    if (moves && usable_all) {
+      ENSURE(c->xr_ret, n_send * 4 + 8);
+      TRY(x_exchange(c, cm, packed, recv_counts, false, c->xr_ret.p, send_counts, 4));
+      ret = c->xr_ret.as<u32>();
+    }
+    if (n_local)
+      hipLaunchKernelGGL(k_gather_results, dim3(grid_stride_blocks(n_local)), dim3(256), 0, st, (const u32 *)c->xo_inv.as<u32>(), ret,
+                         (u32)n_send, (u32)n_local, d_cluster_id, d_keep);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    XT("return");
+    if (xtrace) fprintf(stderr, "[xtrace] rank %u/%u (edit distance) |%s\n", r, P, xt_line.c_str());
+    if (summary) {
+      memset(summary, 0, sizeof *summary);
+      summary->total = total;
+      summary->usable = usable;
+      summary->unique = u_total;
+      summary->clusters = clusters_e;
+      summary->edges = E_e;
+      summary->nonsingle = M_e;
+      summary->ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    }
+    if (info) {
+      info->unique_local = u_local;
+      info->id_base = goff;
+      info->n_nodes = M_e;
+      info->n_pairs = E_e;
+      info->d_unique_count = lc;
+      info->d_unique_degree = u_local ? c->xo_ldeg.as<u32>() : nullptr;
+    }
+    return HUMID_OK;
+  }
   // ---- 4. neighbour pairs in global unique indices, each with the counts of its endpoints ----
   u64 e_mine = 0;                                                    // 16-byte records in xr_eloc
   auto append_pairs = [&](const u64 *rec, u64 n_rec) -> int {

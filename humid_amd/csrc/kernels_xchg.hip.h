@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(256)
 k_own_results(BitRank in_graph, BitRank noncreator, BitRank xc, const u32 *__restrict__ xcid_all, const u32 *__restrict__ nodes,
               const u32 *__restrict__ cl_of, const u32 *__restrict__ maxleaf, const u32 *__restrict__ deg, u32 id0, u32 n_local,
               u32 creators_before_rank, u32 *__restrict__ l_cid, u8 *__restrict__ l_ismax, u32 *__restrict__ l_deg,
-              const u32 *__restrict__ s_first, const u32 *__restrict__ s_slot, u64 *__restrict__ slot_out) {
+              const u32 *__restrict__ s_first, const u32 *__restrict__ s_slot, u64 *__restrict__ slot_out, bool whole_graph = false) {
   HUMID_GUARD_LAST_VGPR();
   const u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n_local) return;
@@ -356,7 +356,9 @@ k_own_results(BitRank in_graph, BitRank noncreator, BitRank xc, const u32 *__res
     dg = deg[c];
   }
   u32 id;
-  if (xcid_all && br_test(xc, g)) id = xcid_all[br_rank(xc, g)];
+  // whole_graph: this rank holds the graph of ALL ranks (the edit-distance road): every creator's id is closed-form
+  if (whole_graph) id = 1u + g - br_rank(noncreator, g);
+  else if (xcid_all && br_test(xc, g)) id = xcid_all[br_rank(xc, g)];
   else id = own_creator_id(g, id0, creators_before_rank, noncreator, br_rank(noncreator, id0));
   l_cid[u] = id;
   l_ismax[u] = mx ? 1 : 0;

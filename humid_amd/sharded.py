@@ -593,17 +593,18 @@ class ShardedDedup:
     def __init__(self, device: int = 0, word_nt: int = 24, distance: int = 1, method: int = 0,
                  ops=None, dist=None, dense_return: bool = True, partition_search: bool = True,
                  mode: str = None, edit: bool = False):
-        # -e: distance <= 1 IS the Hamming search (equal-length words); 2 to 5 run in the all-gather
-        # mode, the joins of the shifted-segment search dealt out over the ranks
+        # -e: distance <= 1 IS the Hamming search (equal-length words); 2 to 5: the joins of the shifted-segment
+        # search are dealt out over the ranks -- inside the library's exchange pass (round 3: the unique words
+        # are all-gathered there), or stage by stage in the all-gather mode below
         self.edit = bool(edit) and distance >= 2
+        self.edit_in_library = False
         # 33 <= word_nt <= 64 (two int64 per read, tensors of shape [n, 2]): the library's exchange pass only
         import os
         import torch.distributed as tdist
         self.mode = mode or os.environ.get("HUMID_SHARD_MODE", "exchange")
         if self.mode not in ("exchange", "allgather"):
             raise ValueError("mode must be 'exchange' or 'allgather'")
-        if bool(edit) and distance >= 2:
-            self.mode = "allgather"
+        explicit_mode = mode or os.environ.get("HUMID_SHARD_MODE")
         self.dist = dist or tdist
         self.world = self.dist.get_world_size()
         self.rank = self.dist.get_rank()
@@ -617,6 +618,13 @@ class ShardedDedup:
         # HUMID_PY_ORCHESTRATION=1 (or a trace): the stage-by-stage Python form of the exchange mode
         # below instead of the library's single call -- same entry points, same results
         self.py_orchestration = bool(os.environ.get("HUMID_PY_ORCHESTRATION")) or self.trace is not None
+        if self.edit:
+            if hasattr(self.ops, "run_exchange") and not self.py_orchestration and explicit_mode != "allgather":
+                self.mode = "exchange"
+                self.edit_in_library = True
+                self.ops.set_option("edit_distance", 1)
+            else:
+                self.mode = "allgather"
         self.shm_used = False
         if self.world > 1 and hasattr(self.ops, "open_shm") and not self.py_orchestration:
             self.shm_used = self.ops.open_shm(self.dist)
@@ -638,8 +646,8 @@ class ShardedDedup:
 
     def _run(self, d_w, d_f, d_cid, d_keep):
         if self.word_nt > 32:
-            if not hasattr(self.ops, "run_exchange") or self.py_orchestration or self.edit:
-                raise NotImplementedError("words longer than 32 nt: the library's exchange pass only (HIP ops, no -e)")
+            if not hasattr(self.ops, "run_exchange") or self.py_orchestration or (self.edit and not self.edit_in_library):
+                raise NotImplementedError("words longer than 32 nt: the library's exchange pass only (HIP ops)")
             self.mode_used = "exchange"
             self.summary = self.ops.run_exchange(self.dist, d_w, d_f, d_cid, d_keep, self.word_nt, self.distance, self.method)
             return self.summary

@@ -250,9 +250,31 @@ def test_cli_sharded_rccl_transport_with_one_rank(tmp_path):
         assert r.returncode == 1 and "one GPU per rank" in r.stderr
 
 
+@pytest.mark.parametrize("case", [dict(word_nt=24, d=2, x=False, ranks=2), dict(word_nt=24, d=3, x=True, ranks=3),
+                                  dict(word_nt=40, d=2, x=False, ranks=2), dict(word_nt=20, d=4, x=False, ranks=2)])
+def test_cli_sharded_edit_distance(case, tmp_path):
+    """round 3: `humid -g N -e -m 2..5` -- the unique words are all-gathered inside the
+    exchange pass and the shifted-segment joins dealt out over the ranks.  Every output file byte-identical to
+    `-g 1 -e` (which tests/test_gpu_edit.py and test_cli_end_to_end check against the oracle)."""
+    files = synth_fastq(str(tmp_path / "in"), 4000, 91, n_files=2, umi_len=8, umi_in_header=True, read_len=36,
+                        p_sub=8e-3, p_n=2e-3, short_frac=0.01)
+    outs = {}
+    for g in (1, case["ranks"]):
+        out = str(tmp_path / ("out%d" % g))
+        cmd = [HUMID, "-n", str(case["word_nt"]), "-m", str(case["d"]), "-e", "-d", out, "-l", "/dev/null", "-s", "-a", "-g", str(g)]
+        if case["x"]:
+            cmd.append("-x")
+        r = subprocess.run(cmd + files, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs[g] = {f: open(os.path.join(out, f), "rb").read() for f in sorted(os.listdir(out))}
+    assert sorted(outs[1]) == sorted(outs[case["ranks"]])
+    for f in outs[1]:
+        assert outs[1][f] == outs[case["ranks"]][f], f
+
+
 def test_cli_sharded_refuses_what_needs_one_gpu(tmp_path):
     files = synth_fastq(str(tmp_path / "in"), 200, 5, n_files=1, read_len=30)
-    for extra in (["-e", "-m", "2"], ["-g", "17"]):
+    for extra in (["-e", "-m", "6"], ["-g", "17"]):
         r = subprocess.run([HUMID, "-g", "2", "-d", str(tmp_path / "o"), "-l", "/dev/null"] + extra + files,
                            capture_output=True, text=True)
         assert r.returncode == 2, (extra, r.stderr)

@@ -194,20 +194,22 @@ def test_exchange_entry_points_reject_bad_arguments():
 
 @pytest.mark.parametrize("P", [2, 3, 5])
 @pytest.mark.parametrize("d", [2, 3])
-def test_edit_distance_virtual_ranks(P, d):
-    """-e on several ranks: the joins of the Levenshtein search are dealt out over the ranks (all-gather
-    mode), shares gathered and made unique; every shard bit-identical to the oracle's -e run"""
+@pytest.mark.parametrize("mode", ["exchange", "allgather"])
+def test_edit_distance_virtual_ranks(P, d, mode):
+    """-e on several ranks: the joins of the Levenshtein search are dealt out over the ranks, shares gathered and
+    made unique -- inside the library's exchange pass (round 3: it all-gathers the unique words) and stage by
+    stage in the all-gather mode; every shard bit-identical to the oracle's -e run"""
     from test_oracle_vs_bruteforce import indel_words
     rng = np.random.default_rng(40 + P + d)
     words = indel_words(rng, 20_000, 20, p_indel=0.4)
     filt = (rng.random(len(words)) < 0.01).astype(np.uint8)
     ocid, okeep, osum, _ = orc.dedup_run(words, filt, 20, d, 0, edit=True)
-    out, offs = run_ranks(P, words, filt, 20, d, 0, "exchange", edit=True)     # falls to the all-gather mode
+    out, offs = run_ranks(P, words, filt, 20, d, 0, mode, edit=True)
     for r in range(P):
         cid, keep, s, used = out[r]
-        assert used == "allgather"
+        assert used == mode
         assert np.array_equal(cid, ocid[offs[r]:offs[r + 1]]) and np.array_equal(keep, okeep[offs[r]:offs[r + 1]])
-        assert s["clusters"] == osum["clusters"]
+        assert s["clusters"] == osum["clusters"] and s["edges"] == osum["edges"]
 
 
 @pytest.mark.parametrize("P", [1, 2, 5, 16])
