@@ -256,7 +256,8 @@ int main(int argc, char **argv) {
         std::thread pin_thread;                            // the two take ~30 ms and ~40 ms: side by side
         if (getenv("HUMID_NO_PINNED") == nullptr)
           pin_thread = std::thread([&] { pinned = (uint8_t *)humid_host_alloc(pin_bytes); t_pin = since(); });
-        humid_ctx_reserve(ctx, (uint64_t)n, (uint32_t)a.word_length);   // one slab + the code object loaded
+        if (getenv("HUMID_NO_SLAB") == nullptr)
+          humid_ctx_reserve(ctx, (uint64_t)n, (uint32_t)a.word_length);   // one slab + the code object loaded
         t_slab = since();
         if (pin_thread.joinable()) pin_thread.join();
       }

@@ -124,6 +124,7 @@ struct humid_ctx {
   DBuf xo_regs, xo_inv;             // record regions of the pair search; routed position of every read
   u64 xr_ecap = 0;                  // room for pair records in the regions (remembered from pass to pass)
   DBuf xo_send, xo_int, xo_cross, xo_sel, xo_selall, xo_parent, xo_flag, xo_xroot, xo_xcbits, xo_xcblk, xo_xcid, xo_xcall, xo_ldeg, xo_cnt;
+  DBuf pw_a, pw_ai, pw_b, pw_bi;    // two-word words: (word, read index) records of the two partition levels
   DBuf p8_a, p8_b, p8_cur, p8_status;               // 8-byte records of the count stage: level-1 output, level-2 output (kernels_part8.hip.h)
   bool use_rec8 = true;             // option "records8": 0 = always the 12-byte (key, read) pairs of kernels_part.hip.h
   bool last_rec8 = false;           // the last count ran on records: positions are (bucket << 9 | j), the un-permute reads p8_b
@@ -828,6 +829,101 @@ static int stage_count_rec(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   return HUMID_OK;
 }
 
+// Stage A for two-word words on records (kernels_part8.hip.h, second half): the 16-byte word + its read index travel
+// through both padded partition levels, k_dedup_wide_rec reads its bucket as two contiguous streams.  *done = false:
+// not this shape, or a bin outgrew its room -- the caller takes stage_count_lds (keys + gather) or the sort.
+static int stage_count_rec_wide(humid_ctx *c, const W2 *d_words, const u8 *d_filt, u32 N, u32 word_nt, const KeyMap &km,
+                                humid_summary &s, bool *done) {
+  hipStream_t st = c->stream;
+  *done = false;
+  if (!c->use_rec8 || !c->use_tile_partition || !c->pt_padded) return HUMID_OK;
+  const u32 pb = part_bits(N);
+  if (pb < 6 || pb > 18) return HUMID_OK;
+  if ((((u64)N + (1u << UW_MAXSHIFT) - 1) >> UW_MAXSHIFT) > UW_MAXBINS) return HUMID_OK;
+  const u32 d1 = (pb + 1) / 2, d2 = pb - d1, nb1 = 1u << d1, n_parts = 1u << pb;
+  RecKey rk;
+  rk.lo = km.lo; rk.scale = km.scale;
+  rk.pow2 = km.shift < 64 ? 1u : 0u;
+  rk.z = rk.pow2 ? km.shift : 63u - (u32)__builtin_clzll(km.scale);
+  rk.kbits = 64 - rk.z;
+  if (rk.kbits < pb + 1) return HUMID_OK;
+  const u32 hbits = 2 * (word_nt - 32);
+  static const u32 pad_div = getenv("HUMID_PAD_DIV") ? (u32)std::max(1, atoi(getenv("HUMID_PAD_DIV"))) : 4u;
+  const u32 cap1 = (u32)std::min<u64>(0xffffffffull / nb1, (u64)N / nb1 + (u64)N / nb1 / pad_div + 1024);
+  const size_t room1 = (size_t)nb1 * cap1, room2 = (size_t)n_parts << P8_CAP2_LOG;
+  ENSURE(c->pw_a, room1 * 16);
+  ENSURE(c->pw_ai, room1 * 4);
+  ENSURE(c->pw_b, room2 * 16);
+  ENSURE(c->pw_bi, room2 * 4);
+  ENSURE(c->p8_b, room2 * 8);
+  ENSURE(c->pad_word, room2 * 16);
+  ENSURE(c->pad_cf, room2 * 8);
+  ENSURE(c->slot_out, (room2 + 1) * 8);
+  ENSURE(c->pbeg, (size_t)(n_parts + 1) * 4);
+  ENSURE(c->ucount, (size_t)(n_parts + 1) * 4);
+  ENSURE(c->p8_status, ((size_t)n_parts + 1) * 16);
+  u64 *agg = c->p8_status.as<u64>(), *abase = agg + n_parts + 1;
+  ENSURE(c->p8_cur, ((size_t)512 + n_parts + 1026) * 4);
+  u32 *cursor1 = c->p8_cur.as<u32>(), *cursor2 = cursor1 + 512, *cbase = cursor2 + n_parts, *tprefix = cbase + 513;
+  HIPCHK(hipEventRecord(c->ev[0], st));
+  {
+    ZeroList z;
+    memset(&z, 0, sizeof z);
+    z.p[0] = cursor1; z.n[0] = 512 + n_parts;
+    z.p[1] = (u32 *)c->d_ctr; z.n[1] = 2 * CTR_N;
+    z.p[2] = (u32 *)(agg + n_parts); z.n[2] = 2;
+    hipLaunchKernelGGL(k_zero_many, dim3(32), dim3(256), 0, st, z);
+  }
+  const u32 tiles1 = (N + PT_TILE - 1) / PT_TILE, tiles2 = tiles1 + nb1;
+  hipLaunchKernelGGL(k_pw_scatter<1>, dim3(tiles1), dim3(1024), 0, st, d_words, d_filt, (const u32 *)nullptr, N, hbits, rk,
+                     (const u32 *)nullptr, (const u32 *)nullptr, d1, d2, cap1, cursor1, c->pw_a.as<W2>(), c->pw_ai.as<u32>(), c->d_ctr);
+  hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, (const u32 *)cursor1, d1, d2, cbase, tprefix, c->pbeg.as<u32>(),
+                     c->ucount.as<u32>() + n_parts, cap1);
+  if (c->kev_on) HIPCHK(hipEventRecord(c->kev[39], st));
+  hipLaunchKernelGGL(k_pw_scatter<2>, dim3(tiles2), dim3(1024), 0, st, (const W2 *)c->pw_a.as<W2>(), (const u8 *)nullptr,
+                     (const u32 *)c->pw_ai.as<u32>(), N, hbits, rk, (const u32 *)tprefix, (const u32 *)cbase, d1, d2, cap1, cursor2,
+                     c->pw_b.as<W2>(), c->pw_bi.as<u32>(), c->d_ctr);
+  if (c->kev_on) HIPCHK(hipEventRecord(c->kev[40], st));
+  HIPCHK(hipEventRecord(c->kev[0], st));
+  hipLaunchKernelGGL((k_dedup_wide_rec<9, 512, 0, WL_SMALL_LEN>), dim3(n_parts), dim3(256), 0, st, (const W2 *)c->pw_b.as<W2>(),
+                     (const u32 *)c->pw_bi.as<u32>(), (const u32 *)cursor2, hbits, rk, N, pb, c->pad_word.as<W2>(), c->pad_cf.as<uint2>(),
+                     agg, c->p8_b.as<u64>(), c->d_ctr);
+  if (N > WL_SMALL_LEN)
+    hipLaunchKernelGGL((k_dedup_wide_rec<10, 1024, WL_SMALL_LEN, WL_STAGE>), dim3(n_parts), dim3(256), 0, st,
+                       (const W2 *)c->pw_b.as<W2>(), (const u32 *)c->pw_bi.as<u32>(), (const u32 *)cursor2, hbits, rk, N, pb,
+                       c->pad_word.as<W2>(), c->pad_cf.as<uint2>(), agg, c->p8_b.as<u64>(), c->d_ctr);
+  HIPCHK(hipEventRecord(c->kev[1], st));
+  TRY(exscan_in<u64>(c, PtrIn<u64>{agg}, abase, (u64)n_parts + 1));
+  HIPCHK(hipGetLastError());
+  TRY(read_counters(c, (const u32 *)(abase + n_parts), (const u32 *)(abase + n_parts) + 1));   // U, usable
+  if (getenv("HUMID_TRACE_COUNT"))
+    fprintf(stderr, "[rec count, wide] N %u pb %u kbits %u cap1 %u special %llu overfull %llu unique %llu usable %llu\n", N, pb, rk.kbits, cap1,
+            (ull)c->h_ctr[CTR_SPECIAL], (ull)c->h_ctr[CTR_OVERFULL], (ull)(c->h_ctr[CTR_N - 1] & 0xffffffffull), (ull)(c->h_ctr[CTR_N - 2] & 0xffffffffull));
+  if (c->h_ctr[CTR_SPECIAL] || c->h_ctr[CTR_OVERFULL]) return HUMID_OK;       // (the key + gather road decides by itself what to do next)
+  c->last_count_lds = true;
+  c->last_count_sorted = false;
+  c->last_count_ordered = true;
+  c->last_part_tiled = true;
+  c->last_rec8 = true;
+  c->rec_cursor2 = cursor2;
+  c->n_parts = n_parts;
+  const u32 U = (u32)(c->h_ctr[CTR_N - 1] & 0xffffffffull);
+  s.usable = c->usable = c->h_ctr[CTR_N - 2] & 0xffffffffull;
+  s.unique = c->U = U;
+  *done = true;
+  if (U == 0) { HIPCHK(hipEventRecord(c->ev[1], st)); return HUMID_OK; }
+  ENSURE(c->s_word, (size_t)(U + 1) * 16);
+  ENSURE(c->s_slot, (size_t)(U + 1) * 4);
+  ENSURE(c->s_cnt, (size_t)(U + 1) * 4);
+  ENSURE(c->s_first, (size_t)(U + 1) * 4);
+  hipLaunchKernelGGL(k_compact_padded8_wide, dim3(blocks_for((u64)n_parts * 64)), dim3(256), 0, st, (const W2 *)c->pad_word.as<W2>(),
+                     (const uint2 *)c->pad_cf.as<uint2>(), (const u64 *)agg, (const u64 *)abase, n_parts, c->s_word.as<W2>(),
+                     c->s_slot.as<u32>(), c->s_cnt.as<u32>(), c->s_first.as<u32>());
+  HIPCHK(hipEventRecord(c->ev[1], st));
+  HIPCHK(hipGetLastError());
+  return HUMID_OK;
+}
+
 // Would word-ordered buckets fit their LDS tables?  Histogram of the top (up to 12) word bits over
 // a sample of the reads, folded / scaled to the 2^pb buckets the partition will use: the fullest
 // bucket, with a 1.5x margin, must stay below the table's fill limit (a bucket's unique words
@@ -927,7 +1023,11 @@ static int stage_count_wide(humid_ctx *c, const W2 *d_words, const u8 *d_filt, u
       TRY(prefix_fits_ordered(c, c->w_heads.as<u64>(), d_filt, N, word_nt, km, &ordered));
     }
     if (getenv("HUMID_TRACE_COUNT")) fprintf(stderr, "[wide count] N %u order %d fits %d lo %llx scale %llx shift %u\n", N, c->count_order, (int)ordered, (ull)km.lo, (ull)km.scale, km.shift);
+    c->last_rec8 = false;
     if (ordered) {
+      bool done8 = false;
+      TRY(stage_count_rec_wide(c, d_words, d_filt, N, word_nt, km, s, &done8));
+      if (done8) return HUMID_OK;
       bool overflowed = false;
       TRY(stage_count_lds(c, nullptr, d_filt, N, word_nt, 0ull, ~0ull, km, true, s, &overflowed, d_words));
       if (getenv("HUMID_TRACE_COUNT")) fprintf(stderr, "[wide count] overflowed %d special %llu overfull %llu\n", (int)overflowed, (ull)c->h_ctr[CTR_SPECIAL], (ull)c->h_ctr[CTR_OVERFULL]);
@@ -2286,7 +2386,7 @@ void humid_ctx_destroy(humid_ctx *c) {
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
                   &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->big_runs, &c->small_roots, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->e_runlo, &c->e_nch, &c->e_choff, &c->e_pc2, &c->e_poff2, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_heads, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles, &c->xr_hist, &c->xr_recv, &c->xr_eloc, &c->xr_got, &c->xr_eall, &c->xr_ret, &c->xr_heads, &c->xr_send, &c->xr_zero,
                   &c->xo_gw, &c->xo_gc, &c->xo_regs, &c->xo_inv, &c->xo_send, &c->xo_int, &c->xo_cross, &c->xo_sel, &c->xo_selall, &c->xo_parent, &c->xo_flag, &c->xo_xroot, &c->xo_xcbits, &c->xo_xcblk,
-                  &c->xo_xcid, &c->xo_xcall, &c->xo_ldeg, &c->xo_cnt, &c->p8_a, &c->p8_b, &c->p8_cur, &c->p8_status, &c->cg_edges, &c->cg_cur, &c->cg_far, &c->cg_bits, &c->cg_nbits, &c->cg_blk, &c->cg_nblk, &c->cg_nodes, &c->cg_ncnt, &c->cg_deg,
+                  &c->xo_xcid, &c->xo_xcall, &c->xo_ldeg, &c->xo_cnt, &c->pw_a, &c->pw_ai, &c->pw_b, &c->pw_bi, &c->p8_a, &c->p8_b, &c->p8_cur, &c->p8_status, &c->cg_edges, &c->cg_cur, &c->cg_far, &c->cg_bits, &c->cg_nbits, &c->cg_blk, &c->cg_nblk, &c->cg_nodes, &c->cg_ncnt, &c->cg_deg,
                   &c->cg_off, &c->cg_idx, &c->cg_parent, &c->cg_csize, &c->cg_curs, &c->cg_cl_of, &c->cg_maxleaf, &c->cg_cl_size,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,

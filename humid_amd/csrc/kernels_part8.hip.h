@@ -391,4 +391,269 @@ k_unperm_bins8(const u64 *__restrict__ recs, const u32 *__restrict__ cursor2, co
   }
 }
 
+// --------------------------------------------------------------------------------
+// two-word words (33 <= n <= 64 nucleotides): the WORD travels through the partition
+// --------------------------------------------------------------------------------
+// Round 2 partitioned (key, read index) pairs of two-word words and let the count kernel GATHER the 16-byte
+// words by read index: one scattered load per read that fetches 64 bytes for 16 (k_dedup_lds_wide: 1.4 GB of
+// traffic per 10 M reads, 0.27 ms).  Here a record is the word itself (16 B) + its read index (4 B, a second
+// array), bins come from the word's head (the key is recomputed from the word at both levels, it is not
+// stored), and the count kernel reads its bucket as two contiguous streams.  Tiles of PW_TILE records: 64 KB of
+// words + 16 KB of indices in LDS; a workgroup takes the PT_TILE positions of a tile slot in two halves, so the
+// tile bookkeeping (k_pt_scan1, pt_tile_of) is that of the one-word kernels.
+#define PW_TILE 4096u
+#define PW_IPT (PW_TILE / PT_THREADS)
+#include "kernels_wide.hip.h"
+
+// the word-ordered key of a two-word word: its head's top 48 bits through RecKey (see WideReadsSrc)
+__device__ __forceinline__ u64 pw_key(const W2 &x, u32 hbits, const RecKey &rk) {
+  return rk((hbits >= 64 ? x.hi : ((x.hi << (64 - hbits)) | (x.lo >> hbits))) >> WIDE_KEY_DROP);
+}
+
+// bin by bin, words and indices (p8_write_bins for the two arrays of a wide record)
+template <class Dst>
+__device__ __forceinline__ void pw_write_bins(const W2 *sw, const u32 *si, const u32 *loff, u32 nb, u32 G, W2 *__restrict__ ow,
+                                              u32 *__restrict__ oi, Dst dst) {
+  const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  const u32 per_wave = 64 / G, sub = lane / G, gl = lane % G;
+  for (u32 b0 = wv * per_wave; b0 < nb; b0 += n_waves * per_wave) {
+    const u32 bin = b0 + sub;
+    if (bin >= nb) continue;
+    const u32 beg = loff[bin], n = loff[bin + 1] - beg;
+    for (u32 k = gl; k < n; k += G) {
+      const u64 d = dst(bin, k);
+      if (d != ~0ull) { ow[d] = sw[beg + k]; oi[d] = si[beg + k]; }
+    }
+  }
+}
+
+// LEVEL 1: tile slot = PT_TILE consecutive reads; bins = top d1 key bits; padded coarse bins of cap1 records.
+// LEVEL 2: tile slot = up to PT_TILE records of one coarse bin; bins = the next d2 key bits; padded buckets of P8_CAP2.
+template <int LEVEL>
+__global__ void __launch_bounds__(1024)
+k_pw_scatter(const W2 *__restrict__ w_in, const u8 *__restrict__ filtered, const u32 *__restrict__ i_in, u32 n_reads, u32 hbits,
+             RecKey rk, const u32 *__restrict__ tprefix, const u32 *__restrict__ cbase, u32 d1, u32 d2, u32 cap1, u32 *cursor,
+             W2 *__restrict__ w_out, u32 *__restrict__ i_out, ull *ctr) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ W2 sw[PW_TILE];
+  __shared__ u32 si[PW_TILE];
+  __shared__ u32 cnt[PT_MAXBINS], loff[PT_MAXBINS + 1], goff[PT_MAXBINS], room[PT_MAXBINS], wsum[8];
+  __shared__ u32 s_c, s_beg, s_cnt;
+  const u32 nb = 1u << (LEVEL == 1 ? d1 : d2);
+  u32 t_beg, t_cnt, coarse = 0;
+  if (LEVEL == 1) {
+    t_beg = blockIdx.x * PT_TILE;
+    t_cnt = (t_beg >= n_reads) ? 0u : ((n_reads - t_beg < PT_TILE) ? n_reads - t_beg : PT_TILE);
+  } else {
+    if (blockIdx.x >= tprefix[1u << d1]) return;              // beyond the last tile (uniform exit)
+    if (threadIdx.x == 0) {
+      u32 c, b, n;
+      pt_tile_of(tprefix, cbase, 1u << d1, blockIdx.x, cap1, c, b, n);
+      s_c = c; s_beg = b; s_cnt = n;
+    }
+    __syncthreads();
+    coarse = s_c; t_beg = s_beg; t_cnt = s_cnt;
+  }
+  const u32 kshift = LEVEL == 1 ? rk.kbits - d1 : rk.kbits - d1 - d2;
+  for (u32 h0 = 0; h0 < t_cnt; h0 += PW_TILE) {               // the tile slot in halves of PW_TILE records
+    const u32 h_cnt = t_cnt - h0 < PW_TILE ? t_cnt - h0 : PW_TILE;
+    for (u32 b = threadIdx.x; b < nb; b += PT_THREADS) cnt[b] = 0;
+    __syncthreads();
+    W2 w[PW_IPT];
+    u32 idx[PW_IPT], binrank[PW_IPT];
+#pragma unroll
+    for (u32 q = 0; q < PW_IPT; q++) {
+      const u32 j = threadIdx.x + q * PT_THREADS;
+      binrank[q] = NONE32;
+      if (j < h_cnt) {
+        const u32 p = t_beg + h0 + j;
+        bool ok = true;
+        if (LEVEL == 1) { ok = !(filtered && filtered[p]); idx[q] = p; }
+        else idx[q] = i_in[p];
+        if (ok) {
+          W2 x = w_in[p];
+          if (LEVEL == 1 && hbits < 64) x.hi &= (1ull << hbits) - 1ull;
+          w[q] = x;
+          const u32 bin = (u32)(pw_key(x, hbits, rk) >> kshift) & (nb - 1);
+          binrank[q] = bin << 16 | atomicAdd(&cnt[bin], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    block_exscan_512(cnt, loff, nb, wsum);
+    if (threadIdx.x < nb) {
+      const u32 c = cnt[threadIdx.x];
+      const u32 g = LEVEL == 1 ? threadIdx.x : ((coarse << d2) | threadIdx.x);
+      const u32 cap = LEVEL == 1 ? cap1 : P8_CAP2;
+      const u32 had = c ? atomicAdd(&cursor[g], c) : 0u;
+      goff[threadIdx.x] = had;
+      room[threadIdx.x] = had >= cap ? 0u : cap - had;
+      if (had + c > cap) ctr[CTR_SPECIAL] = 1;                // the bin outgrew its room: the caller takes the other road
+    }
+#pragma unroll
+    for (u32 q = 0; q < PW_IPT; q++)
+      if (binrank[q] != NONE32) {
+        const u32 p = loff[binrank[q] >> 16] + (binrank[q] & 0xffffu);
+        sw[p] = w[q];
+        si[p] = idx[q];
+      }
+    __syncthreads();
+    const u64 stride = LEVEL == 1 ? (u64)cap1 : (u64)P8_CAP2;
+    const u64 gbase = LEVEL == 1 ? 0ull : (u64)(coarse << d2) * stride;
+    pw_write_bins(sw, si, loff, nb, p8_group(loff[nb], nb), w_out, i_out, [&](u32 bin, u32 k) -> u64 {
+      return k < room[bin] ? gbase + (u64)bin * stride + goff[bin] + k : ~0ull;
+    });
+    __syncthreads();
+  }
+}
+
+// ---- the LDS count of one bucket of two-word words, from its contiguous records (k_dedup_lds_wide) ----
+// Two size classes as there (a launch takes its own buckets and leaves the others at once).  Outputs: pad_word /
+// pad_cf at [g << P8_CAP2_LOG, + unique words) in word order, agg[g] = reads << 32 | unique words, and per
+// position out8 = (padded slot of its word << 32 | read index): what k_unperm_bins8 reads.
+template <u32 SB, u32 STAGE, u32 LEN_MIN, u32 LEN_MAX>
+__global__ void __launch_bounds__(256)
+k_dedup_wide_rec(const W2 *__restrict__ recw, const u32 *__restrict__ reci, const u32 *__restrict__ cursor2, u32 hbits, RecKey rk,
+                 u32 n_reads, u32 pb, W2 *__restrict__ pad_word, uint2 *__restrict__ pad_cf, u64 *__restrict__ agg,
+                 u64 *__restrict__ out8, ull *ctr) {
+  HUMID_GUARD_LAST_VGPR();
+  constexpr u32 SLOTS = 1u << SB, Q = STAGE / 256u;
+  static_assert(STAGE % 256u == 0 && (STAGE & (STAGE - 1)) == 0 && LEN_MAX <= STAGE && LEN_MAX <= SLOTS, "size class");
+  __shared__ W2 wk[STAGE];                             // the bucket's words by position
+  __shared__ u32 ltag[SLOTS];                          // position of the claiming read, NONE32 = empty
+  __shared__ u32 lcnt[SLOTS];
+  __shared__ u32 lfirst[SLOTS];
+  __shared__ unsigned short lslot_of[SLOTS];           // unique index (claim order, then rank) -> table entry
+  __shared__ unsigned short lpos[SLOTS];               // unique index -> position of its claimer
+  __shared__ unsigned short lorder[512];
+  __shared__ u32 lcount;
+  const u32 g = blockIdx.x;
+  u32 len = cursor2[g];
+  if (len > P8_CAP2) len = P8_CAP2;                    // (reported by the scatter: the run is discarded)
+  if (len == 0) {
+    if (LEN_MIN == 0 && threadIdx.x == 0) agg[g] = 0;
+    return;
+  }
+  if (len <= LEN_MIN || len > LEN_MAX) return;         // the other class's bucket
+  const size_t beg = (size_t)g << P8_CAP2_LOG;
+  W2 wq[Q];
+  u32 vq[Q];
+#pragma unroll
+  for (u32 q = 0; q < Q; q++) {
+    const u32 p = threadIdx.x + 256u * q;
+    vq[q] = NONE32;
+    if (p < len) { vq[q] = reci[beg + p]; wq[q] = recw[beg + p]; wk[p] = wq[q]; }
+  }
+  for (u32 s = threadIdx.x; s < SLOTS; s += 256) { ltag[s] = NONE32; lcnt[s] = 0; lfirst[s] = NONE32; }
+  if (threadIdx.x == 0) lcount = 0;
+  __syncthreads();
+  // table home = the key bits just below the bucket bits
+  const int hs = (int)rk.kbits - (int)pb - (int)SB;
+  auto home = [&](const W2 &w) -> u32 {
+    const u64 k = pw_key(w, hbits, rk);
+    return hs >= 0 ? (u32)(k >> hs) & (SLOTS - 1) : (u32)(k << (-hs)) & (SLOTS - 1);
+  };
+  bool overflow = false;
+#pragma unroll
+  for (u32 q = 0; q < Q; q++) {
+    const u32 p = threadIdx.x + 256u * q;
+    if (p >= len || overflow) continue;
+    const u32 v = vq[q];
+    if (v >= n_reads) { overflow = true; continue; }   // a malformed index is never used
+    const W2 w = wq[q];
+    u32 s = home(w), probes = 0;
+    bool placed = false;
+    while (probes++ <= SLOTS) {
+      u32 cur = ltag[s];
+      if (cur == NONE32) cur = atomicCAS(&ltag[s], NONE32, p);
+      if (cur == NONE32 || w_eq(wk[cur & (STAGE - 1)], w)) { placed = true; break; }
+      s = (s + 1) & (SLOTS - 1);
+    }
+    if (!placed) { overflow = true; continue; }
+    if (atomicAdd(&lcnt[s], 1u) == 0u) lslot_of[atomicAdd(&lcount, 1u)] = (unsigned short)s;
+    atomicMin(&lfirst[s], v);
+  }
+  if (overflow) ctr[CTR_OVERFULL] = 1;
+  __syncthreads();
+  const u32 n_uniq = lcount < SLOTS ? lcount : SLOTS;
+  for (u32 li = threadIdx.x; li < n_uniq; li += 256) lpos[li] = (unsigned short)ltag[lslot_of[li]];
+  __syncthreads();
+  if (n_uniq <= 512) {
+    // rank of an entry = number of smaller words among the bucket's unique words (all distinct)
+    for (u32 li = threadIdx.x; li < n_uniq; li += 256) {
+      const W2 w = wk[lpos[li]];
+      u32 r = 0;
+      for (u32 j = 0; j < n_uniq; j++) r += w_less(wk[lpos[j]], w) ? 1u : 0u;
+      lorder[r] = lslot_of[li];
+    }
+    __syncthreads();
+    for (u32 li = threadIdx.x; li < n_uniq; li += 256) lslot_of[li] = lorder[li];
+    __syncthreads();
+  } else if (LEN_MAX > 512) {
+    // bitonic network over the claim-order list, keys through the claimer's staged word
+    u32 npow = 1;
+    while (npow < n_uniq) npow <<= 1;
+    for (u32 i = n_uniq + threadIdx.x; i < npow; i += 256) lslot_of[i] = 0xffff;      // padding: above every word
+    __syncthreads();
+    for (u32 k = 2; k <= npow; k <<= 1) {
+      for (u32 j = k >> 1; j > 0; j >>= 1) {
+        for (u32 t = threadIdx.x; t < npow; t += 256) {
+          const u32 x = t ^ j;
+          if (x > t) {
+            const u32 a = lslot_of[t], bb = lslot_of[x];
+            const bool pa = a == 0xffff, pbd = bb == 0xffff;
+            bool gt;
+            if (pa) gt = !pbd;
+            else if (pbd) gt = false;
+            else gt = w_less(wk[ltag[bb] & (STAGE - 1)], wk[ltag[a] & (STAGE - 1)]);
+            if (gt == ((t & k) == 0)) { lslot_of[t] = (unsigned short)bb; lslot_of[x] = (unsigned short)a; }
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  for (u32 li = threadIdx.x; li < n_uniq; li += 256) {
+    const u32 s = lslot_of[li];
+    pad_word[beg + li] = wk[ltag[s] & (STAGE - 1)];
+    pad_cf[beg + li] = make_uint2(lcnt[s], lfirst[s]);
+    lfirst[s] = li;
+  }
+  if (threadIdx.x == 0) agg[g] = ((u64)len << 32) | n_uniq;
+  __syncthreads();
+#pragma unroll
+  for (u32 q = 0; q < Q; q++) {
+    const u32 p = threadIdx.x + 256u * q;
+    if (p >= len) continue;
+    const W2 w = wq[q];
+    u32 s = home(w), probes = 0, li = NONE32;
+    while (probes++ <= SLOTS) {
+      const u32 t = ltag[s];
+      if (t == NONE32) break;                          // (cannot happen for a word that was inserted)
+      if (w_eq(wk[t & (STAGE - 1)], w)) { li = lfirst[s]; break; }
+      s = (s + 1) & (SLOTS - 1);
+    }
+    out8[beg + p] = ((u64)(li < len ? (u32)beg + li : NOSLOT) << 32) | vq[q];
+  }
+}
+
+// padded -> dense unique arrays of two-word words, one wave per bucket
+__global__ void __launch_bounds__(256)
+k_compact_padded8_wide(const W2 *__restrict__ pad_word, const uint2 *__restrict__ pad_cf, const u64 *__restrict__ agg,
+                       const u64 *__restrict__ abase, u32 n_parts, W2 *__restrict__ s_word, u32 *__restrict__ s_slot,
+                       u32 *__restrict__ s_cnt, u32 *__restrict__ s_first) {
+  HUMID_GUARD_LAST_VGPR();
+  const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const u32 lane = threadIdx.x & 63;
+  if (wave >= n_parts) return;
+  const u32 beg = wave << P8_CAP2_LOG, uc = (u32)agg[wave], ub = (u32)abase[wave];
+  for (u32 j = lane; j < uc; j += 64) {
+    s_word[ub + j] = pad_word[beg + j];
+    s_slot[ub + j] = beg + j;
+    const uint2 cf = pad_cf[beg + j];
+    s_cnt[ub + j] = cf.x;
+    s_first[ub + j] = cf.y;
+  }
+}
+
 #endif  // HUMID_KERNELS_PART8_HIP_H
