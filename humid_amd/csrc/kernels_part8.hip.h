@@ -508,9 +508,19 @@ k_pw_scatter(const W2 *__restrict__ w_in, const u8 *__restrict__ filtered, const
 }
 
 // ---- the LDS count of one bucket of two-word words, from its contiguous records (k_dedup_lds_wide) ----
-// Two size classes as there (a launch takes its own buckets and leaves the others at once).  Outputs: pad_word /
-// pad_cf at [g << P8_CAP2_LOG, + unique words) in word order, agg[g] = reads << 32 | unique words, and per
-// position out8 = (padded slot of its word << 32 | read index): what k_unperm_bins8 reads.
+// A 128-bit word cannot be claimed with one LDS compare-and-swap.  k_dedup_lds_wide therefore keeps the POSITION of
+// the claiming read in the table and compares through it (two dependent LDS reads, 16 bytes, per probe).  Here the
+// table holds a 64-bit FINGERPRINT of the word (mix64 of both halves), claimed and compared like a one-word key
+// -- one 8-byte LDS read per probe -- and exactness is restored afterwards: every position checks that its word
+// EQUALS the word of the read that registered its entry; two different words with one fingerprint (probability
+// ~10^-15 per bucket) raise ctr[CTR_OVERFULL] and the caller counts this read set with the position-tag kernel.
+// Two size classes (a launch takes its own buckets and leaves the others at once).  Outputs: pad_word / pad_cf
+// at [g << P8_CAP2_LOG, + unique words) in word order, agg[g] = reads << 32 | unique words, and per position
+// out8 = (padded slot of its word << 32 | read index): what k_unperm_bins8 reads.
+__device__ __forceinline__ u64 w2_fingerprint(const W2 &w) {
+  const u64 f = mix64(w.lo ^ mix64(w.hi + 0x9e3779b97f4a7c15ull));
+  return f == EMPTY_KEY ? EMPTY_KEY - 1 : f;
+}
 template <u32 SB, u32 STAGE, u32 LEN_MIN, u32 LEN_MAX>
 __global__ void __launch_bounds__(256)
 k_dedup_wide_rec(const W2 *__restrict__ recw, const u32 *__restrict__ reci, const u32 *__restrict__ cursor2, u32 hbits, RecKey rk,
@@ -520,11 +530,11 @@ k_dedup_wide_rec(const W2 *__restrict__ recw, const u32 *__restrict__ reci, cons
   constexpr u32 SLOTS = 1u << SB, Q = STAGE / 256u;
   static_assert(STAGE % 256u == 0 && (STAGE & (STAGE - 1)) == 0 && LEN_MAX <= STAGE && LEN_MAX <= SLOTS, "size class");
   __shared__ W2 wk[STAGE];                             // the bucket's words by position
-  __shared__ u32 ltag[SLOTS];                          // position of the claiming read, NONE32 = empty
+  __shared__ u64 lkey[SLOTS];                          // fingerprint, EMPTY_KEY = free
   __shared__ u32 lcnt[SLOTS];
   __shared__ u32 lfirst[SLOTS];
+  __shared__ unsigned short lclaim[SLOTS];             // position of the read that registered the entry
   __shared__ unsigned short lslot_of[SLOTS];           // unique index (claim order, then rank) -> table entry
-  __shared__ unsigned short lpos[SLOTS];               // unique index -> position of its claimer
   __shared__ unsigned short lorder[512];
   __shared__ u32 lcount;
   const u32 g = blockIdx.x;
@@ -537,53 +547,51 @@ k_dedup_wide_rec(const W2 *__restrict__ recw, const u32 *__restrict__ reci, cons
   if (len <= LEN_MIN || len > LEN_MAX) return;         // the other class's bucket
   const size_t beg = (size_t)g << P8_CAP2_LOG;
   W2 wq[Q];
-  u32 vq[Q];
+  u32 vq[Q], sq[Q];
 #pragma unroll
   for (u32 q = 0; q < Q; q++) {
     const u32 p = threadIdx.x + 256u * q;
     vq[q] = NONE32;
+    sq[q] = NONE32;
     if (p < len) { vq[q] = reci[beg + p]; wq[q] = recw[beg + p]; wk[p] = wq[q]; }
   }
-  for (u32 s = threadIdx.x; s < SLOTS; s += 256) { ltag[s] = NONE32; lcnt[s] = 0; lfirst[s] = NONE32; }
+  for (u32 s = threadIdx.x; s < SLOTS; s += 256) { lkey[s] = EMPTY_KEY; lcnt[s] = 0; lfirst[s] = NONE32; }
   if (threadIdx.x == 0) lcount = 0;
   __syncthreads();
-  // table home = the key bits just below the bucket bits
-  const int hs = (int)rk.kbits - (int)pb - (int)SB;
-  auto home = [&](const W2 &w) -> u32 {
-    const u64 k = pw_key(w, hbits, rk);
-    return hs >= 0 ? (u32)(k >> hs) & (SLOTS - 1) : (u32)(k << (-hs)) & (SLOTS - 1);
-  };
-  bool overflow = false;
+  bool bad = false;
 #pragma unroll
   for (u32 q = 0; q < Q; q++) {
     const u32 p = threadIdx.x + 256u * q;
-    if (p >= len || overflow) continue;
+    if (p >= len || bad) continue;
     const u32 v = vq[q];
-    if (v >= n_reads) { overflow = true; continue; }   // a malformed index is never used
-    const W2 w = wq[q];
-    u32 s = home(w), probes = 0;
+    if (v >= n_reads) { bad = true; continue; }        // a malformed index is never used
+    const u64 f = w2_fingerprint(wq[q]);
+    u32 s = (u32)(f >> 20) & (SLOTS - 1), probes = 0;
     bool placed = false;
     while (probes++ <= SLOTS) {
-      u32 cur = ltag[s];
-      if (cur == NONE32) cur = atomicCAS(&ltag[s], NONE32, p);
-      if (cur == NONE32 || w_eq(wk[cur & (STAGE - 1)], w)) { placed = true; break; }
+      u64 cur = lkey[s];
+      if (cur == EMPTY_KEY) cur = atomicCAS((ull *)&lkey[s], EMPTY_KEY, (ull)f);
+      if (cur == EMPTY_KEY || cur == f) { placed = true; break; }
       s = (s + 1) & (SLOTS - 1);
     }
-    if (!placed) { overflow = true; continue; }
-    if (atomicAdd(&lcnt[s], 1u) == 0u) lslot_of[atomicAdd(&lcount, 1u)] = (unsigned short)s;
+    if (!placed) { bad = true; continue; }
+    sq[q] = s;
+    if (atomicAdd(&lcnt[s], 1u) == 0u) { lclaim[s] = (unsigned short)p; lslot_of[atomicAdd(&lcount, 1u)] = (unsigned short)s; }
     atomicMin(&lfirst[s], v);
   }
-  if (overflow) ctr[CTR_OVERFULL] = 1;
   __syncthreads();
+  // exactness: the word of every position against the word that registered its entry
+#pragma unroll
+  for (u32 q = 0; q < Q; q++)
+    if (sq[q] != NONE32 && !w_eq(wk[lclaim[sq[q]]], wq[q])) bad = true;
+  if (bad) ctr[CTR_OVERFULL] = 1;
   const u32 n_uniq = lcount < SLOTS ? lcount : SLOTS;
-  for (u32 li = threadIdx.x; li < n_uniq; li += 256) lpos[li] = (unsigned short)ltag[lslot_of[li]];
-  __syncthreads();
   if (n_uniq <= 512) {
     // rank of an entry = number of smaller words among the bucket's unique words (all distinct)
     for (u32 li = threadIdx.x; li < n_uniq; li += 256) {
-      const W2 w = wk[lpos[li]];
+      const W2 w = wk[lclaim[lslot_of[li]]];
       u32 r = 0;
-      for (u32 j = 0; j < n_uniq; j++) r += w_less(wk[lpos[j]], w) ? 1u : 0u;
+      for (u32 j = 0; j < n_uniq; j++) r += w_less(wk[lclaim[lslot_of[j]]], w) ? 1u : 0u;
       lorder[r] = lslot_of[li];
     }
     __syncthreads();
@@ -605,7 +613,7 @@ k_dedup_wide_rec(const W2 *__restrict__ recw, const u32 *__restrict__ reci, cons
             bool gt;
             if (pa) gt = !pbd;
             else if (pbd) gt = false;
-            else gt = w_less(wk[ltag[bb] & (STAGE - 1)], wk[ltag[a] & (STAGE - 1)]);
+            else gt = w_less(wk[lclaim[bb]], wk[lclaim[a]]);
             if (gt == ((t & k) == 0)) { lslot_of[t] = (unsigned short)bb; lslot_of[x] = (unsigned short)a; }
           }
         }
@@ -615,9 +623,9 @@ k_dedup_wide_rec(const W2 *__restrict__ recw, const u32 *__restrict__ reci, cons
   }
   for (u32 li = threadIdx.x; li < n_uniq; li += 256) {
     const u32 s = lslot_of[li];
-    pad_word[beg + li] = wk[ltag[s] & (STAGE - 1)];
+    pad_word[beg + li] = wk[lclaim[s]];
     pad_cf[beg + li] = make_uint2(lcnt[s], lfirst[s]);
-    lfirst[s] = li;
+    lfirst[s] = li;                                    // entry -> rank
   }
   if (threadIdx.x == 0) agg[g] = ((u64)len << 32) | n_uniq;
   __syncthreads();
@@ -625,14 +633,7 @@ k_dedup_wide_rec(const W2 *__restrict__ recw, const u32 *__restrict__ reci, cons
   for (u32 q = 0; q < Q; q++) {
     const u32 p = threadIdx.x + 256u * q;
     if (p >= len) continue;
-    const W2 w = wq[q];
-    u32 s = home(w), probes = 0, li = NONE32;
-    while (probes++ <= SLOTS) {
-      const u32 t = ltag[s];
-      if (t == NONE32) break;                          // (cannot happen for a word that was inserted)
-      if (w_eq(wk[t & (STAGE - 1)], w)) { li = lfirst[s]; break; }
-      s = (s + 1) & (SLOTS - 1);
-    }
+    const u32 li = sq[q] != NONE32 ? lfirst[sq[q]] : NONE32;
     out8[beg + p] = ((u64)(li < len ? (u32)beg + li : NOSLOT) << 32) | vq[q];
   }
 }
