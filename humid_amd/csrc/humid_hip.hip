@@ -2147,7 +2147,8 @@ static int unpermute_tiled(humid_ctx *c, u32 N, bool packed, u32 *d_cid, u8 *d_k
   hipStream_t st = c->stream;
   *done = false;
   if (!c->use_tile_partition || N == 0) return HUMID_OK;
-  u32 wshift = 14;
+  static const u32 uw_pref = getenv("HUMID_UW_SHIFT") ? (u32)atoi(getenv("HUMID_UW_SHIFT")) : 14u;   // (experiments)
+  u32 wshift = uw_pref == 15 ? 15u : 14u;
   if (((u64)N + (1u << wshift) - 1) >> wshift > UW_MAXBINS) wshift = UW_MAXSHIFT;
   const u32 n_bins = (u32)(((u64)N + (1u << wshift) - 1) >> wshift);
   if (n_bins > UW_MAXBINS) return HUMID_OK;
