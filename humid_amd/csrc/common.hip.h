@@ -31,7 +31,8 @@ typedef unsigned long long ull;
 enum { CTR_UNIQUE = 0, CTR_USABLE, CTR_EDGES, CTR_NONSINGLE, CTR_MEMBERS, CTR_SPECIAL,
        CTR_CLUSTERS, CTR_OVERFULL, CTR_BIGMASK /* combos with a bucket beyond k_pairs' walk */,
        CTR_SMALLROOTS /* components of 3 .. SMALL_COMP leaves listed by k_comp_count */,
-       CTR_EOVER /* low word: an append region of the pair list was full (kernels_cgraph.hip.h) */, CTR_N = 16 };
+       CTR_EOVER /* low word: an append region of the pair list was full (kernels_cgraph.hip.h) */,
+       CTR_GOVER /* a padded coarse bin of the graph stage's grouping was full (group_words_by_stretch) */, CTR_N = 16 };
 
 // --------------------------------------------------------------------------------
 // device helpers

@@ -88,9 +88,15 @@ struct humid_ctx {
   bool own_stream = false;
   std::string err;
   ull *d_ctr = nullptr;
+  PsChain *ps_chain = nullptr;   // behind the counters
+  u32 ps_epoch = 0;
   ull *h_ctr = nullptr;   // pinned mirror (CTR_N counters + the sequence word of read_counters)
   ull *h_ctr_dev = nullptr;   // the same memory as the device sees it
   ull ctr_seq = 0;
+  u32 *ucur_clean = nullptr;     // the un-permute's bin cursors at this address are all zero
+  DBuf gf_cur;                    // cursors of the padded grouping (512 u32, kept at zero between uses)
+  bool gf_padded = true;  // bucket orders of the compact graph stage through padded coarse bins (until one was full)
+  bool no_chain = false;  // HUMID_NO_SCAN_CHAIN: scans without k_ps_scan_chain (experiment / cross-check)
   bool no_poll = false;   // HUMID_NO_POLL / a failed first try: blit copies + stream wait instead
   DBuf in_words, in_filt, in_bases, out_cid, out_keep;       // host entry point staging
   DBuf table, slot_out, slot_of_read, uniq_slot;             // table (cap+1) and per-read
@@ -234,7 +240,7 @@ static int sort_keys(humid_ctx *c, const K *kin, K *kout, u64 n, u32 b0, u32 b1)
 template <class T, class In>
 static int exscan_in(humid_ctx *c, In in, T *out, u64 n) {
   ENSURE(c->tmp, ps_scan_scratch_items(n) * sizeof(T) + 256);
-  HIPCHK((ps_exscan<T>(in, out, n, (T *)c->tmp.p, c->stream)));
+  HIPCHK((ps_exscan<T>(in, out, n, (T *)c->tmp.p, c->stream, c->no_chain ? nullptr : c->ps_chain, &c->ps_epoch)));
   return HUMID_OK;
 }
 static int exscan_u32(humid_ctx *c, const u32 *in, u32 *out, u64 n) { return exscan_in<u32>(c, PtrIn<u32>{in}, out, n); }
@@ -608,7 +614,7 @@ static int count_partition(humid_ctx *c, const SRC &src, u32 N, u32 pb, bool *us
   }
   hipLaunchKernelGGL((k_pt_scatter<1, SRC>), dim3(tiles1), dim3(1024), 0, st, src, N, (const u64 *)nullptr,
                      (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr, d1, d2, cbase, cursor1, k1, v1,
-                     (u32 *)nullptr, cap1, c->d_ctr);
+                     (u32 *)nullptr, cap1, &c->d_ctr[CTR_SPECIAL]);
   if (padded)
     hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, (const u32 *)cursor1, d1, d2, cbase, tprefix, c->pbeg.as<u32>(),
                        c->ucount.as<u32>() + n_parts, cap1);
@@ -616,7 +622,7 @@ static int count_partition(humid_ctx *c, const SRC &src, u32 N, u32 pb, bool *us
   if (d2) {
     hipLaunchKernelGGL(k_pt_hist2<SRC>, dim3(tiles2), dim3(1024), 0, st, src, k1, tprefix, cbase, d1, d2, hist_fine, cap1);
     hipLaunchKernelGGL((k_pt_scatter<2, SRC>), dim3(tiles2), dim3(1024), 0, st, src, N, k1, v1, tprefix, cbase, d1, d2,
-                       hist_fine, cursor2, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(), c->pbeg.as<u32>(), cap1, c->d_ctr);
+                       hist_fine, cursor2, c->pk_keys.as<u64>(), c->pk_vals.as<u32>(), c->pbeg.as<u32>(), cap1, &c->d_ctr[CTR_SPECIAL]);
   }
   if (c->kev_on) HIPCHK(hipEventRecord(c->kev[40], st));
   return HUMID_OK;
@@ -1132,7 +1138,8 @@ static int find_big_runs(humid_ctx *c, const WT *W, u32 n, WT mask, u32 walk_max
 // shape (the caller sorts).
 static ComboFields plan_fields(const ComboPlan &plan, u32 cb);
 template <class SRC, class WT>
-static int group_words_by_stretch(humid_ctx *c, const ComboPlan &plan, u32 cb, const WT *W, u32 n, u64 *ws, u32 *vs, bool *done) {
+static int group_words_by_stretch(humid_ctx *c, const ComboPlan &plan, u32 cb, const WT *W, u32 n, u64 *ws, u32 *vs, bool *done,
+                                  bool may_pad = false) {
   hipStream_t st = c->stream;
   u32 bit_n = 0;
   for (u32 f = 0; f < plan.nfield[cb]; f++) bit_n += plan.width[cb][f];
@@ -1140,29 +1147,48 @@ static int group_words_by_stretch(humid_ctx *c, const ComboPlan &plan, u32 cb, c
   if (!*done) return HUMID_OK;
   const u32 d1 = bit_n >= 18 ? 9u : (bit_n + 1) / 2, d2 = bit_n - d1;          // d2 <= 15: 2^15 LDS counters at most
   const u32 nb1 = 1u << d1;
+  // may_pad (the caller reads CTR_GOVER at its host wait and comes back without it when a bin was full): level 1
+  // scatters into PADDED coarse bins (mean + 25 % + 1024, as the count stage's first level) -- no histogram pass
+  // over the words in front, the bins' counts are the cursors left behind; and no bin can hold more than its
+  // room, so the launches for bin sizes beyond it are left out
+  const bool padded = may_pad && c->gf_padded;
+  const u32 cap1 = padded ? n / nb1 + n / nb1 / 4 + 1024 : 0u;
+  const size_t room = padded ? (size_t)nb1 * cap1 : (size_t)n;
   // scratch: [hist1 512 | cursor1 512] zeroed, then [cbase 513 | tprefix 513 | pbeg dummy 514]
   ENSURE(c->pt_work, (size_t)(1024 + 513 + 513 + 516) * 4);
   u32 *hist1 = c->pt_work.as<u32>(), *cursor1 = hist1 + 512, *cbase = cursor1 + 512, *tprefix = cbase + 513, *dummy = tprefix + 513;
-  HIPCHK(hipMemsetAsync(c->pt_work.p, 0, 1024 * 4, st));
-  ENSURE(c->seg_k0, (size_t)n * 8);
-  ENSURE(c->seg_v0, (size_t)n * 4);
+  if (padded) {                                              // its own cursors, cleared by the scan that reads them
+    if (!c->gf_cur.p) {
+      ENSURE(c->gf_cur, 512 * 4);
+      HIPCHK(hipMemsetAsync(c->gf_cur.p, 0, 512 * 4, st));
+    }
+    cursor1 = c->gf_cur.as<u32>();
+  } else HIPCHK(hipMemsetAsync(c->pt_work.p, 0, 1024 * 4, st));
+  ENSURE(c->seg_k0, room * 8);
+  ENSURE(c->seg_v0, room * 4);
   const SRC src{W, plan_fields(plan, cb), bit_n};
   const u32 tiles1 = (n + PT_TILE - 1) / PT_TILE;
-  hipLaunchKernelGGL(k_pt_hist1<SRC>, dim3(tiles1 < 512 ? tiles1 : 512), dim3(1024), 0, st, src, n, d1, hist1);
-  hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, (const u32 *)hist1, d1, 0u, cbase, tprefix, dummy, dummy + 513, 0u);
+  if (!padded) {
+    hipLaunchKernelGGL(k_pt_hist1<SRC>, dim3(tiles1 < 512 ? tiles1 : 512), dim3(1024), 0, st, src, n, d1, hist1);
+    hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, (const u32 *)hist1, d1, 0u, cbase, tprefix, dummy, dummy + 513, 0u);
+  }
   hipLaunchKernelGGL((k_pt_scatter<1, SRC>), dim3(tiles1), dim3(1024), 0, st, src, n, (const u64 *)nullptr,
                      (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr, d1, d2, (const u32 *)cbase, cursor1,
-                     c->seg_k0.as<u64>(), c->seg_v0.as<u32>(), (u32 *)nullptr, 0u, c->d_ctr);
-  // three launches over the coarse bins, by bin size; which sizes cannot occur is known from n alone only
-  // roughly (the bins of a skewed key can be any size), so only the impossible ones are left out
+                     c->seg_k0.as<u64>(), c->seg_v0.as<u32>(), (u32 *)nullptr, cap1, &c->d_ctr[CTR_GOVER]);
+  if (padded)
+    hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, (const u32 *)cursor1, d1, 0u, cbase, tprefix, dummy, dummy + 513, cap1, cursor1);
+  // up to three launches over the coarse bins, by bin size; which sizes cannot occur is known from n alone only
+  // roughly (the bins of a skewed key can be any size) unless the bins are padded, so only the impossible
+  // ones are left out
+  const u32 largest = padded ? cap1 : n;
   hipLaunchKernelGGL((k_group_fine<SRC, 0>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
-                     (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs);
-  if (n > GF_SMALL)
+                     (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs, cap1);
+  if (largest > GF_SMALL)
     hipLaunchKernelGGL((k_group_fine<SRC, 1>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
-                       (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs);
-  if (n > GF_MID)
+                       (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs, cap1);
+  if (largest > GF_MID)
     hipLaunchKernelGGL((k_group_fine<SRC, 2>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
-                       (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs);
+                       (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs, cap1);
   HIPCHK(hipGetLastError());
   return HUMID_OK;
 }
@@ -1189,18 +1215,18 @@ static int sort_words_by_stretch(humid_ctx *c, const ComboPlan &plan, u32 cb, co
 // position i, vs[i] = its walk index.  Keys of <= 24 bits: two-level grouping; one stretch of the word:
 // the words themselves as sort keys; else keys + sort + gather.  Scratch: seg_k0 / seg_v0 / seg_ks.
 template <class WT>
-static int bucket_order(humid_ctx *c, const ComboPlan &plan, u32 seg, const WT *g_word, u32 U, WT *ws, u32 *vs) {
+static int bucket_order(humid_ctx *c, const ComboPlan &plan, u32 seg, const WT *g_word, u32 U, WT *ws, u32 *vs, bool may_pad = false) {
   hipStream_t st = c->stream;
   u32 kb = 0;                                            // key bits of THIS combination
   for (u32 f = 0; f < plan.nfield[seg]; f++) kb += plan.width[seg][f];
   if (kb == 0) kb = 1;
   bool stretch = false;
   if (std::is_same<WT, u64>::value) {
-    TRY((group_words_by_stretch<FieldsSrc, u64>(c, plan, seg, (const u64 *)g_word, U, (u64 *)ws, vs, &stretch)));
+    TRY((group_words_by_stretch<FieldsSrc, u64>(c, plan, seg, (const u64 *)g_word, U, (u64 *)ws, vs, &stretch, may_pad)));
     if (!stretch) TRY(sort_words_by_stretch(c, plan, seg, (const u64 *)g_word, U, (u64 *)ws, vs, &stretch));
   } else {
     // two-word words: the keys are grouped (scratch), the words follow through the grouped positions
-    TRY((group_words_by_stretch<FieldsSrcW2, W2>(c, plan, seg, (const W2 *)g_word, U, c->seg_ks.as<u64>(), vs, &stretch)));
+    TRY((group_words_by_stretch<FieldsSrcW2, W2>(c, plan, seg, (const W2 *)g_word, U, c->seg_ks.as<u64>(), vs, &stretch, may_pad)));
     if (stretch) hipLaunchKernelGGL(k_gather_bucket_words<WT>, dim3(blocks_for(U)), dim3(256), 0, st, g_word, vs, U, ws);
   }
   if (stretch) return HUMID_OK;
@@ -1451,6 +1477,7 @@ struct CgSource {
 };
 struct CgStatus {
   bool overflow = false;       // an append region was full: `wanted` says how much room the search wants in all
+  bool group_over = false;     // a padded coarse bin of a bucket order was full (CTR_GOVER)
   u64 wanted = 0, big_mask = 0, E = 0, M = 0, Mbig = 0;
 };
 static GraphArrays cg_arrays(humid_ctx *c) {
@@ -1479,8 +1506,7 @@ static int cg_build(humid_ctx *c, CgSource &src, u32 method, CgStatus &out) {
   ENSURE(c->cg_cl_size, ((size_t)Mb + 1) * 8);
   ENSURE(c->small_roots, ((size_t)Mb / 3 + 2) * 4);
   ENSURE(c->small, 64);
-  hipLaunchKernelGGL(k_bits_blocks, dim3(blocks_for((u64)n_blk + 1)), dim3(256), 0, st, c->cg_bits.as<u32>(), n_blk, c->cg_blk.as<u32>());
-  TRY(exscan_u32(c, c->cg_blk.as<u32>(), c->cg_blk.as<u32>(), (u64)n_blk + 1));
+  TRY(exscan_in<u32>(c, BitsBlockIn{c->cg_bits.as<u32>(), n_blk}, c->cg_blk.as<u32>(), (u64)n_blk + 1));
   const BitRank br{c->cg_bits.as<u32>(), c->cg_blk.as<u32>()};
   const u32 *m_dev = c->cg_blk.as<u32>() + n_blk;
   const GraphArrays g = cg_arrays(c);
@@ -1512,7 +1538,7 @@ static int cg_build(humid_ctx *c, CgSource &src, u32 method, CgStatus &out) {
   hipLaunchKernelGGL(k_comp_stats, dim3(blocks_for(Mb)), dim3(256), 0, st, g.deg, g.parent, Mb, g.csize, m_dev);
   {
     const u32 gx = (u32)std::min<u64>(std::max<u64>(blocks_for(std::max<u64>(src.er.cap_r, src.er.n_far)), 1), 4096);
-    hipLaunchKernelGGL(k_pairs_fill, dim3(gx, ER_REGIONS + 1), dim3(256), 0, st, src.er, (const u32 *)g.off, c->cg_curs.as<u32>(), g.idx);
+    hipLaunchKernelGGL(k_pairs_fill, dim3(gx, ER_REGIONS + 1), dim3(256), 0, st, src.er, (const u32 *)g.off, c->cg_curs.as<u32>(), g.idx, c->small.as<u32>());
   }
   hipLaunchKernelGGL(k_sort_lists, dim3(blocks_for(Mb)), dim3(256), 0, st, (const u32 *)g.off, Mb, g.idx);
   if (c->kev_on) HIPCHK(hipEventRecord(c->kev[2], st));
@@ -1525,11 +1551,11 @@ static int cg_build(humid_ctx *c, CgSource &src, u32 method, CgStatus &out) {
     hipLaunchKernelGGL(k_cg_trivial<false>, dim3(tg), dim3(256), 0, st, (const u32 *)g.parent, (const u32 *)g.csize, m_dev,
                        (const u32 *)c->cg_ncnt.as<u32>(), (const u32 *)g.off, (const u32 *)g.idx, g.cl_of, g.maxleaf, g.cl_size, c->d_ctr,
                        c->small_roots.as<u32>());
-  hipLaunchKernelGGL(k_regions_max, dim3(1), dim3(64), 0, st, src.er, c->small.as<u32>());
   HIPCHK(hipGetLastError());
   TRY(read_counters(c, g.off + Mb, c->small.as<u32>(), m_dev));              // 2E, pairs the fullest region wanted, M
   out.wanted = (c->h_ctr[CTR_N - 2] & 0xffffffffull) * ER_REGIONS;            // (as a total: every region has the same room)
   out.overflow = (c->h_ctr[CTR_EOVER] & 0xffffffffull) != 0;
+  out.group_over = c->h_ctr[CTR_GOVER] != 0;
   out.big_mask = c->h_ctr[CTR_BIGMASK];
   out.E = (c->h_ctr[CTR_N - 1] & 0xffffffffull) / 2;
   out.M = c->h_ctr[CTR_N - 3] & 0xffffffffull;
@@ -1548,8 +1574,7 @@ static int cg_cluster_rest(humid_ctx *c, u32 n_ids, u64 M, u64 Mbig, u32 method)
   if (M > 0)
     hipLaunchKernelGGL(k_noncreator_bits, dim3(blocks_for(M)), dim3(256), 0, st, (const u32 *)g.cl_of, c->cg_nodes.as<u32>(), (u32)M,
                        c->cg_nbits.as<u32>());
-  hipLaunchKernelGGL(k_bits_blocks, dim3(blocks_for((u64)n_blk + 1)), dim3(256), 0, st, c->cg_nbits.as<u32>(), n_blk, c->cg_nblk.as<u32>());
-  TRY(exscan_u32(c, c->cg_nblk.as<u32>(), c->cg_nblk.as<u32>(), (u64)n_blk + 1));
+  TRY(exscan_in<u32>(c, BitsBlockIn{c->cg_nbits.as<u32>(), n_blk}, c->cg_nblk.as<u32>(), (u64)n_blk + 1));
   HIPCHK(hipGetLastError());
   return HUMID_OK;
 }
@@ -1626,7 +1651,7 @@ static int stage_graph_compact(humid_ctx *c, const WT *g_word, const u32 *g_cnt,
       z.p[0] = c->cg_bits.as<u32>(); z.n[0] = n_words;
       z.p[1] = c->cg_nbits.as<u32>(); z.n[1] = n_words;
       z.p[2] = c->cg_cur.as<u32>(); z.n[2] = ER_REGIONS * ER_STRIDE + 8;
-      z.p[3] = (u32 *)&c->d_ctr[CTR_EDGES]; z.n[3] = 2 * (CTR_EOVER - CTR_EDGES + 1);
+      z.p[3] = (u32 *)&c->d_ctr[CTR_EDGES]; z.n[3] = 2 * (CTR_GOVER - CTR_EDGES + 1);
       hipLaunchKernelGGL(k_zero_many, dim3(64), dim3(256), 0, st, z);
     }
     for (u32 seg = 0; seg < nseg; seg++) {
@@ -1638,7 +1663,7 @@ static int stage_graph_compact(humid_ctx *c, const WT *g_word, const u32 *g_cnt,
       } else {
         u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
         WT *ws = c->seg_ws.as<WT>() + (size_t)(seg - 1) * U;
-        if (!ordered_seg[seg]) TRY(bucket_order<WT>(c, plan, seg, g_word, U, ws, vs));
+        if (!ordered_seg[seg]) TRY(bucket_order<WT>(c, plan, seg, g_word, U, ws, vs, true));
         ordered_seg[seg] = true;
         if (seg < 8 && c->kev_on) HIPCHK(hipEventRecord(c->kev[20 + 2 * seg], st));
         hipLaunchKernelGGL((k_pairs_append<false, WT>), dim3(blocks_for(U)), dim3(256), 0, st, (const WT *)ws, (const u32 *)vs, U,
@@ -1654,6 +1679,13 @@ static int stage_graph_compact(humid_ctx *c, const WT *g_word, const u32 *g_cnt,
     src.pairs_bound = ecap + n_far;
     TRY(cg_build(c, src, method, cgs));
     er = src.er;
+    if (cgs.group_over) {                                // a padded coarse bin of a grouping was full: words are missing
+      c->gf_padded = false;                              // from a bucket order -- all of it again with exact bins
+      for (u32 q = 0; q < MAX_COMBOS; q++) ordered_seg[q] = false;
+      far = given ? ext_edges : nullptr;
+      n_far = given ? n_ext_edges : 0;
+      continue;
+    }
     if (cgs.overflow) {                                  // a region was full: more room, once more
       c->cg_ecap = cgs.wanted + cgs.wanted / 2 + ER_REGIONS * 64;
       continue;
@@ -2155,7 +2187,9 @@ static int unpermute_tiled(humid_ctx *c, u32 N, bool packed, u32 *d_cid, u8 *d_k
   ENSURE(c->unperm_rec, ((size_t)n_bins << wshift) * 8 + (size_t)UW_MAXBINS * 4);
   u64 *rec = c->unperm_rec.as<u64>();
   u32 *ucur = (u32 *)(rec + ((size_t)n_bins << wshift));
-  HIPCHK(hipMemsetAsync(ucur, 0, (size_t)n_bins * 4, st));
+  // the bins' cursors: k_unperm_window leaves every cursor it read at zero, so only a new place needs a clear
+  if (c->ucur_clean != ucur) HIPCHK(hipMemsetAsync(ucur, 0, (size_t)UW_MAXBINS * 4, st));
+  c->ucur_clean = nullptr;
   // positions in use: all N for the sorted (wide-word) count, else up to pbeg[n_parts] (on the device)
   const bool bucketed = c->n_parts && !c->last_count_sorted;
   const u32 *n_pos_dev = bucketed ? c->pbeg.as<u32>() + c->n_parts : (const u32 *)nullptr;
@@ -2183,6 +2217,8 @@ static int unpermute_tiled(humid_ctx *c, u32 N, bool packed, u32 *d_cid, u8 *d_k
     else hipLaunchKernelGGL((k_unperm_window<false, 15>), dim3(n_bins), dim3(512), 0, st, rec, ucur, N, d_cid, d_keep);
   }
   if (c->kev_on) HIPCHK(hipEventRecord(c->kev[41], st));
+  HIPCHK(hipGetLastError());
+  c->ucur_clean = ucur;
   *done = true;
   return HUMID_OK;
 }
@@ -2364,11 +2400,15 @@ int humid_ctx_create(humid_ctx **out, int device, void *stream) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     c->own_stream = true;
   }
-  if ((e = hipMalloc((void **)&c->d_ctr, CTR_N * sizeof(ull))) != hipSuccess) return bail(e, "hipMalloc");
+  if ((e = hipMalloc((void **)&c->d_ctr, CTR_N * sizeof(ull) + sizeof(PsChain))) != hipSuccess) return bail(e, "hipMalloc");
+  c->ps_chain = (PsChain *)(c->d_ctr + CTR_N);                 // the scans' chain (prims.hip.h): zero once, epochs after that
+  if ((e = hipMemset(c->ps_chain, 0, sizeof(PsChain))) != hipSuccess) return bail(e, "hipMemset");
   if ((e = hipHostMalloc((void **)&c->h_ctr, (CTR_N + 2) * sizeof(ull), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
   memset(c->h_ctr, 0, (CTR_N + 2) * sizeof(ull));
   if (hipHostGetDevicePointer((void **)&c->h_ctr_dev, c->h_ctr, 0) != hipSuccess) { c->h_ctr_dev = nullptr; (void)hipGetLastError(); }
   c->no_poll = getenv("HUMID_NO_POLL") != nullptr;
+  c->no_chain = getenv("HUMID_NO_SCAN_CHAIN") != nullptr;
+  c->gf_padded = getenv("HUMID_NO_GROUP_PAD") == nullptr;
   for (auto &ev : c->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
   for (auto &ev : c->kev)
@@ -2387,7 +2427,7 @@ void humid_ctx_destroy(humid_ctx *c) {
                   &c->pbeg, &c->ucount, &c->pusable, &c->ubase, &c->pad_word, &c->pad_cf, &c->pslot,
                   &c->opos, &c->own_packed, &c->owner, &c->owner_sorted, &c->perm, &c->small, &c->pc, &c->poff, &c->share_edges, &c->own_words, &c->heads, &c->had, &c->big_runs, &c->small_roots, &c->e_kx, &c->e_vx, &c->e_ky, &c->e_vy, &c->e_raw, &c->e_sorted, &c->e_edges, &c->e_head, &c->e_hpos, &c->e_runlo, &c->e_nch, &c->e_choff, &c->e_pc2, &c->e_poff2, &c->x_slot, &c->x_slot_s, &c->x_cnt, &c->x_cnts, &c->x_rec, &c->x_ncnt, &c->x_route, &c->x_creator, &c->x_base, &c->x_mark, &c->x_markcr, &c->x_scan, &c->x_lcid, &c->x_lismax, &c->x_items, &c->x_w, &c->x_id, &c->x_ids, &c->x_ends, &c->x_ends_s, &c->x_head, &c->x_hpos, &c->x_nodes, &c->x_cedges, &c->w_heads, &c->w_sorted, &c->w_head, &c->w_hpos, &c->w_start, &c->pt_work, &c->unperm_rec, &c->route_tiles, &c->xr_hist, &c->xr_recv, &c->xr_eloc, &c->xr_got, &c->xr_eall, &c->xr_ret, &c->xr_heads, &c->xr_send, &c->xr_zero,
                   &c->xo_gw, &c->xo_gc, &c->xo_regs, &c->xo_inv, &c->xo_send, &c->xo_int, &c->xo_cross, &c->xo_sel, &c->xo_selall, &c->xo_parent, &c->xo_flag, &c->xo_xroot, &c->xo_xcbits, &c->xo_xcblk,
-                  &c->xo_xcid, &c->xo_xcall, &c->xo_ldeg, &c->xo_cnt, &c->pw_a, &c->pw_ai, &c->pw_b, &c->pw_bi, &c->p8_a, &c->p8_b, &c->p8_cur, &c->p8_status, &c->cg_edges, &c->cg_cur, &c->cg_far, &c->cg_bits, &c->cg_nbits, &c->cg_blk, &c->cg_nblk, &c->cg_nodes, &c->cg_ncnt, &c->cg_deg,
+                  &c->xo_xcid, &c->xo_xcall, &c->xo_ldeg, &c->xo_cnt, &c->pw_a, &c->pw_ai, &c->pw_b, &c->pw_bi, &c->gf_cur, &c->p8_a, &c->p8_b, &c->p8_cur, &c->p8_status, &c->cg_edges, &c->cg_cur, &c->cg_far, &c->cg_bits, &c->cg_nbits, &c->cg_blk, &c->cg_nblk, &c->cg_nodes, &c->cg_ncnt, &c->cg_deg,
                   &c->cg_off, &c->cg_idx, &c->cg_parent, &c->cg_csize, &c->cg_curs, &c->cg_cl_of, &c->cg_maxleaf, &c->cg_cl_size,
                   &c->slot_out, &c->slot_of_read, &c->uniq_slot, &c->uniq_word, &c->s_word, &c->s_slot,
                   &c->s_cnt, &c->s_first, &c->deg, &c->nbr_off, &c->nbr_idx, &c->seg_k0, &c->seg_ks,
@@ -3131,7 +3171,7 @@ static int run_exchange_impl(humid_ctx *c, const humid_comm *cm, const uint64_t 
       memset(&z, 0, sizeof z);
       z.p[0] = c->cg_bits.as<u32>(); z.n[0] = nw;
       z.p[1] = c->cg_nbits.as<u32>(); z.n[1] = nw;
-      z.p[2] = (u32 *)&c->d_ctr[CTR_EDGES]; z.n[2] = 2 * (CTR_EOVER - CTR_EDGES + 1);
+      z.p[2] = (u32 *)&c->d_ctr[CTR_EDGES]; z.n[2] = 2 * (CTR_GOVER - CTR_EDGES + 1);
       z.p[3] = c->cg_cur.as<u32>(); z.n[3] = ER_REGIONS * ER_STRIDE + 8;
       hipLaunchKernelGGL(k_zero_many, dim3(64), dim3(256), 0, st, z);
     }
@@ -3290,7 +3330,7 @@ static int run_exchange_impl(humid_ctx *c, const humid_comm *cm, const uint64_t 
     memset(&z, 0, sizeof z);
     z.p[0] = c->cg_cur.as<u32>(); z.n[0] = ER_REGIONS * ER_STRIDE + 8;
     z.p[1] = dcnt; z.n[1] = 64;
-    z.p[2] = (u32 *)&c->d_ctr[CTR_EDGES]; z.n[2] = 2 * (CTR_EOVER - CTR_EDGES + 1);
+    z.p[2] = (u32 *)&c->d_ctr[CTR_EDGES]; z.n[2] = 2 * (CTR_GOVER - CTR_EDGES + 1);
     hipLaunchKernelGGL(k_zero_many, dim3(8), dim3(256), 0, st, z);
     return HUMID_OK;
   };
@@ -3538,7 +3578,7 @@ static int run_exchange_impl(humid_ctx *c, const humid_comm *cm, const uint64_t 
     z.p[0] = c->cg_bits.as<u32>(); z.n[0] = nw;
     z.p[1] = c->cg_nbits.as<u32>(); z.n[1] = nw;
     z.p[2] = X_total ? c->xo_xcbits.as<u32>() : nullptr; z.n[2] = X_total ? nw : 0;
-    z.p[3] = (u32 *)&c->d_ctr[CTR_EDGES]; z.n[3] = 2 * (CTR_EOVER - CTR_EDGES + 1);
+    z.p[3] = (u32 *)&c->d_ctr[CTR_EDGES]; z.n[3] = 2 * (CTR_GOVER - CTR_EDGES + 1);
     z.p[4] = c->cg_cur.as<u32>(); z.n[4] = ER_REGIONS * ER_STRIDE;   // (not the bad flag behind them)
     hipLaunchKernelGGL(k_zero_many, dim3(64), dim3(256), 0, st, z);
   }
@@ -3582,8 +3622,7 @@ static int run_exchange_impl(humid_ctx *c, const humid_comm *cm, const uint64_t 
                        (const u8 *)c->xo_xroot.as<u8>(), (const u32 *)c->cg_nodes.as<u32>(), (u32)M_mine, c->xo_xcbits.as<u32>());
   }
   if (X_total) {
-    hipLaunchKernelGGL(k_bits_blocks, dim3(blocks_for((u64)nblk + 1)), dim3(256), 0, st, c->xo_xcbits.as<u32>(), nblk, c->xo_xcblk.as<u32>());
-    TRY(exscan_u32(c, c->xo_xcblk.as<u32>(), c->xo_xcblk.as<u32>(), (u64)nblk + 1));
+    TRY(exscan_in<u32>(c, BitsBlockIn{c->xo_xcbits.as<u32>(), nblk}, c->xo_xcblk.as<u32>(), (u64)nblk + 1));
   }
   hipLaunchKernelGGL(k_own_totals, dim3(1), dim3(64), 0, st, br_nc, br_in, (u32)goff, (u32)u_local, dcnt + 56);
   HIPCHK(hipGetLastError());

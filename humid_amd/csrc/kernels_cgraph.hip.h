@@ -64,6 +64,19 @@ __device__ __forceinline__ u32 br_rank(const BitRank &br, u32 u) {
   return r;
 }
 
+// the same as the input of a scan (prims.hip.h): item b = set bits of block b, item n_blk = 0 -- the rank
+// blocks come out of ONE launch, without the array of counts in between
+struct BitsBlockIn {
+  const u32 *bits;
+  u32 n_blk;
+  __device__ __forceinline__ u32 operator()(u64 b) const {
+    if (b >= n_blk) return 0u;
+    const uint4 *p = (const uint4 *)(bits + 8 * (size_t)b);
+    const uint4 x = p[0], y = p[1];
+    return (u32)(__popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w) + __popc(y.x) + __popc(y.y) + __popc(y.z) + __popc(y.w));
+  }
+};
+
 // set bits of every block of 256 leaves (8 words); cnt[n_blk] = 0 is the scan's sentinel
 __global__ void __launch_bounds__(256)
 k_bits_blocks(const u32 *__restrict__ bits, u32 n_blk, u32 *__restrict__ cnt) {
@@ -238,8 +251,15 @@ k_pairs_relabel(EdgeRegs er, BitRank br, const u32 *__restrict__ ncnt, u32 *deg,
 
 // CSR rows through per-row cursors (put in ascending order afterwards by k_sort_lists)
 __global__ void __launch_bounds__(256)
-k_pairs_fill(EdgeRegs er, const u32 *__restrict__ off, u32 *cur, u32 *__restrict__ idx) {
+k_pairs_fill(EdgeRegs er, const u32 *__restrict__ off, u32 *cur, u32 *__restrict__ idx, u32 *__restrict__ regions_max) {
   HUMID_GUARD_LAST_VGPR();
+  if (regions_max && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
+    // the fullest region's cursor (what the search wanted of ONE region: all regions have the same room)
+    u32 c = er.cur[threadIdx.x * ER_STRIDE];
+#pragma unroll
+    for (u32 d = 32; d >= 1; d >>= 1) { const u32 y = __shfl_xor(c, d); c = y > c ? y : c; }
+    if (threadIdx.x == 0) regions_max[0] = c;
+  }
   const u32 r = blockIdx.y;
   const u32 n_r = er_count(er, r);
   for (u32 k = blockIdx.x * blockDim.x + threadIdx.x; k < n_r; k += gridDim.x * blockDim.x) {
@@ -248,15 +268,6 @@ k_pairs_fill(EdgeRegs er, const u32 *__restrict__ off, u32 *cur, u32 *__restrict
     idx[off[a] + atomicAdd(&cur[a], 1u)] = b;
     idx[off[b] + atomicAdd(&cur[b], 1u)] = a;
   }
-}
-
-// the fullest region's cursor (what the search wanted of ONE region: all regions have the same room) -> out[0]
-__global__ void k_regions_max(EdgeRegs er, u32 *__restrict__ out) {
-  HUMID_GUARD_LAST_VGPR();
-  u32 c = er.cur[threadIdx.x * ER_STRIDE];
-#pragma unroll
-  for (u32 d = 32; d >= 1; d >>= 1) { const u32 y = __shfl_xor(c, d); c = y > c ? y : c; }
-  if (threadIdx.x == 0) out[0] = c;
 }
 
 // ---- pair RECORDS as the source (multi-GPU: pairs in global unique indices with both ends' counts) ----

@@ -142,7 +142,7 @@ k_pt_hist1(SRC src, u32 n_reads, u32 d1, u32 *__restrict__ hist1) {
 // EMPTY coarse bins (no tile) and the final pbeg[2^(d1+d2)] = number of records ----
 __global__ void __launch_bounds__(1024)
 k_pt_scan1(const u32 *__restrict__ hist1, u32 d1, u32 d2, u32 *__restrict__ cbase, u32 *__restrict__ tprefix,
-           u32 *__restrict__ pbeg, u32 *__restrict__ ucount_tail, u32 cap1) {
+           u32 *__restrict__ pbeg, u32 *__restrict__ ucount_tail, u32 cap1, u32 *clear = nullptr) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u32 cnt[PT_MAXBINS], off[PT_MAXBINS + 1], wsum[8];
   const u32 nb = 1u << d1;
@@ -165,6 +165,8 @@ k_pt_scan1(const u32 *__restrict__ hist1, u32 d1, u32 d2, u32 *__restrict__ cbas
   __syncthreads();
   block_exscan_512(cnt, off, nb, wsum);
   if (threadIdx.x <= nb) tprefix[threadIdx.x] = off[threadIdx.x];
+  // clear (= hist1, the cursors of a padded level 1 that nobody reads after this): left at zero for the next use
+  if (clear && threadIdx.x < nb) clear[threadIdx.x] = 0;
 }
 
 // ---- the scatter of one level ----
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(1024)
 k_pt_scatter(SRC src, u32 n_reads, const u64 *__restrict__ k_in, const u32 *__restrict__ v_in,
              const u32 *__restrict__ tprefix, const u32 *__restrict__ cbase, u32 d1, u32 d2,
              const u32 *__restrict__ base, u32 *cursor, u64 *__restrict__ k_out, u32 *__restrict__ v_out,
-             u32 *__restrict__ pbeg_out, u32 cap1, ull *ctr) {
+             u32 *__restrict__ pbeg_out, u32 cap1, ull *over) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u64 skey[PT_TILE];
   __shared__ u32 sval[PT_TILE];
@@ -232,13 +234,13 @@ k_pt_scatter(SRC src, u32 n_reads, const u64 *__restrict__ k_in, const u32 *__re
   if (threadIdx.x < nb) {
     const u32 c = cnt[threadIdx.x];
     const u32 g = (LEVEL == 1) ? threadIdx.x : ((coarse << d2) | threadIdx.x);
-    // LEVEL 1 with cap1: the bin's fixed room; what does not fit is dropped and reported (ctr[CTR_SPECIAL]):
+    // LEVEL 1 with cap1: the bin's fixed room; what does not fit is dropped and reported (*over):
     // the caller repeats the partition with a histogram pass in front
     const u32 b0 = (LEVEL == 1) ? (cap1 ? g * cap1 : base[g]) : cbase[coarse] + fbase[threadIdx.x];
     const u32 had_before = c ? atomicAdd(&cursor[g], c) : 0u;
     goff[threadIdx.x] = b0 + had_before;
     room[threadIdx.x] = (LEVEL == 1 && cap1) ? (had_before >= cap1 ? 0u : cap1 - had_before) : 0xffffffffu;
-    if (LEVEL == 1 && cap1 && had_before + c > cap1) ctr[CTR_SPECIAL] = 1;
+    if (LEVEL == 1 && cap1 && had_before + c > cap1) *over = 1;
   }
 #pragma unroll
   for (u32 q = 0; q < PT_IPT; q++)
@@ -308,7 +310,7 @@ k_pt_hist2(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ tprefi
 template <class SRC, int SIZE>
 __global__ void __launch_bounds__(GF_THREADS)
 k_group_fine(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ v_in, const u32 *__restrict__ cbase, u32 d1,
-             u32 d2, u64 *__restrict__ k_out, u32 *__restrict__ v_out) {
+             u32 d2, u64 *__restrict__ k_out, u32 *__restrict__ v_out, u32 cap1) {
   HUMID_GUARD_LAST_VGPR();
   constexpr bool BIG = SIZE == 2;
   constexpr u32 INV_WORDS = SIZE == 0 ? 4096u : (1u << (GF_MAXBITS - 1)) + 16u;       // 16-bit entries, two per word, + the wave sums
@@ -318,6 +320,10 @@ k_group_fine(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ v_in
   if (beg >= end) return;
   const u32 n = end - beg;
   if ((n <= GF_SMALL ? 0 : (n <= GF_MID ? 1 : 2)) != SIZE) return;                    // another launch's bin
+  // cap1 > 0: level 1 was the PADDED scatter -- coarse bin c sits in its fixed room, the grouped words go
+  // to the dense positions cbase[] (the scan of the bins' counts)
+  const u32 ibeg = cap1 ? c * cap1 : beg;
+  k_in += ibeg; v_in += ibeg; k_out += beg; v_out += beg;
   u32 *wsum = BIG ? gf_lds + (1u << GF_MAXBITS) : gf_lds + (1u << (GF_MAXBITS - 1)) + INV_WORDS - 16;
   const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   auto fine = [&](u64 w) { return (u32)(src.key(w) >> (64 - d1 - d2)) & (nb - 1); };
@@ -326,7 +332,7 @@ k_group_fine(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ v_in
     for (u32 b = threadIdx.x; b < (1u << (GF_MAXBITS - 1)); b += GF_THREADS) gf_lds[b] = 0;   // 2^15 16-bit counters, two per word
     __syncthreads();
     for (u32 j = threadIdx.x; j < n; j += GF_THREADS) {
-      const u32 f = fine(k_in[beg + j]);
+      const u32 f = fine(k_in[j]);
       atomicAdd(&gf_lds[f >> 1], 1u << (16 * (f & 1)));                               // (no carry: n < 2^16)
     }
     __syncthreads();
@@ -355,21 +361,21 @@ k_group_fine(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ v_in
       }
     __syncthreads();
     for (u32 j = threadIdx.x; j < n; j += GF_THREADS) {
-      const u32 f = fine(k_in[beg + j]);
+      const u32 f = fine(k_in[j]);
       const u32 old = atomicAdd(&gf_lds[f >> 1], 1u << (16 * (f & 1)));
       inv[(old >> (16 * (f & 1))) & 0xffffu] = (unsigned short)j;
     }
     __syncthreads();
     for (u32 q = threadIdx.x; q < n; q += GF_THREADS) {
       const u32 j = inv[q];
-      k_out[beg + q] = k_in[beg + j];
-      v_out[beg + q] = v_in[beg + j];
+      k_out[q] = k_in[j];
+      v_out[q] = v_in[j];
     }
     return;
   }
   for (u32 b = threadIdx.x; b < nb; b += GF_THREADS) gf_lds[b] = 0;
   __syncthreads();
-  for (u32 j = beg + threadIdx.x; j < end; j += GF_THREADS) atomicAdd(&gf_lds[fine(k_in[j])], 1u);
+  for (u32 j = threadIdx.x; j < n; j += GF_THREADS) atomicAdd(&gf_lds[fine(k_in[j])], 1u);
   __syncthreads();
   const u32 per = nb >= GF_THREADS ? nb / GF_THREADS : 1u;
   const u32 b0 = threadIdx.x * per;
@@ -393,9 +399,9 @@ k_group_fine(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ v_in
       run += x;
     }
   __syncthreads();
-  for (u32 j = beg + threadIdx.x; j < end; j += GF_THREADS) {
+  for (u32 j = threadIdx.x; j < n; j += GF_THREADS) {
     const u64 w = k_in[j];
-    const u32 p = beg + atomicAdd(&gf_lds[fine(w)], 1u);
+    const u32 p = atomicAdd(&gf_lds[fine(w)], 1u);
     k_out[p] = w;
     v_out[p] = v_in[j];
   }
@@ -499,7 +505,7 @@ k_unperm_bins(const u32 *__restrict__ vals, const u32 *__restrict__ pslot, const
 // (64 KiB window, two workgroups per CU) or 15 (read sets beyond 32 M reads)
 template <bool PACKED, u32 WSHIFT>
 __global__ void __launch_bounds__(512)
-k_unperm_window(const u64 *__restrict__ rec, const u32 *__restrict__ ucur, u32 n_reads,
+k_unperm_window(const u64 *__restrict__ rec, u32 *__restrict__ ucur, u32 n_reads,
                 u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u32 win[1u << WSHIFT];
@@ -512,6 +518,8 @@ k_unperm_window(const u64 *__restrict__ rec, const u32 *__restrict__ ucur, u32 n
   __syncthreads();
   u32 n = ucur[bin];
   if (n > W) n = W;                                           // never beyond the bin's room
+  __syncthreads();
+  if (threadIdx.x == 0) ucur[bin] = 0;                        // the next pass finds its cursors at zero (no memset in front of it)
   const u64 *rb = rec + r0;
   for (u32 j = threadIdx.x; j < n; j += 512) {
     const u64 x = rb[j];

@@ -208,13 +208,98 @@ k_ps_scan_tiny(In in, u32 n, T *out) {
   }
 }
 
+// up to PS_CHAIN_WGS workgroups in ONE launch, n <= PS_CHAIN_WGS x 1024 x 8: a workgroup scans its tile of
+// 1024 x ITEMS items, publishes the tile's sum (value, then a flag that holds this launch's EPOCH, so the
+// chain is never cleared), and its first wave collects the sums of ALL tiles before it -- one lane per
+// earlier tile, at most 63 -- instead of walking a chain.  The grid is at most 64 workgroups on 256 CUs,
+// so every tile a workgroup waits for is running.  Launches that share a PsChain must be ordered (one stream).
+#define PS_CHAIN_WGS 64u
+#define PS_CHAIN_MAX (PS_CHAIN_WGS * PS_SMALL_THREADS * 8u)
+struct PsChain {
+  unsigned long long val[PS_CHAIN_WGS];
+  u32 flag[PS_CHAIN_WGS];
+};
+template <class T, class In, u32 ITEMS>
+__global__ void __launch_bounds__(PS_SMALL_THREADS)
+// (out may be the array `in` reads: a workgroup reads its tile before it writes it, tiles are disjoint)
+k_ps_scan_chain(In in, u32 n, T *out, PsChain *ch, u32 epoch) {
+  HUMID_GUARD_LAST_VGPR();
+  __shared__ T stage[ITEMS > 1 ? PS_SMALL_THREADS * (ITEMS + 1) : 1];
+  __shared__ T lds[PS_SMALL_THREADS / 64 + 1];
+  __shared__ T s_before;
+  auto at = [](u32 j) { return j + j / ITEMS; };
+  const u32 base = blockIdx.x * PS_SMALL_THREADS * ITEMS;
+  T v[ITEMS];
+  T s = 0;
+  if (ITEMS == 1) {
+    const u32 i = base + threadIdx.x;
+    v[0] = i < n ? in(i) : (T)0;
+    s = v[0];
+  } else {
+#pragma unroll
+    for (u32 k = 0; k < ITEMS; k++) {
+      const u32 i = base + k * PS_SMALL_THREADS + threadIdx.x;
+      stage[at(k * PS_SMALL_THREADS + threadIdx.x)] = i < n ? in(i) : (T)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < ITEMS; k++) { v[k] = stage[at(threadIdx.x * ITEMS + k)]; s += v[k]; }
+  }
+  T tot;
+  T run = ps_block_exscan<T, PS_SMALL_THREADS>(s, lds, &tot);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&ch->val[blockIdx.x], (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ch->flag[blockIdx.x], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x < 64) {
+    T mine = 0;
+    if (threadIdx.x < blockIdx.x) {
+      while (__hip_atomic_load(&ch->flag[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+      mine = (T)__hip_atomic_load(&ch->val[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (u32 d = 32; d; d >>= 1) mine += __shfl_xor(mine, d);
+    if (threadIdx.x == 0) s_before = mine;
+  }
+  __syncthreads();
+  run += s_before;
+  if (ITEMS == 1) {
+    const u32 i = base + threadIdx.x;
+    if (i < n) out[i] = run;
+  } else {
+#pragma unroll
+    for (u32 k = 0; k < ITEMS; k++) { stage[at(threadIdx.x * ITEMS + k)] = run; run += v[k]; }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < ITEMS; k++) {
+      const u32 i = base + k * PS_SMALL_THREADS + threadIdx.x;
+      if (i < n) out[i] = stage[at(k * PS_SMALL_THREADS + threadIdx.x)];
+    }
+  }
+}
+
 // scratch (in T) the scan of n items needs
 static inline size_t ps_scan_scratch_items(u64 n) { return n <= PS_SMALL_MAX ? 0 : (size_t)((n + PS_TILE - 1) / PS_TILE); }
 
 // out[i] = sum of in(j), j < i, for i < n.  scratch: ps_scan_scratch_items(n) entries of T.
+// chain + epoch (optional): a zero-initialised PsChain in device memory and a counter that is different for
+// every launch on it (never 0); then up to PS_CHAIN_MAX items are scanned by k_ps_scan_chain in one launch.
 template <class T, class In>
-static inline hipError_t ps_exscan(In in, T *out, u64 n, T *scratch, hipStream_t st) {
+static inline hipError_t ps_exscan(In in, T *out, u64 n, T *scratch, hipStream_t st, PsChain *chain = nullptr, u32 *epoch = nullptr) {
   if (n == 0) return hipSuccess;
+  if (chain && n > 2048 && n <= PS_CHAIN_MAX) {
+    if (++*epoch == 0) ++*epoch;
+    const u32 per = (u32)((n + PS_CHAIN_WGS * PS_SMALL_THREADS - 1) / (PS_CHAIN_WGS * PS_SMALL_THREADS));   // items per thread at 64 workgroups
+    if (per <= 1)
+      hipLaunchKernelGGL((k_ps_scan_chain<T, In, 1>), dim3((u32)((n + 1023) / 1024)), dim3(PS_SMALL_THREADS), 0, st, in, (u32)n, out, chain, *epoch);
+    else if (per <= 2)
+      hipLaunchKernelGGL((k_ps_scan_chain<T, In, 2>), dim3((u32)((n + 2047) / 2048)), dim3(PS_SMALL_THREADS), 0, st, in, (u32)n, out, chain, *epoch);
+    else if (per <= 4)
+      hipLaunchKernelGGL((k_ps_scan_chain<T, In, 4>), dim3((u32)((n + 4095) / 4096)), dim3(PS_SMALL_THREADS), 0, st, in, (u32)n, out, chain, *epoch);
+    else
+      hipLaunchKernelGGL((k_ps_scan_chain<T, In, 8>), dim3((u32)((n + 8191) / 8192)), dim3(PS_SMALL_THREADS), 0, st, in, (u32)n, out, chain, *epoch);
+    return hipGetLastError();
+  }
   if (n <= PS_TINY_MAX) {
     hipLaunchKernelGGL((k_ps_scan_tiny<T, In>), dim3(1), dim3(PS_SMALL_THREADS), 0, st, in, (u32)n, out);
     return hipGetLastError();
