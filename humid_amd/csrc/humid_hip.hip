@@ -2435,6 +2435,14 @@ void humid_ctx_destroy(humid_ctx *c) {
                   &c->maxleaf, &c->cl_size, &c->flag, &c->pos, &c->cid, &c->ismax, &c->stk, &c->tmp,
                   &c->scratch};
   for (DBuf *b : bufs) b->release();
+#ifdef DR_PHASE_CLOCKS                                       // (experiment builds only: kernels_part8.hip.h)
+  {
+    ull h[8] = {0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dr_phase), sizeof h) == hipSuccess)
+      fprintf(stderr, "[k_dedup_rec phases, 100 MHz ticks of thread 0 summed over the sampled workgroups] fill+records+clear %llu | (landed) %llu | insert %llu | barrier %llu | ranks+out %llu | barrier %llu | final %llu\n",
+              h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+  }
+#endif
   if (c->arena.base) (void)hipFree(c->arena.base);
   if (c->d_ctr) (void)hipFree(c->d_ctr);
   if (c->h_ctr) (void)hipHostFree(c->h_ctr);

@@ -187,33 +187,68 @@ k_p8_scatter2(const u64 *__restrict__ in, const u32 *__restrict__ tprefix, const
 // key bits.  Outputs as k_dedup_lds: pad_word / pad_cf at [g << P8_CAP2_LOG, + unique words) in word order,
 // agg[g] = reads << 32 | unique words; and, IN PLACE of every record, (padded slot of its word << 32 | read index) -- what the
 // un-permute wants of a position (k_unperm_bins8), so that no separate slot array is written.
+// What bounds this kernel (profiles/r03e_dedup_rec.md): a workgroup lives ~7 us and the CU holds all the waves it can
+// (8 workgroups), and those waves keep the vector unit half busy: both the NUMBER of instructions and the LENGTH of
+// the chains of dependent LDS operations count, HBM does not (the same loads and stores alone: 40 us).  Clocks inside
+// the kernel: fill + records + clear 1.35 us, insert 1.4, ranks 3.4 (comparing every unique word with every other),
+// store drain 0.7.
+//
+// Ranks without comparing: the table is NOT circular -- a probe that passes entry LDS_SLOTS - 1 goes on into DR_SPILL
+// more entries (a bucket whose keys run past those is reported as overfull, like a full table) -- and the home of a
+// key is monotone in the key (the key bits right below the bucket bits), so the TABLE ORDER IS THE KEY ORDER except
+// inside a run of neighbouring occupied entries, where probing may have swapped keys.  The thread that claims an
+// entry sets its bit in an occupancy bitmap; rank of an entry = bits set in front of its run + smaller keys inside the
+// run (runs are ~1.1 entries long at the usual load of 8 %).
+#ifdef DR_PHASE_CLOCKS
+__device__ ull dr_phase[8];      // experiment: wall-clock ticks of thread 0 per phase, summed over sampled workgroups
+#endif
+#define DR_SPILL 64u
+#define DR_SLOTS (LDS_SLOTS + DR_SPILL)
+#define DR_WORDS (DR_SLOTS / 32u)                  // 34 words of the occupancy bitmap
+#define DR_EARLY 2u                                // of the P8_RPT records per thread: requested before the fill is known
 __global__ void __launch_bounds__(256)
 k_dedup_rec(u64 *recs, const u32 *__restrict__ cursor2, u32 n_reads, u32 pb, u32 d1, u32 ibits, RecKey rk,
             u64 *__restrict__ pad_word, uint2 *__restrict__ pad_cf, u64 *__restrict__ agg, ull *ctr) {
   HUMID_GUARD_LAST_VGPR();
-  __shared__ u64 lkey[LDS_SLOTS];
-  __shared__ u32 lcnt[LDS_SLOTS];
-  __shared__ u32 lfirst[LDS_SLOTS];
-  __shared__ unsigned short lslot_of[LDS_SLOTS];       // unique index (claim order, then rank) -> table entry
-  __shared__ unsigned short lorder[P8_CAP2];
+#ifdef DR_PHASE_CLOCKS
+  u64 dr_t[8];
+#define DR_CLK(k) dr_t[k] = wall_clock64()
+#else
+#define DR_CLK(k)
+#endif
+  __shared__ u64 lkey[DR_SLOTS];
+  __shared__ uint2 lcf[DR_SLOTS];                      // (count, first read); after the rank phase .y = the entry's rank
+  __shared__ unsigned short lslot_of[P8_CAP2];         // claim order -> table entry
+  __shared__ u32 lbits[DR_WORDS + 2], lpre[DR_WORDS + 2];   // occupancy bitmap (one word of zeros behind it), set bits in front of each word
   __shared__ u32 lcount;
   const u32 g = blockIdx.x;
+  const size_t beg = (size_t)g << P8_CAP2_LOG;
+  DR_CLK(0);
+  // the first half of the bucket's room is requested before its fill is known (the room exists whatever it holds;
+  // what lies behind the fill is never looked at): the two round trips overlap
+  u64 rq[P8_RPT];
+#pragma unroll
+  for (u32 q = 0; q < DR_EARLY; q++) rq[q] = recs[beg + threadIdx.x + 256u * q];
   u32 n = cursor2[g];
   if (n > P8_CAP2) n = P8_CAP2;                        // (an overfull bucket was reported by the scatter: the run is discarded)
   if (n == 0) {
     if (threadIdx.x == 0) agg[g] = 0;
     return;
   }
-  const size_t beg = (size_t)g << P8_CAP2_LOG;
-  u64 rq[P8_RPT];
 #pragma unroll
-  for (u32 q = 0; q < P8_RPT; q++) {
+  for (u32 q = DR_EARLY; q < P8_RPT; q++) {
     const u32 i = threadIdx.x + 256u * q;
     if (i < n) rq[q] = recs[beg + i];
   }
-  for (u32 s = threadIdx.x; s < LDS_SLOTS; s += 256) { lkey[s] = EMPTY_KEY; lcnt[s] = 0; lfirst[s] = NONE32; }
+  for (u32 s = threadIdx.x; s < DR_SLOTS; s += 256) { lkey[s] = EMPTY_KEY; lcf[s] = make_uint2(0u, NONE32); }
+  if (threadIdx.x < DR_WORDS + 2) lbits[threadIdx.x] = 0;
   if (threadIdx.x == 0) lcount = 0;
   __syncthreads();
+  DR_CLK(1);
+#ifdef DR_PHASE_CLOCKS
+  if (rq[0] == 0x123456789abcull) dr_phase[0] = 1;     // (the loads have landed)
+#endif
+  DR_CLK(2);
   const u32 rbits = rk.kbits - d1, d2 = pb - d1;
   const u64 top = (u64)(g >> d2) << rbits;             // the coarse bin: the key's top d1 bits
   const u64 imask = (1ull << ibits) - 1ull;
@@ -221,56 +256,88 @@ k_dedup_rec(u64 *recs, const u32 *__restrict__ cursor2, u32 n_reads, u32 pb, u32
   const int hs = (int)rk.kbits - (int)pb - (int)LDS_SLOT_BITS;
   auto home = [&](u64 k) -> u32 { return hs >= 0 ? (u32)(k >> hs) & (LDS_SLOTS - 1) : (u32)k & ((1u << (rk.kbits - pb)) - 1u); };
   bool bad = false;
+  u32 sq[P8_RPT];
 #pragma unroll
   for (u32 q = 0; q < P8_RPT; q++) {
     const u32 i = threadIdx.x + 256u * q;
+    sq[q] = NONE32;
     if (i >= n) continue;
     const u64 k = top | (rq[q] >> ibits);
     const u32 v = (u32)(rq[q] & imask);
     if (v >= n_reads) { bad = true; continue; }        // a malformed index is never used
-    u32 s = home(k), probes = 0;
+    u32 s = home(k);
+    bool claimed = false;
     while (true) {
       u64 cur = lkey[s];
-      if (cur == EMPTY_KEY) cur = atomicCAS((ull *)&lkey[s], EMPTY_KEY, (ull)k);
-      if (cur == EMPTY_KEY || cur == k) break;
-      s = (s + 1) & (LDS_SLOTS - 1);
-      if (++probes >= LDS_SLOTS) { bad = true; break; }
+      if (cur == EMPTY_KEY) { cur = atomicCAS((ull *)&lkey[s], EMPTY_KEY, (ull)k); claimed = cur == EMPTY_KEY; }
+      if (claimed || cur == k) break;
+      if (++s >= DR_SLOTS) break;
     }
-    if (bad) continue;
-    if (atomicAdd(&lcnt[s], 1u) == 0u) lslot_of[atomicAdd(&lcount, 1u)] = (unsigned short)s;
-    atomicMin(&lfirst[s], v);
+    if (s >= DR_SLOTS) { bad = true; continue; }
+    sq[q] = s;
+    atomicAdd(&lcf[s].x, 1u);
+    atomicMin(&lcf[s].y, v);
+    if (claimed) {                                     // the entry is this record's: its place in the list and its bit
+      lslot_of[atomicAdd(&lcount, 1u)] = (unsigned short)s;
+      atomicOr(&lbits[s >> 5], 1u << (s & 31));
+    }
   }
   if (bad) ctr[CTR_OVERFULL] = 1;
+  DR_CLK(3);
   __syncthreads();
-  const u32 n_uniq = lcount;                           // <= n <= P8_CAP2 = the table's entries
-  // rank of an entry = number of smaller keys (keys are distinct: the ranks are a permutation)
-  for (u32 li = threadIdx.x; li < n_uniq; li += 256) {
-    const u32 s = lslot_of[li];
-    const u64 k = lkey[s];
-    u32 r = 0;
-    for (u32 j = 0; j < n_uniq; j++) r += (lkey[lslot_of[j]] < k) ? 1u : 0u;
-    lorder[r] = (unsigned short)s;
+  DR_CLK(4);
+  const u32 n_uniq = lcount;                           // <= n <= P8_CAP2
+  // set bits in front of every bitmap word: each wave that has entries to rank scans the 34 counts for itself
+  // (identical values: the waves may overwrite each other)
+  const u32 lane = threadIdx.x & 63;
+  if ((threadIdx.x & ~63u) < n_uniq) {
+    const u32 pc = lane < DR_WORDS ? (u32)__popc(lbits[lane]) : 0u;
+    u32 incl = pc;
+#pragma unroll
+    for (u32 dd = 1; dd < 64; dd <<= 1) {
+      const u32 y = __shfl_up(incl, dd);
+      if (lane >= dd) incl += y;
+    }
+    if (lane < DR_WORDS) lpre[lane] = incl - pc;
   }
-  __syncthreads();
   for (u32 li = threadIdx.x; li < n_uniq; li += 256) {
-    const u32 s = lorder[li];
-    pad_word[beg + li] = rk.word(lkey[s]);
-    pad_cf[beg + li] = make_uint2(lcnt[s], lfirst[s]);
-    lfirst[s] = li;                                    // entry -> rank
+    const u32 sl = lslot_of[li];
+    const u32 w = sl >> 5, bit = sl & 31;
+    const u32 bw = lbits[w];
+    u32 r = lpre[w] + (u32)__popc(bw & ((1u << bit) - 1u));     // occupied entries in front of sl
+    const bool left = bit ? ((bw >> (bit - 1)) & 1u) != 0 : (w > 0 && (lbits[w - 1] >> 31) != 0);
+    const bool right = bit < 31 ? ((bw >> (bit + 1)) & 1u) != 0 : (lbits[w + 1] & 1u) != 0;
+    const u64 k = lkey[sl];
+    if (left || right) {                               // a run of several entries: order inside it by comparing
+      u32 start = sl, smaller = 0;
+      while (start > 0 && lkey[start - 1] != EMPTY_KEY) start--;
+      for (u32 j = start; j < DR_SLOTS; j++) {
+        const u64 kj = lkey[j];
+        if (kj == EMPTY_KEY) break;
+        smaller += kj < k ? 1u : 0u;
+      }
+      r = r - (sl - start) + smaller;                  // (all of [start, sl) is occupied)
+    }
+    const uint2 cf = lcf[sl];
+    pad_word[beg + r] = rk.word(k);
+    pad_cf[beg + r] = cf;
+    lcf[sl].y = r;                                     // entry -> rank
   }
   if (threadIdx.x == 0) agg[g] = ((u64)n << 32) | n_uniq;     // one scan of these gives both prefixes and both totals
+  DR_CLK(5);
   __syncthreads();
+  DR_CLK(6);
 #pragma unroll
   for (u32 q = 0; q < P8_RPT; q++) {
     const u32 i = threadIdx.x + 256u * q;
     if (i >= n) continue;
-    const u64 k = top | (rq[q] >> ibits);
-    const u32 v = (u32)(rq[q] & imask);
-    u32 s = home(k), probes = 0;
-    while (lkey[s] != k && probes++ < LDS_SLOTS) s = (s + 1) & (LDS_SLOTS - 1);
-    const u32 li = lfirst[s];
-    recs[beg + i] = ((u64)(li < n ? (u32)beg + li : NOSLOT) << 32) | v;
+    const u32 li = sq[q] != NONE32 ? lcf[sq[q]].y : NONE32;    // (the entry of the record is still in its register)
+    recs[beg + i] = ((u64)(li < n ? (u32)beg + li : NOSLOT) << 32) | (u32)(rq[q] & imask);
   }
+  DR_CLK(7);
+#ifdef DR_PHASE_CLOCKS
+  if (threadIdx.x == 0 && (g & 255u) == 77u) for (int t = 1; t < 8; t++) atomicAdd(&dr_phase[t], (ull)(dr_t[t] - dr_t[t - 1]));
+#endif
 }
 
 // padded (fixed room per bucket) -> dense unique arrays in walk order, one wave per bucket
