@@ -47,6 +47,51 @@ enum { CTR_UNIQUE = 0, CTR_USABLE, CTR_EDGES, CTR_NONSINGLE, CTR_MEMBERS, CTR_SP
 // register that can be hit holds nothing (1000 launches x 45 k waves: 0 hits with the guard, 34
 // launches hit without, profiles/r02_edge_loss/).  No instruction is emitted.
 #define HUMID_GUARD_LAST_VGPR() asm volatile("" ::: "a0")
+
+// Inclusive prefix sum over the 64 lanes of a wave with DPP moves (row shifts inside the rows of 16 lanes, then the two
+// row broadcasts): six vector instructions of a few cycles each, where six __shfl_up steps are six round trips through
+// the LDS crossbar (ds_bpermute).  All lanes of the wave must be active.
+template <int CTRL, int ROWS, class T>
+__device__ __forceinline__ T wave_dpp_add(T x) {
+  if constexpr (sizeof(T) == 4) {
+    return x + (T)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)x, CTRL, ROWS, 0xf, false);
+  } else {
+    static_assert(sizeof(T) == 8, "32- or 64-bit integers");
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(u64)x, CTRL, ROWS, 0xf, false);
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)((u64)x >> 32), CTRL, ROWS, 0xf, false);
+    return x + (T)(((u64)hi << 32) | lo);
+  }
+}
+template <class T>
+__device__ __forceinline__ T wave_incl_scan(T x) {
+  x = wave_dpp_add<0x111, 0xf>(x);       // row_shr:1
+  x = wave_dpp_add<0x112, 0xf>(x);       // row_shr:2
+  x = wave_dpp_add<0x114, 0xf>(x);       // row_shr:4
+  x = wave_dpp_add<0x118, 0xf>(x);       // row_shr:8 -> inclusive inside every row of 16
+  x = wave_dpp_add<0x142, 0xa>(x);       // row_bcast:15 -> rows 1 and 3 take the total of the row in front
+  x = wave_dpp_add<0x143, 0xc>(x);       // row_bcast:31 -> rows 2 and 3 take the total of the first half
+  return x;
+}
+// Experiment builds only (-DHUMID_PHASE_CLOCKS; tools/phase_clocks.sh): thread 0 of a sampled workgroup reads the
+// 100 MHz wall clock at the phase boundaries PH(k) of a kernel and adds the differences to humid_phase[id][k];
+// [id][0] counts the sampled workgroups.  humid_ctx_destroy prints the table.
+#ifdef HUMID_PHASE_CLOCKS
+#define PH_KERNELS 8
+#define PH_MAX 12
+__device__ unsigned long long humid_phase[PH_KERNELS][PH_MAX];
+#define PH_DECL unsigned long long ph_t[PH_MAX]
+#define PH(k) ph_t[k] = wall_clock64()
+#define PH_END(id, last, sampled)                                                                       \
+  if (threadIdx.x == 0 && (sampled)) {                                                                  \
+    atomicAdd(&humid_phase[id][0], 1ull);                                                               \
+    for (int ph_k = 1; ph_k <= (last); ph_k++) atomicAdd(&humid_phase[id][ph_k], ph_t[ph_k] - ph_t[ph_k - 1]); \
+  }
+#else
+#define PH_DECL
+#define PH(k)
+#define PH_END(id, last, sampled)
+#endif
+
 __device__ __forceinline__ u64 mix64(u64 x) {
   x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
   x ^= x >> 27; x *= 0x94d049bb133111ebull;

@@ -93,6 +93,7 @@ struct humid_ctx {
   ull *h_ctr = nullptr;   // pinned mirror (CTR_N counters + the sequence word of read_counters)
   ull *h_ctr_dev = nullptr;   // the same memory as the device sees it
   ull ctr_seq = 0;
+  const u32 *gf_valid = nullptr; // set by the last bucket order: device count of the words it holds (padded grouping), or null
   u32 *ucur_clean = nullptr;     // the un-permute's bin cursors at this address are all zero
   DBuf gf_cur;                    // cursors of the padded grouping (512 u32, kept at zero between uses)
   bool gf_padded = true;  // bucket orders of the compact graph stage through padded coarse bins (until one was full)
@@ -1144,6 +1145,7 @@ static int group_words_by_stretch(humid_ctx *c, const ComboPlan &plan, u32 cb, c
   u32 bit_n = 0;
   for (u32 f = 0; f < plan.nfield[cb]; f++) bit_n += plan.width[cb][f];
   *done = c->group_buckets && plan.nfield[cb] >= 1 && bit_n >= 2 && bit_n <= 24 && n >= 4096;
+  c->gf_valid = nullptr;
   if (!*done) return HUMID_OK;
   const u32 d1 = bit_n >= 18 ? 9u : (bit_n + 1) / 2, d2 = bit_n - d1;          // d2 <= 15: 2^15 LDS counters at most
   const u32 nb1 = 1u << d1;
@@ -1180,6 +1182,7 @@ static int group_words_by_stretch(humid_ctx *c, const ComboPlan &plan, u32 cb, c
   // up to three launches over the coarse bins, by bin size; which sizes cannot occur is known from n alone only
   // roughly (the bins of a skewed key can be any size) unless the bins are padded, so only the impossible
   // ones are left out
+  c->gf_valid = padded ? (const u32 *)(cbase + nb1) : (const u32 *)nullptr;    // words the order holds (< n: a bin was full)
   const u32 largest = padded ? cap1 : n;
   hipLaunchKernelGGL((k_group_fine<SRC, 0>), dim3(nb1), dim3(GF_THREADS), 0, st, src,
                      (const u64 *)c->seg_k0.as<u64>(), (const u32 *)c->seg_v0.as<u32>(), (const u32 *)cbase, d1, d2, ws, vs, cap1);
@@ -1227,7 +1230,7 @@ static int bucket_order(humid_ctx *c, const ComboPlan &plan, u32 seg, const WT *
   } else {
     // two-word words: the keys are grouped (scratch), the words follow through the grouped positions
     TRY((group_words_by_stretch<FieldsSrcW2, W2>(c, plan, seg, (const W2 *)g_word, U, c->seg_ks.as<u64>(), vs, &stretch, may_pad)));
-    if (stretch) hipLaunchKernelGGL(k_gather_bucket_words<WT>, dim3(blocks_for(U)), dim3(256), 0, st, g_word, vs, U, ws);
+    if (stretch) hipLaunchKernelGGL(k_gather_bucket_words<WT>, dim3(blocks_for(U)), dim3(256), 0, st, g_word, vs, U, ws, c->gf_valid);
   }
   if (stretch) return HUMID_OK;
   const ComboFields cf = plan_fields(plan, seg);
@@ -1634,8 +1637,9 @@ static int stage_graph_compact(humid_ctx *c, const WT *g_word, const u32 *g_cnt,
   // second run may order a bucket differently -- and the near / far split of a large bucket (walk
   // distance) must be the same in the search that follows the tiles as in the one before them
   bool ordered_seg[MAX_COMBOS] = {false};
+  const u32 *seg_valid[MAX_COMBOS] = {nullptr};
   for (int attempt = 0;; attempt++) {
-    if (attempt > 4) return fail(c, HUMID_E_INVALID, "internal: the pair list does not settle");
+    if (attempt > 5) return fail(c, HUMID_E_INVALID, "internal: the pair list does not settle");
     if (search && c->cg_ecap == 0) c->cg_ecap = std::max<u64>((u64)U / 4, 4096);
     const u64 ecap = search ? c->cg_ecap : ER_REGIONS;
     if (ecap / ER_REGIONS + 1 > 0xfffffff0ull) return fail(c, HUMID_E_OVERFLOW, "too many neighbour pairs");
@@ -1663,12 +1667,18 @@ static int stage_graph_compact(humid_ctx *c, const WT *g_word, const u32 *g_cnt,
       } else {
         u32 *vs = c->seg_vs.as<u32>() + (size_t)(seg - 1) * U;
         WT *ws = c->seg_ws.as<WT>() + (size_t)(seg - 1) * U;
-        if (!ordered_seg[seg]) TRY(bucket_order<WT>(c, plan, seg, g_word, U, ws, vs, true));
+        // the count of words a padded grouping holds (pt_work: the next grouping overwrites it only behind this search,
+        // in stream order); an order kept from an earlier attempt is complete, or that attempt would have been discarded
+        seg_valid[seg] = nullptr;
+        if (!ordered_seg[seg]) {
+          TRY(bucket_order<WT>(c, plan, seg, g_word, U, ws, vs, true));
+          seg_valid[seg] = c->gf_valid;
+        }
         ordered_seg[seg] = true;
         if (seg < 8 && c->kev_on) HIPCHK(hipEventRecord(c->kev[20 + 2 * seg], st));
         hipLaunchKernelGGL((k_pairs_append<false, WT>), dim3(blocks_for(U)), dim3(256), 0, st, (const WT *)ws, (const u32 *)vs, U,
                            w_from<WT>(plan.mask[seg]), d_masks, seg, distance, walk_max, er, c->cg_bits.as<u32>(),
-                           &c->d_ctr[CTR_BIGMASK], (u32 *)&c->d_ctr[CTR_EOVER]);
+                           &c->d_ctr[CTR_BIGMASK], (u32 *)&c->d_ctr[CTR_EOVER], seg_valid[seg]);
       }
       if (seg < 8 && c->kev_on) HIPCHK(hipEventRecord(c->kev[21 + 2 * seg], st));
     }
@@ -2435,12 +2445,18 @@ void humid_ctx_destroy(humid_ctx *c) {
                   &c->maxleaf, &c->cl_size, &c->flag, &c->pos, &c->cid, &c->ismax, &c->stk, &c->tmp,
                   &c->scratch};
   for (DBuf *b : bufs) b->release();
-#ifdef DR_PHASE_CLOCKS                                       // (experiment builds only: kernels_part8.hip.h)
+#ifdef HUMID_PHASE_CLOCKS                                    // (experiment builds only: common.hip.h)
   {
-    ull h[8] = {0};
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dr_phase), sizeof h) == hipSuccess)
-      fprintf(stderr, "[k_dedup_rec phases, 100 MHz ticks of thread 0 summed over the sampled workgroups] fill+records+clear %llu | (landed) %llu | insert %llu | barrier %llu | ranks+out %llu | barrier %llu | final %llu\n",
-              h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    static const char *names[PH_KERNELS] = {"k_dedup_rec", "k_p8_scatter1", "k_p8_scatter2", "k_unperm_bins8", "k_group_fine", "k_pairs_append", "k_unperm_window", "-"};
+    ull h[PH_KERNELS][PH_MAX];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(humid_phase), sizeof h) == hipSuccess)
+      for (int k = 0; k < PH_KERNELS; k++) {
+        if (!h[k][0]) continue;
+        fprintf(stderr, "[phase clocks] %-16s %6llu workgroups sampled; us per workgroup by phase:", names[k], h[k][0]);
+        double tot = 0;
+        for (int t = 1; t < PH_MAX; t++) { fprintf(stderr, " %.2f", (double)h[k][t] / (double)h[k][0] / 100.0); tot += (double)h[k][t]; }
+        fprintf(stderr, " | sum %.2f\n", tot / (double)h[k][0] / 100.0);
+      }
   }
 #endif
   if (c->arena.base) (void)hipFree(c->arena.base);

@@ -118,10 +118,14 @@ k_zero_many(ZeroList z) {
 template <bool PASS0, class WT>
 __global__ void __launch_bounds__(256)
 k_pairs_append(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, WT mask, EarlierMasksT<WT> em, u32 cb,
-               u32 distance, u32 walk_max, EdgeRegs er, u32 *bits, ull *big, u32 *overflow) {
+               u32 distance, u32 walk_max, EdgeRegs er, u32 *bits, ull *big, u32 *overflow,
+               const u32 *__restrict__ n_valid = nullptr) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u32 lds[8];
   __shared__ u32 s_base;
+  // n_valid: the walked order came from a padded grouping; had a coarse bin been full, words were dropped and the
+  // order ends at *n_valid (what lies behind it was never written; the caller discards this search)
+  if (n_valid && *n_valid < n) n = *n_valid;
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   u32 found = 0, first_off = 0;
   WT wi;
@@ -147,11 +151,7 @@ k_pairs_append(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, WT ma
   // room for the workgroup's pairs: exclusive position of this thread's, one atomic per workgroup
   const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   u32 incl = found;
-#pragma unroll
-  for (u32 d = 1; d < 64; d <<= 1) {
-    const u32 y = __shfl_up(incl, d);
-    if (lane >= d) incl += y;
-  }
+  incl = wave_incl_scan(incl);
   if (lane == 63) lds[wv] = incl;
   __syncthreads();
   u32 before = 0, total = 0;

@@ -340,9 +340,10 @@ k_pairs_tiles(const WT *__restrict__ W, const u32 *__restrict__ V, const BigRun 
 // words of a sorted combo in bucket order (one gather per combo instead of one per comparison)
 template <class WT>
 __global__ void k_gather_bucket_words(const WT *__restrict__ s_word, const u32 *__restrict__ V, u32 n,
-                                      WT *__restrict__ wv) {
+                                      WT *__restrict__ wv, const u32 *__restrict__ n_valid = nullptr) {
   HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_valid && *n_valid < n) n = *n_valid;           // (a padded grouping that dropped words: V ends there)
   if (i < n) wv[i] = s_word[V[i]];
 }
 

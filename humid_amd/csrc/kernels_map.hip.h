@@ -506,11 +506,7 @@ k_route_scan(u32 *tile_cnt, u32 n_tiles, OwnerBases ob, u32 *bad) {
     const u32 t = t0 + lane;
     const u32 x = t < n_tiles ? tile_cnt[t * MAX_RANKS + q] : 0u;
     u32 incl = x;
-#pragma unroll
-    for (u32 d = 1; d < 64; d <<= 1) {
-      const u32 y = __shfl_up(incl, d);
-      if (lane >= d) incl += y;
-    }
+    incl = wave_incl_scan(incl);
     if (t < n_tiles) tile_cnt[t * MAX_RANKS + q] = run + incl - x;
     run += __shfl(incl, 63);
   }

@@ -74,11 +74,7 @@ __device__ __forceinline__ void block_exscan_512(const u32 *cnt, u32 *off, u32 n
   const u32 t = threadIdx.x, lane = t & 63, wv = t >> 6;
   u32 x = (t < nb) ? cnt[t] : 0u, incl = x;
   if (t < 512) {
-#pragma unroll
-    for (u32 d = 1; d < 64; d <<= 1) {
-      const u32 y = __shfl_up(incl, d);
-      if (lane >= d) incl += y;
-    }
+    incl = wave_incl_scan(incl);
     if (lane == 63) wsum[wv] = incl;
   }
   __syncthreads();
@@ -343,11 +339,7 @@ k_group_fine(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ v_in
     if (w0 < words)
       for (u32 q = 0; q < per; q++) { const u32 x = gf_lds[w0 + q]; mine += (x & 0xffffu) + (x >> 16); }
     u32 incl = mine;
-#pragma unroll
-    for (u32 dd = 1; dd < 64; dd <<= 1) {
-      const u32 y = __shfl_up(incl, dd);
-      if (lane >= dd) incl += y;
-    }
+    incl = wave_incl_scan(incl);
     if (lane == 63) wsum[wv] = incl;
     __syncthreads();
     u32 run = incl - mine;
@@ -383,11 +375,7 @@ k_group_fine(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ v_in
   if (b0 < nb)
     for (u32 q = 0; q < per; q++) mine += gf_lds[b0 + q];
   u32 incl = mine;
-#pragma unroll
-  for (u32 dd = 1; dd < 64; dd <<= 1) {
-    const u32 y = __shfl_up(incl, dd);
-    if (lane >= dd) incl += y;
-  }
+  incl = wave_incl_scan(incl);
   if (lane == 63) wsum[wv] = incl;
   __syncthreads();
   u32 run = incl - mine;
@@ -467,11 +455,7 @@ k_unperm_bins(const u32 *__restrict__ vals, const u32 *__restrict__ pslot, const
     const u32 s = ca + cb;
     const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     u32 incl = s;
-#pragma unroll
-    for (u32 d = 1; d < 64; d <<= 1) {
-      const u32 y = __shfl_up(incl, d);
-      if (lane >= d) incl += y;
-    }
+    incl = wave_incl_scan(incl);
     if (lane == 63) wsum[wv] = incl;
     __syncthreads();
     u32 before = 0;

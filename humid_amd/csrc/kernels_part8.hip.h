@@ -91,10 +91,13 @@ k_p8_scatter1(SRC src, u32 n_reads, u32 kbits, u32 d1, u32 ibits, u32 cap1, u32 
   __shared__ u64 srec[PT_TILE];
   __shared__ u32 cnt[PT_MAXBINS], loff[PT_MAXBINS + 1], goff[PT_MAXBINS], room[PT_MAXBINS], wsum[8];
   const u32 nb = 1u << d1;
+  PH_DECL;
+  PH(0);
   const u32 t_beg = blockIdx.x * PT_TILE;
   const u32 t_cnt = (t_beg >= n_reads) ? 0u : ((n_reads - t_beg < PT_TILE) ? n_reads - t_beg : PT_TILE);
   for (u32 b = threadIdx.x; b < nb; b += PT_THREADS) cnt[b] = 0;
   __syncthreads();
+  PH(1);
   const u32 rbits = kbits - d1;                               // key bits a record keeps
   u64 rec[PT_IPT];
   u32 binrank[PT_IPT];                                        // bin << 16 | rank inside (tile, bin); ~0: none
@@ -109,8 +112,11 @@ k_p8_scatter1(SRC src, u32 n_reads, u32 kbits, u32 d1, u32 ibits, u32 cap1, u32 
       binrank[q] = bin << 16 | atomicAdd(&cnt[bin], 1u);
     }
   }
+  PH(2);
   __syncthreads();
+  PH(3);
   block_exscan_512(cnt, loff, nb, wsum);
+  PH(4);
   if (threadIdx.x < nb) {
     const u32 c = cnt[threadIdx.x];
     const u32 had = c ? atomicAdd(&cursor[threadIdx.x], c) : 0u;
@@ -118,12 +124,16 @@ k_p8_scatter1(SRC src, u32 n_reads, u32 kbits, u32 d1, u32 ibits, u32 cap1, u32 
     room[threadIdx.x] = had >= cap1 ? 0u : cap1 - had;
     if (had + c > cap1) ctr[CTR_SPECIAL] = 1;                 // the bin outgrew its room: the caller repartitions
   }
+  PH(5);
 #pragma unroll
   for (u32 q = 0; q < PT_IPT; q++)
     if (binrank[q] != NONE32) srec[loff[binrank[q] >> 16] + (binrank[q] & 0xffffu)] = rec[q];
   __syncthreads();
+  PH(6);
   p8_write_bins(srec, loff, nb, p8_group(loff[nb], nb), out,
                 [&](u32 bin, u32 k) -> u64 { return k < room[bin] ? (u64)goff[bin] + k : ~0ull; });
+  PH(7);
+  PH_END(1, 7, (blockIdx.x & 15u) == 3u);  // 1 clear | 2 loads + LDS ranks | 3 barrier | 4 scan | 5 global cursors | 6 sort in LDS + barrier | 7 write out
 }
 
 // ---- level 2: one tile of one coarse bin -> padded fine buckets (the next d2 key bits) ----
@@ -135,6 +145,8 @@ k_p8_scatter2(const u64 *__restrict__ in, const u32 *__restrict__ tprefix, const
   __shared__ u64 srec[PT_TILE];
   __shared__ u32 cnt[PT_MAXBINS], loff[PT_MAXBINS + 1], goff[PT_MAXBINS], room[PT_MAXBINS], wsum[8];
   __shared__ u32 s_c, s_beg, s_cnt;
+  PH_DECL;
+  PH(0);
   if (blockIdx.x >= tprefix[1u << d1]) return;                // beyond the last tile (uniform exit)
   const u32 nb = 1u << d2;
   if (threadIdx.x == 0) {
@@ -144,6 +156,7 @@ k_p8_scatter2(const u64 *__restrict__ in, const u32 *__restrict__ tprefix, const
   }
   for (u32 b = threadIdx.x; b < nb; b += PT_THREADS) cnt[b] = 0;
   __syncthreads();
+  PH(1);
   const u32 coarse = s_c, t_beg = s_beg, t_cnt = s_cnt;
   const u32 fshift = ibits + kbits - d1 - d2;                 // where a record keeps the fine bits
   u64 rec[PT_IPT];
@@ -162,8 +175,11 @@ k_p8_scatter2(const u64 *__restrict__ in, const u32 *__restrict__ tprefix, const
       binrank[q] = bin << 16 | atomicAdd(&cnt[bin], 1u);
     }
   }
+  PH(2);
   __syncthreads();
+  PH(3);
   block_exscan_512(cnt, loff, nb, wsum);
+  PH(4);
   if (threadIdx.x < nb) {
     const u32 c = cnt[threadIdx.x];
     const u32 g = (coarse << d2) | threadIdx.x;
@@ -172,14 +188,18 @@ k_p8_scatter2(const u64 *__restrict__ in, const u32 *__restrict__ tprefix, const
     room[threadIdx.x] = had >= P8_CAP2 ? 0u : P8_CAP2 - had;
     if (had + c > P8_CAP2) ctr[CTR_SPECIAL] = 1;
   }
+  PH(5);
 #pragma unroll
   for (u32 q = 0; q < PT_IPT; q++)
     if (binrank[q] != NONE32) srec[loff[binrank[q] >> 16] + (binrank[q] & 0xffffu)] = rec[q];
   __syncthreads();
+  PH(6);
   const u64 gbase = (u64)(coarse << d2) << P8_CAP2_LOG;
   p8_write_bins(srec, loff, nb, p8_group(loff[nb], nb), out, [&](u32 bin, u32 k) -> u64 {
     return k < room[bin] ? gbase + ((u64)bin << P8_CAP2_LOG) + goff[bin] + k : ~0ull;
   });
+  PH(7);
+  PH_END(2, 7, (blockIdx.x & 15u) == 3u);  // 1 tile lookup + clear | 2 loads + LDS ranks | 3 barrier | 4 scan | 5 global cursors | 6 sort in LDS | 7 write out
 }
 
 // ---- the LDS count of one bucket, on records (k_dedup_lds<true> of kernels_count.hip.h) ----
@@ -199,9 +219,6 @@ k_p8_scatter2(const u64 *__restrict__ in, const u32 *__restrict__ tprefix, const
 // inside a run of neighbouring occupied entries, where probing may have swapped keys.  The thread that claims an
 // entry sets its bit in an occupancy bitmap; rank of an entry = bits set in front of its run + smaller keys inside the
 // run (runs are ~1.1 entries long at the usual load of 8 %).
-#ifdef DR_PHASE_CLOCKS
-__device__ ull dr_phase[8];      // experiment: wall-clock ticks of thread 0 per phase, summed over sampled workgroups
-#endif
 #define DR_SPILL 64u
 #define DR_SLOTS (LDS_SLOTS + DR_SPILL)
 #define DR_WORDS (DR_SLOTS / 32u)                  // 34 words of the occupancy bitmap
@@ -210,12 +227,7 @@ __global__ void __launch_bounds__(256)
 k_dedup_rec(u64 *recs, const u32 *__restrict__ cursor2, u32 n_reads, u32 pb, u32 d1, u32 ibits, RecKey rk,
             u64 *__restrict__ pad_word, uint2 *__restrict__ pad_cf, u64 *__restrict__ agg, ull *ctr) {
   HUMID_GUARD_LAST_VGPR();
-#ifdef DR_PHASE_CLOCKS
-  u64 dr_t[8];
-#define DR_CLK(k) dr_t[k] = wall_clock64()
-#else
-#define DR_CLK(k)
-#endif
+  PH_DECL;
   __shared__ u64 lkey[DR_SLOTS];
   __shared__ uint2 lcf[DR_SLOTS];                      // (count, first read); after the rank phase .y = the entry's rank
   __shared__ unsigned short lslot_of[P8_CAP2];         // claim order -> table entry
@@ -223,7 +235,7 @@ k_dedup_rec(u64 *recs, const u32 *__restrict__ cursor2, u32 n_reads, u32 pb, u32
   __shared__ u32 lcount;
   const u32 g = blockIdx.x;
   const size_t beg = (size_t)g << P8_CAP2_LOG;
-  DR_CLK(0);
+  PH(0);
   // the first half of the bucket's room is requested before its fill is known (the room exists whatever it holds;
   // what lies behind the fill is never looked at): the two round trips overlap
   u64 rq[P8_RPT];
@@ -244,11 +256,7 @@ k_dedup_rec(u64 *recs, const u32 *__restrict__ cursor2, u32 n_reads, u32 pb, u32
   if (threadIdx.x < DR_WORDS + 2) lbits[threadIdx.x] = 0;
   if (threadIdx.x == 0) lcount = 0;
   __syncthreads();
-  DR_CLK(1);
-#ifdef DR_PHASE_CLOCKS
-  if (rq[0] == 0x123456789abcull) dr_phase[0] = 1;     // (the loads have landed)
-#endif
-  DR_CLK(2);
+  PH(1);
   const u32 rbits = rk.kbits - d1, d2 = pb - d1;
   const u64 top = (u64)(g >> d2) << rbits;             // the coarse bin: the key's top d1 bits
   const u64 imask = (1ull << ibits) - 1ull;
@@ -283,9 +291,9 @@ k_dedup_rec(u64 *recs, const u32 *__restrict__ cursor2, u32 n_reads, u32 pb, u32
     }
   }
   if (bad) ctr[CTR_OVERFULL] = 1;
-  DR_CLK(3);
+  PH(2);
   __syncthreads();
-  DR_CLK(4);
+  PH(3);
   const u32 n_uniq = lcount;                           // <= n <= P8_CAP2
   // set bits in front of every bitmap word: each wave that has entries to rank scans the 34 counts for itself
   // (identical values: the waves may overwrite each other)
@@ -293,11 +301,7 @@ k_dedup_rec(u64 *recs, const u32 *__restrict__ cursor2, u32 n_reads, u32 pb, u32
   if ((threadIdx.x & ~63u) < n_uniq) {
     const u32 pc = lane < DR_WORDS ? (u32)__popc(lbits[lane]) : 0u;
     u32 incl = pc;
-#pragma unroll
-    for (u32 dd = 1; dd < 64; dd <<= 1) {
-      const u32 y = __shfl_up(incl, dd);
-      if (lane >= dd) incl += y;
-    }
+    incl = wave_incl_scan(incl);
     if (lane < DR_WORDS) lpre[lane] = incl - pc;
   }
   for (u32 li = threadIdx.x; li < n_uniq; li += 256) {
@@ -324,9 +328,9 @@ k_dedup_rec(u64 *recs, const u32 *__restrict__ cursor2, u32 n_reads, u32 pb, u32
     lcf[sl].y = r;                                     // entry -> rank
   }
   if (threadIdx.x == 0) agg[g] = ((u64)n << 32) | n_uniq;     // one scan of these gives both prefixes and both totals
-  DR_CLK(5);
+  PH(4);
   __syncthreads();
-  DR_CLK(6);
+  PH(5);
 #pragma unroll
   for (u32 q = 0; q < P8_RPT; q++) {
     const u32 i = threadIdx.x + 256u * q;
@@ -334,10 +338,8 @@ k_dedup_rec(u64 *recs, const u32 *__restrict__ cursor2, u32 n_reads, u32 pb, u32
     const u32 li = sq[q] != NONE32 ? lcf[sq[q]].y : NONE32;    // (the entry of the record is still in its register)
     recs[beg + i] = ((u64)(li < n ? (u32)beg + li : NOSLOT) << 32) | (u32)(rq[q] & imask);
   }
-  DR_CLK(7);
-#ifdef DR_PHASE_CLOCKS
-  if (threadIdx.x == 0 && (g & 255u) == 77u) for (int t = 1; t < 8; t++) atomicAdd(&dr_phase[t], (ull)(dr_t[t] - dr_t[t - 1]));
-#endif
+  PH(6);
+  PH_END(0, 6, (g & 255u) == 77u);       // 1 fill + records + clear | 2 insert | 3 barrier | 4 ranks + out | 5 barrier | 6 final
 }
 
 // padded (fixed room per bucket) -> dense unique arrays in walk order, one wave per bucket
@@ -373,6 +375,8 @@ k_unperm_bins8(const u64 *__restrict__ recs, const u32 *__restrict__ cursor2, co
   __shared__ u64 srec[PT_TILE];
   __shared__ u32 cnt[NBMAX], loff[NBMAX + 1], goff[NBMAX], wsum[16];
   __shared__ u32 bpre[65];                                    // records before bucket g0 + b in this workgroup's stretch
+  PH_DECL;
+  PH(0);
   const u32 g0 = blockIdx.x * B;
   if (g0 >= n_parts) return;
   const u32 nbk = (n_parts - g0 < B) ? n_parts - g0 : B;      // <= 64
@@ -380,15 +384,12 @@ k_unperm_bins8(const u64 *__restrict__ recs, const u32 *__restrict__ cursor2, co
     u32 c = threadIdx.x < nbk ? cursor2[g0 + threadIdx.x] : 0u;
     if (c > P8_CAP2) c = P8_CAP2;
     u32 incl = c;
-#pragma unroll
-    for (u32 d = 1; d < 64; d <<= 1) {
-      const u32 y = __shfl_up(incl, d);
-      if (threadIdx.x >= d) incl += y;
-    }
+    incl = wave_incl_scan(incl);
     bpre[threadIdx.x + 1] = incl;
     if (threadIdx.x == 0) bpre[0] = 0;
   }
   __syncthreads();
+  PH(1);
   const u32 T = bpre[nbk];
   for (u32 c0 = 0; c0 < T; c0 += PT_TILE) {
     for (u32 b = threadIdx.x; b < n_bins; b += PT_THREADS) cnt[b] = 0;
@@ -409,6 +410,7 @@ k_unperm_bins8(const u64 *__restrict__ recs, const u32 *__restrict__ cursor2, co
         binrank[q] = 0;
       }
     }
+    PH(2);
 #pragma unroll
     for (u32 q = 0; q < PT_IPT; q++) {
       if (binrank[q] == NONE32) continue;
@@ -422,18 +424,16 @@ k_unperm_bins8(const u64 *__restrict__ recs, const u32 *__restrict__ cursor2, co
         binrank[q] = bin << 16 | atomicAdd(&cnt[bin], 1u);    // (bin < 2048, rank < 8192)
       }
     }
+    PH(3);
     __syncthreads();
+    PH(4);
     {
       const u32 a = 2 * threadIdx.x, b = a + 1;               // exclusive scan of up to 2048 counters: two per thread
       const u32 ca = a < n_bins ? cnt[a] : 0u, cb = b < n_bins ? cnt[b] : 0u;
       const u32 s = ca + cb;
       const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
       u32 incl = s;
-#pragma unroll
-      for (u32 d = 1; d < 64; d <<= 1) {
-        const u32 y = __shfl_up(incl, d);
-        if (lane >= d) incl += y;
-      }
+      incl = wave_incl_scan(incl);
       if (lane == 63) wsum[wv] = incl;
       __syncthreads();
       u32 before = 0;
@@ -444,18 +444,25 @@ k_unperm_bins8(const u64 *__restrict__ recs, const u32 *__restrict__ cursor2, co
       if (threadIdx.x == 1023) loff[n_bins] = before + incl;
     }
     __syncthreads();
+    PH(5);
     for (u32 b = threadIdx.x; b < n_bins; b += PT_THREADS) {
       const u32 c = cnt[b];
       goff[b] = (b << wshift) + (c ? atomicAdd(&ucur[b], c) : 0u);
     }
+    PH(6);
 #pragma unroll
     for (u32 q = 0; q < PT_IPT; q++)
       if (binrank[q] != NONE32) srec[loff[binrank[q] >> 16] + (binrank[q] & 0xffffu)] = r64[q];
     __syncthreads();
+    PH(7);
     p8_write_bins(srec, loff, n_bins, p8_group(loff[n_bins], n_bins), rec,
                   [&](u32 bin, u32 k) -> u64 { return (u64)goff[bin] + k; });
     __syncthreads();
+    PH(8);
   }
+  // 1 fills of the buckets | 2 bucket lookup + record loads issued | 3 gather of the results + LDS ranks | 4 barrier | 5 scan |
+  // 6 global cursors | 7 sort in LDS | 8 write out
+  PH_END(3, 8, (blockIdx.x & 15u) == 3u);
 }
 
 // --------------------------------------------------------------------------------

@@ -70,11 +70,7 @@ k_pairs_records(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, WT m
   }
   const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   u32 incl = found;
-#pragma unroll
-  for (u32 d = 1; d < 64; d <<= 1) {
-    const u32 y = __shfl_up(incl, d);
-    if (lane >= d) incl += y;
-  }
+  incl = wave_incl_scan(incl);
   if (lane == 63) lds[wv] = incl;
   __syncthreads();
   u32 before = 0, total = 0;

@@ -49,11 +49,7 @@ template <class T, u32 THREADS>
 __device__ __forceinline__ T ps_block_exscan(T x, T *lds, T *total) {
   const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   T incl = x;
-#pragma unroll
-  for (u32 d = 1; d < 64; d <<= 1) {
-    const T y = __shfl_up(incl, d);
-    if (lane >= d) incl += y;
-  }
+  incl = wave_incl_scan(incl);
   if (lane == 63) lds[wv] = incl;
   __syncthreads();
   T before = 0, tot = 0;
