@@ -792,8 +792,13 @@ static int stage_count_rec(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   const bool check_range = !(range_lo == 0 && range_hi == ~0ull);
   const Reads8 src{d_words, d_filt, range_lo, range_hi, check_range ? 1u : 0u, rk};
   const u32 tiles1 = (N + PT_TILE - 1) / PT_TILE, tiles2 = tiles1 + nb1;
-  hipLaunchKernelGGL(k_p8_scatter1<Reads8>, dim3(tiles1), dim3(1024), 0, st, src, N, rk.kbits, d1, ibits, cap1, cursor1,
-                     c->p8_a.as<u64>(), c->d_ctr);
+  static const bool s1_small = getenv("HUMID_S1_THREADS") ? atoi(getenv("HUMID_S1_THREADS")) == 512 : false;  // (experiments: 512 is 20 us slower)
+  if (s1_small)
+    hipLaunchKernelGGL((k_p8_scatter1<Reads8, 512>), dim3((N + 4095) / 4096), dim3(512), 0, st, src, N, rk.kbits, d1, ibits, cap1, cursor1,
+                       c->p8_a.as<u64>(), c->d_ctr);
+  else
+    hipLaunchKernelGGL((k_p8_scatter1<Reads8, 1024>), dim3(tiles1), dim3(1024), 0, st, src, N, rk.kbits, d1, ibits, cap1, cursor1,
+                       c->p8_a.as<u64>(), c->d_ctr);
   hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, (const u32 *)cursor1, d1, d2, cbase, tprefix, c->pbeg.as<u32>(),
                      c->ucount.as<u32>() + n_parts, cap1);
   if (c->kev_on) HIPCHK(hipEventRecord(c->kev[39], st));

@@ -51,8 +51,8 @@ struct Reads8 {
   u32 check_range;
   RecKey key;
   __device__ __forceinline__ bool load(u32 j, u64 &k) const {
+    const u64 w = words[j];                            // (requested together with the flag, not behind it)
     if (filtered && filtered[j]) return false;
-    const u64 w = words[j];
     if (check_range && (w < rlo || w > rhi)) return false;
     k = key(w);
     return true;
@@ -84,18 +84,21 @@ __device__ __forceinline__ u32 p8_group(u32 records, u32 nb) {
 }
 
 // ---- level 1: reads -> padded coarse bins (top d1 key bits), records as described above ----
-template <class SRC>
-__global__ void __launch_bounds__(1024, 8)
+// THREADS x PT_IPT reads per tile (1024: the tile of the other levels; 512: twice the workgroups per CU, whose
+// load / rank / write phases then overlap more)
+template <class SRC, u32 THREADS>
+__global__ void __launch_bounds__(THREADS)
 k_p8_scatter1(SRC src, u32 n_reads, u32 kbits, u32 d1, u32 ibits, u32 cap1, u32 *cursor, u64 *__restrict__ out, ull *ctr) {
   HUMID_GUARD_LAST_VGPR();
-  __shared__ u64 srec[PT_TILE];
+  constexpr u32 TILE = THREADS * PT_IPT;
+  __shared__ u64 srec[TILE];
   __shared__ u32 cnt[PT_MAXBINS], loff[PT_MAXBINS + 1], goff[PT_MAXBINS], room[PT_MAXBINS], wsum[8];
   const u32 nb = 1u << d1;
   PH_DECL;
   PH(0);
-  const u32 t_beg = blockIdx.x * PT_TILE;
-  const u32 t_cnt = (t_beg >= n_reads) ? 0u : ((n_reads - t_beg < PT_TILE) ? n_reads - t_beg : PT_TILE);
-  for (u32 b = threadIdx.x; b < nb; b += PT_THREADS) cnt[b] = 0;
+  const u32 t_beg = blockIdx.x * TILE;
+  const u32 t_cnt = (t_beg >= n_reads) ? 0u : ((n_reads - t_beg < TILE) ? n_reads - t_beg : TILE);
+  for (u32 b = threadIdx.x; b < nb; b += THREADS) cnt[b] = 0;
   __syncthreads();
   PH(1);
   const u32 rbits = kbits - d1;                               // key bits a record keeps
@@ -103,7 +106,7 @@ k_p8_scatter1(SRC src, u32 n_reads, u32 kbits, u32 d1, u32 ibits, u32 cap1, u32 
   u32 binrank[PT_IPT];                                        // bin << 16 | rank inside (tile, bin); ~0: none
 #pragma unroll
   for (u32 q = 0; q < PT_IPT; q++) {
-    const u32 j = threadIdx.x + q * PT_THREADS;
+    const u32 j = threadIdx.x + q * THREADS;
     binrank[q] = NONE32;
     u64 k;
     if (j < t_cnt && src.load(t_beg + j, k)) {
@@ -389,8 +392,8 @@ k_unperm_bins8(const u64 *__restrict__ recs, const u32 *__restrict__ cursor2, co
     if (threadIdx.x == 0) bpre[0] = 0;
   }
   __syncthreads();
-  PH(1);
   const u32 T = bpre[nbk];
+  PH(1);
   for (u32 c0 = 0; c0 < T; c0 += PT_TILE) {
     for (u32 b = threadIdx.x; b < n_bins; b += PT_THREADS) cnt[b] = 0;
     __syncthreads();
