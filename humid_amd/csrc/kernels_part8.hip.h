@@ -598,21 +598,25 @@ __device__ __forceinline__ u64 w2_fingerprint(const W2 &w) {
   const u64 f = mix64(w.lo ^ mix64(w.hi + 0x9e3779b97f4a7c15ull));
   return f == EMPTY_KEY ? EMPTY_KEY - 1 : f;
 }
+// Ranks as in k_dedup_rec: the HOME of a word is the part of its partition key right below the bucket bits -- monotone in
+// the word -- in a table that does not wrap (DR_SPILL entries behind it), so the table order is the word order except
+// inside a run of neighbouring occupied entries; an occupancy bitmap gives the entries in front of a run, the words
+// of a run are compared (through the claimers' staged words).  Round 3 first ranked by comparing all unique words with
+// each other, three dependent LDS reads per compare.
 template <u32 SB, u32 STAGE, u32 LEN_MIN, u32 LEN_MAX>
 __global__ void __launch_bounds__(256)
 k_dedup_wide_rec(const W2 *__restrict__ recw, const u32 *__restrict__ reci, const u32 *__restrict__ cursor2, u32 hbits, RecKey rk,
                  u32 n_reads, u32 pb, W2 *__restrict__ pad_word, uint2 *__restrict__ pad_cf, u64 *__restrict__ agg,
                  u64 *__restrict__ out8, ull *ctr) {
   HUMID_GUARD_LAST_VGPR();
-  constexpr u32 SLOTS = 1u << SB, Q = STAGE / 256u;
-  static_assert(STAGE % 256u == 0 && (STAGE & (STAGE - 1)) == 0 && LEN_MAX <= STAGE && LEN_MAX <= SLOTS, "size class");
+  constexpr u32 SLOTS = 1u << SB, TS = SLOTS + DR_SPILL, WORDS = TS / 32u, Q = STAGE / 256u;
+  static_assert(STAGE % 256u == 0 && (STAGE & (STAGE - 1)) == 0 && LEN_MAX <= STAGE && LEN_MAX <= SLOTS && WORDS <= 62, "size class");
   __shared__ W2 wk[STAGE];                             // the bucket's words by position
-  __shared__ u64 lkey[SLOTS];                          // fingerprint, EMPTY_KEY = free
-  __shared__ u32 lcnt[SLOTS];
-  __shared__ u32 lfirst[SLOTS];
-  __shared__ unsigned short lclaim[SLOTS];             // position of the read that registered the entry
-  __shared__ unsigned short lslot_of[SLOTS];           // unique index (claim order, then rank) -> table entry
-  __shared__ unsigned short lorder[512];
+  __shared__ u64 lkey[TS];                             // fingerprint, EMPTY_KEY = free
+  __shared__ uint2 lcf[TS];                            // (count, first read); after the rank phase .y = the entry's rank
+  __shared__ unsigned short lclaim[TS];                // position of the read that registered the entry
+  __shared__ unsigned short lslot_of[STAGE];           // claim order -> table entry
+  __shared__ u32 lbits[WORDS + 2], lpre[WORDS + 2];    // occupancy bitmap (a word of zeros behind it), set bits in front of each word
   __shared__ u32 lcount;
   const u32 g = blockIdx.x;
   u32 len = cursor2[g];
@@ -632,9 +636,12 @@ k_dedup_wide_rec(const W2 *__restrict__ recw, const u32 *__restrict__ reci, cons
     sq[q] = NONE32;
     if (p < len) { vq[q] = reci[beg + p]; wq[q] = recw[beg + p]; wk[p] = wq[q]; }
   }
-  for (u32 s = threadIdx.x; s < SLOTS; s += 256) { lkey[s] = EMPTY_KEY; lcnt[s] = 0; lfirst[s] = NONE32; }
+  for (u32 s = threadIdx.x; s < TS; s += 256) { lkey[s] = EMPTY_KEY; lcf[s] = make_uint2(0u, NONE32); }
+  if (threadIdx.x < WORDS + 2) lbits[threadIdx.x] = 0;
   if (threadIdx.x == 0) lcount = 0;
   __syncthreads();
+  const int hs = (int)rk.kbits - (int)pb - (int)SB;
+  auto home = [&](u64 k) -> u32 { return hs >= 0 ? (u32)(k >> hs) & (SLOTS - 1) : (u32)k & ((1u << (rk.kbits - pb)) - 1u); };
   bool bad = false;
 #pragma unroll
   for (u32 q = 0; q < Q; q++) {
@@ -643,18 +650,23 @@ k_dedup_wide_rec(const W2 *__restrict__ recw, const u32 *__restrict__ reci, cons
     const u32 v = vq[q];
     if (v >= n_reads) { bad = true; continue; }        // a malformed index is never used
     const u64 f = w2_fingerprint(wq[q]);
-    u32 s = (u32)(f >> 20) & (SLOTS - 1), probes = 0;
-    bool placed = false;
-    while (probes++ <= SLOTS) {
+    u32 s = home(pw_key(wq[q], hbits, rk));
+    bool claimed = false;
+    while (true) {
       u64 cur = lkey[s];
-      if (cur == EMPTY_KEY) cur = atomicCAS((ull *)&lkey[s], EMPTY_KEY, (ull)f);
-      if (cur == EMPTY_KEY || cur == f) { placed = true; break; }
-      s = (s + 1) & (SLOTS - 1);
+      if (cur == EMPTY_KEY) { cur = atomicCAS((ull *)&lkey[s], EMPTY_KEY, (ull)f); claimed = cur == EMPTY_KEY; }
+      if (claimed || cur == f) break;
+      if (++s >= TS) break;
     }
-    if (!placed) { bad = true; continue; }
+    if (s >= TS) { bad = true; continue; }
     sq[q] = s;
-    if (atomicAdd(&lcnt[s], 1u) == 0u) { lclaim[s] = (unsigned short)p; lslot_of[atomicAdd(&lcount, 1u)] = (unsigned short)s; }
-    atomicMin(&lfirst[s], v);
+    atomicAdd(&lcf[s].x, 1u);
+    atomicMin(&lcf[s].y, v);
+    if (claimed) {
+      lclaim[s] = (unsigned short)p;
+      lslot_of[atomicAdd(&lcount, 1u)] = (unsigned short)s;
+      atomicOr(&lbits[s >> 5], 1u << (s & 31));
+    }
   }
   __syncthreads();
   // exactness: the word of every position against the word that registered its entry
@@ -662,47 +674,36 @@ k_dedup_wide_rec(const W2 *__restrict__ recw, const u32 *__restrict__ reci, cons
   for (u32 q = 0; q < Q; q++)
     if (sq[q] != NONE32 && !w_eq(wk[lclaim[sq[q]]], wq[q])) bad = true;
   if (bad) ctr[CTR_OVERFULL] = 1;
-  const u32 n_uniq = lcount < SLOTS ? lcount : SLOTS;
-  if (n_uniq <= 512) {
-    // rank of an entry = number of smaller words among the bucket's unique words (all distinct)
-    for (u32 li = threadIdx.x; li < n_uniq; li += 256) {
-      const W2 w = wk[lclaim[lslot_of[li]]];
-      u32 r = 0;
-      for (u32 j = 0; j < n_uniq; j++) r += w_less(wk[lclaim[lslot_of[j]]], w) ? 1u : 0u;
-      lorder[r] = lslot_of[li];
-    }
-    __syncthreads();
-    for (u32 li = threadIdx.x; li < n_uniq; li += 256) lslot_of[li] = lorder[li];
-    __syncthreads();
-  } else if (LEN_MAX > 512) {
-    // bitonic network over the claim-order list, keys through the claimer's staged word
-    u32 npow = 1;
-    while (npow < n_uniq) npow <<= 1;
-    for (u32 i = n_uniq + threadIdx.x; i < npow; i += 256) lslot_of[i] = 0xffff;      // padding: above every word
-    __syncthreads();
-    for (u32 k = 2; k <= npow; k <<= 1) {
-      for (u32 j = k >> 1; j > 0; j >>= 1) {
-        for (u32 t = threadIdx.x; t < npow; t += 256) {
-          const u32 x = t ^ j;
-          if (x > t) {
-            const u32 a = lslot_of[t], bb = lslot_of[x];
-            const bool pa = a == 0xffff, pbd = bb == 0xffff;
-            bool gt;
-            if (pa) gt = !pbd;
-            else if (pbd) gt = false;
-            else gt = w_less(wk[lclaim[bb]], wk[lclaim[a]]);
-            if (gt == ((t & k) == 0)) { lslot_of[t] = (unsigned short)bb; lslot_of[x] = (unsigned short)a; }
-          }
-        }
-        __syncthreads();
-      }
-    }
+  const u32 n_uniq = lcount < STAGE ? lcount : STAGE;
+  const u32 lane = threadIdx.x & 63;
+  if ((threadIdx.x & ~63u) < n_uniq) {                 // (identical values: the waves may overwrite each other)
+    const u32 pc = lane < WORDS ? (u32)__popc(lbits[lane]) : 0u;
+    const u32 incl = wave_incl_scan(pc);
+    if (lane < WORDS) lpre[lane] = incl - pc;
   }
   for (u32 li = threadIdx.x; li < n_uniq; li += 256) {
-    const u32 s = lslot_of[li];
-    pad_word[beg + li] = wk[lclaim[s]];
-    pad_cf[beg + li] = make_uint2(lcnt[s], lfirst[s]);
-    lfirst[s] = li;                                    // entry -> rank
+    const u32 sl = lslot_of[li];
+    const u32 w32 = sl >> 5, bit = sl & 31;
+    const u32 bw = lbits[w32];
+    u32 r = lpre[w32] + (u32)__popc(bw & ((1u << bit) - 1u));    // occupied entries in front of sl
+    const bool left = bit ? ((bw >> (bit - 1)) & 1u) != 0 : (w32 > 0 && (lbits[w32 - 1] >> 31) != 0);
+    const bool right = bit < 31 ? ((bw >> (bit + 1)) & 1u) != 0 : (lbits[w32 + 1] & 1u) != 0;
+    const W2 w = wk[lclaim[sl]];
+    if (left || right) {                               // a run of several entries: order inside it by comparing the words
+      u32 start = sl, smaller = 0;
+      while (start > 0 && lkey[start - 1] != EMPTY_KEY) start--;
+      for (u32 j = start; j < TS; j++) {
+        if (lkey[j] == EMPTY_KEY) break;
+        smaller += w_less(wk[lclaim[j]], w) ? 1u : 0u;
+      }
+      r = r - (sl - start) + smaller;                  // (all of [start, sl) is occupied)
+    }
+    const uint2 cf = lcf[sl];
+    if (r < STAGE) {
+      pad_word[beg + r] = w;
+      pad_cf[beg + r] = cf;
+    }
+    lcf[sl].y = r;                                     // entry -> rank
   }
   if (threadIdx.x == 0) agg[g] = ((u64)len << 32) | n_uniq;
   __syncthreads();
@@ -710,7 +711,7 @@ k_dedup_wide_rec(const W2 *__restrict__ recw, const u32 *__restrict__ reci, cons
   for (u32 q = 0; q < Q; q++) {
     const u32 p = threadIdx.x + 256u * q;
     if (p >= len) continue;
-    const u32 li = sq[q] != NONE32 ? lfirst[sq[q]] : NONE32;
+    const u32 li = sq[q] != NONE32 ? lcf[sq[q]].y : NONE32;
     out8[beg + p] = ((u64)(li < len ? (u32)beg + li : NOSLOT) << 32) | vq[q];
   }
 }
