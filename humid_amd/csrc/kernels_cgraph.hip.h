@@ -123,6 +123,8 @@ k_pairs_append(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, WT ma
   HUMID_GUARD_LAST_VGPR();
   __shared__ u32 lds[8];
   __shared__ u32 s_base;
+  PH_DECL;
+  PH(0);
   // n_valid: the walked order came from a padded grouping; had a coarse bin been full, words were dropped and the
   // order ends at *n_valid (what lies behind it was never written; the caller discards this search)
   if (n_valid && *n_valid < n) n = *n_valid;
@@ -132,10 +134,11 @@ k_pairs_append(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, WT ma
   u32 jend = 0;
   if (i < n) {
     wi = W[i];
+    const WT w1 = W[i + 1 < n ? i + 1 : i];          // requested together with W[i]: most walks end at this word
     jend = (walk_max && n - i > walk_max + 1) ? i + walk_max + 1 : n;
     u32 j = i + 1;
     for (; j < jend; j++) {
-      const WT x = w_xor(wi, W[j]);
+      const WT x = w_xor(wi, j == i + 1 ? w1 : W[j]);
       if (w_hits(x, mask)) break;                    // left the bucket
       if (w_mismatch(x) > distance) continue;
       bool first = true;
@@ -148,6 +151,7 @@ k_pairs_append(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, WT ma
     }
     if (big && j == jend && jend < n && !w_hits(w_xor(wi, W[jend]), mask)) atomicOr(big, 1ull << cb);
   }
+  PH(1);
   // room for the workgroup's pairs: exclusive position of this thread's, one atomic per workgroup
   const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   u32 incl = found;
@@ -157,10 +161,13 @@ k_pairs_append(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, WT ma
   u32 before = 0, total = 0;
 #pragma unroll
   for (u32 k = 0; k < 4; k++) { if (k < wv) before += lds[k]; total += lds[k]; }
-  if (total == 0) return;                              // (uniform)
+  PH(2);
+  if (total == 0) { PH(3); PH(4); PH_END(5, 4, (blockIdx.x & 63u) == 5u); return; }                              // (uniform)
   const u32 region = blockIdx.x % ER_REGIONS;
   if (threadIdx.x == 0) s_base = atomicAdd(&er.cur[region * ER_STRIDE], total);
   __syncthreads();
+  PH(3);
+  if (threadIdx.x == 0) { PH(4); PH_END(5, 4, (blockIdx.x & 63u) == 5u); }   // 1 walk | 2 block scan | 3 region cursor | (4 -)
   if (!found) return;
   u32 at = s_base + before + incl - found;
   if (at + found > er.cap_r) { *overflow = 1; if (at >= er.cap_r) return; }

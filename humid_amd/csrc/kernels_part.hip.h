@@ -294,7 +294,7 @@ k_pt_hist2(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ tprefi
 // gather of the words behind them: 0.18 -> 0.05 ms at 2.7 M words and 24 key bits.
 #define GF_THREADS 1024u
 #define GF_MAXBITS 15u
-#define GF_SMALL 8160u           // a coarse bin of up to this many words: 80 KB of LDS, two workgroups per CU
+#define GF_SMALL 7872u           // a coarse bin of up to this many words: 79.4 KB of LDS, two workgroups per CU (2 x 80 KB is ALL of a CU's LDS: the second workgroup did not get in)
 #define GF_MID 32768u            // up to this many: 128 KB, still coalesced stores
 // BIG = false: the normal case, a few thousand words per coarse bin -- 2^15 16-bit counters and the inverse
 // permutation (output position -> input position, 16 bits each) in 80 KB of LDS, so two workgroups share a
@@ -304,14 +304,16 @@ k_pt_hist2(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ tprefi
 // SIZE 0: bins of <= GF_SMALL words, SIZE 1: <= GF_MID (the same road with room for a longer permutation),
 // SIZE 2: the rest.  Three launches, each takes its own bins and leaves the others at once.
 template <class SRC, int SIZE>
-__global__ void __launch_bounds__(GF_THREADS)
+__global__ void __launch_bounds__(GF_THREADS, SIZE == 0 ? 8 : 4)       // SIZE 0: <= 64 registers, two workgroups per CU
 k_group_fine(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ v_in, const u32 *__restrict__ cbase, u32 d1,
              u32 d2, u64 *__restrict__ k_out, u32 *__restrict__ v_out, u32 cap1) {
   HUMID_GUARD_LAST_VGPR();
   constexpr bool BIG = SIZE == 2;
-  constexpr u32 INV_WORDS = SIZE == 0 ? 4096u : (1u << (GF_MAXBITS - 1)) + 16u;       // 16-bit entries, two per word, + the wave sums
+  constexpr u32 INV_WORDS = SIZE == 0 ? GF_SMALL / 2u + 16u : (1u << (GF_MAXBITS - 1)) + 16u;       // 16-bit entries, two per word, + the wave sums
   __shared__ u32 gf_lds[BIG ? (1u << GF_MAXBITS) + 16 : (1u << (GF_MAXBITS - 1)) + INV_WORDS];
   const u32 nb = 1u << d2, c = blockIdx.x;
+  PH_DECL;
+  PH(0);
   const u32 beg = cbase[c], end = cbase[c + 1];
   if (beg >= end) return;
   const u32 n = end - beg;
@@ -325,33 +327,100 @@ k_group_fine(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ v_in
   auto fine = [&](u64 w) { return (u32)(src.key(w) >> (64 - d1 - d2)) & (nb - 1); };
   if (!BIG) {
     unsigned short *inv = (unsigned short *)(gf_lds + (1u << (GF_MAXBITS - 1)));      // GF_SMALL / GF_MID entries, then the 16 wave sums
+    // SIZE 0: the bin's words (at most 8 per thread) are requested ONCE, all together, and stay in registers for both
+    // counting passes -- a loop of load / count / load / count is a chain of memory round trips (this kernel is one
+    // round of 512 workgroups: its time IS the latency of one workgroup, 49 us before, see profiles/r03e)
+    constexpr u32 GF_RPT = 8;
+    u64 kk[GF_RPT];
+    u32 ff[GF_RPT];
+    if constexpr (SIZE == 0) {
+#pragma unroll
+      for (u32 q = 0; q < GF_RPT; q++) {
+        const u32 j = threadIdx.x + q * GF_THREADS;
+        kk[q] = j < n ? k_in[j] : 0ull;
+      }
+    }
     for (u32 b = threadIdx.x; b < (1u << (GF_MAXBITS - 1)); b += GF_THREADS) gf_lds[b] = 0;   // 2^15 16-bit counters, two per word
     __syncthreads();
-    for (u32 j = threadIdx.x; j < n; j += GF_THREADS) {
-      const u32 f = fine(k_in[j]);
-      atomicAdd(&gf_lds[f >> 1], 1u << (16 * (f & 1)));                               // (no carry: n < 2^16)
+    PH(1);
+    if constexpr (SIZE == 0) {
+#pragma unroll
+      for (u32 q = 0; q < GF_RPT; q++) {
+        const u32 j = threadIdx.x + q * GF_THREADS;
+        ff[q] = fine(kk[q]);
+        if (j < n) atomicAdd(&gf_lds[ff[q] >> 1], 1u << (16 * (ff[q] & 1)));          // (no carry: n < 2^16)
+      }
+    } else {
+      for (u32 j = threadIdx.x; j < n; j += GF_THREADS) {
+        const u32 f = fine(k_in[j]);
+        atomicAdd(&gf_lds[f >> 1], 1u << (16 * (f & 1)));                             // (no carry: n < 2^16)
+      }
+    }
+    PH(2);
+    __syncthreads();
+    PH(3);
+    // exclusive scan of the 16-bit counters in place.  A wave owns a stretch of words / 16 consecutive words and walks it
+    // in rows of 64 (lane l takes word 64 i + l: no bank conflict; a thread owning 16 CONSECUTIVE words, as before,
+    // hit two banks with 64 lanes -- 10.7 of the kernel's 20 us per workgroup): totals first, then the offsets.
+    const u32 words = nb >= 2 ? nb / 2 : 1u;
+    const u32 n_waves = GF_THREADS / 64u;
+    const u32 per_wave = (words + n_waves - 1) / n_waves, wbeg = wv * per_wave, wend = wbeg + per_wave < words ? wbeg + per_wave : words;
+    u32 tot = 0;
+    for (u32 w = wbeg + lane; w < wend; w += 64) { const u32 x = gf_lds[w]; tot += (x & 0xffffu) + (x >> 16); }
+#pragma unroll
+    for (u32 dd = 32; dd; dd >>= 1) tot += __shfl_xor(tot, dd);
+    if (lane == 0) wsum[wv] = tot;
+    __syncthreads();
+    u32 run = 0;
+    for (u32 q = 0; q < wv; q++) run += wsum[q];
+    for (u32 w0 = wbeg; w0 < wend; w0 += 64) {                                        // (wave-uniform bounds)
+      const u32 w = w0 + lane;
+      const u32 x = w < wend ? gf_lds[w] : 0u;
+      const u32 mine = (x & 0xffffu) + (x >> 16);
+      const u32 incl = wave_incl_scan(mine);
+      const u32 lo = run + incl - mine, hi = lo + (x & 0xffffu);
+      if (w < wend) gf_lds[w] = lo | (hi << 16);                                      // offsets < n <= 2^15
+      run += (u32)__builtin_amdgcn_readlane((int)incl, 63);
     }
     __syncthreads();
-    // exclusive scan of the 16-bit counters in place: thread t owns words [t * per, (t + 1) * per)
-    const u32 words = nb >= 2 ? nb / 2 : 1u;
-    const u32 per = words >= GF_THREADS ? words / GF_THREADS : 1u, w0 = threadIdx.x * per;
-    u32 mine = 0;
-    if (w0 < words)
-      for (u32 q = 0; q < per; q++) { const u32 x = gf_lds[w0 + q]; mine += (x & 0xffffu) + (x >> 16); }
-    u32 incl = mine;
-    incl = wave_incl_scan(incl);
-    if (lane == 63) wsum[wv] = incl;
-    __syncthreads();
-    u32 run = incl - mine;
-    for (u32 q = 0; q < wv; q++) run += wsum[q];
-    if (w0 < words)
-      for (u32 q = 0; q < per; q++) {
-        const u32 x = gf_lds[w0 + q];
-        const u32 lo = run, hi = run + (x & 0xffffu);
-        gf_lds[w0 + q] = lo | (hi << 16);                                             // offsets < n <= 2^15
-        run = hi + (x >> 16);
+    PH(4);
+    if constexpr (SIZE == 0) {
+      u32 oldq[GF_RPT];
+#pragma unroll
+      for (u32 q = 0; q < GF_RPT; q++) {
+        const u32 j = threadIdx.x + q * GF_THREADS;
+        oldq[q] = j < n ? atomicAdd(&gf_lds[ff[q] >> 1], 1u << (16 * (ff[q] & 1))) : 0u;
       }
-    __syncthreads();
+#pragma unroll
+      for (u32 q = 0; q < GF_RPT; q++) {
+        const u32 j = threadIdx.x + q * GF_THREADS;
+        if (j < n) inv[(oldq[q] >> (16 * (ff[q] & 1))) & 0xffffu] = (unsigned short)j;
+      }
+      PH(5);
+      __syncthreads();
+      PH(6);
+      // output position q <- input position inv[q]: eight gathers in flight per thread (the lines were just read), coalesced stores
+      u32 jj[GF_RPT], vo[GF_RPT];
+      u64 ko[GF_RPT];
+#pragma unroll
+      for (u32 t = 0; t < GF_RPT; t++) {
+        const u32 q = threadIdx.x + t * GF_THREADS;
+        jj[t] = q < n ? inv[q] : 0u;
+      }
+#pragma unroll
+      for (u32 t = 0; t < GF_RPT; t++) {
+        const u32 q = threadIdx.x + t * GF_THREADS;
+        if (q < n) { ko[t] = k_in[jj[t]]; vo[t] = v_in[jj[t]]; }
+      }
+#pragma unroll
+      for (u32 t = 0; t < GF_RPT; t++) {
+        const u32 q = threadIdx.x + t * GF_THREADS;
+        if (q < n) { k_out[q] = ko[t]; v_out[q] = vo[t]; }
+      }
+      PH(7);
+      PH_END(4, 7, (c & 7u) == 3u);    // 1 bounds + loads issued + clear | 2 count | 3 barrier | 4 scan | 5 place | 6 barrier | 7 gather + store
+      return;
+    }
     for (u32 j = threadIdx.x; j < n; j += GF_THREADS) {
       const u32 f = fine(k_in[j]);
       const u32 old = atomicAdd(&gf_lds[f >> 1], 1u << (16 * (f & 1)));
