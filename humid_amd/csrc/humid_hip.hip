@@ -810,6 +810,17 @@ static int stage_count_rec(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
                      c->pad_word.as<u64>(), c->pad_cf.as<uint2>(), agg, c->d_ctr);
   HIPCHK(hipEventRecord(c->kev[1], st));
   TRY(exscan_in<u64>(c, PtrIn<u64>{agg}, abase, (u64)n_parts + 1));
+  // the walk-order arrays are squeezed out of the padded ones BEFORE the host knows how many unique words there are
+  // (at most N: a bucket never reports more words than records it holds): the host's wait for the counters -- it
+  // needs U to shape the graph stage -- then runs beside this kernel instead of an idle GPU
+  ENSURE(c->s_word, (size_t)(N + 1) * 8);
+  ENSURE(c->s_slot, (size_t)(N + 1) * 4);
+  ENSURE(c->s_cnt, (size_t)(N + 1) * 4);
+  ENSURE(c->s_first, (size_t)(N + 1) * 4);
+  hipLaunchKernelGGL(k_compact_padded8, dim3(blocks_for((u64)n_parts * 64)), dim3(256), 0, st, c->pad_word.as<u64>(),
+                     c->pad_cf.as<uint2>(), (const u64 *)agg, (const u64 *)abase, n_parts, c->s_word.as<u64>(),
+                     c->s_slot.as<u32>(), c->s_cnt.as<u32>(), c->s_first.as<u32>());
+  HIPCHK(hipEventRecord(c->ev[1], st));
   HIPCHK(hipGetLastError());
   TRY(read_counters(c, (const u32 *)(abase + n_parts), (const u32 *)(abase + n_parts) + 1));   // U, usable
   if (getenv("HUMID_TRACE_COUNT"))
@@ -828,16 +839,6 @@ static int stage_count_rec(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   s.usable = c->usable = c->h_ctr[CTR_N - 2] & 0xffffffffull;
   s.unique = c->U = U;
   *done = true;
-  if (U == 0) { HIPCHK(hipEventRecord(c->ev[1], st)); return HUMID_OK; }
-  ENSURE(c->s_word, (size_t)(U + 1) * 8);
-  ENSURE(c->s_slot, (size_t)(U + 1) * 4);
-  ENSURE(c->s_cnt, (size_t)(U + 1) * 4);
-  ENSURE(c->s_first, (size_t)(U + 1) * 4);
-  hipLaunchKernelGGL(k_compact_padded8, dim3(blocks_for((u64)n_parts * 64)), dim3(256), 0, st, c->pad_word.as<u64>(),
-                     c->pad_cf.as<uint2>(), (const u64 *)agg, (const u64 *)abase, n_parts, c->s_word.as<u64>(),
-                     c->s_slot.as<u32>(), c->s_cnt.as<u32>(), c->s_first.as<u32>());
-  HIPCHK(hipEventRecord(c->ev[1], st));
-  HIPCHK(hipGetLastError());
   return HUMID_OK;
 }
 
@@ -906,6 +907,15 @@ static int stage_count_rec_wide(humid_ctx *c, const W2 *d_words, const u8 *d_fil
                        c->pad_word.as<W2>(), c->pad_cf.as<uint2>(), agg, c->p8_b.as<u64>(), c->d_ctr);
   HIPCHK(hipEventRecord(c->kev[1], st));
   TRY(exscan_in<u64>(c, PtrIn<u64>{agg}, abase, (u64)n_parts + 1));
+  // (as in stage_count_rec: squeezed out beside the host's wait for the counters; at most N unique words)
+  ENSURE(c->s_word, (size_t)(N + 1) * 16);
+  ENSURE(c->s_slot, (size_t)(N + 1) * 4);
+  ENSURE(c->s_cnt, (size_t)(N + 1) * 4);
+  ENSURE(c->s_first, (size_t)(N + 1) * 4);
+  hipLaunchKernelGGL(k_compact_padded8_wide, dim3(blocks_for((u64)n_parts * 64)), dim3(256), 0, st, (const W2 *)c->pad_word.as<W2>(),
+                     (const uint2 *)c->pad_cf.as<uint2>(), (const u64 *)agg, (const u64 *)abase, n_parts, c->s_word.as<W2>(),
+                     c->s_slot.as<u32>(), c->s_cnt.as<u32>(), c->s_first.as<u32>());
+  HIPCHK(hipEventRecord(c->ev[1], st));
   HIPCHK(hipGetLastError());
   TRY(read_counters(c, (const u32 *)(abase + n_parts), (const u32 *)(abase + n_parts) + 1));   // U, usable
   if (getenv("HUMID_TRACE_COUNT"))
@@ -923,16 +933,6 @@ static int stage_count_rec_wide(humid_ctx *c, const W2 *d_words, const u8 *d_fil
   s.usable = c->usable = c->h_ctr[CTR_N - 2] & 0xffffffffull;
   s.unique = c->U = U;
   *done = true;
-  if (U == 0) { HIPCHK(hipEventRecord(c->ev[1], st)); return HUMID_OK; }
-  ENSURE(c->s_word, (size_t)(U + 1) * 16);
-  ENSURE(c->s_slot, (size_t)(U + 1) * 4);
-  ENSURE(c->s_cnt, (size_t)(U + 1) * 4);
-  ENSURE(c->s_first, (size_t)(U + 1) * 4);
-  hipLaunchKernelGGL(k_compact_padded8_wide, dim3(blocks_for((u64)n_parts * 64)), dim3(256), 0, st, (const W2 *)c->pad_word.as<W2>(),
-                     (const uint2 *)c->pad_cf.as<uint2>(), (const u64 *)agg, (const u64 *)abase, n_parts, c->s_word.as<W2>(),
-                     c->s_slot.as<u32>(), c->s_cnt.as<u32>(), c->s_first.as<u32>());
-  HIPCHK(hipEventRecord(c->ev[1], st));
-  HIPCHK(hipGetLastError());
   return HUMID_OK;
 }
 
