@@ -1179,9 +1179,15 @@ static int group_words_by_stretch(humid_ctx *c, const ComboPlan &plan, u32 cb, c
     hipLaunchKernelGGL(k_pt_hist1<SRC>, dim3(tiles1 < 512 ? tiles1 : 512), dim3(1024), 0, st, src, n, d1, hist1);
     hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, (const u32 *)hist1, d1, 0u, cbase, tprefix, dummy, dummy + 513, 0u);
   }
-  hipLaunchKernelGGL((k_pt_scatter<1, SRC>), dim3(tiles1), dim3(1024), 0, st, src, n, (const u64 *)nullptr,
-                     (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr, d1, d2, (const u32 *)cbase, cursor1,
-                     c->seg_k0.as<u64>(), c->seg_v0.as<u32>(), (u32 *)nullptr, cap1, &c->d_ctr[CTR_GOVER]);
+  static const bool gs_small = getenv("HUMID_GS_THREADS") ? atoi(getenv("HUMID_GS_THREADS")) == 512 : false;  // (experiments: 512-thread tiles are 7 us slower -- shorter runs per bin)
+  if (gs_small)
+    hipLaunchKernelGGL((k_pt_scatter<1, SRC, 512>), dim3((n + 4095) / 4096), dim3(512), 0, st, src, n, (const u64 *)nullptr,
+                       (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr, d1, d2, (const u32 *)cbase, cursor1,
+                       c->seg_k0.as<u64>(), c->seg_v0.as<u32>(), (u32 *)nullptr, cap1, &c->d_ctr[CTR_GOVER]);
+  else
+    hipLaunchKernelGGL((k_pt_scatter<1, SRC>), dim3(tiles1), dim3(1024), 0, st, src, n, (const u64 *)nullptr,
+                       (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr, d1, d2, (const u32 *)cbase, cursor1,
+                       c->seg_k0.as<u64>(), c->seg_v0.as<u32>(), (u32 *)nullptr, cap1, &c->d_ctr[CTR_GOVER]);
   if (padded)
     hipLaunchKernelGGL(k_pt_scan1, dim3(1), dim3(1024), 0, st, (const u32 *)cursor1, d1, 0u, cbase, tprefix, dummy, dummy + 513, cap1, cursor1);
   // up to three launches over the coarse bins, by bin size; which sizes cannot occur is known from n alone only
@@ -2225,11 +2231,11 @@ static int unpermute_tiled(humid_ctx *c, u32 N, bool packed, u32 *d_cid, u8 *d_k
                      c->pslot.as<u32>(), c->slot_out.as<u64>(), n_pos_dev, N, N, wshift, n_bins, ucur, rec);
   HIPCHK(hipEventRecord(ev_mid, st));
   if (packed) {
-    if (wshift == 14) hipLaunchKernelGGL((k_unperm_window<true, 14>), dim3(n_bins), dim3(512), 0, st, rec, ucur, N, d_cid, d_keep);
-    else hipLaunchKernelGGL((k_unperm_window<true, 15>), dim3(n_bins), dim3(512), 0, st, rec, ucur, N, d_cid, d_keep);
+    if (wshift == 14) hipLaunchKernelGGL((k_unperm_window<true, 14>), dim3(n_bins), dim3(UW_THREADS), 0, st, rec, ucur, N, d_cid, d_keep);
+    else hipLaunchKernelGGL((k_unperm_window<true, 15>), dim3(n_bins), dim3(UW_THREADS), 0, st, rec, ucur, N, d_cid, d_keep);
   } else {
-    if (wshift == 14) hipLaunchKernelGGL((k_unperm_window<false, 14>), dim3(n_bins), dim3(512), 0, st, rec, ucur, N, d_cid, d_keep);
-    else hipLaunchKernelGGL((k_unperm_window<false, 15>), dim3(n_bins), dim3(512), 0, st, rec, ucur, N, d_cid, d_keep);
+    if (wshift == 14) hipLaunchKernelGGL((k_unperm_window<false, 14>), dim3(n_bins), dim3(UW_THREADS), 0, st, rec, ucur, N, d_cid, d_keep);
+    else hipLaunchKernelGGL((k_unperm_window<false, 15>), dim3(n_bins), dim3(UW_THREADS), 0, st, rec, ucur, N, d_cid, d_keep);
   }
   if (c->kev_on) HIPCHK(hipEventRecord(c->kev[41], st));
   HIPCHK(hipGetLastError());

@@ -171,23 +171,27 @@ k_pt_scan1(const u32 *__restrict__ hist1, u32 d1, u32 d2, u32 *__restrict__ cbas
 //          below; base = the level-2 histogram: the region of (c, f) starts at cbase[c] + the fine
 //          counts of c before f, which the first tile of c also writes to pbeg_out[c << d2 | f].
 //          cursor[]: records already placed in each region (zeroed before the launch).
-template <int LEVEL, class SRC>
-__global__ void __launch_bounds__(1024)
+// THREADS: 1024 (tiles of PT_TILE records: the tile bookkeeping of level 2 assumes it), or 512 for a LEVEL 1 whose 120 KB
+// of LDS per 1024-thread workgroup would leave one workgroup per CU (the graph stage's grouping: 333 tiles on 256 CUs)
+template <int LEVEL, class SRC, u32 THREADS = 1024u>
+__global__ void __launch_bounds__(THREADS)
 k_pt_scatter(SRC src, u32 n_reads, const u64 *__restrict__ k_in, const u32 *__restrict__ v_in,
              const u32 *__restrict__ tprefix, const u32 *__restrict__ cbase, u32 d1, u32 d2,
              const u32 *__restrict__ base, u32 *cursor, u64 *__restrict__ k_out, u32 *__restrict__ v_out,
              u32 *__restrict__ pbeg_out, u32 cap1, ull *over) {
   HUMID_GUARD_LAST_VGPR();
-  __shared__ u64 skey[PT_TILE];
-  __shared__ u32 sval[PT_TILE];
-  __shared__ unsigned short sbin[PT_TILE];
+  static_assert(LEVEL == 1 || THREADS == PT_THREADS, "level 2 works on tiles of PT_TILE records");
+  constexpr u32 TILE = THREADS * PT_IPT;
+  __shared__ u64 skey[TILE];
+  __shared__ u32 sval[TILE];
+  __shared__ unsigned short sbin[TILE];
   __shared__ u32 cnt[PT_MAXBINS], loff[PT_MAXBINS + 1], goff[PT_MAXBINS], room[PT_MAXBINS], fbase[PT_MAXBINS + 1], wsum[8];
   __shared__ u32 s_c, s_beg, s_cnt, s_first;
   const u32 nb = 1u << (LEVEL == 1 ? d1 : d2);
   u32 t_beg, t_cnt, coarse = 0;
   if (LEVEL == 1) {
-    t_beg = blockIdx.x * PT_TILE;
-    t_cnt = (t_beg >= n_reads) ? 0u : ((n_reads - t_beg < PT_TILE) ? n_reads - t_beg : PT_TILE);
+    t_beg = blockIdx.x * TILE;
+    t_cnt = (t_beg >= n_reads) ? 0u : ((n_reads - t_beg < TILE) ? n_reads - t_beg : TILE);
   } else {
     if (blockIdx.x >= tprefix[1u << d1]) return;             // beyond the last tile (uniform exit)
     if (threadIdx.x == 0) {
@@ -205,14 +209,14 @@ k_pt_scatter(SRC src, u32 n_reads, const u64 *__restrict__ k_in, const u32 *__re
     block_exscan_512(cnt, fbase, nb, wsum);
     if (s_first && threadIdx.x < nb) pbeg_out[(coarse << d2) | threadIdx.x] = cbase[coarse] + fbase[threadIdx.x];
   }
-  for (u32 b = threadIdx.x; b < nb; b += PT_THREADS) cnt[b] = 0;
+  for (u32 b = threadIdx.x; b < nb; b += THREADS) cnt[b] = 0;
   __syncthreads();
   if (LEVEL == 2) { t_beg = s_beg; t_cnt = s_cnt; }
   u64 key[PT_IPT];
   u32 val[PT_IPT], binrank[PT_IPT];                           // bin << 16 | rank inside (tile, bin); ~0: none
 #pragma unroll
   for (u32 q = 0; q < PT_IPT; q++) {
-    const u32 j = threadIdx.x + q * PT_THREADS;
+    const u32 j = threadIdx.x + q * THREADS;
     binrank[q] = NONE32;
     if (j < t_cnt) {
       bool ok = true;
@@ -248,7 +252,7 @@ k_pt_scatter(SRC src, u32 n_reads, const u64 *__restrict__ k_in, const u32 *__re
     }
   __syncthreads();
   const u32 total = loff[nb];
-  for (u32 s = threadIdx.x; s < total; s += PT_THREADS) {
+  for (u32 s = threadIdx.x; s < total; s += THREADS) {
     const u32 bin = sbin[s];
     const u32 within = s - loff[bin];
     if (within >= room[bin]) continue;
@@ -556,8 +560,9 @@ k_unperm_bins(const u32 *__restrict__ vals, const u32 *__restrict__ pslot, const
 
 // PACKED: one u32 per read (multi-GPU return stream); else cluster_id u32 + keep u8.  WSHIFT: 14
 // (64 KiB window, two workgroups per CU) or 15 (read sets beyond 32 M reads)
+#define UW_THREADS 1024u
 template <bool PACKED, u32 WSHIFT>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(UW_THREADS)
 k_unperm_window(const u64 *__restrict__ rec, u32 *__restrict__ ucur, u32 n_reads,
                 u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
   HUMID_GUARD_LAST_VGPR();
@@ -567,30 +572,38 @@ k_unperm_window(const u64 *__restrict__ rec, u32 *__restrict__ ucur, u32 n_reads
   const u32 bin = blockIdx.x;
   const u32 r0 = bin << wshift;
   if (r0 >= n_reads) return;
-  for (u32 j = threadIdx.x; j < W; j += 512) win[j] = 0;
-  __syncthreads();
-  u32 n = ucur[bin];
+  u32 n = ucur[bin];                                          // (requested first: it is back when the window is clear)
+  for (u32 j = threadIdx.x; j < W; j += UW_THREADS) win[j] = 0;
   if (n > W) n = W;                                           // never beyond the bin's room
   __syncthreads();
   if (threadIdx.x == 0) ucur[bin] = 0;                        // the next pass finds its cursors at zero (no memset in front of it)
   const u64 *rb = rec + r0;
-  for (u32 j = threadIdx.x; j < n; j += 512) {
-    const u64 x = rb[j];
-    win[(u32)x & (W - 1)] = (u32)(x >> 32);
+  for (u32 j0 = 0; j0 < n; j0 += 8 * UW_THREADS) {            // eight records per thread in flight
+    u64 x[8];
+#pragma unroll
+    for (u32 q = 0; q < 8; q++) {
+      const u32 j = j0 + q * UW_THREADS + threadIdx.x;
+      x[q] = j < n ? rb[j] : ~0ull;
+    }
+#pragma unroll
+    for (u32 q = 0; q < 8; q++) {
+      const u32 j = j0 + q * UW_THREADS + threadIdx.x;
+      if (j < n) win[(u32)x[q] & (W - 1)] = (u32)(x[q] >> 32);
+    }
   }
   __syncthreads();
   const u32 cntw = (n_reads - r0 < W) ? n_reads - r0 : W;
   if (PACKED) {
-    for (u32 j = threadIdx.x; j < cntw; j += 512) cluster_id[r0 + j] = win[j];
+    for (u32 j = threadIdx.x; j < cntw; j += UW_THREADS) cluster_id[r0 + j] = win[j];
   } else {
-    for (u32 j = threadIdx.x; j < cntw; j += 512) cluster_id[r0 + j] = win[j] & 0x7fffffffu;
+    for (u32 j = threadIdx.x; j < cntw; j += UW_THREADS) cluster_id[r0 + j] = win[j] & 0x7fffffffu;
     // keep flags: four per thread, one 4-byte store (r0 and W are multiples of 4)
     u32 *k4 = (u32 *)(keep + r0);
     const u32 n4 = (((uintptr_t)keep & 3) == 0) ? cntw >> 2 : 0u;
-    for (u32 j = threadIdx.x; j < n4; j += 512)
+    for (u32 j = threadIdx.x; j < n4; j += UW_THREADS)
       k4[j] = (win[4 * j] >> 31) | ((win[4 * j + 1] >> 31) << 8) | ((win[4 * j + 2] >> 31) << 16) |
               ((win[4 * j + 3] >> 31) << 24);
-    for (u32 j = (n4 << 2) + threadIdx.x; j < cntw; j += 512) keep[r0 + j] = (u8)(win[j] >> 31);
+    for (u32 j = (n4 << 2) + threadIdx.x; j < cntw; j += UW_THREADS) keep[r0 + j] = (u8)(win[j] >> 31);
   }
 }
 

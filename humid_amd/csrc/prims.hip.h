@@ -211,6 +211,7 @@ k_ps_scan_tiny(In in, u32 n, T *out) {
 // so every tile a workgroup waits for is running.  Launches that share a PsChain must be ordered (one stream).
 #define PS_CHAIN_WGS 64u
 #define PS_CHAIN_MAX (PS_CHAIN_WGS * PS_SMALL_THREADS * 8u)
+#define PS_CHAIN_MAX32 (PS_CHAIN_WGS * PS_SMALL_THREADS * 16u)   // 4-byte items: 16 per thread still fit the LDS staging (70 KB)
 struct PsChain {
   unsigned long long val[PS_CHAIN_WGS];
   u32 flag[PS_CHAIN_WGS];
@@ -283,7 +284,7 @@ static inline size_t ps_scan_scratch_items(u64 n) { return n <= PS_SMALL_MAX ? 0
 template <class T, class In>
 static inline hipError_t ps_exscan(In in, T *out, u64 n, T *scratch, hipStream_t st, PsChain *chain = nullptr, u32 *epoch = nullptr) {
   if (n == 0) return hipSuccess;
-  if (chain && n > 2048 && n <= PS_CHAIN_MAX) {
+  if (chain && n > 2048 && n <= (sizeof(T) == 4 ? PS_CHAIN_MAX32 : PS_CHAIN_MAX)) {
     if (++*epoch == 0) ++*epoch;
     const u32 per = (u32)((n + PS_CHAIN_WGS * PS_SMALL_THREADS - 1) / (PS_CHAIN_WGS * PS_SMALL_THREADS));   // items per thread at 64 workgroups
     if (per <= 1)
@@ -292,8 +293,10 @@ static inline hipError_t ps_exscan(In in, T *out, u64 n, T *scratch, hipStream_t
       hipLaunchKernelGGL((k_ps_scan_chain<T, In, 2>), dim3((u32)((n + 2047) / 2048)), dim3(PS_SMALL_THREADS), 0, st, in, (u32)n, out, chain, *epoch);
     else if (per <= 4)
       hipLaunchKernelGGL((k_ps_scan_chain<T, In, 4>), dim3((u32)((n + 4095) / 4096)), dim3(PS_SMALL_THREADS), 0, st, in, (u32)n, out, chain, *epoch);
-    else
+    else if (per <= 8)
       hipLaunchKernelGGL((k_ps_scan_chain<T, In, 8>), dim3((u32)((n + 8191) / 8192)), dim3(PS_SMALL_THREADS), 0, st, in, (u32)n, out, chain, *epoch);
+    else
+      hipLaunchKernelGGL((k_ps_scan_chain<T, In, (sizeof(T) == 4 ? 16 : 8)>), dim3((u32)((n + 16383) / 16384)), dim3(PS_SMALL_THREADS), 0, st, in, (u32)n, out, chain, *epoch);
     return hipGetLastError();
   }
   if (n <= PS_TINY_MAX) {
