@@ -1672,7 +1672,7 @@ static int stage_graph_compact(humid_ctx *c, const WT *g_word, const u32 *g_cnt,
     for (u32 seg = 0; seg < nseg; seg++) {
       if (seg == 0) {
         if (c->kev_on) HIPCHK(hipEventRecord(c->kev[20], st));
-        hipLaunchKernelGGL((k_pairs_append<true, WT>), dim3(blocks_for(U)), dim3(256), 0, st, g_word, (const u32 *)nullptr, U,
+        hipLaunchKernelGGL((k_pairs_append<true, WT>), dim3(blocks_for(U, PA_PPT * 256)), dim3(256), 0, st, g_word, (const u32 *)nullptr, U,
                            w_from<WT>(plan.mask[0]), d_masks, 0u, distance, walk_max, er, c->cg_bits.as<u32>(),
                            &c->d_ctr[CTR_BIGMASK], (u32 *)&c->d_ctr[CTR_EOVER]);
       } else {
@@ -1687,7 +1687,7 @@ static int stage_graph_compact(humid_ctx *c, const WT *g_word, const u32 *g_cnt,
         }
         ordered_seg[seg] = true;
         if (seg < 8 && c->kev_on) HIPCHK(hipEventRecord(c->kev[20 + 2 * seg], st));
-        hipLaunchKernelGGL((k_pairs_append<false, WT>), dim3(blocks_for(U)), dim3(256), 0, st, (const WT *)ws, (const u32 *)vs, U,
+        hipLaunchKernelGGL((k_pairs_append<false, WT>), dim3(blocks_for(U, PA_PPT * 256)), dim3(256), 0, st, (const WT *)ws, (const u32 *)vs, U,
                            w_from<WT>(plan.mask[seg]), d_masks, seg, distance, walk_max, er, c->cg_bits.as<u32>(),
                            &c->d_ctr[CTR_BIGMASK], (u32 *)&c->d_ctr[CTR_EOVER], seg_valid[seg]);
       }

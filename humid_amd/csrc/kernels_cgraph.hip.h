@@ -115,6 +115,10 @@ k_zero_many(ZeroList z) {
 // position with one pair -- nearly all that have any -- writes it from memory, the others walk again.
 // Both ends are marked in `bits`.  A region that is full keeps counting (the cursor says how much room
 // the search wants) and sets *overflow.
+// PA_PPT positions per thread (a workgroup takes PA_PPT x 256 consecutive positions, thread t the positions t, t + 256,
+// ...): the first two words of all its walks are requested together, and a launch has a quarter of the workgroups --
+// with one position per thread the 10^4 workgroups of ~3 us each were bound by how fast workgroups can be started.
+#define PA_PPT 4u
 template <bool PASS0, class WT>
 __global__ void __launch_bounds__(256)
 k_pairs_append(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, WT mask, EarlierMasksT<WT> em, u32 cb,
@@ -128,33 +132,44 @@ k_pairs_append(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, WT ma
   // n_valid: the walked order came from a padded grouping; had a coarse bin been full, words were dropped and the
   // order ends at *n_valid (what lies behind it was never written; the caller discards this search)
   if (n_valid && *n_valid < n) n = *n_valid;
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  u32 found = 0, first_off = 0;
-  WT wi;
-  u32 jend = 0;
-  if (i < n) {
-    wi = W[i];
-    const WT w1 = W[i + 1 < n ? i + 1 : i];          // requested together with W[i]: most walks end at this word
-    jend = (walk_max && n - i > walk_max + 1) ? i + walk_max + 1 : n;
+  const u32 i0 = blockIdx.x * (PA_PPT * 256u) + threadIdx.x;
+  u32 found[PA_PPT], first_off[PA_PPT], jend[PA_PPT];
+  WT wi[PA_PPT], w1[PA_PPT];
+#pragma unroll
+  for (u32 q = 0; q < PA_PPT; q++) {
+    const u32 i = i0 + q * 256u;
+    found[q] = 0; first_off[q] = 0; jend[q] = 0;
+    if (i < n) {
+      wi[q] = W[i];
+      w1[q] = W[i + 1 < n ? i + 1 : i];                // requested together with W[i]: most walks end at this word
+    }
+  }
+  u32 total_found = 0;
+#pragma unroll
+  for (u32 q = 0; q < PA_PPT; q++) {
+    const u32 i = i0 + q * 256u;
+    if (i >= n) continue;
+    jend[q] = (walk_max && n - i > walk_max + 1) ? i + walk_max + 1 : n;
     u32 j = i + 1;
-    for (; j < jend; j++) {
-      const WT x = w_xor(wi, j == i + 1 ? w1 : W[j]);
+    for (; j < jend[q]; j++) {
+      const WT x = w_xor(wi[q], j == i + 1 ? w1[q] : W[j]);
       if (w_hits(x, mask)) break;                    // left the bucket
       if (w_mismatch(x) > distance) continue;
       bool first = true;
 #pragma unroll
-      for (u32 q = 0; q < MAX_COMBOS; q++)
-        first = first && !(q < cb && !w_hits(x, em.m[q]));
+      for (u32 t = 0; t < MAX_COMBOS; t++)
+        first = first && !(t < cb && !w_hits(x, em.m[t]));
       if (!first) continue;
-      if (!found) first_off = j - i;
-      found++;
+      if (!found[q]) first_off[q] = j - i;
+      found[q]++;
     }
-    if (big && j == jend && jend < n && !w_hits(w_xor(wi, W[jend]), mask)) atomicOr(big, 1ull << cb);
+    if (big && j == jend[q] && jend[q] < n && !w_hits(w_xor(wi[q], W[jend[q]]), mask)) atomicOr(big, 1ull << cb);
+    total_found += found[q];
   }
   PH(1);
   // room for the workgroup's pairs: exclusive position of this thread's, one atomic per workgroup
   const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  u32 incl = found;
+  u32 incl = total_found;
   incl = wave_incl_scan(incl);
   if (lane == 63) lds[wv] = incl;
   __syncthreads();
@@ -162,34 +177,39 @@ k_pairs_append(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, WT ma
 #pragma unroll
   for (u32 k = 0; k < 4; k++) { if (k < wv) before += lds[k]; total += lds[k]; }
   PH(2);
-  if (total == 0) { PH(3); PH(4); PH_END(5, 4, (blockIdx.x & 63u) == 5u); return; }                              // (uniform)
+  if (total == 0) { PH(3); PH(4); PH_END(5, 4, (blockIdx.x & 15u) == 5u); return; }                              // (uniform)
   const u32 region = blockIdx.x % ER_REGIONS;
   if (threadIdx.x == 0) s_base = atomicAdd(&er.cur[region * ER_STRIDE], total);
   __syncthreads();
   PH(3);
-  if (threadIdx.x == 0) { PH(4); PH_END(5, 4, (blockIdx.x & 63u) == 5u); }   // 1 walk | 2 block scan | 3 region cursor | (4 -)
-  if (!found) return;
-  u32 at = s_base + before + incl - found;
-  if (at + found > er.cap_r) { *overflow = 1; if (at >= er.cap_r) return; }
+  if (threadIdx.x == 0) { PH(4); PH_END(5, 4, (blockIdx.x & 15u) == 5u); }   // 1 walks | 2 block scan | 3 region cursor | (4 -)
+  if (!total_found) return;
+  u32 at = s_base + before + incl - total_found;
+  if (at + total_found > er.cap_r) { *overflow = 1; if (at >= er.cap_r) return; }
   u64 *out = er.e + (size_t)region * er.cap_r;
-  const u32 ri = PASS0 ? i : V[i];
-  auto emit = [&](u32 j) {
-    if (at >= er.cap_r) return;
-    const u32 rj = PASS0 ? j : V[j];
-    out[at++] = ri < rj ? (((u64)ri << 32) | rj) : (((u64)rj << 32) | ri);
-    atomicOr(&bits[rj >> 5], 1u << (rj & 31));
-  };
-  atomicOr(&bits[ri >> 5], 1u << (ri & 31));
-  if (found == 1) { emit(i + first_off); return; }
-  for (u32 j = i + first_off; j < jend; j++) {
-    const WT x = w_xor(wi, W[j]);
-    if (w_hits(x, mask)) break;
-    if (w_mismatch(x) > distance) continue;
-    bool first = true;
 #pragma unroll
-    for (u32 q = 0; q < MAX_COMBOS; q++)
-      first = first && !(q < cb && !w_hits(x, em.m[q]));
-    if (first) emit(j);
+  for (u32 q = 0; q < PA_PPT; q++) {
+    if (!found[q]) continue;
+    const u32 i = i0 + q * 256u;
+    const u32 ri = PASS0 ? i : V[i];
+    auto emit = [&](u32 j) {
+      if (at >= er.cap_r) return;
+      const u32 rj = PASS0 ? j : V[j];
+      out[at++] = ri < rj ? (((u64)ri << 32) | rj) : (((u64)rj << 32) | ri);
+      atomicOr(&bits[rj >> 5], 1u << (rj & 31));
+    };
+    atomicOr(&bits[ri >> 5], 1u << (ri & 31));
+    if (found[q] == 1) { emit(i + first_off[q]); continue; }
+    for (u32 j = i + first_off[q]; j < jend[q]; j++) {
+      const WT x = w_xor(wi[q], W[j]);
+      if (w_hits(x, mask)) break;
+      if (w_mismatch(x) > distance) continue;
+      bool first = true;
+#pragma unroll
+      for (u32 t = 0; t < MAX_COMBOS; t++)
+        first = first && !(t < cb && !w_hits(x, em.m[t]));
+      if (first) emit(j);
+    }
   }
 }
 
