@@ -271,12 +271,14 @@ def main():
             ks[k] /= max(a.steps, 1)
         return dt, ks, last
 
-    DETAIL = ("ms_k_pairs", "ms_k_cluster", "ms_k_map", "ms_k_part", "ms_k_unperm")
+    DETAIL = ("ms_k_pairs", "ms_k_cluster", "ms_k_map", "ms_k_part", "ms_k_unperm", "ms_count", "ms_neighbours", "ms_cluster",
+              "ms_map")
 
     def detail_times(step, set_option, ks):
-        """the per-kernel event times of the library are off in the timed passes (their 13 event records
-        cost 2-4 % of a pass); three more passes, untimed, with them on fill the other kernels' columns.
-        The dominant kernel's time (ms_k_insert) stays the one measured inside the timed passes."""
+        """the per-kernel and per-stage event times of the library are off in the timed passes (an event record
+        between two kernels is a marker the second one waits behind: the 17 of them cost 5-8 % of a pass); three
+        more passes, untimed, with them on fill the other kernels' and the stages' columns.  The dominant
+        kernel's time (ms_k_insert) and ms_total stay the ones measured inside the timed passes."""
         try:
             set_option("kernel_timing", 1)
         except Exception:

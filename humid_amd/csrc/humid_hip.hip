@@ -169,6 +169,8 @@ struct humid_ctx {
   DBuf deg, nbr_off, nbr_idx, seg_k0, seg_v0, seg_ks, seg_vs, seg_ws, csize, cur;
   DBuf parent, mk0, mk1, cl_of, maxleaf, cl_size, flag, pos, cid, ismax, stk, tmp, scratch;
   hipEvent_t ev[6] = {};
+  bool lean_events = false;  // set by run_device while the per-kernel timing is off: only ev[0], ev[4] and the count kernel's pair are recorded
+                             // (an event record between two kernels is a marker the second one waits behind: ~4 us of idle GPU each, 8 per pass)
   bool kev_on = false;       // option "kernel_timing": events around the single kernels beyond the count kernel's kev[0..1] (13 more records per pass: 20-45 us)
   hipEvent_t kev[44] = {};   // per-kernel timing: [0,1] insert, [2,3] cluster, [4..19] pairs fill, [20..35] pairs count
   bool have_run = false;     // a full dedup run completed (all accessors valid)
@@ -519,7 +521,7 @@ static int stage_count_global(humid_ctx *c, const u64 *d_words, const u8 *d_filt
   const u32 U = (u32)c->h_ctr[CTR_UNIQUE];
   s.usable = c->usable = c->h_ctr[CTR_USABLE];
   s.unique = c->U = U;
-  if (U == 0) { HIPCHK(hipEventRecord(c->ev[1], st)); return HUMID_OK; }
+  if (U == 0) { if (!c->lean_events) HIPCHK(hipEventRecord(c->ev[1], st)); return HUMID_OK; }
   ENSURE(c->s_word, (size_t)U * 8);
   ENSURE(c->s_slot, (size_t)U * 4);
   ENSURE(c->s_cnt, (size_t)U * 4);
@@ -528,7 +530,7 @@ static int stage_count_global(humid_ctx *c, const u64 *d_words, const u8 *d_filt
                            c->s_slot.as<u32>(), U, 0, 2 * word_nt));
   hipLaunchKernelGGL(k_post_sort, dim3(blocks_for(U)), dim3(256), 0, st, c->s_slot.as<u32>(),
                      c->table.as<Slot>(), U, c->s_cnt.as<u32>(), c->s_first.as<u32>());
-  HIPCHK(hipEventRecord(c->ev[1], st));
+  if (!c->lean_events) HIPCHK(hipEventRecord(c->ev[1], st));
   HIPCHK(hipGetLastError());
   return HUMID_OK;
 }
@@ -712,7 +714,7 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   const u32 U = (u32)c->h_ctr[CTR_UNIQUE];
   s.usable = c->usable = c->h_ctr[CTR_USABLE];
   s.unique = c->U = U;
-  if (U == 0) { HIPCHK(hipEventRecord(c->ev[1], st)); return HUMID_OK; }
+  if (U == 0) { if (!c->lean_events) HIPCHK(hipEventRecord(c->ev[1], st)); return HUMID_OK; }
   ENSURE(c->s_word, (size_t)(U + 1) * wsize);
   ENSURE(c->s_slot, (size_t)(U + 1) * 4);
   ENSURE(c->s_cnt, (size_t)(U + 1) * 4);
@@ -738,7 +740,7 @@ static int stage_count_lds(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
     hipLaunchKernelGGL(k_post_sort_padded, dim3(blocks_for(U)), dim3(256), 0, st, c->s_slot.as<u32>(),
                        c->pad_cf.as<uint2>(), U, c->s_cnt.as<u32>(), c->s_first.as<u32>());
   }
-  HIPCHK(hipEventRecord(c->ev[1], st));
+  if (!c->lean_events) HIPCHK(hipEventRecord(c->ev[1], st));
   HIPCHK(hipGetLastError());
   return HUMID_OK;
 }
@@ -820,7 +822,7 @@ static int stage_count_rec(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   hipLaunchKernelGGL(k_compact_padded8, dim3(blocks_for((u64)n_parts * 64)), dim3(256), 0, st, c->pad_word.as<u64>(),
                      c->pad_cf.as<uint2>(), (const u64 *)agg, (const u64 *)abase, n_parts, c->s_word.as<u64>(),
                      c->s_slot.as<u32>(), c->s_cnt.as<u32>(), c->s_first.as<u32>());
-  HIPCHK(hipEventRecord(c->ev[1], st));
+  if (!c->lean_events) HIPCHK(hipEventRecord(c->ev[1], st));
   HIPCHK(hipGetLastError());
   TRY(read_counters(c, (const u32 *)(abase + n_parts), (const u32 *)(abase + n_parts) + 1));   // U, usable
   if (getenv("HUMID_TRACE_COUNT"))
@@ -915,7 +917,7 @@ static int stage_count_rec_wide(humid_ctx *c, const W2 *d_words, const u8 *d_fil
   hipLaunchKernelGGL(k_compact_padded8_wide, dim3(blocks_for((u64)n_parts * 64)), dim3(256), 0, st, (const W2 *)c->pad_word.as<W2>(),
                      (const uint2 *)c->pad_cf.as<uint2>(), (const u64 *)agg, (const u64 *)abase, n_parts, c->s_word.as<W2>(),
                      c->s_slot.as<u32>(), c->s_cnt.as<u32>(), c->s_first.as<u32>());
-  HIPCHK(hipEventRecord(c->ev[1], st));
+  if (!c->lean_events) HIPCHK(hipEventRecord(c->ev[1], st));
   HIPCHK(hipGetLastError());
   TRY(read_counters(c, (const u32 *)(abase + n_parts), (const u32 *)(abase + n_parts) + 1));   // U, usable
   if (getenv("HUMID_TRACE_COUNT"))
@@ -1100,7 +1102,7 @@ static int stage_count_wide(humid_ctx *c, const W2 *d_words, const u8 *d_filt, u
   if (U)
     hipLaunchKernelGGL(k_wide_counts, dim3(blocks_for(U)), dim3(256), 0, st, c->w_start.as<u32>(), U,
                        c->s_cnt.as<u32>(), c->s_slot.as<u32>());
-  HIPCHK(hipEventRecord(c->ev[1], st));
+  if (!c->lean_events) HIPCHK(hipEventRecord(c->ev[1], st));
   HIPCHK(hipGetLastError());
   return HUMID_OK;
 }
@@ -1459,7 +1461,7 @@ static int stage_graph(humid_ctx *c, const WT *g_word, const u32 *g_cnt, u32 U, 
     hipLaunchKernelGGL(k_sort_lists, dim3(blocks_for(U)), dim3(256), 0, st, c->nbr_off.as<u32>(), U,
                        c->nbr_idx.as<u32>());
   }
-  HIPCHK(hipEventRecord(c->ev[2], st));
+  if (!c->lean_events) HIPCHK(hipEventRecord(c->ev[2], st));
 
   // clusters
   TRY(cluster_stage(c, g_cnt, U, M, Mbig, method));
@@ -1765,7 +1767,7 @@ static int stage_graph_compact(humid_ctx *c, const WT *g_word, const u32 *g_cnt,
   s.edges = c->E = E;
   s.nonsingle = c->M = M;
   c->cg_M = (u32)M;
-  HIPCHK(hipEventRecord(c->ev[2], st));
+  if (!c->lean_events) HIPCHK(hipEventRecord(c->ev[2], st));
   TRY(cg_cluster_rest(c, U, M, Mbig, method));
   const GraphArrays g = cg_arrays(c);
   const bool own = ((const void *)g_word == c->s_word.p) && U == (u32)c->U;
@@ -2229,7 +2231,7 @@ static int unpermute_tiled(humid_ctx *c, u32 N, bool packed, u32 *d_cid, u8 *d_k
   else
   hipLaunchKernelGGL(k_unperm_bins, dim3((N + PT_TILE - 1) / PT_TILE), dim3(1024), 0, st, c->pk_vals.as<u32>(),
                      c->pslot.as<u32>(), c->slot_out.as<u64>(), n_pos_dev, N, N, wshift, n_bins, ucur, rec);
-  HIPCHK(hipEventRecord(ev_mid, st));
+  if (!c->lean_events) HIPCHK(hipEventRecord(ev_mid, st));
   if (packed) {
     if (wshift == 14) hipLaunchKernelGGL((k_unperm_window<true, 14>), dim3(n_bins), dim3(UW_THREADS), 0, st, rec, ucur, N, d_cid, d_keep);
     else hipLaunchKernelGGL((k_unperm_window<true, 15>), dim3(n_bins), dim3(UW_THREADS), 0, st, rec, ucur, N, d_cid, d_keep);
@@ -2255,7 +2257,7 @@ static int stage_map(humid_ctx *c, const u32 *l_cid, const u8 *l_ismax, u32 N, u
   if (U > 0 && !fused)
     hipLaunchKernelGGL(k_slot_results, dim3(blocks_for(U)), dim3(256), 0, st, l_cid, l_ismax,
                        c->s_first.as<u32>(), c->s_slot.as<u32>(), U, c->slot_out.as<u64>());
-  HIPCHK(hipEventRecord(c->ev[3], st));
+  if (!c->lean_events) HIPCHK(hipEventRecord(c->ev[3], st));
   if (c->last_count_lds) {
     bool tiled = false;
     TRY(unpermute_tiled(c, N, false, d_cid, d_keep, c->kev[36], &tiled));
@@ -2317,6 +2319,10 @@ static int run_device(humid_ctx *c, const WT *d_words, const u8 *d_filt, u64 n_r
   c->word_nt = word_nt; c->distance = distance; c->method = method;
   c->gU = 0;
   if (N == 0) { if (sum) *sum = s; c->have_run = c->have_graph = true; return HUMID_OK; }
+  // the stages' own events only with the per-kernel timing (ms_count .. ms_map are 0 without it; ms_total and the
+  // count kernel's time are always measured)
+  struct LeanEvents { humid_ctx *c; ~LeanEvents() { c->lean_events = false; } } lean_guard{c};
+  c->lean_events = !c->kev_on && getenv("HUMID_ALL_EVENTS") == nullptr;
   if constexpr (WIDE) TRY(stage_count_wide(c, d_words, d_filt, N, word_nt, s));
   else TRY(stage_count(c, d_words, d_filt, N, word_nt, 0ull, ~0ull, 0, s));
   const u32 U = (u32)c->U;
@@ -2353,10 +2359,14 @@ static int run_device(humid_ctx *c, const WT *d_words, const u8 *d_filt, u64 n_r
   // (the last host wait watches a mapped flag, not the stream: the runtime may not have seen the last
   // event's signal yet -- "device not ready" from hipEventElapsedTime once in ~10^3 runs)
   HIPCHK(hipEventSynchronize(c->ev[4]));
-  HIPCHK(hipEventElapsedTime(&s.ms_count, c->ev[0], c->ev[1]));
-  HIPCHK(hipEventElapsedTime(&s.ms_neighbours, c->ev[1], c->ev[2]));
-  HIPCHK(hipEventElapsedTime(&s.ms_cluster, c->ev[2], c->ev[3]));
-  HIPCHK(hipEventElapsedTime(&s.ms_map, c->ev[3], c->ev[4]));
+  const bool lean = c->lean_events;
+  c->lean_events = false;
+  if (!lean) {                                               // the stages' shares: option kernel_timing
+    HIPCHK(hipEventElapsedTime(&s.ms_count, c->ev[0], c->ev[1]));
+    HIPCHK(hipEventElapsedTime(&s.ms_neighbours, c->ev[1], c->ev[2]));
+    HIPCHK(hipEventElapsedTime(&s.ms_cluster, c->ev[2], c->ev[3]));
+    HIPCHK(hipEventElapsedTime(&s.ms_map, c->ev[3], c->ev[4]));
+  }
   HIPCHK(hipEventElapsedTime(&s.ms_total, c->ev[0], c->ev[4]));
   HIPCHK(hipEventElapsedTime(&s.ms_k_insert, c->kev[0], c->kev[1]));
   if (!c->kev_on) s.ms_k_map = s.ms_map;
@@ -3219,7 +3229,7 @@ static int run_exchange_impl(humid_ctx *c, const humid_comm *cm, const uint64_t 
       src.er.e = nullptr; src.er.cap_r = 0; src.er.cur = c->cg_cur.as<u32>(); src.er.far = c->e_edges.as<u64>(); src.er.n_far = (u32)E_e;
       src.recs = nullptr; src.n_recs = 0; src.segs = nullptr; src.cnt_by_id = gc; src.n_ids = n_ids;
       src.pairs_bound = E_e;
-      HIPCHK(hipEventRecord(c->ev[2], st));
+      if (!c->lean_events) HIPCHK(hipEventRecord(c->ev[2], st));
       TRY(cg_build(c, src, method, cgs));
       if (c->h_ctr[CTR_OVERFULL]) return fail(c, HUMID_E_INVALID, "internal: an edit-distance pair outside the unique words");
       M_e = cgs.M;
@@ -3630,7 +3640,7 @@ static int run_exchange_impl(humid_ctx *c, const humid_comm *cm, const uint64_t 
     src.er.e = nullptr; src.er.cap_r = 0; src.er.cur = c->cg_cur.as<u32>(); src.er.far = nullptr; src.er.n_far = 0;
     src.recs = nullptr; src.n_recs = 0; src.segs = &segs; src.cnt_by_id = nullptr; src.n_ids = n_ids;
     src.pairs_bound = n_recs_all;
-    HIPCHK(hipEventRecord(c->ev[2], st));
+    if (!c->lean_events) HIPCHK(hipEventRecord(c->ev[2], st));
     TRY(cg_build(c, src, method, cgs));
     if (c->h_ctr[CTR_OVERFULL]) return fail(c, HUMID_E_INVALID, "a pair record with an index outside the unique words");
     M_mine = cgs.M;
