@@ -20,7 +20,7 @@ def _sources():
     for d, _, fs in os.walk(os.path.join(HERE, "csrc")):
         if os.sep + "host" in d:
             continue
-        out += [os.path.join(d, f) for f in fs if f.endswith((".hip", ".h", ".hpp"))]
+        out += [os.path.join(d, f) for f in fs if f.endswith((".hip", ".h", ".hpp", ".cpp"))]
     return out
 
 
@@ -31,11 +31,16 @@ def is_stale() -> bool:
     return any(os.path.getmtime(p) > t for p in _sources())
 
 
+# translation units of the library: the HIP one (pipeline, C ABI, exchange pass: kernels + host side) and the
+# host-only ones (plain C++ that hipcc compiles as such)
+HOST_UNITS = [os.path.join(HERE, "csrc", "shm.cpp")]
+
+
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return SO
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", SO, SRC]
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", SO, SRC] + HOST_UNITS
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=ROOT)

@@ -68,7 +68,7 @@ def main():
             fh.write('#include "common.hip.h"\n#undef HUMID_GUARD_LAST_VGPR\n#define HUMID_GUARD_LAST_VGPR()\n'
                      '#include "humid_hip.hip"\n')
         so2 = os.path.join(tmp, "noguard.so")
-        subprocess.check_call(["hipcc"] + build.HIPCC_FLAGS + ["-I", os.path.join(ROOT, "humid_amd", "csrc"), "-o", so2, src], cwd=ROOT)
+        subprocess.check_call(["hipcc"] + build.HIPCC_FLAGS + ["-I", os.path.join(ROOT, "humid_amd", "csrc"), "-o", so2, src] + build.HOST_UNITS, cwd=ROOT)
         show("the same sources with the guard defined away (scratch build, not shipped)", so2, names, tmp)
 
 
