@@ -1553,10 +1553,11 @@ static int cg_build(humid_ctx *c, CgSource &src, u32 method, CgStatus &out) {
                        g.deg, g.parent, by_count);
   }
   TRY(exscan_in<u32>(c, DegIn{g.deg, m_dev}, g.off, (u64)Mb + 1));
-  hipLaunchKernelGGL(k_comp_stats, dim3(blocks_for(Mb)), dim3(256), 0, st, g.deg, g.parent, Mb, g.csize, m_dev);
   {
+    // CSR rows and component sizes side by side (one launch: kernels_cgraph.hip.h)
     const u32 gx = (u32)std::min<u64>(std::max<u64>(blocks_for(std::max<u64>(src.er.cap_r, src.er.n_far)), 1), 4096);
-    hipLaunchKernelGGL(k_pairs_fill, dim3(gx, ER_REGIONS + 1), dim3(256), 0, st, src.er, (const u32 *)g.off, c->cg_curs.as<u32>(), g.idx, c->small.as<u32>());
+    hipLaunchKernelGGL(k_fill_and_stats, dim3(gx * (ER_REGIONS + 1) + blocks_for(Mb)), dim3(256), 0, st, src.er, (const u32 *)g.off,
+                       c->cg_curs.as<u32>(), g.idx, c->small.as<u32>(), gx, (const u32 *)g.deg, g.parent, Mb, g.csize, m_dev);
   }
   hipLaunchKernelGGL(k_sort_lists, dim3(blocks_for(Mb)), dim3(256), 0, st, (const u32 *)g.off, Mb, g.idx);
   if (c->kev_on) HIPCHK(hipEventRecord(c->kev[2], st));

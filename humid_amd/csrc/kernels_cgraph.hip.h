@@ -276,6 +276,40 @@ k_pairs_relabel(EdgeRegs er, BitRank br, const u32 *__restrict__ ncnt, u32 *deg,
   }
 }
 
+// k_pairs_fill and k_comp_stats in ONE launch (the first gx * (ER_REGIONS + 1) workgroups fill the CSR rows, the rest
+// flatten the forest and size the components): neither reads what the other writes, and each alone is one round of
+// workgroups whose time is a chain of memory round trips -- side by side the two chains overlap
+__global__ void __launch_bounds__(256)
+k_fill_and_stats(EdgeRegs er, const u32 *__restrict__ off, u32 *cur, u32 *__restrict__ idx, u32 *__restrict__ regions_max, u32 gx,
+                 const u32 *__restrict__ deg, u32 *P, u32 n, u32 *csize, const u32 *__restrict__ n_dev) {
+  HUMID_GUARD_LAST_VGPR();
+  const u32 nf = gx * (ER_REGIONS + 1);
+  if (blockIdx.x >= nf) {
+    const u32 u = (blockIdx.x - nf) * blockDim.x + threadIdx.x;
+    if (n_dev && *n_dev < n) n = *n_dev;
+    if (u >= n || deg[u] == 0) return;
+    const u32 root = uf_find(P, u);
+    P[u] = root;
+    atomicAdd(&csize[root], 1u);
+    return;
+  }
+  const u32 bx = blockIdx.x % gx, r = blockIdx.x / gx;
+  if (regions_max && blockIdx.x == 0 && threadIdx.x < 64) {
+    // the fullest region's cursor (what the search wanted of ONE region: all regions have the same room)
+    u32 c = er.cur[threadIdx.x * ER_STRIDE];
+#pragma unroll
+    for (u32 d = 32; d >= 1; d >>= 1) { const u32 y = __shfl_xor(c, d); c = y > c ? y : c; }
+    if (threadIdx.x == 0) regions_max[0] = c;
+  }
+  const u32 n_r = er_count(er, r);
+  for (u32 k = bx * blockDim.x + threadIdx.x; k < n_r; k += gx * blockDim.x) {
+    const u64 e = *er_at(er, r, k);
+    const u32 a = (u32)(e >> 32), b = (u32)e;
+    idx[off[a] + atomicAdd(&cur[a], 1u)] = b;
+    idx[off[b] + atomicAdd(&cur[b], 1u)] = a;
+  }
+}
+
 // CSR rows through per-row cursors (put in ascending order afterwards by k_sort_lists)
 __global__ void __launch_bounds__(256)
 k_pairs_fill(EdgeRegs er, const u32 *__restrict__ off, u32 *cur, u32 *__restrict__ idx, u32 *__restrict__ regions_max) {
