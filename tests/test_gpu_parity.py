@@ -482,6 +482,35 @@ def test_padded_partition_outgrown_by_duplicated_words(dd):
     dd.set_option("padded_partition", 1)
 
 
+@pytest.mark.parametrize("top30,n_special,expect_records", [(0x15555555, 40, True), (0x2aaaaaaa, 200, True), (0x3fffffff, 40, True),
+                                                            (0x3fffffff, 90, False)])
+def test_count_table_runs_and_spill(top30, n_special, expect_records):
+    """k_dedup_rec ranks the unique words of a bucket by their place in a table whose home function is monotone in
+    the word and which does not wrap: words that share bucket AND home bits form one run of
+    neighbouring entries and are ordered by comparing inside the run; a run that passes the table's spill entries
+    is an overflow and the read set is counted by the kernels of round 2.  n_special distinct words with the same
+    first 15 nucleotides (every bucket and home bit, whatever the bucket count) among 300 000 ordinary reads: runs
+    of 40 and 200 entries in the middle of the table and 40 words whose home is its LAST entry (they fit the 64 spill
+    entries) stay on the record path, 90 such words do not -- all against the oracle, unique words and their order
+    included.  Word-ordered buckets are FORCED (count_order = 1): left to itself the pipeline samples the reads first
+    and would not try ordered buckets on the fuller of these read sets at all."""
+    rng = np.random.default_rng(top30 & 0xffff)
+    words, filt = synth_words(300_000, 31, 24, p_sub=3e-3, p_n=1e-3)
+    low = rng.choice(1 << 18, size=n_special, replace=False).astype(np.uint64)
+    special = (np.uint64(top30) << np.uint64(18)) | low
+    special = np.repeat(special, rng.integers(1, 5, size=n_special))
+    words = np.concatenate([words, special])
+    filt = np.concatenate([filt, np.zeros(len(special), np.uint8)])
+    perm = rng.permutation(len(words))
+    words, filt = words[perm], filt[perm]
+    dq = humid_amd.Dedup()
+    dq.set_option("count_order", 1)
+    for rep in range(2):                                    # (the second run: what the context remembers of the first)
+        s = check_against_oracle(dq, words, filt, 24, 1, False, deep=(rep == 0))
+        assert bool(s.get("records8")) == expect_records, (s["count_mode_used"], s.get("records8"))
+    dq.close()
+
+
 def test_long_chain_component(dd):
     """a path-shaped component thousands of leaves deep (the reference recursion overflows here)"""
     # words 0..L-1 in unary-like Gray walk: consecutive words differ in one nucleotide
