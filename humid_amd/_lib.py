@@ -122,6 +122,8 @@ SYMBOLS = {
                                             C.POINTER(C.c_void_p), u64p]),
     "humid_stage_owner_perm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, u64p, u64p,
                                          C.c_uint32, C.POINTER(C.c_void_p), u64p]),
+    "humid_stage_owner_perm_wide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, u64p, u64p,
+                                              C.c_uint32, C.POINTER(C.c_void_p), u64p]),
     "humid_stage_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                       C.c_void_p, C.c_void_p]),
     "humid_dedup_run_exchange": (C.c_int, [C.c_void_p, C.POINTER(HumidComm), C.c_void_p, C.c_void_p, C.c_uint64,
@@ -166,7 +168,7 @@ def load(import_torch: bool = True):
             raise HumidLibraryError("%s does not export %s" % (SO_PATH, name)) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.humid_abi_version() != 4:
+    if lib.humid_abi_version() != 5:
         raise HumidLibraryError("ABI version mismatch")
     _LIB = lib
     return lib

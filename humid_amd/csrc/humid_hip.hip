@@ -3778,17 +3778,34 @@ int humid_at_least_double(humid_ctx *c, uint64_t a, uint64_t b, int *result) {
 }
 
 // ---- multi-GPU stages (device pointers; see humid_amd/sharded.py) ----------------------------
+// Two-word words (33 <= word_nt <= 64; two uint64 per word, 16-byte aligned) in the stages of the ALL-GATHER mode
+// (round 3: humid_stage_histogram, _count_dense, _unique, _graph, _graph_edges, _owner_perm): value ranges are ranges
+// of HEADS -- the top 64 bits of a word's 2n-bit value -- as in the exchange pass, so the histogram and the
+// splitters are those of 32-nt words over the heads.
+static int stage_heads(humid_ctx *c, const u64 *d_words, u32 n, u32 word_nt, const u64 **heads) {
+  if ((uintptr_t)d_words & 15) return fail(c, HUMID_E_INVALID, "wide words must be 16-byte aligned on the device");
+  ENSURE(c->xr_heads, (size_t)n * 8 + 16);
+  hipLaunchKernelGGL(k_wide_head64, dim3(blocks_for(n)), dim3(256), 0, c->stream, (const W2 *)d_words, n, 2 * (word_nt - 32),
+                     c->xr_heads.as<u64>(), 0u);
+  HIPCHK(hipGetLastError());
+  *heads = c->xr_heads.as<u64>();
+  return HUMID_OK;
+}
+
 int humid_stage_histogram(humid_ctx *c, const uint64_t *d_words, const uint8_t *d_filtered,
                           uint64_t n_reads, uint32_t word_nt, uint32_t bits, uint32_t *d_hist) {
   if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
-  TRY(check_run_args(c, n_reads, word_nt, 0));
+  TRY(check_run_args(c, n_reads, word_nt, 0, 64));
   if (bits == 0 || bits > 12 || bits > 2 * word_nt || !d_hist) return fail(c, HUMID_E_INVALID, "bits must be 1..min(12, 2*word_nt)");
   HIPCHK(hipSetDevice(c->device));
   const u32 n_bins = 1u << bits;
   HIPCHK(hipMemsetAsync(d_hist, 0, n_bins * 4, c->stream));
-  if (n_reads)
-    hipLaunchKernelGGL(k_top_hist, dim3(256), dim3(1024), n_bins * 4, c->stream, d_words, d_filtered,
+  if (n_reads) {
+    const u64 *keys = d_words;
+    if (word_nt > 32) TRY(stage_heads(c, d_words, (u32)n_reads, word_nt, &keys));
+    hipLaunchKernelGGL(k_top_hist, dim3(256), dim3(1024), n_bins * 4, c->stream, keys, d_filtered,
                        (u32)n_reads, (u64)0, word_nt >= 32 ? (u64)1 : ((u64)1 << (64 - 2 * word_nt)), bits, d_hist);
+  }
   HIPCHK(hipGetLastError());
   return HUMID_OK;              // queued on the context's stream; no host value is returned
 }
@@ -3826,7 +3843,10 @@ int humid_stage_count_dense(humid_ctx *c, const uint64_t *d_words, const uint8_t
   c->have_run = c->have_graph = false;
   c->graph_mode = false;
   c->dense_mode = false;
-  TRY(check_run_args(c, n_reads, word_nt, 0));
+  TRY(check_run_args(c, n_reads, word_nt, 0, 64));
+  const bool wide = word_nt > 32;
+  if (wide && d_filtered == nullptr)
+    return fail(c, HUMID_E_UNSUPPORTED, "two-word words in the stage-by-stage exchange form: use humid_dedup_run_exchange");
   if (!shard_begin || !counts || n_shards == 0 || n_shards > 4096) return fail(c, HUMID_E_INVALID, "bad argument");
   // d_filtered == NULL: every read is usable and lies in [range_lo, range_hi] (exchange mode: the
   // reads were routed here because they do); the array is counted as it stands, no compaction
@@ -3860,8 +3880,10 @@ int humid_stage_count_dense(humid_ctx *c, const uint64_t *d_words, const uint8_t
     return HUMID_OK;
   }
   ENSURE(c->opos, ((size_t)N + 1) * 4);
+  const u64 *range_keys = d_words;                      // what the range is a range of: the words, or their heads
+  if (wide) TRY(stage_heads(c, d_words, N, word_nt, &range_keys));
   {
-    ComposeIn<OwnedRangeFlagOp, IotaIn> fin{OwnedRangeFlagOp{d_words, d_filtered, range_lo, range_hi, N}, IotaIn{}};
+    ComposeIn<OwnedRangeFlagOp, IotaIn> fin{OwnedRangeFlagOp{range_keys, d_filtered, range_lo, range_hi, N}, IotaIn{}};
     TRY(exscan_in<u32>(c, fin, c->opos.as<u32>(), (u64)N + 1));
   }
   std::vector<u32> got(n_shards + 1);
@@ -3872,7 +3894,17 @@ int humid_stage_count_dense(humid_ctx *c, const uint64_t *d_words, const uint8_t
   for (u32 q = 0; q < n_shards; q++) counts[q] = got[q + 1] - got[q];
   c->N = n_own;
   if (n_own == 0) return HUMID_OK;
-  ENSURE(c->own_words, (size_t)n_own * 8);
+  ENSURE(c->own_words, (size_t)n_own * (wide ? 16 : 8));
+  if (wide) {
+    hipLaunchKernelGGL(k_gather_owned_w2, dim3(grid_stride_blocks(N)), dim3(256), 0, st, (const W2 *)d_words, range_keys, d_filtered,
+                       (const u32 *)c->opos.as<u32>(), range_lo, range_hi, N, c->own_words.as<W2>());
+    HIPCHK(hipGetLastError());
+    TRY(stage_count_wide(c, c->own_words.as<W2>(), nullptr, n_own, word_nt, s));
+    HIPCHK(hipStreamSynchronize(st));
+    if (n_unique) *n_unique = c->U;
+    if (n_usable) *n_usable = c->usable;
+    return HUMID_OK;
+  }
   hipLaunchKernelGGL(k_gather_owned, dim3(grid_stride_blocks(N)), dim3(256), 0, st, d_words, d_filtered,
                      c->opos.as<u32>(), range_lo, range_hi, N, c->own_words.as<u64>());
   HIPCHK(hipGetLastError());
@@ -3941,7 +3973,7 @@ int humid_stage_graph(humid_ctx *c, const uint64_t *d_g_word, const uint32_t *d_
   if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
   c->have_graph = false;
   c->graph_mode = false;
-  TRY(check_run_args(c, n_unique, word_nt, method));
+  TRY(check_run_args(c, n_unique, word_nt, method, 64));
   HIPCHK(hipSetDevice(c->device));
   humid_summary s;
   memset(&s, 0, sizeof s);
@@ -3953,6 +3985,10 @@ int humid_stage_graph(humid_ctx *c, const uint64_t *d_g_word, const uint32_t *d_
   if (n_unique) {
     if (!d_g_word || !d_g_count) return fail(c, HUMID_E_INVALID, "null buffer");
     u32 nps = 0;
+    if (word_nt > 32) {
+      if ((uintptr_t)d_g_word & 15) return fail(c, HUMID_E_INVALID, "wide words must be 16-byte aligned on the device");
+      TRY(stage_graph<W2>(c, (const W2 *)d_g_word, d_g_count, (u32)n_unique, word_nt, distance, method, s, nps));
+    } else
     TRY(stage_graph(c, d_g_word, d_g_count, (u32)n_unique, word_nt, distance, method, s, nps));
     TRY(n_clusters_from_scan(c, (u32)n_unique, &c->C));
     s.clusters = c->C;
@@ -4002,7 +4038,7 @@ int humid_stage_graph_edges(humid_ctx *c, const uint64_t *d_g_word, const uint32
   if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
   c->have_graph = false;
   c->graph_mode = false;
-  TRY(check_run_args(c, n_unique, word_nt, method));
+  TRY(check_run_args(c, n_unique, word_nt, method, 64));
   if (n_edges >= 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "2*edges exceeds 32 bits");
   HIPCHK(hipSetDevice(c->device));
   humid_summary s;
@@ -4016,6 +4052,11 @@ int humid_stage_graph_edges(humid_ctx *c, const uint64_t *d_g_word, const uint32
     if (!d_g_word || !d_g_count || (n_edges && !d_edges)) return fail(c, HUMID_E_INVALID, "null buffer");
     u32 nps = 0;
     static const u64 no_edges = 0;
+    if (word_nt > 32) {
+      if ((uintptr_t)d_g_word & 15) return fail(c, HUMID_E_INVALID, "wide words must be 16-byte aligned on the device");
+      TRY(stage_graph<W2>(c, (const W2 *)d_g_word, d_g_count, (u32)n_unique, word_nt, distance, method, s, nps,
+                          n_edges ? d_edges : &no_edges, n_edges));
+    } else
     TRY(stage_graph(c, d_g_word, d_g_count, (u32)n_unique, word_nt, distance, method, s, nps,
                     n_edges ? d_edges : &no_edges, n_edges));
     TRY(n_clusters_from_scan(c, (u32)n_unique, &c->C));
@@ -4697,7 +4738,14 @@ int humid_stage_owned_results(humid_ctx *c, const uint32_t *d_local_cluster_id, 
 int humid_stage_owner_perm(humid_ctx *c, const uint64_t *d_words, const uint8_t *d_filtered, uint64_t n_reads,
                            const uint64_t *range_lo, const uint64_t *range_hi, uint32_t n_ranks,
                            const uint32_t **d_perm, uint64_t *counts) {
+  return humid_stage_owner_perm_wide(c, d_words, d_filtered, n_reads, 32, range_lo, range_hi, n_ranks, d_perm, counts);
+}
+
+int humid_stage_owner_perm_wide(humid_ctx *c, const uint64_t *d_words, const uint8_t *d_filtered, uint64_t n_reads,
+                                uint32_t word_nt, const uint64_t *range_lo, const uint64_t *range_hi, uint32_t n_ranks,
+                                const uint32_t **d_perm, uint64_t *counts) {
   if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
+  if (word_nt == 0 || word_nt > 64) return fail(c, HUMID_E_UNSUPPORTED, "word_nt must be 1 .. 64");
   if (!range_lo || !range_hi || !counts || !d_perm || n_ranks == 0) return fail(c, HUMID_E_INVALID, "bad argument");
   if (n_ranks > MAX_RANKS) return fail(c, HUMID_E_UNSUPPORTED, "more than %d ranks", MAX_RANKS);
   if (n_reads > 0x7fffffffull) return fail(c, HUMID_E_OVERFLOW, "n_reads exceeds 2^31-1");
@@ -4713,7 +4761,9 @@ int humid_stage_owner_perm(humid_ctx *c, const uint64_t *d_words, const uint8_t 
   ENSURE(c->owner, (size_t)n);
   ENSURE(c->owner_sorted, (size_t)n);
   ENSURE(c->perm, (size_t)n * 4);
-  hipLaunchKernelGGL(k_owner_of, dim3(blocks_for(n)), dim3(256), 0, st, d_words, d_filtered, n, rg, n_ranks,
+  const u64 *range_keys = d_words;                      // (two-word words: their heads)
+  if (word_nt > 32) TRY(stage_heads(c, d_words, n, word_nt, &range_keys));
+  hipLaunchKernelGGL(k_owner_of, dim3(blocks_for(n)), dim3(256), 0, st, range_keys, d_filtered, n, rg, n_ranks,
                      c->owner.as<u8>());
   {
     TRY((sort_pairs_in<u8, u32>(c, PtrIn<u8>{c->owner.as<u8>()}, c->owner_sorted.as<u8>(), IotaIn{}, c->perm.as<u32>(), n, 0, 8)));

@@ -141,6 +141,18 @@ k_gather_owned(const u64 *__restrict__ words, const u8 *__restrict__ filtered, c
   }
 }
 
+// the same for two-word words: the range is one of HEADS (k_wide_head64), the words follow
+__global__ void __launch_bounds__(256)
+k_gather_owned_w2(const W2 *__restrict__ words, const u64 *__restrict__ heads, const u8 *__restrict__ filtered,
+                  const u32 *__restrict__ opos, u64 lo, u64 hi, u32 n_reads, W2 *__restrict__ own_words) {
+  HUMID_GUARD_LAST_VGPR();
+  for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
+    if (filtered[r]) continue;
+    const u64 h = heads[r];
+    if (h >= lo && h <= hi) own_words[opos[r]] = words[r];
+  }
+}
+
 struct OwnedFlagOp {            // 1 for the reads this rank counted (global-table variant)
   const u32 *slot_of_read;
   u32 n;

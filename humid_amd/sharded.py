@@ -110,8 +110,8 @@ class HipStageOps(Context):
 
     def histogram(self, g_w, g_f, word_nt, bits):
         hist = torch.zeros(1 << bits, dtype=torch.int32, device=self.device)
-        self._call(self._lib.humid_stage_histogram, self._p(g_w), self._p(g_f), g_w.numel(), word_nt, bits,
-                   C.c_void_p(hist.data_ptr()))
+        self._call(self._lib.humid_stage_histogram, self._p(g_w), self._p(g_f), g_f.numel(), word_nt, bits,
+                   C.c_void_p(hist.data_ptr()))             # (g_f: one flag per read; g_w has two entries per read beyond 32 nt)
         return hist
 
     def count_dense(self, g_w, g_f, word_nt, lo, hi, shard_begin):
@@ -122,7 +122,8 @@ class HipStageOps(Context):
         counts = (C.c_uint64 * n)()
         nu, ns = C.c_uint64(), C.c_uint64()
         self.set_option("count_mode", 0)
-        self._call(self._lib.humid_stage_count_dense, self._p(g_w), self._p(g_f), g_w.numel(), word_nt,
+        self._wpr = 2 if word_nt > 32 else 1
+        self._call(self._lib.humid_stage_count_dense, self._p(g_w), self._p(g_f), g_w.numel() // self._wpr, word_nt,
                    C.c_uint64(lo), C.c_uint64(hi), sb, n, counts, C.byref(nu), C.byref(ns))
         self._u = nu.value
         return nu.value, ns.value, [int(x) for x in counts]
@@ -136,6 +137,7 @@ class HipStageOps(Context):
     def count(self, g_w, g_f, word_nt, lo, hi, expected):
         self.set_option("count_mode", 1)      # partial range + slot_of_read over N: global table
         nu, ns = C.c_uint64(), C.c_uint64()
+        self._wpr = 1
         self._n_reads = g_w.numel()
         self._call(self._lib.humid_stage_count, self._p(g_w), self._p(g_f), g_w.numel(), word_nt,
                    C.c_uint64(lo), C.c_uint64(hi), expected, C.byref(nu), C.byref(ns))
@@ -145,14 +147,14 @@ class HipStageOps(Context):
     def unique(self):
         pw, pc, pf = C.c_void_p(), C.c_void_p(), C.c_void_p()
         self._call(self._lib.humid_stage_unique, C.byref(pw), C.byref(pc), C.byref(pf))
-        w = _wrap(pw.value, self._u, "<i8", torch.int64, self.device)
+        w = _wrap(pw.value, self._u * getattr(self, "_wpr", 1), "<i8", torch.int64, self.device)    # (two entries per word beyond 32 nt)
         c = _wrap(pc.value, self._u, "<i4", torch.int32, self.device)
         return w, c
 
     def graph(self, g_word, g_cnt, word_nt, distance, method):
         pc, pm = C.c_void_p(), C.c_void_p()
         s = _lib.HumidSummary()
-        n = g_word.numel()
+        n = g_cnt.numel()
         self._call(self._lib.humid_stage_graph, self._p(g_word), self._p(g_cnt), n, word_nt, distance,
                    method, C.byref(pc), C.byref(pm), C.byref(s))
         cid = _wrap(pc.value, n, "<i4", torch.int32, self.device)
@@ -170,7 +172,7 @@ class HipStageOps(Context):
     def graph_edges(self, g_word, g_cnt, edges, word_nt, distance, method):
         pc, pm = C.c_void_p(), C.c_void_p()
         s = _lib.HumidSummary()
-        n = g_word.numel()
+        n = g_cnt.numel()
         self._call(self._lib.humid_stage_graph_edges, self._p(g_word), self._p(g_cnt), n, self._p(edges),
                    edges.numel(), word_nt, distance, method, C.byref(pc), C.byref(pm), C.byref(s))
         cid = _wrap(pc.value, n, "<i4", torch.int32, self.device)
@@ -188,23 +190,26 @@ class HipStageOps(Context):
         counts = [int(x) for x in counts]
         return _wrap(pp.value, sum(counts), "<i4", torch.int32, self.device), counts
 
-    def owner_perm(self, d_w, d_f, ranges):
-        """owner-major stable order of this rank's own reads + receive split sizes per owner"""
+    def owner_perm(self, d_w, d_f, ranges, word_nt=32):
+        """owner-major stable order of this rank's own reads + receive split sizes per owner
+        (word_nt > 32: two entries per read in d_w, the ranges are ranges of heads)"""
         P = len(ranges)
         lo = (C.c_uint64 * P)(*[r[0] for r in ranges])
         hi = (C.c_uint64 * P)(*[r[1] for r in ranges])
         counts = (C.c_uint64 * P)()
         pp = C.c_void_p()
-        self._call(self._lib.humid_stage_owner_perm, self._p(d_w), self._p(d_f), d_w.numel(), lo, hi, P,
+        n = d_f.numel()
+        self._call(self._lib.humid_stage_owner_perm_wide, self._p(d_w), self._p(d_f), n, word_nt, lo, hi, P,
                    C.byref(pp), counts)
         counts = [int(x) for x in counts]
-        return _wrap(pp.value, d_w.numel(), "<i4", torch.int32, self.device), counts
+        return _wrap(pp.value, n, "<i4", torch.int32, self.device), counts
 
     def scatter(self, perm, recv, out_cid, out_keep):
         self._call(self._lib.humid_stage_scatter, self._p(perm), self._p(recv), recv.numel(),
                    out_cid.numel(), self._p(out_cid), self._p(out_keep))
 
     max_ranks_dense = 16
+    wide_allgather = True       # the all-gather mode's stages take two-word words (33 .. 64 nt)
 
     # ---- exchange mode ----
     def plan_info(self, word_nt, distance, plan_unique):
@@ -646,8 +651,12 @@ class ShardedDedup:
 
     def _run(self, d_w, d_f, d_cid, d_keep):
         if self.word_nt > 32:
+            # two-word words: the library's exchange pass, or -- asked for by name -- the all-gather mode stage by stage
+            if self.mode == "allgather" and getattr(self.ops, "wide_allgather", False) and not self.edit:
+                self.mode_used = "allgather"
+                return self._run_allgather(d_w, d_f, d_cid, d_keep)
             if not hasattr(self.ops, "run_exchange") or self.py_orchestration or (self.edit and not self.edit_in_library):
-                raise NotImplementedError("words longer than 32 nt: the library's exchange pass only (HIP ops)")
+                raise NotImplementedError("words longer than 32 nt: the library's exchange pass or the all-gather mode (HIP ops)")
             self.mode_used = "exchange"
             self.summary = self.ops.run_exchange(self.dist, d_w, d_f, d_cid, d_keep, self.word_nt, self.distance, self.method)
             return self.summary
@@ -794,7 +803,13 @@ class ShardedDedup:
         if hasattr(self.ops, "set_option"):
             self.ops.set_option("count_order", -1)
         dev = d_w.device
-        n_local = d_w.numel()
+        # words of 33 .. 64 nt: two int64 per read / unique word; value ranges are ranges of HEADS (the top 64 bits of
+        # a word's value), i.e. the histogram and the splitters are those of 32-nt words
+        wpr = 2 if self.word_nt > 32 else 1
+        range_nt = 32 if wpr == 2 else self.word_nt
+        if wpr == 2 and (self.edit or not self.dense_return or P > getattr(self.ops, "max_ranks_dense", 0)):
+            raise NotImplementedError("words longer than 32 nt in the all-gather mode: dense return, <= 16 ranks, no -e")
+        n_local = d_f.numel()
         if self._n_max is None:                      # shard sizes are fixed per instance
             t = torch.tensor([n_local], dtype=torch.int64, device=dev)
             sizes = torch.empty(P, dtype=torch.int64, device=dev)
@@ -806,17 +821,18 @@ class ShardedDedup:
         if n_local == n_max:
             pw, pf = d_w, d_f
         else:
-            pw = torch.zeros(n_max, dtype=torch.int64, device=dev)
+            pw = torch.zeros(n_max * wpr, dtype=torch.int64, device=dev)
             pf = torch.ones(n_max, dtype=torch.uint8, device=dev)
-            pw[:n_local] = d_w
+            pw[:n_local * wpr] = d_w.reshape(-1)
             pf[:n_local] = d_f
-        g_w = torch.empty(P * n_max, dtype=torch.int64, device=dev)
+        pw = pw.reshape(-1)
+        g_w = torch.empty(P * n_max * wpr, dtype=torch.int64, device=dev)
         g_f = torch.empty(P * n_max, dtype=torch.uint8, device=dev)
         _all_gather_flat(dist, g_w, pw, P)
         _all_gather_flat(dist, g_f, pf, P)
         # ---- 2. balanced ordered ranges (replicated, deterministic) ----
         hist = self.ops.histogram(g_w, g_f, self.word_nt, self.bits)
-        ranges = splitters_from_hist(hist.cpu().numpy(), P, self.word_nt, self.bits)
+        ranges = splitters_from_hist(hist.cpu().numpy(), P, range_nt, self.bits)
         lo, hi, exp = ranges[r]
         # ---- 3. exact counts of this rank's range ----
         shard_begin = [q * n_max for q in range(P + 1)]
@@ -840,18 +856,18 @@ class ShardedDedup:
         if u_total > 0:
             # ---- 4. all-gather of the per-range unique arrays -> global walk order ----
             lw, lc = self.ops.unique()
-            sw = torch.zeros(u_max, dtype=torch.int64, device=dev)
+            sw = torch.zeros(u_max * wpr, dtype=torch.int64, device=dev)
             sc = torch.zeros(u_max, dtype=torch.int32, device=dev)
-            sw[:u_local] = lw
+            sw[:u_local * wpr] = lw
             sc[:u_local] = lc
-            aw = torch.empty(P * u_max, dtype=torch.int64, device=dev)
+            aw = torch.empty(P * u_max * wpr, dtype=torch.int64, device=dev)
             ac = torch.empty(P * u_max, dtype=torch.int32, device=dev)
             _all_gather_flat(dist, aw, sw, P)
             _all_gather_flat(dist, ac, sc, P)
             if all(u == u_max for u in u_all):
                 gw, gc = aw, ac
             else:
-                gw = torch.cat([aw[q * u_max:q * u_max + u_all[q]] for q in range(P)])
+                gw = torch.cat([aw[q * u_max * wpr:(q * u_max + u_all[q]) * wpr] for q in range(P)])
                 gc = torch.cat([ac[q * u_max:q * u_max + u_all[q]] for q in range(P)])
             # ---- 5. neighbours + clusters over the global unique array ----
             if self.edit:
@@ -862,7 +878,7 @@ class ShardedDedup:
                 e_all = self.ops.unique_edges(e_raw, gw.numel())
                 cid_g, ismax_g, gs = self.ops.graph_edges(gw, gc, e_all, self.word_nt, self.distance,
                                                           self.method)
-            elif self.partition_search and hasattr(self.ops, "pairs"):
+            elif self.partition_search and hasattr(self.ops, "pairs") and wpr == 1:
                 # every rank searches its share of the pairs; the shares are all-gathered (tiny:
                 # ~2 % of N pairs) and every rank builds the graph from the same complete list
                 e_loc = self.ops.pairs(gw, self.word_nt, self.distance, r, P)
@@ -894,7 +910,8 @@ class ShardedDedup:
                 else:
                     packed, send_counts = self.ops.owned_results(cid_g[goff:goff + u_local],
                                                                  ismax_g[goff:goff + u_local], shard_begin)
-                perm, recv_counts = self.ops.owner_perm(d_w, d_f, ranges)
+                perm, recv_counts = (self.ops.owner_perm(d_w.reshape(-1), d_f, ranges, self.word_nt) if wpr == 2
+                                     else self.ops.owner_perm(d_w, d_f, ranges))
                 recv = torch.empty(sum(recv_counts), dtype=torch.int32, device=dev)
                 _all_to_all_v(dist, recv, packed, recv_counts, send_counts, P, r)
                 self.ops.scatter(perm, recv, d_cid, d_keep)

@@ -18,8 +18,11 @@
  * 33 <= n <= 64 ("wide" words): TWO uint64 per read, [2r] = the first n-32 nucleotides packed the
  * same way (right-aligned), [2r+1] = the last 32; every words / word array of the single-GPU entry
  * points (humid_dedup_run, humid_dedup_run_device, humid_get_leaves) then holds 2 entries per
- * read / leaf, 16-byte aligned on the device.  n > 64, and n > 32 in the multi-GPU humid_stage_*
- * entry points, return HUMID_E_UNSUPPORTED.
+ * read / leaf, 16-byte aligned on the device.  n > 64 returns HUMID_E_UNSUPPORTED.  Several GPUs:
+ * humid_dedup_run_exchange takes wide words; of the humid_stage_* entry points those of the all-gather mode do
+ * (humid_stage_histogram, _count_dense with a filter array, _unique, _graph, _graph_edges,
+ * humid_stage_owner_perm_wide: value ranges are then ranges of HEADS, the top 64 bits of a word's 2n-bit value, and
+ * the histogram is that of 32-nt words over the heads); the others return HUMID_E_UNSUPPORTED for n > 32.
  */
 #ifndef HUMID_HIP_H
 #define HUMID_HIP_H
@@ -42,7 +45,7 @@ extern "C" {
 #define HUMID_METHOD_DIRECTIONAL 0u  /* default; src/cluster.cc:82-87               */
 #define HUMID_METHOD_MAXIMUM     1u  /* -x;      src/cluster.cc:72-80               */
 
-#define HUMID_ABI_VERSION 4u   /* 4: humid_exchange_info.d_unique_degree replaces d_compact_edges (owner-local clustering, round 3); 3: humid_dedup_run_exchange, humid_comm, humid_shm_* (round 2); 2: humid_dedup_run_bases, humid_stage_route ... */
+#define HUMID_ABI_VERSION 5u   /* 5: humid_stage_owner_perm_wide, wide words in the all-gather stages; 4: humid_exchange_info.d_unique_degree replaces d_compact_edges (owner-local clustering, round 3); 3: humid_dedup_run_exchange, humid_comm, humid_shm_* (round 2); 2: humid_dedup_run_bases, humid_stage_route ... */
 
 typedef struct humid_ctx humid_ctx;   /* device workspace + stream; not thread-safe */
 
@@ -291,6 +294,10 @@ int humid_stage_owned_results(humid_ctx *ctx, const uint32_t *d_local_cluster_id
 int humid_stage_owner_perm(humid_ctx *ctx, const uint64_t *d_words, const uint8_t *d_filtered,
                            uint64_t n_reads, const uint64_t *range_lo, const uint64_t *range_hi,
                            uint32_t n_ranks, const uint32_t **d_perm, uint64_t *counts);
+/* the same for words of word_nt nucleotides (33 .. 64: two uint64 per read, ranges of heads; <= 32: as above) */
+int humid_stage_owner_perm_wide(humid_ctx *ctx, const uint64_t *d_words, const uint8_t *d_filtered,
+                                uint64_t n_reads, uint32_t word_nt, const uint64_t *range_lo, const uint64_t *range_hi,
+                                uint32_t n_ranks, const uint32_t **d_perm, uint64_t *counts);
 int humid_stage_scatter(humid_ctx *ctx, const uint32_t *d_perm, const uint32_t *d_packed,
                         uint64_t n_recv, uint64_t n_reads, uint32_t *d_cluster_id, uint8_t *d_keep);
 

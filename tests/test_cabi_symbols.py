@@ -25,7 +25,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SYMBOLS) == names
-    assert lib.humid_abi_version() == 4
+    assert lib.humid_abi_version() == 5
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -64,7 +64,7 @@ def test_header_is_plain_c_and_links(tmp_path):
            "-Wl,-rpath-link,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     out = subprocess.check_output([str(exe)]).decode()
-    assert out.split()[0] == "4"
+    assert out.split()[0] == "5"
 
 
 def test_pigeonhole_plan_never_exceeds_its_tables():

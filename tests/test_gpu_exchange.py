@@ -365,6 +365,23 @@ def test_exchange_wide_words(P, n, d):
         assert s["edges"] == osum["edges"] and s["clusters"] == osum["clusters"] and s["unique"] == osum["unique"]
 
 
+@pytest.mark.parametrize("P", [1, 2, 3])
+@pytest.mark.parametrize("n,d,method", [(33, 1, 0), (40, 2, 0), (48, 1, 1), (64, 2, 0)])
+def test_allgather_mode_wide_words(P, n, d, method):
+    """33 <= word_nt <= 64 in the ALL-GATHER mode, stage by stage (round 3: humid_stage_histogram / _count_dense /
+    _unique / _graph / _owner_perm_wide take two-word words; value ranges are ranges of the words' top 64 bits):
+    every rank's shard, of uneven sizes, against one oracle run over the whole read set"""
+    from humid_amd.synth import synth_wide_words
+    words, filt = synth_wide_words(30_000 + 7 * P, 300 * P + n + d, n, p_sub=6e-3, p_n=2e-3)
+    ocid, okeep, osum, _ = orc.dedup_run(words, filt, n, d, method)
+    out, offs = run_ranks(P, words, filt, n, d, method, "allgather")
+    for r in range(P):
+        cid, keep, s, used = out[r]
+        assert used == "allgather"
+        assert np.array_equal(cid, ocid[offs[r]:offs[r + 1]]) and np.array_equal(keep, okeep[offs[r]:offs[r + 1]])
+        assert s["edges"] == osum["edges"] and s["clusters"] == osum["clusters"] and s["unique"] == osum["unique"]
+
+
 @pytest.mark.parametrize("P,method", [(4, 0), (4, 1), (8, 0), (3, 0)])
 def test_exchange_components_spanning_three_and_more_ranges(P, method):
     """owner-local clustering (round 3): clusters whose leaves lie in three and four value ranges -- families whose
