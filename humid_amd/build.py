@@ -31,9 +31,10 @@ def is_stale() -> bool:
     return any(os.path.getmtime(p) > t for p in _sources())
 
 
-# translation units of the library: the HIP one (pipeline, C ABI, exchange pass: kernels + host side) and the
-# host-only ones (plain C++ that hipcc compiles as such)
-HOST_UNITS = [os.path.join(HERE, "csrc", "shm.cpp")]
+# translation units of the library: the HIP ones -- humid_hip.hip (context, single-GPU entry points, accessors) and
+# humid_exchange.hip (exchange pass, multi-GPU stages), both over pipeline.hip.h -- and the host-only ones (plain
+# C++ that hipcc compiles as such)
+HOST_UNITS = [os.path.join(HERE, "csrc", "humid_exchange.hip"), os.path.join(HERE, "csrc", "shm.cpp")]
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:

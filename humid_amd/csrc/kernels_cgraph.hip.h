@@ -78,7 +78,7 @@ struct BitsBlockIn {
 };
 
 // set bits of every block of 256 leaves (8 words); cnt[n_blk] = 0 is the scan's sentinel
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_bits_blocks(const u32 *__restrict__ bits, u32 n_blk, u32 *__restrict__ cnt) {
   HUMID_GUARD_LAST_VGPR();
   const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -96,7 +96,7 @@ struct ZeroList {
   u32 *p[ZERO_MAX];
   u32 n[ZERO_MAX];               // in u32
 };
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_zero_many(ZeroList z) {
   HUMID_GUARD_LAST_VGPR();
   const u32 stride = gridDim.x * blockDim.x;
@@ -215,7 +215,7 @@ k_pairs_append(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, WT ma
 
 // both ends of a plain pair list marked in the bitmap (pairs that were not found by k_pairs_append: the
 // large-bucket tiles, the edit-distance joins)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_mark_pairs(const u64 *__restrict__ pairs, u32 n_pairs, u32 n_leaves, u32 *bits, u32 *bad) {
   HUMID_GUARD_LAST_VGPR();
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -230,7 +230,7 @@ k_mark_pairs(const u64 *__restrict__ pairs, u32 n_pairs, u32 n_leaves, u32 *bits
 // ---- compact nodes -----------------------------------------------------------------------------------
 // one thread per bitmap word: the marked leaves of the word become nodes[c], c ascending with the walk
 // index; their counts are gathered and the per-node arrays of the graph stage initialised
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_nodes_init(BitRank br, u32 n_words, const u32 *__restrict__ s_cnt, u32 *__restrict__ nodes, u32 *__restrict__ ncnt,
              u32 *__restrict__ deg, u32 *__restrict__ parent, u32 *__restrict__ csize, u32 *__restrict__ cur, u32 n_blk) {
   HUMID_GUARD_LAST_VGPR();
@@ -260,7 +260,7 @@ struct DegIn {
 
 // pairs in walk indices -> pairs in compact indices (in place), degrees, component forest
 // grid: x over the positions of a region, y = region (ER_REGIONS + 1 of them)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_pairs_relabel(EdgeRegs er, BitRank br, const u32 *__restrict__ ncnt, u32 *deg, u32 *parent, bool join_by_count) {
   HUMID_GUARD_LAST_VGPR();
   const u32 r = blockIdx.y;
@@ -279,7 +279,7 @@ k_pairs_relabel(EdgeRegs er, BitRank br, const u32 *__restrict__ ncnt, u32 *deg,
 // k_pairs_fill and k_comp_stats in ONE launch (the first gx * (ER_REGIONS + 1) workgroups fill the CSR rows, the rest
 // flatten the forest and size the components): neither reads what the other writes, and each alone is one round of
 // workgroups whose time is a chain of memory round trips -- side by side the two chains overlap
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_fill_and_stats(EdgeRegs er, const u32 *__restrict__ off, u32 *cur, u32 *__restrict__ idx, u32 *__restrict__ regions_max, u32 gx,
                  const u32 *__restrict__ deg, u32 *P, u32 n, u32 *csize, const u32 *__restrict__ n_dev) {
   HUMID_GUARD_LAST_VGPR();
@@ -311,7 +311,7 @@ k_fill_and_stats(EdgeRegs er, const u32 *__restrict__ off, u32 *cur, u32 *__rest
 }
 
 // CSR rows through per-row cursors (put in ascending order afterwards by k_sort_lists)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_pairs_fill(EdgeRegs er, const u32 *__restrict__ off, u32 *cur, u32 *__restrict__ idx, u32 *__restrict__ regions_max) {
   HUMID_GUARD_LAST_VGPR();
   if (regions_max && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
@@ -333,7 +333,7 @@ k_pairs_fill(EdgeRegs er, const u32 *__restrict__ off, u32 *cur, u32 *__restrict
 
 // ---- pair RECORDS as the source (multi-GPU: pairs in global unique indices with both ends' counts) ----
 // record = {smaller id << 32 | larger id, count(smaller) | count(larger) << 32}
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_mark_records(const ulonglong2 *__restrict__ recs, u32 n_recs, u32 n_ids, u32 *bits, u32 *bad) {
   HUMID_GUARD_LAST_VGPR();
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -346,7 +346,7 @@ k_mark_records(const ulonglong2 *__restrict__ recs, u32 n_recs, u32 n_ids, u32 *
 }
 // records -> compact pairs (a dense list: the `far` region of an EdgeRegs), the nodes' counts (all records
 // of a node carry the same count: equal values race freely), degrees, component forest
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_records_relabel(const ulonglong2 *__restrict__ recs, u32 n_recs, u32 n_ids, BitRank br, u64 *__restrict__ cpairs,
                   u32 *__restrict__ ncnt, u32 *deg, u32 *parent, bool join_by_count) {
   HUMID_GUARD_LAST_VGPR();
@@ -450,7 +450,7 @@ k_cg_trivial(const u32 *__restrict__ P, const u32 *__restrict__ csize, const u32
 
 // ---- results -------------------------------------------------------------------------------------------
 // nodes that did not create a cluster, as a bitmap over walk indices
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_noncreator_bits(const u32 *__restrict__ cl_of, const u32 *__restrict__ nodes, u32 m, u32 *bits) {
   HUMID_GUARD_LAST_VGPR();
   const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -462,7 +462,7 @@ k_noncreator_bits(const u32 *__restrict__ cl_of, const u32 *__restrict__ nodes, 
 // per unique word: (read to keep, cluster id) at the slot of its word.  Cluster ids follow
 // src/humid.cc:177-180: 1 + the number of cluster-creating leaves before the creator in the walk =
 // 1 + creator - (nodes before it that created nothing).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_finalize_leaves(BitRank in_graph, BitRank noncreator, const u32 *__restrict__ nodes, const u32 *__restrict__ cl_of,
                   const u32 *__restrict__ maxleaf, u32 n, const u32 *__restrict__ s_first, const u32 *__restrict__ s_slot,
                   u64 *__restrict__ slot_out, u32 *__restrict__ cid_out, u8 *__restrict__ ismax_out) {
@@ -483,7 +483,7 @@ k_finalize_leaves(BitRank in_graph, BitRank noncreator, const u32 *__restrict__ 
 }
 
 // ---- the legacy (per unique word) view, built on demand for the accessors -------------------------
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_expand_leaves(BitRank in_graph, const u32 *__restrict__ nodes, const u32 *__restrict__ cdeg, const u32 *__restrict__ ccl_of,
                 const u32 *__restrict__ cmaxleaf, const u64 *__restrict__ ccl_size, const u32 *__restrict__ cnt, u32 n,
                 u32 *__restrict__ deg, u32 *__restrict__ cl_of, u32 *__restrict__ maxleaf, u64 *__restrict__ cl_size) {
@@ -498,7 +498,7 @@ k_expand_leaves(BitRank in_graph, const u32 *__restrict__ nodes, const u32 *__re
   cl_of[u] = nodes[cc] + 1u;
   if (cc == c) { maxleaf[u] = nodes[cmaxleaf[c]]; cl_size[u] = ccl_size[c]; }
 }
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_expand_rows(const u32 *__restrict__ nodes, const u32 *__restrict__ coff, const u32 *__restrict__ cidx, u32 m,
               const u32 *__restrict__ off, u32 *__restrict__ idx) {
   HUMID_GUARD_LAST_VGPR();

@@ -113,7 +113,7 @@ k_cluster_components(const u64 *__restrict__ mkeys, u32 n_members, const u32 *__
 // O(edges / 256) here instead of O(edges) dependent loads on one lane.
 // heads[h] = position in mkeys of the first member of component h; fr = 2 words of scratch per
 // member.  cl_of is claimed with atomicCAS and read with agent-scope loads.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_cluster_big_coop(const u64 *__restrict__ mkeys, u32 n_members, const u32 *__restrict__ heads,
                    const ull *__restrict__ ctr, const u32 *__restrict__ cnt, const u32 *__restrict__ off,
                    const u32 *__restrict__ idx, u32 *cl_of, u32 *maxleaf, u64 *cl_size, u32 *fr) {
@@ -212,7 +212,7 @@ k_cluster_big_coop(const u64 *__restrict__ mkeys, u32 n_members, const u32 *__re
 }
 
 // heads of the runs of equal root in the sorted member keys (fixed grid, one atomic per block)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_comp_heads(const u64 *__restrict__ mkeys, u32 n_members, u32 *__restrict__ heads, ull *ctr) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u32 lds[8];
@@ -368,7 +368,7 @@ k_cluster_small_lds(const u32 *__restrict__ roots, const ull *__restrict__ ctr, 
   cluster_one_component<MAXIMUM>([&](u32 m) { return mem[m]; }, nm, cnt, off, idx, cl_of, maxleaf, cl_size, st);
 }
 
-__global__ void k_creator_flags(const u32 *__restrict__ cl_of, u32 n, u32 *flag) {
+static __global__ void k_creator_flags(const u32 *__restrict__ cl_of, u32 n, u32 *flag) {
   HUMID_GUARD_LAST_VGPR();
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u < n) flag[u] = (cl_of[u] == u + 1) ? 1u : 0u;
@@ -376,7 +376,7 @@ __global__ void k_creator_flags(const u32 *__restrict__ cl_of, u32 n, u32 *flag)
 
 // per node: final cluster id (creators numbered in walk order) and maxLeaf flag; on one GPU also
 // the per-slot result word (slot_out != null), which saves the separate k_slot_results pass
-__global__ void k_finalize_nodes(const u32 *__restrict__ cl_of, const u32 *__restrict__ pos,
+static __global__ void k_finalize_nodes(const u32 *__restrict__ cl_of, const u32 *__restrict__ pos,
                                  const u32 *__restrict__ maxleaf, u32 n, u32 *__restrict__ cid,
                                  u8 *__restrict__ ismax, const u32 *__restrict__ s_first,
                                  const u32 *__restrict__ s_slot, u64 *__restrict__ slot_out) {
@@ -392,7 +392,7 @@ __global__ void k_finalize_nodes(const u32 *__restrict__ cl_of, const u32 *__res
 }
 
 // per hash slot: (cluster id, read to keep) of the word it holds
-__global__ void k_slot_results(const u32 *__restrict__ l_cid, const u8 *__restrict__ l_ismax,
+static __global__ void k_slot_results(const u32 *__restrict__ l_cid, const u8 *__restrict__ l_ismax,
                                const u32 *__restrict__ s_first, const u32 *__restrict__ s_slot, u32 n,
                                u64 *__restrict__ slot_out) {
   HUMID_GUARD_LAST_VGPR();
@@ -401,7 +401,7 @@ __global__ void k_slot_results(const u32 *__restrict__ l_cid, const u8 *__restri
   slot_out[s_slot[u]] = ((u64)(l_ismax[u] ? s_first[u] : NONE32) << 32) | l_cid[u];
 }
 
-__global__ void k_export_clusters(const u32 *__restrict__ flag, const u32 *__restrict__ pos,
+static __global__ void k_export_clusters(const u32 *__restrict__ flag, const u32 *__restrict__ pos,
                                   const u32 *__restrict__ maxleaf, const u64 *__restrict__ cl_size,
                                   const u32 *__restrict__ cnt, u32 n, u64 *o_size, u32 *o_maxcount,
                                   u32 *o_maxleaf) {

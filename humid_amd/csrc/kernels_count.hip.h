@@ -58,7 +58,7 @@ struct __attribute__((aligned(16))) Slot {
   u32 first;   // smallest read index with this word
 };
 
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_hash_insert(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n_reads,
               Slot *tab, u32 cap_log2, u32 *__restrict__ slot_of_read, u64 range_lo, u64 range_hi,
               u32 max_probe, ull *ctr) {
@@ -121,7 +121,7 @@ __device__ __forceinline__ u32 block_rank(bool flag, u32 *lds /* >= 4 u32 */, u3
 }
 
 // occupied slots -> (word, slot) list in arbitrary order; also sums the usable reads
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_compact_table(const Slot *__restrict__ tab, u32 n_slots, u64 *__restrict__ uniq_word,
                 u32 *__restrict__ uniq_slot, u32 uniq_cap, ull *ctr) {
   HUMID_GUARD_LAST_VGPR();
@@ -194,7 +194,7 @@ struct ReadTagOp {               // values_input transform: read index | exclude
 };
 
 // first position of every bucket in the partitioned key array (binary search)
-__global__ void k_part_bounds(const u64 *__restrict__ keys, u32 n, u32 pb, u32 n_parts, u32 *__restrict__ pbeg,
+static __global__ void k_part_bounds(const u64 *__restrict__ keys, u32 n, u32 pb, u32 n_parts, u32 *__restrict__ pbeg,
                               u32 *__restrict__ ucount) {
   HUMID_GUARD_LAST_VGPR();
   u32 p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -368,7 +368,7 @@ k_dedup_lds(const u64 *__restrict__ keys, const u32 *__restrict__ vals, const u3
 
 // totals over the buckets: U = sum ucount, usable = sum pusable (a few blocks, two atomics each;
 // the counters were zeroed at the start of the stage)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_part_totals(const u32 *__restrict__ ucount, const u32 *__restrict__ pusable, u32 n_parts, ull *ctr) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u32 lds[4];
@@ -408,7 +408,7 @@ k_compact_padded(const u64 *__restrict__ pad_word, const uint2 *__restrict__ pad
 }
 
 // after the sort, padded variant: gather count / first read of rank i (one 8-byte gather)
-__global__ void k_post_sort_padded(const u32 *__restrict__ s_slot, const uint2 *__restrict__ pad_cf, u32 n,
+static __global__ void k_post_sort_padded(const u32 *__restrict__ s_slot, const uint2 *__restrict__ pad_cf, u32 n,
                                    u32 *__restrict__ s_cnt, u32 *__restrict__ s_first) {
   HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -420,7 +420,7 @@ __global__ void k_post_sort_padded(const u32 *__restrict__ s_slot, const uint2 *
 }
 
 // after the sort: per rank i gather count / first read from the table
-__global__ void k_post_sort(const u32 *__restrict__ s_slot, const Slot *__restrict__ tab, u32 n,
+static __global__ void k_post_sort(const u32 *__restrict__ s_slot, const Slot *__restrict__ tab, u32 n,
                             u32 *__restrict__ s_cnt, u32 *__restrict__ s_first) {
   HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;

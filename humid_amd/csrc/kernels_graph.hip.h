@@ -571,14 +571,14 @@ k_edit_join_chunks(const KeyT *__restrict__ KX, const u32 *__restrict__ VX, cons
 }
 
 // head[i] = 1 where a new value starts in the sorted 64-bit array; head[n] = 0 (scan sentinel)
-__global__ void k_heads_u64(const u64 *__restrict__ sorted, u32 n, u32 *__restrict__ head) {
+static __global__ void k_heads_u64(const u64 *__restrict__ sorted, u32 n, u32 *__restrict__ head) {
   HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n) return;
   head[i] = (i < n && (i == 0 || sorted[i] != sorted[i - 1])) ? 1u : 0u;
 }
 
-__global__ void k_compact_heads_u64(const u64 *__restrict__ sorted, const u32 *__restrict__ head,
+static __global__ void k_compact_heads_u64(const u64 *__restrict__ sorted, const u32 *__restrict__ head,
                                     const u32 *__restrict__ hpos, u32 n, u64 *__restrict__ out) {
   HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -586,7 +586,7 @@ __global__ void k_compact_heads_u64(const u64 *__restrict__ sorted, const u32 *_
 }
 
 // every CSR row ascending (the order NLeaf::neighbours has under the trie hypotheses H1+H2)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_sort_lists(const u32 *__restrict__ off, u32 n, u32 *idx) {
   HUMID_GUARD_LAST_VGPR();
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -638,7 +638,7 @@ k_sort_lists(const u32 *__restrict__ off, u32 n, u32 *idx) {
 
 // flatten the forest and count the leaves of every component at its root
 // n_dev (may be null): the number of nodes as the device knows it, when the launch is sized by a bound
-__global__ void k_comp_stats(const u32 *__restrict__ deg, u32 *P, u32 n, u32 *csize, const u32 *__restrict__ n_dev = nullptr) {
+static __global__ void k_comp_stats(const u32 *__restrict__ deg, u32 *P, u32 n, u32 *csize, const u32 *__restrict__ n_dev = nullptr) {
   HUMID_GUARD_LAST_VGPR();
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
   if (n_dev && *n_dev < n) n = *n_dev;
@@ -652,7 +652,7 @@ __global__ void k_comp_stats(const u32 *__restrict__ deg, u32 *P, u32 n, u32 *cs
 // the degrees (= 2E) in 64 bits: the CSR offsets are 32-bit, so the host must see an overflow
 // BEFORE it sizes nbr_idx from a wrapped scan
 #define CC_ROOTS 2048u      // listed roots a workgroup of k_comp_count holds before it flushes them
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_comp_count(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *__restrict__ csize, u32 n,
              ull *ctr, u32 *__restrict__ small_roots, const u32 *__restrict__ n_dev = nullptr) {
   HUMID_GUARD_LAST_VGPR();
@@ -731,7 +731,7 @@ k_comp_count(const u32 *__restrict__ deg, const u32 *__restrict__ P, const u32 *
 
 // one pass instead of three memsets and an iota: parent[i] = i, deg = csize = cur = 0 (deg has
 // n + 1 entries: the extra one is the sentinel of the exclusive scan)
-__global__ void k_graph_init(u32 *__restrict__ parent, u32 *__restrict__ deg, u32 *__restrict__ csize,
+static __global__ void k_graph_init(u32 *__restrict__ parent, u32 *__restrict__ deg, u32 *__restrict__ csize,
                              u32 *__restrict__ cur, u32 n) {
   HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -739,14 +739,14 @@ __global__ void k_graph_init(u32 *__restrict__ parent, u32 *__restrict__ deg, u3
   if (i == n) deg[i] = 0;
 }
 
-__global__ void k_iota(u32 *p, u32 n) {
+static __global__ void k_iota(u32 *p, u32 n) {
   HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
 }
 
 // explicit-graph entry point: union every CSR entry (u, nbr) the clustering can cross
-__global__ void k_union_csr(const u32 *__restrict__ off, const u32 *__restrict__ idx, u32 n, u32 *P,
+static __global__ void k_union_csr(const u32 *__restrict__ off, const u32 *__restrict__ idx, u32 n, u32 *P,
                             const u32 *__restrict__ cnt) {
   HUMID_GUARD_LAST_VGPR();
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -756,7 +756,7 @@ __global__ void k_union_csr(const u32 *__restrict__ off, const u32 *__restrict__
 }
 
 // members of the BIG components, keyed (root << 32 | rank); unordered, sorted afterwards
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_member_keys(const u32 *__restrict__ deg, u32 *P, const u32 *__restrict__ csize, u32 n, u64 *mkeys,
               ull *ctr) {
   HUMID_GUARD_LAST_VGPR();

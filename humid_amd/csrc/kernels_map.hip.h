@@ -12,7 +12,7 @@
 // --------------------------------------------------------------------------------
 // keep = this read is the first (input order) whose word is its cluster's maxLeaf
 // (/root/reference/src/humid.cc:224-231); cluster 0 for filtered reads (:272).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_read_map(const u32 *__restrict__ slot_of_read, const u64 *__restrict__ slot_out, u32 n_reads,
            u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
   HUMID_GUARD_LAST_VGPR();
@@ -34,7 +34,7 @@ k_read_map(const u32 *__restrict__ slot_of_read, const u64 *__restrict__ slot_ou
 // holds read vals[i] and the slot of its word; the slot lookups are partition-local (cached).
 // The un-permute is ONE scattered 4-byte store per read (cluster id | keep << 31; ids < 2^31
 // because n_reads < 2^31); k_split_out then writes both output arrays coalesced.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_read_map_part(const u32 *__restrict__ vals, const u32 *__restrict__ pslot, const u64 *__restrict__ slot_out,
                 u32 n_reads, u32 *__restrict__ packed) {
   HUMID_GUARD_LAST_VGPR();
@@ -56,7 +56,7 @@ k_read_map_part(const u32 *__restrict__ vals, const u32 *__restrict__ pslot, con
 // their result words are first copied into LDS with one coalesced read and the per-position look-up
 // never leaves the CU.  What remains is the scattered store itself (a bare random scatter of 10 M
 // 4-byte values takes 0.13 ms on this GPU, tools/scatter_roofline.py).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_read_map_bucket(const u32 *__restrict__ vals, const u32 *__restrict__ pslot, const u64 *__restrict__ slot_out,
                   const u32 *__restrict__ pbeg, const u32 *__restrict__ ucount, u32 n_reads,
                   u32 *__restrict__ packed) {
@@ -83,7 +83,7 @@ k_read_map_bucket(const u32 *__restrict__ vals, const u32 *__restrict__ pslot, c
 }
 
 // global-table variant with the packed result word as output (every read is owned and usable)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_read_map_packed(const u32 *__restrict__ slot_of_read, const u64 *__restrict__ slot_out, u32 n_reads,
                   u32 *__restrict__ packed) {
   HUMID_GUARD_LAST_VGPR();
@@ -98,7 +98,7 @@ k_read_map_packed(const u32 *__restrict__ slot_of_read, const u64 *__restrict__ 
   }
 }
 
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_split_out(const u32 *__restrict__ packed, u32 n_reads, u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
   HUMID_GUARD_LAST_VGPR();
   for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
@@ -130,7 +130,7 @@ struct OwnedRangeFlagOp {       // 1 for the usable reads whose word lies in [lo
 };
 
 // dense copy of the owned reads' words, in read order
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_gather_owned(const u64 *__restrict__ words, const u8 *__restrict__ filtered, const u32 *__restrict__ opos,
                u64 lo, u64 hi, u32 n_reads, u64 *__restrict__ own_words) {
   HUMID_GUARD_LAST_VGPR();
@@ -142,7 +142,7 @@ k_gather_owned(const u64 *__restrict__ words, const u8 *__restrict__ filtered, c
 }
 
 // the same for two-word words: the range is one of HEADS (k_wide_head64), the words follow
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_gather_owned_w2(const W2 *__restrict__ words, const u64 *__restrict__ heads, const u8 *__restrict__ filtered,
                   const u32 *__restrict__ opos, u64 lo, u64 hi, u32 n_reads, W2 *__restrict__ own_words) {
   HUMID_GUARD_LAST_VGPR();
@@ -160,7 +160,7 @@ struct OwnedFlagOp {            // 1 for the reads this rank counted (global-tab
 };
 
 // packed result (cluster id | keep << 31) of every owned read, dense, in read order
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_owned_results(const u32 *__restrict__ slot_of_read, const u32 *__restrict__ opos,
                 const u64 *__restrict__ slot_out, u32 n_reads, u32 *__restrict__ packed) {
   HUMID_GUARD_LAST_VGPR();
@@ -173,7 +173,7 @@ k_owned_results(const u32 *__restrict__ slot_of_read, const u32 *__restrict__ op
 }
 
 // owner rank of every local read (n_ranks = nobody: filtered reads)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_owner_of(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n, OwnerRanges rg,
            u32 n_ranks, u8 *__restrict__ owner) {
   HUMID_GUARD_LAST_VGPR();
@@ -190,7 +190,7 @@ k_owner_of(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n
 }
 
 // first position of every owner in the owner-sorted order (n_ranks + 2 boundaries)
-__global__ void k_owner_bounds(const u8 *__restrict__ sorted_owner, u32 n, u32 n_ranks, u32 *__restrict__ bounds) {
+static __global__ void k_owner_bounds(const u8 *__restrict__ sorted_owner, u32 n, u32 n_ranks, u32 *__restrict__ bounds) {
   HUMID_GUARD_LAST_VGPR();
   u32 q = threadIdx.x;
   if (q > n_ranks + 1) return;
@@ -203,7 +203,7 @@ __global__ void k_owner_bounds(const u8 *__restrict__ sorted_owner, u32 n, u32 n
 }
 
 // received dense stream (owner-major, read order inside) -> this shard's outputs
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_scatter_results(const u32 *__restrict__ perm, const u32 *__restrict__ packed, u32 n_recv,
                   u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
   HUMID_GUARD_LAST_VGPR();
@@ -240,7 +240,7 @@ k_combo_owner(const WT *__restrict__ words, u32 n, ComboFields cf, u32 n_ranks, 
 }
 
 // (word, id | count << 32) items in routed order: id = id_base + index in the local unique array
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_route_items(const u64 *__restrict__ words, const u32 *__restrict__ counts, const u32 *__restrict__ perm, u32 n,
               u64 id_base, ulonglong2 *__restrict__ items) {
   HUMID_GUARD_LAST_VGPR();
@@ -252,7 +252,7 @@ k_route_items(const u64 *__restrict__ words, const u32 *__restrict__ counts, con
 
 // ---- the same for two-word (wide) words: 24-byte items (hi, lo, id | count << 32) ----
 struct Item3 { u64 hi, lo, idc; };
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_route_items_w2(const W2 *__restrict__ words, const u32 *__restrict__ counts, const u32 *__restrict__ perm, u32 n,
                  u64 id_base, Item3 *__restrict__ items) {
   HUMID_GUARD_LAST_VGPR();
@@ -262,7 +262,7 @@ k_route_items_w2(const W2 *__restrict__ words, const u32 *__restrict__ counts, c
   const W2 w = words[i];
   items[k] = Item3{w.hi, w.lo, (id_base + i) | ((u64)(counts ? counts[i] : 0u) << 32)};
 }
-__global__ void k_split_items_w2(const Item3 *__restrict__ items, u32 n, W2 *__restrict__ w, u32 *__restrict__ id,
+static __global__ void k_split_items_w2(const Item3 *__restrict__ items, u32 n, W2 *__restrict__ w, u32 *__restrict__ id,
                                  u32 *__restrict__ cnt) {
   HUMID_GUARD_LAST_VGPR();
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -275,20 +275,20 @@ __global__ void k_split_items_w2(const Item3 *__restrict__ items, u32 n, W2 *__r
 // the top 64 bits of a wide word's 2n-bit value (hbits = 2 (n - 32) bits live in .hi): value ranges cut
 // at the bins of a <= 12-bit prefix histogram are decided by these bits alone
 // (drop: that many low bits of the head are shifted out -- the count stage's partition keys, WideReadsSrc)
-__global__ void k_wide_head64(const W2 *__restrict__ w, u32 n, u32 hbits, u64 *__restrict__ out, u32 drop = 0) {
+static __global__ void k_wide_head64(const W2 *__restrict__ w, u32 n, u32 hbits, u64 *__restrict__ out, u32 drop = 0) {
   HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const W2 x = w[i];
   out[i] = (hbits >= 64 ? x.hi : ((x.hi << (64 - hbits)) | (x.lo >> hbits))) >> drop;
 }
-__global__ void k_gather_w2(const W2 *__restrict__ w, const u32 *__restrict__ perm, u32 n, W2 *__restrict__ out) {
+static __global__ void k_gather_w2(const W2 *__restrict__ w, const u32 *__restrict__ perm, u32 n, W2 *__restrict__ out) {
   HUMID_GUARD_LAST_VGPR();
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < n) out[k] = w[perm[k]];
 }
 
-__global__ void k_split_items(const ulonglong2 *__restrict__ items, u32 n, u64 *__restrict__ w,
+static __global__ void k_split_items(const ulonglong2 *__restrict__ items, u32 n, u64 *__restrict__ w,
                               u32 *__restrict__ id, u32 *__restrict__ cnt) {
   HUMID_GUARD_LAST_VGPR();
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -301,7 +301,7 @@ __global__ void k_split_items(const ulonglong2 *__restrict__ items, u32 n, u64 *
 
 // pairs over item POSITIONS -> records {smaller id << 32 | larger id, count(smaller) | count(larger) << 32}
 // id_of == null: id = id_base + position (the plain ascending array of the prefix combination)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_edge_records(const u64 *__restrict__ pos_edges, u32 n_edges, const u32 *__restrict__ id_of, u32 id_base,
                const u32 *__restrict__ cnt_of, ulonglong2 *__restrict__ rec) {
   HUMID_GUARD_LAST_VGPR();
@@ -315,13 +315,13 @@ k_edge_records(const u64 *__restrict__ pos_edges, u32 n_edges, const u32 *__rest
   rec[k] = make_ulonglong2(((u64)a << 32) | b, (u64)ca | ((u64)cb << 32));
 }
 
-__global__ void k_iota_base(u32 *p, u32 n, u32 base) {
+static __global__ void k_iota_base(u32 *p, u32 n, u32 base) {
   HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = base + i;
 }
 
-__global__ void k_gather_u32(const u32 *__restrict__ src, const u32 *__restrict__ idx, u32 n, u32 *__restrict__ dst) {
+static __global__ void k_gather_u32(const u32 *__restrict__ src, const u32 *__restrict__ idx, u32 n, u32 *__restrict__ dst) {
   HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[idx[i]];
@@ -329,7 +329,7 @@ __global__ void k_gather_u32(const u32 *__restrict__ src, const u32 *__restrict_
 
 // both endpoints of every edge (smaller << 32 | larger) with their slot 2k / 2k+1; stride = uint64
 // per edge record (1 or 2)
-__global__ void k_edge_ends(const u64 *__restrict__ edges, u32 n_edges, u32 stride, u32 *__restrict__ ends,
+static __global__ void k_edge_ends(const u64 *__restrict__ edges, u32 n_edges, u32 stride, u32 *__restrict__ ends,
                             u32 *__restrict__ slot) {
   HUMID_GUARD_LAST_VGPR();
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -342,14 +342,14 @@ __global__ void k_edge_ends(const u64 *__restrict__ edges, u32 n_edges, u32 stri
 }
 
 // head[i] = 1 where a new value starts in the sorted array; head[n] = 0 (scan sentinel)
-__global__ void k_heads_u32(const u32 *__restrict__ sorted, u32 n, u32 *__restrict__ head) {
+static __global__ void k_heads_u32(const u32 *__restrict__ sorted, u32 n, u32 *__restrict__ head) {
   HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n) return;
   head[i] = (i < n && (i == 0 || sorted[i] != sorted[i - 1])) ? 1u : 0u;
 }
 
-__global__ void k_compact_heads_u32(const u32 *__restrict__ sorted, const u32 *__restrict__ head,
+static __global__ void k_compact_heads_u32(const u32 *__restrict__ sorted, const u32 *__restrict__ head,
                                     const u32 *__restrict__ hpos, u32 n, u32 *__restrict__ out) {
   HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -360,7 +360,7 @@ __global__ void k_compact_heads_u32(const u32 *__restrict__ sorted, const u32 *_
 // to the edge's slot: cends[slot] = hpos[i] + head[i] - 1; with records (stride 2) also the node's
 // count (all records of a node carry the same count).  One scattered 4-byte store per endpoint
 // instead of a binary search over the node list.
-__global__ void k_relabel_ends(const u32 *__restrict__ slot_s, const u32 *__restrict__ head,
+static __global__ void k_relabel_ends(const u32 *__restrict__ slot_s, const u32 *__restrict__ head,
                                const u32 *__restrict__ hpos, u32 n_ends, const u64 *__restrict__ records,
                                u32 stride, u32 *__restrict__ cends, u32 *__restrict__ node_cnt) {
   HUMID_GUARD_LAST_VGPR();
@@ -376,7 +376,7 @@ __global__ void k_relabel_ends(const u32 *__restrict__ slot_s, const u32 *__rest
 }
 
 // (position of the smaller end, position of the larger end) -> one 64-bit compact edge
-__global__ void k_pack_cedges(const u32 *__restrict__ cends, u32 n_edges, u64 *__restrict__ out) {
+static __global__ void k_pack_cedges(const u32 *__restrict__ cends, u32 n_edges, u64 *__restrict__ out) {
   HUMID_GUARD_LAST_VGPR();
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < n_edges) out[k] = ((u64)cends[2 * k] << 32) | cends[2 * k + 1];
@@ -384,7 +384,7 @@ __global__ void k_pack_cedges(const u32 *__restrict__ cends, u32 n_edges, u64 *_
 
 // ---- compact node list through a mark array (ids below a known bound) instead of a sort ----
 // mark[id] = 1 and cnt_of[id] = count for both ends of every pair record (equal values race freely)
-__global__ void k_mark_ends(const u64 *__restrict__ records, u32 n_edges, u32 stride, u32 id_bound,
+static __global__ void k_mark_ends(const u64 *__restrict__ records, u32 n_edges, u32 stride, u32 id_bound,
                             u8 *__restrict__ mark, u32 *__restrict__ cnt_of, ull *ctr) {
   HUMID_GUARD_LAST_VGPR();
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -401,7 +401,7 @@ __global__ void k_mark_ends(const u64 *__restrict__ records, u32 n_edges, u32 st
   }
 }
 // pos = exclusive scan of mark: nodes[pos[id]] = id, node_cnt[pos[id]] = cnt_of[id] for the marked ids
-__global__ void k_marked_nodes(const u8 *__restrict__ mark, const u32 *__restrict__ pos, const u32 *__restrict__ cnt_of,
+static __global__ void k_marked_nodes(const u8 *__restrict__ mark, const u32 *__restrict__ pos, const u32 *__restrict__ cnt_of,
                                u32 id_bound, bool counts, u32 *__restrict__ nodes, u32 *__restrict__ node_cnt) {
   HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -410,7 +410,7 @@ __global__ void k_marked_nodes(const u8 *__restrict__ mark, const u32 *__restric
   nodes[q] = i;
   if (counts) node_cnt[q] = cnt_of[i];
 }
-__global__ void k_relabel_pairs(const u64 *__restrict__ records, u32 n_edges, u32 stride, u32 id_bound,
+static __global__ void k_relabel_pairs(const u64 *__restrict__ records, u32 n_edges, u32 stride, u32 id_bound,
                                 const u32 *__restrict__ pos, u64 *__restrict__ out) {
   HUMID_GUARD_LAST_VGPR();
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -421,7 +421,7 @@ __global__ void k_relabel_pairs(const u64 *__restrict__ records, u32 n_edges, u3
 }
 
 // routed copy of the usable reads' words (owner-major order of humid_stage_owner_perm)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_route_words(const u64 *__restrict__ words, const u32 *__restrict__ perm, u32 n, u64 *__restrict__ out) {
   HUMID_GUARD_LAST_VGPR();
   for (u32 k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) out[k] = words[perm[k]];
@@ -450,7 +450,7 @@ __device__ __forceinline__ u32 owner_of_word(const OwnerRanges &rg, u32 n_ranks,
 #define ROUTE_BINS 4096u
 // the table is computed once (k_route_table, one block) and copied into LDS by every workgroup: filling it
 // from the ranges in each of the ~1200 workgroups cost as many instructions as the routing itself
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_route_table(OwnerRanges rg, u32 n_ranks, u32 shift, u8 *__restrict__ table) {
   HUMID_GUARD_LAST_VGPR();
   for (u32 b = threadIdx.x; b < ROUTE_BINS; b += blockDim.x) table[b] = (u8)owner_of_word(rg, n_ranks, (u64)b << shift);
@@ -509,7 +509,7 @@ struct OwnerBases { u32 b[MAX_RANKS + 1]; };       // first routed position of e
 
 // one block, one wave per owner: tile_cnt[t][q] -> exclusive offset of tile t inside owner q's block
 // (in place), + the block's base; bad[0] = 1 if an owner's total differs from the host's count
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_route_scan(u32 *tile_cnt, u32 n_tiles, OwnerBases ob, u32 *bad) {
   HUMID_GUARD_LAST_VGPR();
   const u32 q = threadIdx.x >> 6, lane = threadIdx.x & 63;       // 16 waves = MAX_RANKS owners
@@ -587,7 +587,7 @@ k_route_scatter(const u64 *__restrict__ words, const u8 *__restrict__ filtered, 
 }
 
 // this shard's outputs from the received dense stream through the routed position of every read
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_gather_results(const u32 *__restrict__ inv, const u32 *__restrict__ packed, u32 n_recv, u32 n_reads,
                  u32 *__restrict__ cluster_id, u8 *__restrict__ keep) {
   HUMID_GUARD_LAST_VGPR();
@@ -601,7 +601,7 @@ k_gather_results(const u32 *__restrict__ inv, const u32 *__restrict__ packed, u3
 
 // ---- cluster ids of one rank's unique words from the replicated compact graph ----
 // creator (smallest member = the leaf whose walk step created the cluster) of every compact cluster
-__global__ void k_xid_creators(const u32 *__restrict__ ccid, u32 n_nodes, u32 n_clusters, u32 *creator) {
+static __global__ void k_xid_creators(const u32 *__restrict__ ccid, u32 n_nodes, u32 n_clusters, u32 *creator) {
   HUMID_GUARD_LAST_VGPR();
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_nodes) return;
@@ -611,7 +611,7 @@ __global__ void k_xid_creators(const u32 *__restrict__ ccid, u32 n_nodes, u32 n_
 
 // base_id[c] = global cluster id - 1 of compact cluster c: creators before it in the whole walk =
 // singletons before its creator (global index - compact position) + compact creators before it (c)
-__global__ void k_xid_base(const u32 *__restrict__ nodes, const u32 *__restrict__ creator, u32 n_nodes,
+static __global__ void k_xid_base(const u32 *__restrict__ nodes, const u32 *__restrict__ creator, u32 n_nodes,
                            u32 n_clusters, u32 goff, u32 u_local, u32 *__restrict__ base_id,
                            u32 *__restrict__ mark_cr) {
   HUMID_GUARD_LAST_VGPR();
@@ -625,7 +625,7 @@ __global__ void k_xid_base(const u32 *__restrict__ nodes, const u32 *__restrict_
 }
 
 // mark[i] = compact position + 1 of local unique word i (0 = singleton)
-__global__ void k_xid_mark(const u32 *__restrict__ nodes, u32 n_nodes, u32 goff, u32 u_local, u32 *__restrict__ mark) {
+static __global__ void k_xid_mark(const u32 *__restrict__ nodes, u32 n_nodes, u32 goff, u32 u_local, u32 *__restrict__ mark) {
   HUMID_GUARD_LAST_VGPR();
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_nodes) return;
@@ -634,7 +634,7 @@ __global__ void k_xid_mark(const u32 *__restrict__ nodes, u32 n_nodes, u32 goff,
 }
 
 // first[0] = compact nodes below goff, first[1] = compact creators below goff (binary searches)
-__global__ void k_xid_first(const u32 *__restrict__ nodes, const u32 *__restrict__ creator, u32 n_nodes,
+static __global__ void k_xid_first(const u32 *__restrict__ nodes, const u32 *__restrict__ creator, u32 n_nodes,
                             u32 n_clusters, u32 goff, u32 *__restrict__ first) {
   HUMID_GUARD_LAST_VGPR();
   if (threadIdx.x == 0) {
@@ -661,7 +661,7 @@ struct XidFlagOp {               // (is compact) | (is compact creator) << 32, s
   }
 };
 
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_xid_assign(const u32 *__restrict__ mark, const u64 *__restrict__ scan, const u32 *__restrict__ first,
              const u32 *__restrict__ ccid, const u8 *__restrict__ cismax, const u32 *__restrict__ base_id,
              u32 n_clusters, u32 goff, u32 u_local, u32 *__restrict__ l_cid, u8 *__restrict__ l_ismax) {
@@ -681,13 +681,13 @@ k_xid_assign(const u32 *__restrict__ mark, const u64 *__restrict__ scan, const u
   }
 }
 
-__global__ void k_widen32(const u32 *__restrict__ in, u32 n, u64 *__restrict__ out) {
+static __global__ void k_widen32(const u32 *__restrict__ in, u32 n, u64 *__restrict__ out) {
   HUMID_GUARD_LAST_VGPR();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i];
 }
 
-__global__ void k_creator_sizes(const u32 *__restrict__ flag, const u32 *__restrict__ pos,
+static __global__ void k_creator_sizes(const u32 *__restrict__ flag, const u32 *__restrict__ pos,
                                 const u64 *__restrict__ cl_size, u32 n, u64 *__restrict__ out) {
   HUMID_GUARD_LAST_VGPR();
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -697,7 +697,7 @@ __global__ void k_creator_sizes(const u32 *__restrict__ flag, const u32 *__restr
 // reads per top-`bits` bin of (word - lo) * scale (usable reads only): balanced range splitters for
 // the multi-GPU path (lo = 0, scale = 2^(64-2n): the top bits of the word itself) and the
 // uniformity check of the word-ordered buckets.  LDS-privatised, fixed grid.
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_top_hist(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n_reads, u64 lo, u64 scale,
            u32 bits, u32 *hist) {
   HUMID_GUARD_LAST_VGPR();
@@ -726,7 +726,7 @@ k_top_hist(const u64 *__restrict__ words, const u8 *__restrict__ filtered, u32 n
     if (lh[b]) atomicAdd(&hist[b], lh[b]);
 }
 
-__global__ void k_at_least_double(u64 a, u64 b, int *out) {
+static __global__ void k_at_least_double(u64 a, u64 b, int *out) {
   HUMID_GUARD_LAST_VGPR(); *out = at_least_double(a, b) ? 1 : 0; }
 
 

@@ -136,7 +136,7 @@ k_pt_hist1(SRC src, u32 n_reads, u32 d1, u32 *__restrict__ hist1) {
 // ---- one block: coarse bin bases, tile table of level 2, and the bucket boundaries pbeg[] that no
 // level-2 tile will write: all of them when there is no second level (d2 = 0), else those of the
 // EMPTY coarse bins (no tile) and the final pbeg[2^(d1+d2)] = number of records ----
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_pt_scan1(const u32 *__restrict__ hist1, u32 d1, u32 d2, u32 *__restrict__ cbase, u32 *__restrict__ tprefix,
            u32 *__restrict__ pbeg, u32 *__restrict__ ucount_tail, u32 cap1, u32 *clear = nullptr) {
   HUMID_GUARD_LAST_VGPR();
@@ -481,7 +481,7 @@ k_group_fine(SRC src, const u64 *__restrict__ k_in, const u32 *__restrict__ v_in
 #define UW_MAXBINS 2048u
 #define UW_MAXSHIFT 15u
 
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_unperm_bins(const u32 *__restrict__ vals, const u32 *__restrict__ pslot, const u64 *__restrict__ slot_out,
               const u32 *__restrict__ n_pos_dev, u32 n_pos_max, u32 n_reads, u32 wshift, u32 n_bins, u32 *ucur,
               u64 *__restrict__ rec) {

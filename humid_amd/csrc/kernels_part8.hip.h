@@ -141,7 +141,7 @@ k_p8_scatter1(SRC src, u32 n_reads, u32 kbits, u32 d1, u32 ibits, u32 cap1, u32 
 
 // ---- level 2: one tile of one coarse bin -> padded fine buckets (the next d2 key bits) ----
 // bucket g = c << d2 | f owns the positions [g << P8_CAP2_LOG, (g + 1) << P8_CAP2_LOG); cursor2[g] = its reads
-__global__ void __launch_bounds__(1024, 8)
+static __global__ void __launch_bounds__(1024, 8)
 k_p8_scatter2(const u64 *__restrict__ in, const u32 *__restrict__ tprefix, const u32 *__restrict__ cbase, u32 kbits, u32 d1,
               u32 d2, u32 ibits, u32 cap1, u32 *cursor2, u64 *__restrict__ out, ull *ctr) {
   HUMID_GUARD_LAST_VGPR();
@@ -226,7 +226,7 @@ k_p8_scatter2(const u64 *__restrict__ in, const u32 *__restrict__ tprefix, const
 #define DR_SLOTS (LDS_SLOTS + DR_SPILL)
 #define DR_WORDS (DR_SLOTS / 32u)                  // 34 words of the occupancy bitmap
 #define DR_EARLY 2u                                // of the P8_RPT records per thread: requested before the fill is known
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_dedup_rec(u64 *recs, const u32 *__restrict__ cursor2, u32 n_reads, u32 pb, u32 d1, u32 ibits, RecKey rk,
             u64 *__restrict__ pad_word, uint2 *__restrict__ pad_cf, u64 *__restrict__ agg, ull *ctr) {
   HUMID_GUARD_LAST_VGPR();
@@ -346,7 +346,7 @@ k_dedup_rec(u64 *recs, const u32 *__restrict__ cursor2, u32 n_reads, u32 pb, u32
 }
 
 // padded (fixed room per bucket) -> dense unique arrays in walk order, one wave per bucket
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_compact_padded8(const u64 *__restrict__ pad_word, const uint2 *__restrict__ pad_cf, const u64 *__restrict__ agg,
                   const u64 *__restrict__ abase, u32 n_parts, u64 *__restrict__ s_word, u32 *__restrict__ s_slot,
                   u32 *__restrict__ s_cnt, u32 *__restrict__ s_first) {
@@ -717,7 +717,7 @@ k_dedup_wide_rec(const W2 *__restrict__ recw, const u32 *__restrict__ reci, cons
 }
 
 // padded -> dense unique arrays of two-word words, one wave per bucket
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_compact_padded8_wide(const W2 *__restrict__ pad_word, const uint2 *__restrict__ pad_cf, const u64 *__restrict__ agg,
                        const u64 *__restrict__ abase, u32 n_parts, W2 *__restrict__ s_word, u32 *__restrict__ s_slot,
                        u32 *__restrict__ s_cnt, u32 *__restrict__ s_first) {

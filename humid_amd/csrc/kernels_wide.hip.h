@@ -17,7 +17,7 @@
 #include "kernels_count.hip.h"
 
 // pass 1 input: key = lo, value = read index; also counts the usable reads (one atomic per block)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_wide_keys_lo(const W2 *__restrict__ words, const u8 *__restrict__ filtered, u32 n, u64 *__restrict__ key,
                u32 *__restrict__ val, ull *ctr) {
   HUMID_GUARD_LAST_VGPR();
@@ -34,7 +34,7 @@ k_wide_keys_lo(const W2 *__restrict__ words, const u8 *__restrict__ filtered, u3
 
 // pass 2 input: key = hi (hbits = 2(n-32) significant bits), filtered reads above every word when
 // there is a spare bit (hbits < 64; n = 64 takes a third one-bit pass instead)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_wide_keys_hi(const W2 *__restrict__ words, const u8 *__restrict__ filtered, const u32 *__restrict__ v1, u32 n,
                u32 hbits, u64 *__restrict__ key) {
   HUMID_GUARD_LAST_VGPR();
@@ -48,7 +48,7 @@ k_wide_keys_hi(const W2 *__restrict__ words, const u8 *__restrict__ filtered, co
 }
 
 // pass 3 input (n = 64 only): key = filtered flag
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_wide_keys_flag(const u8 *__restrict__ filtered, const u32 *__restrict__ v2, u32 n, u32 *__restrict__ key) {
   HUMID_GUARD_LAST_VGPR();
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -56,7 +56,7 @@ k_wide_keys_flag(const u8 *__restrict__ filtered, const u32 *__restrict__ v2, u3
 }
 
 // words in sorted order (one 16-byte gather per read)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_wide_gather(const W2 *__restrict__ words, const u32 *__restrict__ v, u32 n, u32 hbits, W2 *__restrict__ sw) {
   HUMID_GUARD_LAST_VGPR();
   const u64 hmask = hbits >= 64 ? ~0ull : ((1ull << hbits) - 1ull);
@@ -69,7 +69,7 @@ k_wide_gather(const W2 *__restrict__ words, const u32 *__restrict__ v, u32 n, u3
 
 // head[i] = 1 where a new unique word starts among the usable reads (the first ctr[CTR_USABLE]
 // positions); head[n] = 0 is the sentinel of the exclusive scan
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_wide_heads(const W2 *__restrict__ sw, u32 n, const ull *__restrict__ ctr, u32 *__restrict__ head) {
   HUMID_GUARD_LAST_VGPR();
   const u32 usable = (u32)ctr[CTR_USABLE];
@@ -79,7 +79,7 @@ k_wide_heads(const W2 *__restrict__ sw, u32 n, const ull *__restrict__ ctr, u32 
 
 // per position: rank of its word (pslot) and the read tag (vals, bit 31 = filtered); per run head:
 // the unique word, its first read and the run start.  hpos = exclusive scan of head.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_wide_unique(const W2 *__restrict__ sw, const u32 *v, const u32 *__restrict__ head,
               const u32 *__restrict__ hpos, u32 n, const ull *__restrict__ ctr, W2 *__restrict__ s_word,
               u32 *__restrict__ s_first, u32 *__restrict__ start, u32 *__restrict__ pslot, u32 *vals) {
@@ -102,7 +102,7 @@ k_wide_unique(const W2 *__restrict__ sw, const u32 *v, const u32 *__restrict__ h
 }
 
 // count = run length; the slot of leaf u is u itself
-__global__ void k_wide_counts(const u32 *__restrict__ start, u32 n_unique, u32 *__restrict__ s_cnt,
+static __global__ void k_wide_counts(const u32 *__restrict__ start, u32 n_unique, u32 *__restrict__ s_cnt,
                               u32 *__restrict__ s_slot) {
   HUMID_GUARD_LAST_VGPR();
   u32 u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -282,7 +282,7 @@ k_dedup_lds_wide(const u64 *__restrict__ keys, const u32 *__restrict__ vals, con
 }
 
 // padded -> dense unique list of wide words, one wave per bucket (k_compact_padded<true> with W2 words)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_compact_padded_wide(const W2 *__restrict__ pad_word, const uint2 *__restrict__ pad_cf,
                       const u32 *__restrict__ pbeg, const u32 *__restrict__ ucount,
                       const u32 *__restrict__ ubase, u32 n_parts, W2 *__restrict__ uniq_word,

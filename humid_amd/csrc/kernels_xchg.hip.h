@@ -107,7 +107,7 @@ k_pairs_records(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, WT m
 }
 
 // the fullest region's cursor -> out[0], the records in all regions (cursors cut to the room) -> out[1]
-__global__ void k_rec_regions_max(RecRegs rr, u32 *__restrict__ out) {
+static __global__ void k_rec_regions_max(RecRegs rr, u32 *__restrict__ out) {
   HUMID_GUARD_LAST_VGPR();
   u32 c = rr.cur[threadIdx.x * ER_STRIDE];
   u32 t = c < rr.cap_r ? c : rr.cap_r;
@@ -133,7 +133,7 @@ __device__ __forceinline__ u32 rec_dest(const IdRanges &rg, u32 n_ranks, u64 e) 
   return oa == ob ? oa : n_ranks;
 }
 // counts per destination (n_ranks + 1 of them) over all regions; grid: x over a region, y = region
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_rec_dest_count(RecRegs rr, IdRanges rg, u32 n_ranks, u32 *__restrict__ counts) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u32 h[MAX_RANKS + 1];
@@ -147,7 +147,7 @@ k_rec_dest_count(RecRegs rr, IdRanges rg, u32 n_ranks, u32 *__restrict__ counts)
 }
 // the records in destination-major order: base[d] = first slot of destination d (host: prefix of the counts),
 // cursor[d] zeroed; one global atomic per workgroup and destination
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_rec_dest_scatter(RecRegs rr, IdRanges rg, u32 n_ranks, IdRanges base, u32 *cursor, ulonglong2 *__restrict__ out) {
   HUMID_GUARD_LAST_VGPR();
   __shared__ u32 h[MAX_RANKS + 1], hb[MAX_RANKS + 1];
@@ -174,7 +174,7 @@ k_rec_dest_scatter(RecRegs rr, IdRanges rg, u32 n_ranks, IdRanges base, u32 *cur
 
 // ---- which of a rank's interior pairs belong to components a crossing pair touches ----------------
 // forest over this rank's own leaves (local index = global id - id0) from its interior pairs
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_union_records(const ulonglong2 *__restrict__ recs, u32 n, u32 id0, u32 n_local, u32 *parent, bool join_by_count, u32 *bad) {
   HUMID_GUARD_LAST_VGPR();
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -187,7 +187,7 @@ k_union_records(const ulonglong2 *__restrict__ recs, u32 n, u32 id0, u32 n_local
 }
 // every end of a crossing pair that this rank owns flags the root of its component (pairs the clustering
 // never crosses -- counts within a factor of two, directional method -- flag nothing)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_flag_crossing(const ulonglong2 *__restrict__ recs, u32 n, u32 id0, u32 n_local, const u32 *parent, u8 *__restrict__ flag,
                 bool join_by_count) {
   HUMID_GUARD_LAST_VGPR();
@@ -232,7 +232,7 @@ struct RecSegs {
   u32 n[REC_SEGS];
   u32 first[REC_SEGS + 1];       // first[s] = records of the segments before s (positions in the compact pair list)
 };
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_mark_segs(RecSegs sg, u32 n_ids, u32 *bits, u32 *bad) {
   HUMID_GUARD_LAST_VGPR();
   const u32 s = blockIdx.y;
@@ -245,7 +245,7 @@ k_mark_segs(RecSegs sg, u32 n_ids, u32 *bits, u32 *bad) {
     atomicOr(&bits[b >> 5], 1u << (b & 31));
   }
 }
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_segs_relabel(RecSegs sg, u32 n_ids, BitRank br, u64 *__restrict__ cpairs, u32 *__restrict__ ncnt, u32 *deg, u32 *parent,
                bool join_by_count) {
   HUMID_GUARD_LAST_VGPR();
@@ -274,7 +274,7 @@ k_segs_relabel(RecSegs sg, u32 n_ids, BitRank br, u64 *__restrict__ cpairs, u32 
 // (Only pairs the clustering can cross flag anything, exactly as in k_flag_crossing at the owners: the set of
 // crossing clusters must come out the same on every rank, and it is the components of such pairs -- with all
 // their pairs -- that every rank holds.)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_flag_xroots(RecSegs sg, u32 seg, u32 n_ids, BitRank br, const u32 *__restrict__ parent, u8 *__restrict__ xroot, bool join_by_count) {
   HUMID_GUARD_LAST_VGPR();
   const u32 n = sg.n[seg];
@@ -290,7 +290,7 @@ k_flag_xroots(RecSegs sg, u32 seg, u32 n_ids, BitRank br, const u32 *__restrict_
   }
 }
 // the creators of the crossing clusters, as a bitmap over global ids
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_xcreator_bits(const u32 *__restrict__ cl_of, const u32 *__restrict__ parent, const u8 *__restrict__ xroot,
                 const u32 *__restrict__ nodes, u32 m, u32 *bits) {
   HUMID_GUARD_LAST_VGPR();
@@ -305,7 +305,7 @@ __device__ __forceinline__ u32 own_creator_id(u32 g, u32 id0, u32 creators_befor
 }
 // xcid[k] = id of the k-th crossing creator if this rank owns it, else 0 (the ranks' arrays are all-gathered
 // and merged by maximum)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_xcreator_ids(BitRank xc, u32 n_ids_words, u32 id0, u32 n_local, u32 creators_before_rank, BitRank noncreator,
                u32 *__restrict__ xcid) {
   HUMID_GUARD_LAST_VGPR();
@@ -323,7 +323,7 @@ k_xcreator_ids(BitRank xc, u32 n_ids_words, u32 id0, u32 n_local, u32 creators_b
     k++;
   }
 }
-__global__ void k_max_rows(const u32 *__restrict__ rows, u32 n_rows, u32 n, u32 *__restrict__ out) {
+static __global__ void k_max_rows(const u32 *__restrict__ rows, u32 n_rows, u32 n, u32 *__restrict__ out) {
   HUMID_GUARD_LAST_VGPR();
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
@@ -333,7 +333,7 @@ __global__ void k_max_rows(const u32 *__restrict__ rows, u32 n_rows, u32 n, u32 
 }
 // cluster id and maxLeaf flag of this rank's own unique words (local index u, global id0 + u), and their
 // degree (for neigh.dat).  xcid_all: the merged ids of the crossing creators (null: no crossing pair anywhere).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_own_results(BitRank in_graph, BitRank noncreator, BitRank xc, const u32 *__restrict__ xcid_all, const u32 *__restrict__ nodes,
               const u32 *__restrict__ cl_of, const u32 *__restrict__ maxleaf, const u32 *__restrict__ deg, u32 id0, u32 n_local,
               u32 creators_before_rank, u32 *__restrict__ l_cid, u8 *__restrict__ l_ismax, u32 *__restrict__ l_deg,
@@ -362,7 +362,7 @@ k_own_results(BitRank in_graph, BitRank noncreator, BitRank xc, const u32 *__res
   if (slot_out) slot_out[s_slot[u]] = ((u64)(mx ? s_first[u] : NONE32) << 32) | id;   // (k_slot_results of the result return, done here)
 }
 // non-creators and nodes among this rank's own leaves [id0, id0 + n_local): out[0], out[1]
-__global__ void k_own_totals(BitRank noncreator, BitRank in_graph, u32 id0, u32 n_local, u32 *__restrict__ out) {
+static __global__ void k_own_totals(BitRank noncreator, BitRank in_graph, u32 id0, u32 n_local, u32 *__restrict__ out) {
   HUMID_GUARD_LAST_VGPR();
   if (threadIdx.x == 0) {
     out[0] = n_local ? br_rank(noncreator, id0 + n_local - 1) + (br_test(noncreator, id0 + n_local - 1) ? 1u : 0u) - br_rank(noncreator, id0) : 0u;

@@ -460,13 +460,13 @@ static inline hipError_t rs_sort(void *temp, KIn kin, K *kout, VIn vin, V *vout,
 // --------------------------------------------------------------------------------
 // head flags -> scan -> (value, first position) per run; the length of a run is the distance to the
 // next run's first position
-__global__ void k_rle_heads(const u64 *__restrict__ sorted, u32 n, u32 *__restrict__ head) {
+static __global__ void k_rle_heads(const u64 *__restrict__ sorted, u32 n, u32 *__restrict__ head) {
   HUMID_GUARD_LAST_VGPR();
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n) return;
   head[i] = (i < n && (i == 0 || sorted[i] != sorted[i - 1])) ? 1u : 0u;
 }
-__global__ void k_rle_runs(const u64 *__restrict__ sorted, const u32 *__restrict__ head, const u32 *__restrict__ hpos,
+static __global__ void k_rle_runs(const u64 *__restrict__ sorted, const u32 *__restrict__ head, const u32 *__restrict__ hpos,
                            u32 n, u64 *__restrict__ uniq, u32 *__restrict__ start) {
   HUMID_GUARD_LAST_VGPR();
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -474,7 +474,7 @@ __global__ void k_rle_runs(const u64 *__restrict__ sorted, const u32 *__restrict
   if (i == n) { start[hpos[n]] = n; return; }
   if (head[i]) { uniq[hpos[i]] = sorted[i]; start[hpos[i]] = i; }
 }
-__global__ void k_rle_counts(const u32 *__restrict__ start, const u32 *__restrict__ n_runs_dev, u32 *__restrict__ counts) {
+static __global__ void k_rle_counts(const u32 *__restrict__ start, const u32 *__restrict__ n_runs_dev, u32 *__restrict__ counts) {
   HUMID_GUARD_LAST_VGPR();
   const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < *n_runs_dev) counts[j] = start[j + 1] - start[j];

@@ -112,23 +112,35 @@ LLVM_BIN = "/opt/rocm/lib/llvm/bin"
 
 
 def gfx950_kernel_descriptors(so_path, tmp_path):
-    """[(kernel symbol, vgpr_count, agpr_count)] of the gfx950 code object embedded in the library
-    (no GPU needed: llvm-objcopy dumps .hip_fatbin, clang-offload-bundler unbundles it, llvm-readelf
-    prints the AMDGPU metadata note)"""
+    """([(kernel symbol, vgpr_count, agpr_count)], number of code objects) of the gfx950 code objects embedded in the
+    library (no GPU needed: llvm-objcopy dumps .hip_fatbin, clang-offload-bundler unbundles, llvm-readelf prints the
+    AMDGPU metadata note).  The section holds ONE BUNDLE PER HIP TRANSLATION UNIT, one behind the other; the bundler
+    reads only the bundle a file starts with, so the section is cut at every bundle magic first."""
     import subprocess
-    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "gfx950.co")
+    fat = str(tmp_path / "fat.bin")
     subprocess.check_call([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, so_path])
-    subprocess.check_call([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
-                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
-    notes = subprocess.check_output([os.path.join(LLVM_BIN, "llvm-readelf"), "--notes", co]).decode()
+    data = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = []
+    i = data.find(magic)
+    while i >= 0:
+        starts.append(i)
+        i = data.find(magic, i + 1)
     out = []
-    # one "  - .agpr_count: N" ... ".symbol: name.kd" ... ".vgpr_count: N" block per kernel
-    for blk in re.split(r"\n  - (?=\.agpr_count:)", notes)[1:]:
-        ag = int(re.search(r"\.agpr_count:\s+(\d+)", blk).group(1))
-        vg = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
-        sym = re.search(r"\.symbol:\s+'?([^\s']+)", blk).group(1)
-        out.append((sym, vg, ag))
-    return out
+    for k, beg in enumerate(starts):
+        end = starts[k + 1] if k + 1 < len(starts) else len(data)
+        part, co = str(tmp_path / ("bundle%d.bin" % k)), str(tmp_path / ("gfx950_%d.co" % k))
+        open(part, "wb").write(data[beg:end])
+        subprocess.check_call([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + part,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        notes = subprocess.check_output([os.path.join(LLVM_BIN, "llvm-readelf"), "--notes", co]).decode()
+        # one "  - .agpr_count: N" ... ".symbol: name.kd" ... ".vgpr_count: N" block per kernel
+        for blk in re.split(r"\n  - (?=\.agpr_count:)", notes)[1:]:
+            ag = int(re.search(r"\.agpr_count:\s+(\d+)", blk).group(1))
+            vg = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
+            sym = re.search(r"\.symbol:\s+'?([^\s']+)", blk).group(1)
+            out.append((sym, vg, ag))
+    return out, len(starts)
 
 
 def test_code_object_every_kernel_allocates_an_accumulation_register(tmp_path):
@@ -140,8 +152,11 @@ def test_code_object_every_kernel_allocates_an_accumulation_register(tmp_path):
     if not os.path.exists(os.path.join(LLVM_BIN, "clang-offload-bundler")):
         pytest.skip("no LLVM binutils in this image")
     so = build.build_hip()
-    ks = gfx950_kernel_descriptors(so, tmp_path)
-    assert len(ks) >= 100, len(ks)
+    ks, n_objects = gfx950_kernel_descriptors(so, tmp_path)
+    # one code object per HIP translation unit (humid_hip.hip, humid_exchange.hip): every one of them is read
+    n_units = 1 + sum(1 for u in build.HOST_UNITS if u.endswith(".hip"))
+    assert n_objects == n_units, (n_objects, n_units)
+    assert len(ks) >= 100 * n_objects, len(ks)
     bad = [(s, v, a) for s, v, a in ks if v > 0 and a == 0]
     assert not bad, bad[:10]
     foreign = [s for s, _, _ in ks if "rocprim" in s or "hipcub" in s or "thrust" in s]

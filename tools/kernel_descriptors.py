@@ -20,13 +20,32 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 sys.path.insert(0, ROOT)
 
 
-def code_object(so, tmp):
+def code_objects(so, tmp):
+    """the gfx950 code objects of a library: .hip_fatbin holds one bundle per HIP translation unit, one behind the
+    other, and clang-offload-bundler reads only the bundle a file starts with"""
     fat = os.path.join(tmp, "fat.bin")
-    co = os.path.join(tmp, "gfx950.co")
     subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, so])
-    subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
-                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
-    return co
+    data = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = []
+    i = data.find(magic)
+    while i >= 0:
+        starts.append(i)
+        i = data.find(magic, i + 1)
+    out = []
+    for k, beg in enumerate(starts):
+        end = starts[k + 1] if k + 1 < len(starts) else len(data)
+        part, co = os.path.join(tmp, "bundle%d.bin" % k), os.path.join(tmp, "gfx950_%d.co" % k)
+        open(part, "wb").write(data[beg:end])
+        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + part,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        out.append(co)
+    return out
+
+
+def code_object(so, tmp):
+    """(kept for one-unit libraries: the first code object)"""
+    return code_objects(so, tmp)[0]
 
 
 def descriptors(co, names):
@@ -43,9 +62,12 @@ def descriptors(co, names):
 
 def show(title, so, names, tmp):
     print("## " + title)
-    co = code_object(so, tmp)
     demangle = "c++filt"
-    for sym, f in sorted(descriptors(co, names)):
+    found = {}
+    for co in code_objects(so, tmp):                     # (a kernel of pipeline.hip.h is in both units' objects: listed once)
+        for sym, f in descriptors(co, names):
+            found[sym] = f
+    for sym, f in sorted(found.items()):
         nice = subprocess.check_output([demangle, sym.replace(".kd", "")], text=True).strip()
         # on gfx90a+ (unified register file) .vgpr_count is the TOTAL: architectural VGPRs, rounded up to the
         # accumulation offset (a multiple of 4), plus the accumulation registers behind them

@@ -6,7 +6,7 @@
 set -o pipefail
 if [ "$1" = build ]; then
   mkdir -p tools/dbg/tmp
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DHUMID_PHASE_CLOCKS -o tools/dbg/tmp/libhumid_clk.so humid_amd/csrc/humid_hip.hip humid_amd/csrc/shm.cpp
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DHUMID_PHASE_CLOCKS -o tools/dbg/tmp/libhumid_clk.so humid_amd/csrc/humid_hip.hip humid_amd/csrc/humid_exchange.hip humid_amd/csrc/shm.cpp
   exit $?
 fi
 TAG=${1:-clk}
