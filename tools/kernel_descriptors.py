@@ -85,12 +85,18 @@ def main():
     so = build.build_hip()
     with tempfile.TemporaryDirectory() as tmp:
         show("product library (%s), every kernel starts with HUMID_GUARD_LAST_VGPR()" % os.path.relpath(so, ROOT), so, names, tmp)
-        src = os.path.join(tmp, "noguard.hip")
-        with open(src, "w") as fh:
-            fh.write('#include "common.hip.h"\n#undef HUMID_GUARD_LAST_VGPR\n#define HUMID_GUARD_LAST_VGPR()\n'
-                     '#include "humid_hip.hip"\n')
+        # every HIP unit of the library once more with the guard defined away (scratch units that include the real ones)
+        units = [build.SRC] + [u for u in build.HOST_UNITS if u.endswith(".hip")]
+        srcs = []
+        for k, u in enumerate(units):
+            src = os.path.join(tmp, "noguard%d.hip" % k)
+            with open(src, "w") as fh:
+                fh.write('#include "common.hip.h"\n#undef HUMID_GUARD_LAST_VGPR\n#define HUMID_GUARD_LAST_VGPR()\n'
+                         '#include "%s"\n' % os.path.basename(u))
+            srcs.append(src)
         so2 = os.path.join(tmp, "noguard.so")
-        subprocess.check_call(["hipcc"] + build.HIPCC_FLAGS + ["-I", os.path.join(ROOT, "humid_amd", "csrc"), "-o", so2, src] + build.HOST_UNITS, cwd=ROOT)
+        subprocess.check_call(["hipcc"] + build.HIPCC_FLAGS + ["-I", os.path.join(ROOT, "humid_amd", "csrc"), "-o", so2] + srcs +
+                              [u for u in build.HOST_UNITS if not u.endswith(".hip")], cwd=ROOT)
         show("the same sources with the guard defined away (scratch build, not shipped)", so2, names, tmp)
 
 
