@@ -58,6 +58,8 @@ typedef struct humid_summary {
   uint64_t clusters;    /* clusters.size()               src/humid.cc:403         */
   uint64_t edges;       /* undirected neighbour pairs                             */
   uint64_t nonsingle;   /* unique words with >= 1 neighbour                       */
+  /* the four stage times: filled by humid_dedup_run* only with option "kernel_timing" (0 otherwise; round 3: an
+   * event record between two kernels costs ~4 us of idle GPU); ms_total and ms_k_insert are always measured       */
   float ms_count;       /* hash insert + unique sort     (Trie::add, walk order)  */
   float ms_neighbours;  /* bucket passes + CSR           (findHammingNeighbours)  */
   float ms_cluster;     /* components + cluster kernel   (findClusters)           */
@@ -65,7 +67,7 @@ typedef struct humid_summary {
   float ms_total;       /* first kernel to last kernel on the stream              */
   float ms_h2d, ms_d2h; /* host-buffer entry point only                           */
   /* single kernels, HIP events directly around the launches on the ctx stream:      */
-  float ms_k_insert;    /* k_dedup_lds or k_hash_insert (one launch)                */
+  float ms_k_insert;    /* the count kernel: k_dedup_rec / k_dedup_lds / k_hash_insert (one launch) */
   float ms_k_pairs;     /* sum over the 2(d+1) k_pairs launches (count + fill)      */
   float ms_k_cluster;   /* k_cluster_pairs + _small (+ _components): 2-3 launches   */
   float ms_k_map;       /* first kernel of the un-permute: k_unperm_bins (or k_read_map_bucket, _part, k_read_map) */
@@ -106,9 +108,10 @@ const char *humid_last_error(const humid_ctx *ctx);   /* ctx may be NULL */
  * the hand-written LDS-staged partition (two coalesced passes each way); 0 = library radix passes
  * in front and one scattered store per read at the end (the round-1 form, also taken by itself for
  * read sets beyond ~180 M / ~67 M reads).
- * "kernel_timing": 1 = HIP events around the single kernels, so that humid_summary.ms_k_pairs / ms_k_cluster /
- * ms_k_map / ms_k_part / ms_k_unperm are filled (default 0, also HUMID_KERNEL_TIMING: the 13 extra event
- * records cost 20-45 us of a 1 ms pass; ms_k_insert and the stage times ms_count .. ms_map are always there).
+ * "kernel_timing": 1 = HIP events around the single kernels and between the stages, so that
+ * humid_summary.ms_k_pairs / ms_k_cluster / ms_k_map / ms_k_part / ms_k_unperm and the stage times ms_count ..
+ * ms_map of humid_dedup_run* are filled (default 0, also HUMID_KERNEL_TIMING: the 17 extra event records cost
+ * 30-50 us of a 0.7 ms pass; ms_k_insert and ms_total are always there).
  * "padded_partition": 1 (default) = the first level of the tile partition scatters into coarse bins of a
  * fixed room and needs no histogram pass over the reads; a bin that outgrows its room (heavily duplicated
  * words) is detected, the run repeated with the histogram pass, and the option stays 0 for this context.
