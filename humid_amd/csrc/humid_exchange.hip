@@ -943,7 +943,7 @@ int humid_stage_histogram(humid_ctx *c, const uint64_t *d_words, const uint8_t *
   if (n_reads) {
     const u64 *keys = d_words;
     if (word_nt > 32) TRY(stage_heads(c, d_words, (u32)n_reads, word_nt, &keys));
-    hipLaunchKernelGGL(k_top_hist, dim3(256), dim3(1024), n_bins * 4, c->stream, keys, d_filtered,
+    hipLaunchKernelGGL(k_top_hist, dim3(512), dim3(1024), n_bins * 4, c->stream, keys, d_filtered,
                        (u32)n_reads, (u64)0, word_nt >= 32 ? (u64)1 : ((u64)1 << (64 - 2 * word_nt)), bits, d_hist);
   }
   HIPCHK(hipGetLastError());

@@ -281,9 +281,12 @@ k_pairs_relabel(EdgeRegs er, BitRank br, const u32 *__restrict__ ncnt, u32 *deg,
 // workgroups whose time is a chain of memory round trips -- side by side the two chains overlap
 static __global__ void __launch_bounds__(256)
 k_fill_and_stats(EdgeRegs er, const u32 *__restrict__ off, u32 *cur, u32 *__restrict__ idx, u32 *__restrict__ regions_max, u32 gx,
-                 const u32 *__restrict__ deg, u32 *P, u32 n, u32 *csize, const u32 *__restrict__ n_dev) {
+                 const u32 *__restrict__ deg, u32 *P, u32 n, u32 *csize, const u32 *__restrict__ n_dev, u32 r_first) {
   HUMID_GUARD_LAST_VGPR();
-  const u32 nf = gx * (ER_REGIONS + 1);
+  // r_first: the first region this launch covers -- 0, or ER_REGIONS when the pairs are one dense list (records of the
+  // exchange pass, given edges: only the `far` region holds anything; 64 x gx workgroups that find their region empty
+  // cost 30 us of a launch there)
+  const u32 nf = gx * (ER_REGIONS + 1 - r_first);
   if (blockIdx.x >= nf) {
     const u32 u = (blockIdx.x - nf) * blockDim.x + threadIdx.x;
     if (n_dev && *n_dev < n) n = *n_dev;
@@ -293,7 +296,7 @@ k_fill_and_stats(EdgeRegs er, const u32 *__restrict__ off, u32 *cur, u32 *__rest
     atomicAdd(&csize[root], 1u);
     return;
   }
-  const u32 bx = blockIdx.x % gx, r = blockIdx.x / gx;
+  const u32 bx = blockIdx.x % gx, r = r_first + blockIdx.x / gx;
   if (regions_max && blockIdx.x == 0 && threadIdx.x < 64) {
     // the fullest region's cursor (what the search wanted of ONE region: all regions have the same room)
     u32 c = er.cur[threadIdx.x * ER_STRIDE];

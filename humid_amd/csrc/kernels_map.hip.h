@@ -514,13 +514,23 @@ k_route_scan(u32 *tile_cnt, u32 n_tiles, OwnerBases ob, u32 *bad) {
   HUMID_GUARD_LAST_VGPR();
   const u32 q = threadIdx.x >> 6, lane = threadIdx.x & 63;       // 16 waves = MAX_RANKS owners
   u32 run = ob.b[q];
-  for (u32 t0 = 0; t0 < n_tiles; t0 += 64) {
-    const u32 t = t0 + lane;
-    const u32 x = t < n_tiles ? tile_cnt[t * MAX_RANKS + q] : 0u;
-    u32 incl = x;
-    incl = wave_incl_scan(incl);
-    if (t < n_tiles) tile_cnt[t * MAX_RANKS + q] = run + incl - x;
-    run += __shfl(incl, 63);
+  // chunks of 16 rows of 64 tiles: the chunk's counts are requested together (one memory round trip per chunk, not
+  // per row: the kernel is ONE workgroup, its time is its chain of round trips), then scanned row by row
+  constexpr u32 ROWS = 16;
+  for (u32 c0 = 0; c0 < n_tiles; c0 += 64 * ROWS) {
+    u32 x[ROWS];
+#pragma unroll
+    for (u32 k = 0; k < ROWS; k++) {
+      const u32 t = c0 + 64 * k + lane;
+      x[k] = t < n_tiles ? tile_cnt[t * MAX_RANKS + q] : 0u;
+    }
+#pragma unroll
+    for (u32 k = 0; k < ROWS; k++) {
+      const u32 t = c0 + 64 * k + lane;
+      const u32 incl = wave_incl_scan(x[k]);
+      if (t < n_tiles) tile_cnt[t * MAX_RANKS + q] = run + incl - x[k];
+      run += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+    }
   }
   if (lane == 0 && run != ob.b[q + 1]) bad[0] = 1;
 }

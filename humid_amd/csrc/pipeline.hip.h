@@ -1547,8 +1547,9 @@ static int cg_build(humid_ctx *c, CgSource &src, u32 method, CgStatus &out) {
   {
     // CSR rows and component sizes side by side (one launch: kernels_cgraph.hip.h)
     const u32 gx = (u32)std::min<u64>(std::max<u64>(blocks_for(std::max<u64>(src.er.cap_r, src.er.n_far)), 1), 4096);
-    hipLaunchKernelGGL(k_fill_and_stats, dim3(gx * (ER_REGIONS + 1) + blocks_for(Mb)), dim3(256), 0, st, src.er, (const u32 *)g.off,
-                       c->cg_curs.as<u32>(), g.idx, c->small.as<u32>(), gx, (const u32 *)g.deg, g.parent, Mb, g.csize, m_dev);
+    const u32 r_first = src.er.e ? 0u : ER_REGIONS;      // no regions (one dense pair list): the `far` region alone
+    hipLaunchKernelGGL(k_fill_and_stats, dim3(gx * (ER_REGIONS + 1 - r_first) + blocks_for(Mb)), dim3(256), 0, st, src.er, (const u32 *)g.off,
+                       c->cg_curs.as<u32>(), g.idx, c->small.as<u32>(), gx, (const u32 *)g.deg, g.parent, Mb, g.csize, m_dev, r_first);
   }
   hipLaunchKernelGGL(k_sort_lists, dim3(blocks_for(Mb)), dim3(256), 0, st, (const u32 *)g.off, Mb, g.idx);
   if (c->kev_on) HIPCHK(hipEventRecord(c->kev[2], st));
