@@ -468,6 +468,13 @@ def main():
         out["backend"] = dist.get_backend()
         out["ranks"] = ranks_seen
         out["launcher"] = os.environ.get("HUMID_BENCH_LAUNCHER", "external (WORLD_SIZE was set)")
+    else:                                                  # one process, no process group: the same fields, for one rank
+        pr = torch.cuda.get_device_properties(dev)
+        out["world_size"] = 1
+        out["backend"] = None
+        out["ranks"] = [{"rank": 0, "device": local_rank, "name": pr.name, "pci_bus": getattr(pr, "pci_bus_id", None),
+                         "pid": os.getpid()}]
+        out["launcher"] = os.environ.get("HUMID_BENCH_LAUNCHER", "none (one process, no process group)")
     # outside the timed region: every rank draws the whole world x reads set and keeps its slice;
     # rank 0 re-runs the whole set on ONE GPU for verified_vs_single_gpu
     out["synth_s"] = round(synth_s, 1)
