@@ -23,6 +23,7 @@
 #define PT_TILE 8192u            // records per tile: 8 per thread
 #define PT_IPT (PT_TILE / PT_THREADS)
 #define PT_MAXBINS 512u          // fan-out of one level (<= 9 key bits)
+#define PT_MAXBINS1 1024u        // ... of the record path's FIRST level when a record would not fit 64 bits otherwise (10 bits)
 
 // the reads of the count stage
 struct PtInput {
@@ -87,6 +88,20 @@ __device__ __forceinline__ void block_exscan_512(const u32 *cnt, u32 *off, u32 n
   __syncthreads();
 }
 
+// the same for nb <= 1024 (the 10-bit first level of the record path, kernels_part8.hip.h), by a block of 1024 threads
+__device__ __forceinline__ void block_exscan_1024(const u32 *cnt, u32 *off, u32 nb, u32 *wsum /* >= 16 */) {
+  const u32 t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const u32 x = (t < nb) ? cnt[t] : 0u;
+  const u32 incl = wave_incl_scan(x);
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  u32 before = 0;
+  for (u32 k = 0; k < wv; k++) before += wsum[k];
+  if (t < nb) off[t] = before + incl - x;
+  if (t == nb - 1) off[nb] = before + incl;
+  __syncthreads();
+}
+
 // tile -> (coarse bin, first record, record count): tiles never cross a coarse bin
 // cap1 > 0: the level-1 output is PADDED -- coarse bin c owns the fixed room [c * cap1, (c + 1) * cap1) and
 // holds cbase[c + 1] - cbase[c] records at its start (level 1 then needs no histogram pass of its own)
@@ -140,16 +155,16 @@ static __global__ void __launch_bounds__(1024)
 k_pt_scan1(const u32 *__restrict__ hist1, u32 d1, u32 d2, u32 *__restrict__ cbase, u32 *__restrict__ tprefix,
            u32 *__restrict__ pbeg, u32 *__restrict__ ucount_tail, u32 cap1, u32 *clear = nullptr) {
   HUMID_GUARD_LAST_VGPR();
-  __shared__ u32 cnt[PT_MAXBINS], off[PT_MAXBINS + 1], wsum[8];
+  __shared__ u32 cnt[PT_MAXBINS1], off[PT_MAXBINS1 + 1], wsum[16];
   const u32 nb = 1u << d1;
   // cap1 > 0: hist1 = the cursors of a padded level 1 (what each coarse bin received; a bin that
   // overflowed its room is cut to it -- the run is discarded by the caller, nothing may leave its room)
   auto count_of = [&](u32 b) { const u32 v = hist1[b]; return (cap1 && v > cap1) ? cap1 : v; };
   if (threadIdx.x < nb) cnt[threadIdx.x] = count_of(threadIdx.x);
   __syncthreads();
-  block_exscan_512(cnt, off, nb, wsum);
-  if (threadIdx.x <= nb) cbase[threadIdx.x] = off[threadIdx.x];
-  if (threadIdx.x == 0) { pbeg[nb << d2] = off[nb]; *ucount_tail = 0; }
+  block_exscan_1024(cnt, off, nb, wsum);
+  if (threadIdx.x < nb) cbase[threadIdx.x] = off[threadIdx.x];
+  if (threadIdx.x == 0) { cbase[nb] = off[nb]; pbeg[nb << d2] = off[nb]; *ucount_tail = 0; }
   if (d2 == 0) {
     if (threadIdx.x < nb) pbeg[threadIdx.x] = off[threadIdx.x];
   } else {
@@ -159,8 +174,9 @@ k_pt_scan1(const u32 *__restrict__ hist1, u32 d1, u32 d2, u32 *__restrict__ cbas
   __syncthreads();
   if (threadIdx.x < nb) cnt[threadIdx.x] = (count_of(threadIdx.x) + PT_TILE - 1) / PT_TILE;
   __syncthreads();
-  block_exscan_512(cnt, off, nb, wsum);
-  if (threadIdx.x <= nb) tprefix[threadIdx.x] = off[threadIdx.x];
+  block_exscan_1024(cnt, off, nb, wsum);
+  if (threadIdx.x < nb) tprefix[threadIdx.x] = off[threadIdx.x];
+  if (threadIdx.x == 0) tprefix[nb] = off[nb];
   // clear (= hist1, the cursors of a padded level 1 that nobody reads after this): left at zero for the next use
   if (clear && threadIdx.x < nb) clear[threadIdx.x] = 0;
 }

@@ -92,7 +92,9 @@ k_p8_scatter1(SRC src, u32 n_reads, u32 kbits, u32 d1, u32 ibits, u32 cap1, u32 
   HUMID_GUARD_LAST_VGPR();
   constexpr u32 TILE = THREADS * PT_IPT;
   __shared__ u64 srec[TILE];
-  __shared__ u32 cnt[PT_MAXBINS], loff[PT_MAXBINS + 1], goff[PT_MAXBINS], room[PT_MAXBINS], wsum[8];
+  // up to 1024 coarse bins (d1 = 10: chosen when a record would not fit 64 bits with 9, i.e. 24-nt words beyond 33 M
+  // reads); the room left in a bin is what separates its next free place from the end of its room: no array of its own
+  __shared__ u32 cnt[PT_MAXBINS1], loff[PT_MAXBINS1 + 1], goff[PT_MAXBINS1], wsum[16];
   const u32 nb = 1u << d1;
   PH_DECL;
   PH(0);
@@ -118,13 +120,12 @@ k_p8_scatter1(SRC src, u32 n_reads, u32 kbits, u32 d1, u32 ibits, u32 cap1, u32 
   PH(2);
   __syncthreads();
   PH(3);
-  block_exscan_512(cnt, loff, nb, wsum);
+  block_exscan_1024(cnt, loff, nb, wsum);
   PH(4);
   if (threadIdx.x < nb) {
     const u32 c = cnt[threadIdx.x];
     const u32 had = c ? atomicAdd(&cursor[threadIdx.x], c) : 0u;
-    goff[threadIdx.x] = threadIdx.x * cap1 + had;
-    room[threadIdx.x] = had >= cap1 ? 0u : cap1 - had;
+    goff[threadIdx.x] = threadIdx.x * cap1 + (had < cap1 ? had : cap1);     // (a full bin: its end, room 0)
     if (had + c > cap1) ctr[CTR_SPECIAL] = 1;                 // the bin outgrew its room: the caller repartitions
   }
   PH(5);
@@ -134,7 +135,7 @@ k_p8_scatter1(SRC src, u32 n_reads, u32 kbits, u32 d1, u32 ibits, u32 cap1, u32 
   __syncthreads();
   PH(6);
   p8_write_bins(srec, loff, nb, p8_group(loff[nb], nb), out,
-                [&](u32 bin, u32 k) -> u64 { return k < room[bin] ? (u64)goff[bin] + k : ~0ull; });
+                [&](u32 bin, u32 k) -> u64 { return goff[bin] + k < (bin + 1) * cap1 ? (u64)goff[bin] + k : ~0ull; });
   PH(7);
   PH_END(1, 7, (blockIdx.x & 15u) == 3u);  // 1 clear | 2 loads + LDS ranks | 3 barrier | 4 scan | 5 global cursors | 6 sort in LDS + barrier | 7 write out
 }

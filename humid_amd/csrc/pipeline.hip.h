@@ -743,14 +743,20 @@ static int stage_count_rec(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   const u32 pb = part_bits(N);
   if (pb < 6 || pb > 18) return HUMID_OK;
   if ((((u64)N + (1u << UW_MAXSHIFT) - 1) >> UW_MAXSHIFT) > UW_MAXBINS) return HUMID_OK;
-  const u32 d1 = (pb + 1) / 2, d2 = pb - d1, nb1 = 1u << d1, n_parts = 1u << pb;
   RecKey rk;
   rk.lo = km.lo; rk.scale = km.scale;
   rk.pow2 = km.shift < 64 ? 1u : 0u;
   rk.z = rk.pow2 ? km.shift : 63u - (u32)__builtin_clzll(km.scale);
   rk.kbits = 64 - rk.z;
   const u32 ibits = bits_for(N);
-  if (rk.kbits < pb + 1 || rk.kbits - d1 + ibits > 64) return HUMID_OK;
+  // a record = the key bits below the coarse bin + the read index: kbits - d1 + ibits <= 64.  24-nt words over their
+  // whole range have 48 key bits: with the balanced split d1 = pb / 2 <= 9 that ends at 2^25 = 33 M reads; one more
+  // bit in the FIRST level (1024 coarse bins: half as long runs per bin and tile there) carries the record path to the
+  // 67 M reads of the un-permute's bin table (BASELINE configs 3 and 5: 50 M reads)
+  u32 d1 = (pb + 1) / 2;
+  while (d1 < 10 && pb - d1 > 1 && rk.kbits - d1 + ibits > 64) d1++;
+  const u32 d2 = pb - d1, nb1 = 1u << d1, n_parts = 1u << pb;
+  if (rk.kbits < pb + 1 || rk.kbits - d1 + ibits > 64 || d2 > 9 || d2 == 0) return HUMID_OK;
   static const u32 pad_div = getenv("HUMID_PAD_DIV") ? (u32)std::max(1, atoi(getenv("HUMID_PAD_DIV"))) : 4u;
   const u32 cap1 = (u32)std::min<u64>(0xffffffffull / nb1, (u64)N / nb1 + (u64)N / nb1 / pad_div + 1024);
   const size_t room1 = (size_t)nb1 * cap1, room2 = (size_t)n_parts << P8_CAP2_LOG;
@@ -764,16 +770,16 @@ static int stage_count_rec(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   // per bucket (reads << 32 | unique words) and its exclusive scan; entry n_parts = the scan's sentinel -> the totals
   ENSURE(c->p8_status, ((size_t)n_parts + 1) * 16);
   u64 *agg = c->p8_status.as<u64>(), *abase = agg + n_parts + 1;
-  // p8_cur, in u32: [cursor1 512 | cursor2 n_parts] zeroed, then [cbase 513 | tprefix 513].  (Not pt_work: the
+  // p8_cur, in u32: [cursor1 1024 | cursor2 n_parts] zeroed, then [cbase 1025 | tprefix 1025].  (Not pt_work: the
   // reads per bucket, cursor2, are read again by the un-permute at the end of the pass, and the graph
   // stage's grouping uses pt_work in between.)
-  ENSURE(c->p8_cur, ((size_t)512 + n_parts + 1026) * 4);
-  u32 *cursor1 = c->p8_cur.as<u32>(), *cursor2 = cursor1 + 512, *cbase = cursor2 + n_parts, *tprefix = cbase + 513;
+  ENSURE(c->p8_cur, ((size_t)PT_MAXBINS1 + n_parts + 2 * (PT_MAXBINS1 + 1)) * 4);
+  u32 *cursor1 = c->p8_cur.as<u32>(), *cursor2 = cursor1 + PT_MAXBINS1, *cbase = cursor2 + n_parts, *tprefix = cbase + PT_MAXBINS1 + 1;
   HIPCHK(hipEventRecord(c->ev[0], st));
   {
     ZeroList z;
     memset(&z, 0, sizeof z);
-    z.p[0] = cursor1; z.n[0] = 512 + n_parts;
+    z.p[0] = cursor1; z.n[0] = PT_MAXBINS1 + n_parts;
     z.p[1] = (u32 *)c->d_ctr; z.n[1] = 2 * CTR_N;
     z.p[2] = (u32 *)(agg + n_parts); z.n[2] = 2;
     hipLaunchKernelGGL(k_zero_many, dim3(32), dim3(256), 0, st, z);
@@ -782,7 +788,7 @@ static int stage_count_rec(humid_ctx *c, const u64 *d_words, const u8 *d_filt, u
   const Reads8 src{d_words, d_filt, range_lo, range_hi, check_range ? 1u : 0u, rk};
   const u32 tiles1 = (N + PT_TILE - 1) / PT_TILE, tiles2 = tiles1 + nb1;
   static const bool s1_small = getenv("HUMID_S1_THREADS") ? atoi(getenv("HUMID_S1_THREADS")) == 512 : false;  // (experiments: 512 is 20 us slower)
-  if (s1_small)
+  if (s1_small && nb1 <= 512)
     hipLaunchKernelGGL((k_p8_scatter1<Reads8, 512>), dim3((N + 4095) / 4096), dim3(512), 0, st, src, N, rk.kbits, d1, ibits, cap1, cursor1,
                        c->p8_a.as<u64>(), c->d_ctr);
   else

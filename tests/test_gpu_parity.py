@@ -311,6 +311,20 @@ def test_oracle_parity_at_scale_genome_d2(dd1):
     check_against_oracle(dd1, words, filt, 24, 2, False, deep=True)
 
 
+def test_record_path_with_ten_bit_first_level():
+    """8-byte partition records hold the key bits below the coarse bin + the read index: 2 n - d1 + ceil(log2 N) <= 64.
+    When the balanced split of the bucket bits does not fit, the FIRST level takes up to 10 bits (1024 coarse bins) --
+    how 24-nt words stay on the record path between 33 M and 67 M reads (BASELINE configs 3 and 5).  The same
+    arithmetic at a size the oracle finishes: 26-nt words (52 key bits), 3 M reads (22 index bits, 2^14 buckets):
+    52 - 7 + 22 = 67 with the balanced split, 64 with d1 = 10.  Every array against the oracle; the run must have
+    stayed on the record path."""
+    words, filt = synth_words(3_000_000, 1026, 26)
+    dq = humid_amd.Dedup()
+    s = check_against_oracle(dq, words, filt, 26, 1, False, deep=True)
+    assert s["records8"] and s["count_mode_used"] == 2, (s["count_mode_used"], s["records8"])
+    dq.close()
+
+
 def test_oracle_parity_metric_words_d2(dd1):
     """1 M reads of the metric workload at d = 2, both methods"""
     words, filt = synth_words(1_000_000, 1002, 24)
