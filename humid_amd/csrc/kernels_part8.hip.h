@@ -371,12 +371,16 @@ k_compact_padded8(const u64 *__restrict__ pad_word, const uint2 *__restrict__ pa
 // 32 | read).  Otherwise as k_unperm_bins (kernels_part.hip.h): the packed result travels as (result << 32
 // | read) into bin read >> wshift, a tile's records leave bin by bin as contiguous runs.  NBMAX = 1024 (read
 // sets up to 16 M reads): 77 KB of LDS, two workgroups per CU.
-template <u32 NBMAX>
-__global__ void __launch_bounds__(1024, NBMAX <= 1024 ? 8 : 4)
+// UIPT records per thread and chunk (a chunk of 1024 x UIPT records is staged at a time): 8 with up to 1024 bins; 7 with
+// up to 1536 bins (33 M .. 50 M reads), so that the staging area and the three bin tables still leave room for TWO
+// workgroups per CU; 8 again (and one workgroup per CU) beyond
+template <u32 NBMAX, u32 UIPT = 8u>
+__global__ void __launch_bounds__(1024, NBMAX <= 1536 ? 8 : 4)
 k_unperm_bins8(const u64 *__restrict__ recs, const u32 *__restrict__ cursor2, const u64 *__restrict__ slot_out, u32 n_parts,
                u32 B, u32 n_reads, u32 wshift, u32 n_bins, u32 *ucur, u64 *__restrict__ rec) {
   HUMID_GUARD_LAST_VGPR();
-  __shared__ u64 srec[PT_TILE];
+  constexpr u32 UTILE = PT_THREADS * UIPT;
+  __shared__ u64 srec[UTILE];
   __shared__ u32 cnt[NBMAX], loff[NBMAX + 1], goff[NBMAX], wsum[16];
   __shared__ u32 bpre[65];                                    // records before bucket g0 + b in this workgroup's stretch
   PH_DECL;
@@ -395,13 +399,13 @@ k_unperm_bins8(const u64 *__restrict__ recs, const u32 *__restrict__ cursor2, co
   __syncthreads();
   const u32 T = bpre[nbk];
   PH(1);
-  for (u32 c0 = 0; c0 < T; c0 += PT_TILE) {
+  for (u32 c0 = 0; c0 < T; c0 += UTILE) {
     for (u32 b = threadIdx.x; b < n_bins; b += PT_THREADS) cnt[b] = 0;
     __syncthreads();
-    u64 in[PT_IPT], r64[PT_IPT];
-    u32 binrank[PT_IPT];                                      // bin << 16 | rank inside (tile, bin); ~0: none
+    u64 in[UIPT], r64[UIPT];
+    u32 binrank[UIPT];                                      // bin << 16 | rank inside (tile, bin); ~0: none
 #pragma unroll
-    for (u32 q = 0; q < PT_IPT; q++) {                        // all loads of the thread in flight together
+    for (u32 q = 0; q < UIPT; q++) {                        // all loads of the thread in flight together
       const u32 r = c0 + threadIdx.x + q * PT_THREADS;
       binrank[q] = NONE32;
       if (r < T) {
@@ -416,7 +420,7 @@ k_unperm_bins8(const u64 *__restrict__ recs, const u32 *__restrict__ cursor2, co
     }
     PH(2);
 #pragma unroll
-    for (u32 q = 0; q < PT_IPT; q++) {
+    for (u32 q = 0; q < UIPT; q++) {
       if (binrank[q] == NONE32) continue;
       const u32 r = (u32)in[q], sl = (u32)(in[q] >> 32);
       binrank[q] = NONE32;
@@ -455,7 +459,7 @@ k_unperm_bins8(const u64 *__restrict__ recs, const u32 *__restrict__ cursor2, co
     }
     PH(6);
 #pragma unroll
-    for (u32 q = 0; q < PT_IPT; q++)
+    for (u32 q = 0; q < UIPT; q++)
       if (binrank[q] != NONE32) srec[loff[binrank[q] >> 16] + (binrank[q] & 0xffffu)] = r64[q];
     __syncthreads();
     PH(7);

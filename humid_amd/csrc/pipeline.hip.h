@@ -2219,10 +2219,14 @@ static int unpermute_tiled(humid_ctx *c, u32 N, bool packed, u32 *d_cid, u8 *d_k
   if (c->last_rec8) {
     // buckets per workgroup: about 7/8 of a tile's worth of records (reads per bucket: usable / buckets)
     const u64 mean = std::max<u64>(1, c->usable / c->n_parts);
-    const u32 B = (u32)std::min<u64>(64, std::max<u64>(1, (PT_TILE - PT_TILE / 8) / mean));
+    const u32 chunk = (n_bins > 1024 && n_bins <= 1536) ? 7u * PT_THREADS : PT_TILE;     // records the variant below stages at a time
+    const u32 B = (u32)std::min<u64>(64, std::max<u64>(1, (chunk - chunk / 8) / mean));
     const u32 grid = (c->n_parts + B - 1) / B;
     if (n_bins <= 1024)
       hipLaunchKernelGGL(k_unperm_bins8<1024>, dim3(grid), dim3(1024), 0, st, (const u64 *)c->p8_b.as<u64>(), c->rec_cursor2,
+                         (const u64 *)c->slot_out.as<u64>(), c->n_parts, B, N, wshift, n_bins, ucur, rec);
+    else if (n_bins <= 1536)
+      hipLaunchKernelGGL((k_unperm_bins8<1536, 7>), dim3(grid), dim3(1024), 0, st, (const u64 *)c->p8_b.as<u64>(), c->rec_cursor2,
                          (const u64 *)c->slot_out.as<u64>(), c->n_parts, B, N, wshift, n_bins, ucur, rec);
     else
       hipLaunchKernelGGL(k_unperm_bins8<2048>, dim3(grid), dim3(1024), 0, st, (const u64 *)c->p8_b.as<u64>(), c->rec_cursor2,
