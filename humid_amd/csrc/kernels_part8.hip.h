@@ -225,6 +225,33 @@ k_p8_scatter2(const u64 *__restrict__ in, const u32 *__restrict__ tprefix, const
 // run (runs are ~1.1 entries long at the usual load of 8 %).
 #define DR_SPILL 64u
 #define DR_SLOTS (LDS_SLOTS + DR_SPILL)
+// the run of occupied entries around entry sl = 32 w + bit, [start, end), read off the occupancy bitmap (bw = its word
+// w; one word of zeros lies behind the bitmap): no walk through the table, so the keys of the run can be requested
+// together
+__device__ __forceinline__ void dr_run_bounds(const u32 *lbits, u32 w, u32 bit, u32 bw, u32 &start, u32 &end) {
+  const u32 zb = ~bw & ((1u << bit) - 1u);                 // empty entries of the word in front of sl
+  if (zb) start = (w << 5) + (32u - (u32)__clz((int)zb));
+  else {
+    u32 ww = w;
+    start = w << 5;
+    while (ww > 0) {
+      const u32 pz = ~lbits[ww - 1];
+      if (pz) { start = ((ww - 1) << 5) + (32u - (u32)__clz((int)pz)); break; }
+      ww--;
+      start = ww << 5;
+    }
+  }
+  const u32 za = bit < 31 ? (~bw & ~((2u << bit) - 1u)) : 0u;   // empty entries of the word behind sl
+  if (za) end = (w << 5) + (u32)__ffs((int)za) - 1u;
+  else {
+    u32 ww = w + 1;
+    while (true) {                                         // (ends at the zero word behind the bitmap at the latest)
+      const u32 nz = ~lbits[ww];
+      if (nz) { end = (ww << 5) + (u32)__ffs((int)nz) - 1u; break; }
+      ww++;
+    }
+  }
+}
 #define DR_WORDS (DR_SLOTS / 32u)                  // 34 words of the occupancy bitmap
 #define DR_EARLY 1u                                // of the P8_RPT records per thread: requested before the fill is known
 static __global__ void __launch_bounds__(256)
@@ -318,13 +345,10 @@ k_dedup_rec(u64 *recs, const u32 *__restrict__ cursor2, u32 n_reads, u32 pb, u32
     const bool right = bit < 31 ? ((bw >> (bit + 1)) & 1u) != 0 : (lbits[w + 1] & 1u) != 0;
     const u64 k = lkey[sl];
     if (left || right) {                               // a run of several entries: order inside it by comparing
-      u32 start = sl, smaller = 0;
-      while (start > 0 && lkey[start - 1] != EMPTY_KEY) start--;
-      for (u32 j = start; j < DR_SLOTS; j++) {
-        const u64 kj = lkey[j];
-        if (kj == EMPTY_KEY) break;
-        smaller += kj < k ? 1u : 0u;
-      }
+      u32 start, end, smaller = 0;
+      dr_run_bounds(lbits, w, bit, bw, start, end);
+      if (end > DR_SLOTS) end = DR_SLOTS;
+      for (u32 j = start; j < end; j++) smaller += lkey[j] < k ? 1u : 0u;
       r = r - (sl - start) + smaller;                  // (all of [start, sl) is occupied)
     }
     const uint2 cf = lcf[sl];
@@ -696,12 +720,10 @@ k_dedup_wide_rec(const W2 *__restrict__ recw, const u32 *__restrict__ reci, cons
     const bool right = bit < 31 ? ((bw >> (bit + 1)) & 1u) != 0 : (lbits[w32 + 1] & 1u) != 0;
     const W2 w = wk[lclaim[sl]];
     if (left || right) {                               // a run of several entries: order inside it by comparing the words
-      u32 start = sl, smaller = 0;
-      while (start > 0 && lkey[start - 1] != EMPTY_KEY) start--;
-      for (u32 j = start; j < TS; j++) {
-        if (lkey[j] == EMPTY_KEY) break;
-        smaller += w_less(wk[lclaim[j]], w) ? 1u : 0u;
-      }
+      u32 start, end, smaller = 0;
+      dr_run_bounds(lbits, w32, bit, bw, start, end);
+      if (end > TS) end = TS;
+      for (u32 j = start; j < end; j++) smaller += w_less(wk[lclaim[j]], w) ? 1u : 0u;
       r = r - (sl - start) + smaller;                  // (all of [start, sl) is occupied)
     }
     const uint2 cf = lcf[sl];
