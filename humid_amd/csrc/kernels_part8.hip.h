@@ -423,6 +423,7 @@ k_unperm_bins8(const u64 *__restrict__ recs, const u32 *__restrict__ cursor2, co
   }
   __syncthreads();
   const u32 T = bpre[nbk];
+  const u64 inv_mean = T ? (((u64)nbk << 32) / T) : 0;        // buckets per record, 32.32 fixed point
   PH(1);
   for (u32 c0 = 0; c0 < T; c0 += UTILE) {
     for (u32 b = threadIdx.x; b < n_bins; b += PT_THREADS) cnt[b] = 0;
@@ -434,11 +435,12 @@ k_unperm_bins8(const u64 *__restrict__ recs, const u32 *__restrict__ cursor2, co
       const u32 r = c0 + threadIdx.x + q * PT_THREADS;
       binrank[q] = NONE32;
       if (r < T) {
-        u32 lo = 0, hi = nbk;                                 // the bucket holding record r: bpre[lo] <= r < bpre[lo + 1]
-        while (hi - lo > 1) {
-          const u32 mid = (lo + hi) >> 1;
-          if (bpre[mid] <= r) lo = mid; else hi = mid;
-        }
+        // the bucket holding record r (bpre[lo] <= r < bpre[lo + 1]): the buckets of a stretch are about equally
+        // full, so r x buckets / records is the right one or a neighbour -- a step or two instead of a bisection
+        u32 lo = (u32)(((u64)r * inv_mean) >> 32);
+        if (lo >= nbk) lo = nbk - 1;
+        while (bpre[lo] > r) lo--;
+        while (bpre[lo + 1] <= r) lo++;
         in[q] = recs[((size_t)(g0 + lo) << P8_CAP2_LOG) + (r - bpre[lo])];
         binrank[q] = 0;
       }
