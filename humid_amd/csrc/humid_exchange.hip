@@ -510,7 +510,7 @@ static int run_exchange_impl(humid_ctx *c, const humid_comm *cm, const uint64_t 
   ENSURE(c->cg_cur, (size_t)(ER_REGIONS * ER_STRIDE + 8) * 4);
   ENSURE(c->xo_cnt, 64 * 4);
   ENSURE(c->small, 64);
-  u32 *dcnt = c->xo_cnt.as<u32>();                                  // [0, P]: records per destination; [32, 32 + P]: scatter cursors; 48: flagged; 56..: totals
+  u32 *dcnt = c->xo_cnt.as<u32>();                                  // [0, P]: records per destination; [32, 32 + P]: scatter cursors (P <= 16: up to index 48); 52: flagged; 56..: totals
   bool use_regions = !c->edit && d > 0 && u_total > 1 && c->walk_max > 0;
   bool flagged_mine = false;                                         // a region overflowed / a bucket beyond the walk: this pass takes the dense road
   auto zero_discovery = [&]() -> int {
@@ -717,10 +717,10 @@ static int run_exchange_impl(humid_ctx *c, const humid_comm *cm, const uint64_t 
                          (const u32 *)c->xo_parent.as<u32>(), c->xo_flag.as<u8>(), by_count);
       if (n_int) {
         hipLaunchKernelGGL(k_select_flagged<false>, dim3(std::min<u32>(blocks_for(n_int), 1024)), dim3(256), 0, st, d_int, (u32)n_int,
-                           (u32)goff, (const u32 *)c->xo_parent.as<u32>(), (const u8 *)c->xo_flag.as<u8>(), dcnt + 48,
+                           (u32)goff, (const u32 *)c->xo_parent.as<u32>(), (const u8 *)c->xo_flag.as<u8>(), dcnt + 52,
                            c->xo_sel.as<ulonglong2>());
         u32 h = 0;
-        HIPCHK(hipMemcpyAsync(&h, dcnt + 48, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&h, dcnt + 52, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         k_mine = h;
       }

@@ -104,6 +104,31 @@ def test_exchange_ranges_use_word_ordered_buckets():
         assert s["count_mode_used"] in (0, 1) or s["ms_k_insert"] == 0.0     # ranks without reads: nothing ran
 
 
+@pytest.mark.parametrize("P", [16, 11])
+@pytest.mark.parametrize("cfg", [(240_000, 24, 1, 0), (120_000, 24, 2, 1), (90_000, 40, 1, 0)])
+def test_exchange_sixteen_ranks(cfg, P):
+    """the largest group the pass takes (MAX_RANKS = 16 thread ranks on the one GPU) and an odd one between 8 and 16:
+    sixteen value ranges, pairs that cross them in the first two nucleotides, owner-local clustering with fifteen
+    foreign ranges -- one- and two-word words, both methods, every shard against the oracle.  (Round 3 ran the whole
+    pass with at most 8 ranks until the end; at exactly 16 the cursor of the records that go to EVERY rank and the
+    count of the flagged interior records shared a word of a small counter block: the pass failed its own check of
+    the record indices.  Found by this test.)"""
+    n_reads, n, d, method = cfg
+    if n > 32:
+        from humid_amd.synth import synth_wide_words
+        words, filt = synth_wide_words(n_reads, 1600 + n, n, p_sub=5e-3, p_n=1e-3)
+        ocid, okeep, osum, _ = orc.dedup_run(words, filt, n, d, method)
+        out, offs = run_ranks(P, words, filt, n, d, method, "exchange")
+        for r in range(P):
+            cid, keep, s, used = out[r]
+            assert used == "exchange"
+            assert np.array_equal(cid, ocid[offs[r]:offs[r + 1]]) and np.array_equal(keep, okeep[offs[r]:offs[r + 1]])
+            assert s["edges"] == osum["edges"] and s["clusters"] == osum["clusters"] and s["unique"] == osum["unique"]
+        return
+    words, filt = synth_words(n_reads, 1600 + d, n, p_sub=5e-3, p_n=1e-3)
+    check(P, words, filt, n, d, method)
+
+
 def test_exchange_uneven_shards_and_reuse():
     words, filt = synth_words(100_003, 5, 24, p_sub=5e-3, p_n=1e-3)
     check(4, words, filt, 24, 1, 0, sizes=[50_000, 3, 0, 50_000], passes=2)
