@@ -630,6 +630,10 @@ class ShardedDedup:
                 self.ops.set_option("edit_distance", 1)
             else:
                 self.mode = "allgather"
+        if word_nt > 32 and self.world > getattr(self.ops, "max_ranks_dense", 16):
+            # refused here, on every rank alike and before any collective (both modes' two-word stages
+            # return results as dense per-shard streams, which the library lays out for at most 16 ranks)
+            raise NotImplementedError("words longer than 32 nt: at most %d ranks" % getattr(self.ops, "max_ranks_dense", 16))
         self.shm_used = False
         if self.world > 1 and hasattr(self.ops, "open_shm") and not self.py_orchestration:
             self.shm_used = self.ops.open_shm(self.dist)

@@ -172,6 +172,52 @@ def test_allgather_mode_virtual_ranks():
     check(3, words, filt, 24, 1, 0, mode="allgather")
 
 
+@pytest.mark.parametrize("P,mode,expect", [(16, "allgather", "allgather"), (17, "exchange", "allgather"),
+                                           (24, "allgather", "allgather")])
+@pytest.mark.parametrize("cfg", [(150_000, 24, 1, 0), (60_000, 40, 2, 1)])
+def test_more_ranks_than_the_exchange_pass_takes(P, mode, expect, cfg):
+    """groups at and beyond MAX_RANKS = 16: a request for the exchange pass with 17 ranks runs the all-gather stages
+    (DESIGN 4b), and those stages with 16 and 24 ranks -- one- and two-word words, every shard against the oracle"""
+    n_reads, n, d, method = cfg
+    if n > 32 and P > 16:
+        from fake_dist import FakeDist, FakeWorld
+        from humid_amd.sharded import HipStageOps, ShardedDedup
+        ops = HipStageOps(0)
+        with pytest.raises(NotImplementedError, match="at most 16 ranks"):      # a stated limit (DESIGN 7), refused up front
+            ShardedDedup(device=0, word_nt=n, distance=d, method=method, ops=ops, dist=FakeDist(FakeWorld(P), 3), mode=mode)
+        ops.close()
+        return
+    if n > 32:
+        from humid_amd.synth import synth_wide_words
+        words, filt = synth_wide_words(n_reads, 1700 + P + d, n, p_sub=5e-3, p_n=1e-3)
+        ocid, okeep, osum, _ = orc.dedup_run(words, filt, n, d, method)
+        out, offs = run_ranks(P, words, filt, n, d, method, mode)
+        for r in range(P):
+            cid, keep, s, used = out[r]
+            assert used == expect
+            assert np.array_equal(cid, ocid[offs[r]:offs[r + 1]]) and np.array_equal(keep, okeep[offs[r]:offs[r + 1]])
+            assert s["edges"] == osum["edges"] and s["clusters"] == osum["clusters"] and s["unique"] == osum["unique"]
+        return
+    words, filt = synth_words(n_reads, 1700 + P + d, n, p_sub=5e-3, p_n=1e-3)
+    check(P, words, filt, n, d, method, mode=mode, expect_mode=expect)
+
+
+@pytest.mark.parametrize("P,mode,expect", [(16, "exchange", "exchange"), (16, "allgather", "allgather"), (17, None, "allgather")])
+def test_edit_distance_sixteen_ranks(P, mode, expect):
+    """-e with the join dealt out over 16 ranks, and over 17 (no mode named: the all-gather stages)"""
+    from test_oracle_vs_bruteforce import indel_words
+    rng = np.random.default_rng(1616)
+    words = indel_words(rng, 30_000, 20, p_indel=0.4)
+    filt = (rng.random(len(words)) < 0.01).astype(np.uint8)
+    ocid, okeep, osum, _ = orc.dedup_run(words, filt, 20, 2, 0, edit=True)
+    out, offs = run_ranks(P, words, filt, 20, 2, 0, mode, edit=True)
+    for r in range(P):
+        cid, keep, s, used = out[r]
+        assert used == expect
+        assert np.array_equal(cid, ocid[offs[r]:offs[r + 1]]) and np.array_equal(keep, okeep[offs[r]:offs[r + 1]])
+        assert s["clusters"] == osum["clusters"] and s["edges"] == osum["edges"]
+
+
 def test_exchange_entry_points_reject_bad_arguments():
     """the new stage entry points fail with a code and a message, never with a fault"""
     import torch
