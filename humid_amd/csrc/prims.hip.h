@@ -206,7 +206,7 @@ k_ps_scan_tiny(In in, u32 n, T *out) {
 
 // up to PS_CHAIN_WGS workgroups in ONE launch, n <= PS_CHAIN_WGS x 1024 x 8: a workgroup scans its tile of
 // 1024 x ITEMS items, publishes the tile's sum (value, then a flag that holds this launch's EPOCH, so the
-// chain is never cleared), and its first wave collects the sums of ALL tiles before it -- one lane per
+// chain is cleared only when the 32-bit epoch wraps: ps_exscan), and its first wave collects the sums of ALL tiles before it -- one lane per
 // earlier tile, at most 63 -- instead of walking a chain.  The grid is at most 64 workgroups on 256 CUs,
 // so every tile a workgroup waits for is running.  Launches that share a PsChain must be ordered (one stream).
 #define PS_CHAIN_WGS 64u
@@ -285,7 +285,11 @@ template <class T, class In>
 static inline hipError_t ps_exscan(In in, T *out, u64 n, T *scratch, hipStream_t st, PsChain *chain = nullptr, u32 *epoch = nullptr) {
   if (n == 0) return hipSuccess;
   if (chain && n > 2048 && n <= (sizeof(T) == 4 ? PS_CHAIN_MAX32 : PS_CHAIN_MAX)) {
-    if (++*epoch == 0) ++*epoch;
+    if (++*epoch == 0) {   // the 32-bit epoch wrapped: a flag some launch left 2^32 - 1 launches ago would pass for the next one's
+      hipError_t e = hipMemsetAsync(chain, 0, sizeof(PsChain), st);
+      if (e != hipSuccess) return e;
+      ++*epoch;
+    }
     const u32 per = (u32)((n + PS_CHAIN_WGS * PS_SMALL_THREADS - 1) / (PS_CHAIN_WGS * PS_SMALL_THREADS));   // items per thread at 64 workgroups
     if (per <= 1)
       hipLaunchKernelGGL((k_ps_scan_chain<T, In, 1>), dim3((u32)((n + 1023) / 1024)), dim3(PS_SMALL_THREADS), 0, st, in, (u32)n, out, chain, *epoch);
