@@ -325,6 +325,29 @@ def test_record_path_with_ten_bit_first_level():
     dq.close()
 
 
+SHAPE_SIZES = sorted({(350 << k) + e for k in range(5, 13) for e in (0, 1)} |        # the bucket bits change (PART_TARGET 350)
+                     {(1 << k) + e for k in range(14, 21) for e in (0, 1)} |           # the index bits of a record change
+                     {(1 << 15) * 3 + e for e in (-1, 0, 1)} | {8192 * 37 + e for e in (-1, 0, 1)})   # tile edges
+
+
+@pytest.mark.parametrize("order", [1, -1], ids=["ordered_buckets_forced", "default"])
+@pytest.mark.parametrize("n", [24, 13, 31, 32])
+def test_sizes_where_the_partition_changes_shape(n, order):
+    """read counts at which the record path changes its shape -- one bucket bit more (350 x 2^k reads), one index bit
+    more in a record (2^k reads), a last tile of one read -- each at the last size of the old shape and the first
+    of the new one.  With word-ordered buckets forced (the record path from 64 buckets on: asserted for 24-nt words;
+    the default decides for them from 65 536 reads on only) and with the default context; reads, clusters and
+    summary against the oracle."""
+    dq = humid_amd.Dedup()
+    dq.set_option("count_order", order)
+    for N in SHAPE_SIZES if n == 24 else SHAPE_SIZES[::3]:
+        words, filt = synth_words(N, 3000 + n, n, p_sub=3e-3, p_n=1e-3)
+        s = check_against_oracle(dq, words, filt, n, 1, False, deep=False)
+        if n == 24 and order == 1 and N > 350 << 5:       # (the default's sampler keeps a 1.5 x margin and says no at the
+            assert s["records8"] and s["count_mode_used"] == 2, (N, s["count_mode_used"], s["records8"])   # fullest small shapes)
+    dq.close()
+
+
 def test_oracle_parity_metric_words_d2(dd1):
     """1 M reads of the metric workload at d = 2, both methods"""
     words, filt = synth_words(1_000_000, 1002, 24)
