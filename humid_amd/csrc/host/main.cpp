@@ -61,7 +61,7 @@ void usage(const char *argv0) {
                "Deduplicate a dataset.\n"
                "  -n  word length\n  -m  allowed mismatches\n  -l  log file name\n  -d  output directory\n"
                "  -s  calculate statistics\n  -q  write deduplicated FastQ files (flag turns it OFF)\n"
-               "  -a  write annotated FastQ files\n  -e  use edit distance (Levenshtein neighbours; -m <= 5)\n"
+               "  -a  write annotated FastQ files\n  -e  use edit distance (Levenshtein neighbours)\n"
                "  -x  use maximum clustering method\n"
                "  -g  GPUs to shard the read set over (1..16; default 1 or $HUMID_GPUS; no -e beyond -m 1)\n",
                argv0);
@@ -205,10 +205,6 @@ int main(int argc, char **argv) {
   }
   Args a;
   if (!parse(argc, argv, a)) { usage(argv[0]); return 2; }
-  if (a.edit && a.distance > 5) {
-    std::fprintf(stderr, "humid: edit distance (-e) is supported for -m <= 5 by the HIP path\n");
-    return 2;
-  }
   if (a.word_length == 0 || a.word_length > 64) {
     std::fprintf(stderr, "humid: word length %zu is not supported by the HIP path (1..64)\n", a.word_length);
     return 2;

@@ -308,7 +308,6 @@ static int run_exchange_impl(humid_ctx *c, const humid_comm *cm, const uint64_t 
     // (they are slices of the walk order: rank order = walk order), every rank runs every P-th shifted-segment join
     // over the whole array (edit_edges), the shares are gathered and made unique, and every rank clusters the WHOLE
     // graph -- no owner-local split: the joins, not the clustering, are what this mode spends its time on ----
-    if (d > 5) return fail(c, HUMID_E_UNSUPPORTED, "edit distance %u > 5 is not supported", d);
     if (u_total + 8 > 0xffffffffull) return fail(c, HUMID_E_OVERFLOW, "more than 2^32-10 unique words in total");
     const u64 wb = wide ? 16 : 8;
     u64 ucnt[MAX_RANKS];
@@ -1626,7 +1625,6 @@ int humid_stage_pairs_edit(humid_ctx *c, const uint64_t *d_g_word, uint64_t n_un
   if (!c) return fail(nullptr, HUMID_E_INVALID, "ctx is null");
   if (!d_edges || !n_edges || part_world == 0 || part_rank >= part_world) return fail(c, HUMID_E_INVALID, "bad argument");
   TRY(check_run_args(c, n_unique, word_nt, 0));
-  if (distance > 5) return fail(c, HUMID_E_UNSUPPORTED, "edit distance %u > 5 is not supported", distance);
   HIPCHK(hipSetDevice(c->device));
   *d_edges = nullptr;
   *n_edges = 0;

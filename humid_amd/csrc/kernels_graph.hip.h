@@ -473,6 +473,54 @@ __device__ __forceinline__ u32 lev_band(WT x, WT y, u32 n) {
   return BAND == 1 ? lev_band1(x, y, n) : lev_band2(x, y, n);
 }
 
+// The x side of a verification, prepared once per thread (a thread verifies ONE word against a run of candidates).
+// BAND 1, 2: the banded programmes above (d <= 3, d <= 5).  BAND 0: ANY distance (round 3: -e beyond 5 edits) --
+// the whole dynamic programme of the n x n matrix, one COLUMN per step kept as the bit vectors of its vertical
+// differences (Myers 1999 in Hyyro's edit-distance form: the row above the matrix grows by one per column).  n <= 64:
+// one 64-bit vector; peq[s] = the positions of x that hold nucleotide s.
+template <u32 BAND, class WT>
+struct LevX {
+  WT x;
+  u32 n;
+  __device__ __forceinline__ LevX(WT x_, u32 n_) : x(x_), n(n_) {}
+  __device__ __forceinline__ u32 dist(WT y) const { return lev_band<BAND>(x, y, n); }
+};
+template <class WT>
+struct LevX<0, WT> {
+  u64 peq0, peq1, peq2, peq3;
+  u32 n;
+  __device__ __forceinline__ LevX(WT x, u32 n_) : peq0(0), peq1(0), peq2(0), peq3(0), n(n_) {
+    for (u32 i = 0; i < n; i++) {
+      const u32 sx = w_sym(x, n, i);
+      const u64 b = 1ull << i;
+      peq0 |= sx == 0 ? b : 0ull;
+      peq1 |= sx == 1 ? b : 0ull;
+      peq2 |= sx == 2 ? b : 0ull;
+      peq3 |= sx == 3 ? b : 0ull;
+    }
+  }
+  __device__ __forceinline__ u32 dist(WT y) const {
+    u64 pv = ~0ull, mv = 0;
+    u32 score = n;                                       // D[n][0]
+    const u64 last = 1ull << (n - 1);
+    for (u32 j = 0; j < n; j++) {                        // column j -> j + 1
+      const u32 sy = w_sym(y, n, j);
+      const u64 eq = (sy & 2u) ? ((sy & 1u) ? peq3 : peq2) : ((sy & 1u) ? peq1 : peq0);
+      const u64 xv = eq | mv;
+      const u64 xh = (((eq & pv) + pv) ^ pv) | eq;
+      u64 ph = mv | ~(xh | pv);
+      u64 mh = pv & xh;
+      score += (ph & last) ? 1u : 0u;
+      score -= (mh & last) ? 1u : 0u;
+      ph = (ph << 1) | 1ull;                             // D[0][j + 1] = D[0][j] + 1
+      mh <<= 1;
+      pv = mh | ~(xv | ph);
+      mv = ph & xv;
+    }
+    return score;                                        // D[n][n]
+  }
+};
+
 // Candidate join of one combination and one shift pattern: X = the words' own segments (sorted by
 // key), Y = the same segments read at shifted positions (sorted by key).  Thread per X entry: the
 // run of equal keys in Y is found by binary search, every candidate is verified by the dynamic
@@ -502,10 +550,11 @@ k_edit_join(const KeyT *__restrict__ KX, const u32 *__restrict__ VX, const KeyT 
   u32 found = 0;
   u64 e = FILL ? (u64)poff[t] : 0;
   if (!FILL && walk && big && lo + walk < n && KY[lo + walk] == key) { atomicOr(big, 1ull); pc[t] = 0; return; }
+  const LevX<BAND, WT> lx(wx, word_nt);
   for (u32 j = lo; j < n && KY[j] == key; j++) {
     const u32 ry = VY[j];
     if (ry == rx) continue;
-    if (lev_band<BAND>(wx, words[ry], word_nt) > distance) continue;
+    if (lx.dist(words[ry]) > distance) continue;
     if (FILL) edges[e++] = rx < ry ? (((u64)rx << 32) | ry) : (((u64)ry << 32) | rx);
     else found++;
   }
@@ -560,10 +609,11 @@ k_edit_join_chunks(const KeyT *__restrict__ KX, const u32 *__restrict__ VX, cons
   const u32 j0 = run_lo[t] + (p - chunk_off[t]) * walk;
   u32 found = 0;
   u64 e = FILL ? (u64)poff[p] : 0;
+  const LevX<BAND, WT> lx(wx, word_nt);
   for (u32 j = j0; j < n && j - j0 < walk && KY[j] == key; j++) {
     const u32 ry = VY[j];
     if (ry == rx) continue;
-    if (lev_band<BAND>(wx, words[ry], word_nt) > distance) continue;
+    if (lx.dist(words[ry]) > distance) continue;
     if (FILL) edges[e++] = rx < ry ? (((u64)rx << 32) | ry) : (((u64)ry << 32) | rx);
     else found++;
   }

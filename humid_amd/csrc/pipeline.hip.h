@@ -1941,9 +1941,11 @@ static int edit_edges(humid_ctx *c, const WT *g_word, u32 U, u32 word_nt, u32 di
                      c->e_vx.as<u32>(), (const KT *)ky, vy, U, (const u32 *)c->e_runlo.as<u32>(), (const u32 *)c->e_choff.as<u32>(), \
                      (u32)(NP), jwalk, g_word, word_nt, distance, PC, POFF, OUT)
         if (k32) { if (D <= 1) EDIT_JOIN(false, u32, 1, c->pc.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr);
-                   else EDIT_JOIN(false, u32, 2, c->pc.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr); }
+                   else if (D == 2) EDIT_JOIN(false, u32, 2, c->pc.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr);
+                   else EDIT_JOIN(false, u32, 0, c->pc.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr); }
         else { if (D <= 1) EDIT_JOIN(false, u64, 1, c->pc.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr);
-               else EDIT_JOIN(false, u64, 2, c->pc.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr); }
+               else if (D == 2) EDIT_JOIN(false, u64, 2, c->pc.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr);
+               else EDIT_JOIN(false, u64, 0, c->pc.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr); }
         TRY(exscan_u32(c, c->pc.as<u32>(), c->poff.as<u32>(), (u64)U + 1));
         HIPCHK(hipGetLastError());
         TRY(read_counters(c, c->poff.as<u32>() + U));
@@ -1967,9 +1969,11 @@ static int edit_edges(humid_ctx *c, const WT *g_word, u32 U, u32 word_nt, u32 di
           ENSURE(c->e_poff2, ((size_t)n_pieces + 1) * 4);
           HIPCHK(hipMemsetAsync(c->e_pc2.as<u32>() + n_pieces, 0, 4, st));
           if (k32) { if (D <= 1) EDIT_CHUNKS(false, u32, 1, n_pieces, c->e_pc2.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr);
-                     else EDIT_CHUNKS(false, u32, 2, n_pieces, c->e_pc2.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr); }
+                     else if (D == 2) EDIT_CHUNKS(false, u32, 2, n_pieces, c->e_pc2.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr);
+                     else EDIT_CHUNKS(false, u32, 0, n_pieces, c->e_pc2.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr); }
           else { if (D <= 1) EDIT_CHUNKS(false, u64, 1, n_pieces, c->e_pc2.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr);
-                 else EDIT_CHUNKS(false, u64, 2, n_pieces, c->e_pc2.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr); }
+                 else if (D == 2) EDIT_CHUNKS(false, u64, 2, n_pieces, c->e_pc2.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr);
+                 else EDIT_CHUNKS(false, u64, 0, n_pieces, c->e_pc2.as<u32>(), (const u32 *)nullptr, (u64 *)nullptr); }
           TRY(exscan_u32(c, c->e_pc2.as<u32>(), c->e_poff2.as<u32>(), n_pieces + 1));
           HIPCHK(hipGetLastError());
           TRY(read_counters(c, c->e_poff2.as<u32>() + n_pieces));
@@ -1987,14 +1991,18 @@ static int edit_edges(humid_ctx *c, const WT *g_word, u32 U, u32 word_nt, u32 di
         }
         if (n_pieces) {
           if (k32) { if (D <= 1) EDIT_CHUNKS(true, u32, 1, n_pieces, (u32 *)nullptr, (const u32 *)c->e_poff2.as<u32>(), c->e_raw.as<u64>() + raw);
-                     else EDIT_CHUNKS(true, u32, 2, n_pieces, (u32 *)nullptr, (const u32 *)c->e_poff2.as<u32>(), c->e_raw.as<u64>() + raw); }
+                     else if (D == 2) EDIT_CHUNKS(true, u32, 2, n_pieces, (u32 *)nullptr, (const u32 *)c->e_poff2.as<u32>(), c->e_raw.as<u64>() + raw);
+                     else EDIT_CHUNKS(true, u32, 0, n_pieces, (u32 *)nullptr, (const u32 *)c->e_poff2.as<u32>(), c->e_raw.as<u64>() + raw); }
           else { if (D <= 1) EDIT_CHUNKS(true, u64, 1, n_pieces, (u32 *)nullptr, (const u32 *)c->e_poff2.as<u32>(), c->e_raw.as<u64>() + raw);
-                 else EDIT_CHUNKS(true, u64, 2, n_pieces, (u32 *)nullptr, (const u32 *)c->e_poff2.as<u32>(), c->e_raw.as<u64>() + raw); }
+                 else if (D == 2) EDIT_CHUNKS(true, u64, 2, n_pieces, (u32 *)nullptr, (const u32 *)c->e_poff2.as<u32>(), c->e_raw.as<u64>() + raw);
+                 else EDIT_CHUNKS(true, u64, 0, n_pieces, (u32 *)nullptr, (const u32 *)c->e_poff2.as<u32>(), c->e_raw.as<u64>() + raw); }
         } else
         if (k32) { if (D <= 1) EDIT_JOIN(true, u32, 1, (u32 *)nullptr, c->poff.as<u32>(), c->e_raw.as<u64>() + raw);
-                   else EDIT_JOIN(true, u32, 2, (u32 *)nullptr, c->poff.as<u32>(), c->e_raw.as<u64>() + raw); }
+                   else if (D == 2) EDIT_JOIN(true, u32, 2, (u32 *)nullptr, c->poff.as<u32>(), c->e_raw.as<u64>() + raw);
+                   else EDIT_JOIN(true, u32, 0, (u32 *)nullptr, c->poff.as<u32>(), c->e_raw.as<u64>() + raw); }
         else { if (D <= 1) EDIT_JOIN(true, u64, 1, (u32 *)nullptr, c->poff.as<u32>(), c->e_raw.as<u64>() + raw);
-               else EDIT_JOIN(true, u64, 2, (u32 *)nullptr, c->poff.as<u32>(), c->e_raw.as<u64>() + raw); }
+               else if (D == 2) EDIT_JOIN(true, u64, 2, (u32 *)nullptr, c->poff.as<u32>(), c->e_raw.as<u64>() + raw);
+               else EDIT_JOIN(true, u64, 0, (u32 *)nullptr, c->poff.as<u32>(), c->e_raw.as<u64>() + raw); }
 #undef EDIT_CHUNKS
 #undef EDIT_JOIN
         raw += found;
@@ -2341,7 +2349,6 @@ static int run_device(humid_ctx *c, const WT *d_words, const u8 *d_filt, u64 n_r
   u32 n_pair_segs = 0;
   if (c->edit && distance >= 2) {
     // -e: Levenshtein neighbours (src/humid.cc:140-158); distance <= 1 IS the Hamming search
-    if (distance > 5) return fail(c, HUMID_E_UNSUPPORTED, "edit distance %u > 5 is not supported", distance);
     u64 E = 0;
     TRY(edit_edges<WT>(c, c->s_word.as<WT>(), U, word_nt, distance, &E));
     static const u64 no_edges = 0;

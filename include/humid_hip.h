@@ -36,7 +36,7 @@ extern "C" {
 
 #define HUMID_OK             0
 #define HUMID_E_INVALID     -1   /* bad argument                                    */
-#define HUMID_E_UNSUPPORTED -2   /* word_nt > 64 (stages: > 32), edit distance > 5   */
+#define HUMID_E_UNSUPPORTED -2   /* word_nt > 64 (stages: > 32)                      */
 #define HUMID_E_NOMEM       -3   /* device or host allocation failed                */
 #define HUMID_E_HIP         -4   /* HIP runtime error (text in humid_last_error)    */
 #define HUMID_E_OVERFLOW    -5   /* an index exceeded 32 bits (reads, 2*edges)      */
@@ -100,8 +100,9 @@ const char *humid_last_error(const humid_ctx *ctx);   /* ctx may be NULL */
  * "edit_distance": 1 = neighbours under Levenshtein instead of Hamming distance (-e,
  *   findEditNeighbours src/humid.cc:140-158 / Trie::asymmetricLevenshtein) in humid_dedup_run*.
  *   Between equal-length words distance <= 1 is the Hamming search itself; 2 and 3 add the pairs that
- *   need one deletion + one insertion, 4 and 5 those with two of each; distance > 5 returns
- *   HUMID_E_UNSUPPORTED.
+ *   need one deletion + one insertion, 4 and 5 those with two of each (banded dynamic programmes); beyond 5
+ *   every candidate is verified with the whole dynamic programme (no limit on the distance; the joins' keys
+ *   shrink to one segment of n / (d + 1) nucleotides, so the search approaches all pairs, as the trie's does).
  * "coop_big": 1 (default) = components of more than 32 leaves are clustered by one workgroup each
  * (parallel flood), 0 = by one lane each (the literal sequential loop).
  * "tile_partition": 1 (default) = reads reach their count buckets, and results their reads, through

@@ -76,7 +76,6 @@ def test_log_reports_plan(tmp_path):
 
 def test_cli_errors(tmp_path):
     files = synth_fastq(str(tmp_path), 4, 8, n_files=1, read_len=30)
-    assert subprocess.call([HUMID, "-e", "-m", "6"] + files, stderr=subprocess.DEVNULL) == 2      # -e: -m <= 5
     assert subprocess.call([HUMID, "-n", "65"] + files, stderr=subprocess.DEVNULL) == 2
     assert subprocess.call([HUMID], stderr=subprocess.DEVNULL) == 2
     assert subprocess.call([HUMID, str(tmp_path / "missing.fastq")], stderr=subprocess.DEVNULL) == 1

@@ -130,13 +130,51 @@ def test_edit_forced_plans(segs):
     dq.close()
 
 
-def test_edit_unsupported_cases(dd):
+def many_indel_words(rng, n_reads, n, events):
+    bases = rng.integers(0, 4, size=(max(2, n_reads // 15), n))
+    words = np.zeros(n_reads, dtype=np.uint64)
+    for r in range(n_reads):
+        sq = bases[rng.integers(0, len(bases))].tolist()
+        for _ in range(int(rng.integers(0, events + 1))):     # deletion + insertion events
+            del sq[int(rng.integers(0, n))]
+            sq.insert(int(rng.integers(0, n)), int(rng.integers(0, 4)))
+        for _ in range(int(rng.integers(0, 3))):
+            sq[int(rng.integers(0, n))] = int(rng.integers(0, 4))
+        words[r] = orc.pack_word(sq)
+    return words
+
+
+@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("d", [6, 7, 8, 11])
+@pytest.mark.parametrize("maximum", [False, True])
+def test_edit_any_distance(dd, seed, d, maximum):
+    """-e beyond 5 edits (round 3; the reference's trie search has no limit, src/humid.cc:140-158): three and more
+    insertion/deletion pairs -- offsets to +-d/2 in the joins, candidates verified by the whole dynamic programme
+    (bit vectors: LevX<0>).  Families with up to five indel events per member; every array against the oracle."""
+    rng = np.random.default_rng(7000 + 10 * d + seed)
+    n = int(rng.integers(max(12, d + 2), 33))
+    n_reads = int(rng.integers(300, 2000))
+    words = many_indel_words(rng, n_reads, n, 5)
+    filt = (rng.random(n_reads) < 0.02).astype(np.uint8)
+    check_edit(dd, words, filt, n, d, maximum)
+
+
+@pytest.mark.parametrize("n,d", [(5, 6), (8, 8), (12, 30), (24, 21), (7, 6)])
+def test_edit_distances_that_compare_all_pairs(dd, n, d):
+    """d >= n (every pair is a neighbour pair) and d beyond every plan (one join of everything with everything,
+    verified)"""
+    rng = np.random.default_rng(100 * n + d)
+    words = many_indel_words(rng, 700, n, 3)
+    filt = (rng.random(len(words)) < 0.02).astype(np.uint8)
+    check_edit(dd, words, filt, n, d, False)
+    check_edit(dd, words, filt, n, d, True, deep=False)
+
+
+def test_edit_option_does_not_stick(dd):
     w = np.zeros(4, np.uint64)
     f = np.zeros(4, np.uint8)
-    with pytest.raises(humid_amd.HumidError) as e:
-        dd.run(w, f, word_nt=24, distance=6, edit=True)
-    assert e.value.code == -2
-    dd.run(w, f, word_nt=24, distance=1, edit=False)                  # the option does not stick
+    dd.run(w, f, word_nt=24, distance=6, edit=True)
+    dd.run(w, f, word_nt=24, distance=1, edit=False)
 
 
 def wide_indel_words(rng, n_reads, n):
@@ -160,7 +198,7 @@ def wide_indel_words(rng, n_reads, n):
 
 
 @pytest.mark.parametrize("n", [33, 40, 48, 64])
-@pytest.mark.parametrize("d", [2, 3])
+@pytest.mark.parametrize("d", [2, 3, 6])
 def test_edit_wide_words(dd, n, d):
     """-e with two-word (wide) words: shifts across the word boundary, keys cut to 64 bits"""
     rng = np.random.default_rng(n + d)
