@@ -48,7 +48,7 @@ def make_case(rng):
                            genome_bp=int(rng.choice([2000, 50_000, 4_000_000])))
     edit = (not wide) and d in (2, 3) and n_reads <= 70_000 and rng.random() < 0.5
     if (not wide) and n_reads <= 5000 and rng.random() < 0.15:   # two insertion/deletion pairs (round 2)
-        edit, d = True, int(rng.choice([4, 5]))
+        edit, d = True, int(rng.choice([4, 5, 4, 5, 6, 7, 9]))   # (6 and beyond: the whole dynamic programme, end of round 3)
     if edit and rng.random() < 0.5:                       # families with deletions + insertions
         from test_oracle_vs_bruteforce import indel_words
         w = indel_words(np.random.default_rng(seed), n_reads, n, p_indel=0.4)
