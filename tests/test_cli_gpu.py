@@ -251,9 +251,10 @@ def test_cli_sharded_rccl_transport_with_one_rank(tmp_path):
 
 
 @pytest.mark.parametrize("case", [dict(word_nt=24, d=2, x=False, ranks=2), dict(word_nt=24, d=3, x=True, ranks=3),
-                                  dict(word_nt=40, d=2, x=False, ranks=2), dict(word_nt=20, d=4, x=False, ranks=2)])
+                                  dict(word_nt=40, d=2, x=False, ranks=2), dict(word_nt=20, d=4, x=False, ranks=2),
+                                  dict(word_nt=24, d=6, x=False, ranks=2), dict(word_nt=24, d=7, x=True, ranks=3)])
 def test_cli_sharded_edit_distance(case, tmp_path):
-    """round 3: `humid -g N -e -m 2..5` -- the unique words are all-gathered inside the
+    """round 3: `humid -g N -e -m 2...` (beyond 5 since the end of the round) -- the unique words are all-gathered inside the
     exchange pass and the shifted-segment joins dealt out over the ranks.  Every output file byte-identical to
     `-g 1 -e` (which tests/test_gpu_edit.py and test_cli_end_to_end check against the oracle)."""
     files = synth_fastq(str(tmp_path / "in"), 4000, 91, n_files=2, umi_len=8, umi_in_header=True, read_len=36,
@@ -274,7 +275,7 @@ def test_cli_sharded_edit_distance(case, tmp_path):
 
 def test_cli_sharded_refuses_what_needs_one_gpu(tmp_path):
     files = synth_fastq(str(tmp_path / "in"), 200, 5, n_files=1, read_len=30)
-    for extra in (["-e", "-m", "6"], ["-g", "17"]):
+    for extra in (["-g", "17"],):
         r = subprocess.run([HUMID, "-g", "2", "-d", str(tmp_path / "o"), "-l", "/dev/null"] + extra + files,
                            capture_output=True, text=True)
         assert r.returncode == 2, (extra, r.stderr)
