@@ -132,6 +132,10 @@ def test_exchange_sixteen_ranks(cfg, P):
 def test_exchange_uneven_shards_and_reuse():
     words, filt = synth_words(100_003, 5, 24, p_sub=5e-3, p_n=1e-3)
     check(4, words, filt, 24, 1, 0, sizes=[50_000, 3, 0, 50_000], passes=2)
+    # sixteen ranks, among them empty shards, one-read shards and one that holds most of the reads
+    sizes = [0, 1, 0, 20_000, 3, 0, 0, 61_000, 2, 5000, 0, 7, 10_000, 1, 0, 0]
+    sizes[7] += 100_003 - sum(sizes)
+    check(16, words, filt, 24, 1, 0, sizes=sizes, passes=2)
 
 
 def test_exchange_skewed_words():
@@ -147,12 +151,16 @@ def test_exchange_skewed_words():
     f = (rng.random(len(w)) < 0.01).astype(np.uint8)
     check(4, w, f, 24, 1, 0)
     check(3, w, f, 24, 2, 1)
+    check(16, w, f, 24, 1, 0)        # most of the sixteen value ranges hold next to nothing
+    check(13, w, f, 24, 2, 1)
 
 
 def test_exchange_all_filtered_and_tiny():
     w = np.zeros(40, dtype=np.uint64)
     check(2, w, np.ones(40, np.uint8), 24, 1, 0)
     check(4, np.arange(3, dtype=np.uint64), np.zeros(3, np.uint8), 24, 1, 0)
+    check(16, np.arange(5, dtype=np.uint64), np.zeros(5, np.uint8), 24, 1, 0)      # fewer reads than ranks
+    check(16, w, np.ones(40, np.uint8), 24, 1, 0)
     check(2, w, np.zeros(40, np.uint8), 24, 0, 0)        # d = 0: no pairs at all
 
 
@@ -165,6 +173,7 @@ def test_exchange_falls_back_without_prefix():
 def test_exchange_forced_plans(segs):
     words, filt = synth_words(60_000, 21 + segs, 24, p_sub=1e-2, p_n=1e-3)
     check(3, words, filt, 24, 2, 0, plan_segments=segs)
+    check(16, words, filt, 24, 2, 0, plan_segments=segs)
 
 
 def test_allgather_mode_virtual_ranks():
@@ -348,7 +357,7 @@ def test_stage_by_stage_python_form_still_matches(P, monkeypatch):
         assert s["edges"] == osum["edges"] and s["clusters"] == osum["clusters"]
 
 
-@pytest.mark.parametrize("P,walk", [(1, 3), (3, 3), (2, 200), (4, None)])
+@pytest.mark.parametrize("P,walk", [(1, 3), (3, 3), (2, 200), (4, None), (16, 3), (16, None)])
 def test_exchange_large_buckets_go_through_the_tiles(P, walk):
     """the pair search of the exchange mode (emit_pairs: count, scan, fill into an edge list) with the
     bounded walk: buckets longer than the walk are finished by k_pairs_tiles in its emitting modes.
@@ -453,7 +462,7 @@ def test_allgather_mode_wide_words(P, n, d, method):
         assert s["edges"] == osum["edges"] and s["clusters"] == osum["clusters"] and s["unique"] == osum["unique"]
 
 
-@pytest.mark.parametrize("P,method", [(4, 0), (4, 1), (8, 0), (3, 0)])
+@pytest.mark.parametrize("P,method", [(4, 0), (4, 1), (8, 0), (3, 0), (16, 0), (16, 1), (12, 0)])
 def test_exchange_components_spanning_three_and_more_ranges(P, method):
     """owner-local clustering (round 3): clusters whose leaves lie in three and four value ranges -- families whose
     members differ in the FIRST nucleotides, the ones that decide the owner -- with count ladders the
