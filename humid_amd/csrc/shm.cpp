@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -126,6 +127,9 @@ int humid_shm_all_gather(void *shm, const void *mine, uint64_t bytes, void *all)
       if ((++spins & 0xfffu) == 0) {
         if (abort_flag->load(std::memory_order_acquire)) return -1;                      // a rank gave up the group (humid_shm_abort)
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) return -1;
+        // a gather between ranks that all run completes within the first few thousand spins; later than ~0.3 ms the
+        // awaited rank is probably not on a core (more ranks than cores): give ours up instead of spinning it away
+        if (spins > (1u << 16)) sched_yield();
       }
     }
     memcpy((u8 *)all + (u64)q * bytes, h->slot(bank, q), bytes);

@@ -32,18 +32,23 @@ def _rank_main(name, rank, world, rounds, q):
         q.put((rank, repr(e)))
 
 
-def test_shared_memory_gather_between_processes():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world,rounds", [(3, 400), (8, 150), (16, 60)])
+def test_shared_memory_gather_between_processes(world, rounds):
+    """3 ranks; 8 (one node's GPUs: what bench.py --gpus 8 opens); 16 (the largest group of the exchange pass, here
+    more processes than cores: waiting ranks give their core up)"""
     ctx = mp.get_context("spawn")
-    world, rounds = 3, 400
     name = "/humid_test_%d" % os.getpid()
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(name, r, world, rounds, q)) for r in (1, 2, 0)]   # rank 0 comes last
+    procs = [ctx.Process(target=_rank_main, args=(name, r, world, rounds, q)) for r in list(range(1, world)) + [0]]   # rank 0 comes last
     for p in procs:
         p.start()
     got = dict(q.get(timeout=120) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
-    assert got == {0: True, 1: True, 2: True}, got
+    assert got == {r: True for r in range(world)}, got
     assert not os.path.exists("/dev/shm" + name)                      # rank 0 unlinked it on close
 
 
