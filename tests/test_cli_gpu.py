@@ -186,6 +186,30 @@ def test_cli_output_write_errors_are_not_silent(tmp_path):
         assert subprocess.call([HUMID, "-d", str(out), "-l", str(tmp_path / "log.txt"), src]) == 0
 
 
+@pytest.mark.parametrize("case", [
+    dict(n_files=2, umi_len=8, umi_in_header=True, word_nt=24, d=1, x=False, n=40_000),
+    dict(n_files=2, umi_len=8, umi_in_header=True, word_nt=48, d=2, x=True, n=20_000),
+])
+def test_cli_sixteen_ranks(case, tmp_path):
+    """`humid -g 16`, the largest group the exchange pass takes (the library lost a counter at exactly 16 ranks until the
+    end of round 3: tests/test_gpu_exchange.py::test_exchange_sixteen_ranks): every output byte-identical to `-g 1`"""
+    case = dict(case)
+    word_nt, d, x, n = case.pop("word_nt"), case.pop("d"), case.pop("x"), case.pop("n")
+    files = synth_fastq(str(tmp_path / "in"), n, 78, p_sub=4e-3, p_n=2e-3, read_len=36, short_frac=0.01, **case)
+    outs = {}
+    for g in (1, 16):
+        out = str(tmp_path / ("out%d" % g))
+        cmd = [HUMID, "-n", str(word_nt), "-m", str(d), "-d", out, "-l", "/dev/null", "-s", "-a", "-g", str(g)] + (["-x"] if x else [])
+        r = subprocess.run(cmd + files, capture_output=True, text=True, env=dict(os.environ, HUMID_TIMING="1"))
+        assert r.returncode == 0, r.stderr
+        if g > 1:
+            assert "16 ranks, bulk data by copy" in r.stderr
+        outs[g] = {f: open(os.path.join(out, f), "rb").read() for f in sorted(os.listdir(out))}
+    assert sorted(outs[1]) == sorted(outs[16]) and len(outs[1]) == 2 * len(files) + 4
+    for f in outs[1]:
+        assert outs[1][f] == outs[16][f], f
+
+
 @pytest.mark.parametrize("ranks", [2, 3])
 @pytest.mark.parametrize("case", [
     dict(n_files=2, umi_len=8, umi_in_header=True, word_nt=24, d=1, x=False, n=40_000),
