@@ -24,8 +24,11 @@ def make_case(rng):
     n = int(rng.integers(33, 65)) if wide else int(rng.integers(2, 33))
     d = int(rng.choice([0, 1, 1, 1, 2, 2, 3]))
     method = int(rng.random() < 0.3)
-    n_reads = int(rng.choice([1, 7, 300, 5000, 70_000, 300_000]))
+    n_reads = int(rng.choice([1, 7, 300, 5000, 70_000, 300_000, 5000, 70_000, 300_000, 1_300_000]))
     kind = rng.choice(["umi", "genome", "dense", "dup"]) if not wide else "umi"
+    if n_reads > 300_000 and (d >= 2 and n < 20 or kind == "dense"):   # (dense neighbourhoods at this size: minutes of oracle)
+        d = min(d, 1)
+        kind = "umi" if kind == "dense" else kind
     p_sub = float(rng.choice([0, 1e-3, 1e-2, 5e-2]))
     seed = int(rng.integers(1, 1 << 30))
     if wide:
@@ -84,9 +87,9 @@ def main():
         ok = np.array_equal(cid, ocid) and np.array_equal(keep, okeep) and \
             all(s[k] == osum[k] for k in ("usable", "unique", "clusters"))
         ok_x = True
-        if desc["reads"] > 1 and not edit:                          # (two-word words too, since round 2)
-            P = int(rng.integers(2, 6))
-            out, offs = run_ranks(P, w, f, n, d, method, "exchange", bucket_walk=walk)
+        if desc["reads"] > 1:                                       # (two-word words since round 2; -e and up to 16 ranks: end of round 3)
+            P = int(rng.choice([2, 3, 4, 5, 2, 3, 4, 5, 8, 11, 16]))
+            out, offs = run_ranks(P, w, f, n, d, method, "exchange", bucket_walk=walk, edit=edit)
             for r in range(P):
                 c2, k2, s2, used = out[r]
                 ok_x = ok_x and np.array_equal(c2, ocid[offs[r]:offs[r + 1]]) and \
