@@ -141,6 +141,20 @@ def test_wide_lds_buckets_overflow_goes_back_to_the_sort():
     dq.close()
 
 
+@pytest.mark.parametrize("order", [1, -1], ids=["ordered_buckets_forced", "default"])
+@pytest.mark.parametrize("n", [33, 48, 64])
+def test_wide_sizes_where_the_partition_changes_shape(n, order):
+    """two-word words at the read counts where the partition changes shape (tests/test_gpu_parity.py::
+    test_sizes_where_the_partition_changes_shape: bucket bits, index bits, tile edges), a third of them per length"""
+    from test_gpu_parity import SHAPE_SIZES
+    dq = humid_amd.Dedup()
+    dq.set_option("count_order", order)
+    for N in SHAPE_SIZES[(n % 3)::3]:
+        words, filt = synth_wide_words(N, 4000 + n, n, p_sub=3e-3, p_n=1e-3)
+        check_against_oracle(dq, words, filt, n, 1, False, deep=False)
+    dq.close()
+
+
 @pytest.mark.parametrize("n,d,segs", [(64, 1, 3), (64, 1, 4), (48, 2, 5), (40, 1, 6), (64, 2, 3)])
 def test_wide_forced_plans(n, d, segs):
     """plans whose combination keys exceed 64 bits are cut to 64 (make_plan): still every pair"""
