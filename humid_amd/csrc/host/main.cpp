@@ -159,6 +159,9 @@ int write_mapped(const std::string &path, size_t n, unsigned threads, const std:
   // (Measured and rejected: extending the file sparsely and letting the workers' page faults
   // allocate it -- on tmpfs parallel faults into one file contend so badly that pass 2 takes 3x
   // longer than with the single-threaded allocation of posix_fallocate.)
+  // (Also measured and rejected, end of round 3: reserving in 32 MB chunks on a thread of its own while the workers
+  // copy behind it -- the allocation and the faults on the same file slow each other down: 100-190 ms for both
+  // together against 45 + 50-120 one after the other.)
   if (posix_fallocate(fd, 0, (off_t)total) != 0) { ::close(fd); return 0; }      // e.g. a device: buffered writer
   const auto t_alloc = now();
   char *m = (char *)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
