@@ -536,7 +536,7 @@ static int run_exchange_impl(humid_ctx *c, const humid_comm *cm, const uint64_t 
   do {                                                                                                                        \
     EarlierMasksT<WT> em_;                                                                                                    \
     for (u32 t_ = 0; t_ < MAX_COMBOS; t_++) em_.m[t_] = w_from<WT>(plan.mask[t_]);                                            \
-    hipLaunchKernelGGL((k_pairs_records<P0, WT>), dim3(blocks_for(NN)), dim3(256), 0, st, (const WT *)(W), (const u32 *)(V), \
+    hipLaunchKernelGGL((k_pairs_records<P0, WT>), dim3(blocks_for(NN, PA_PPT * 256)), dim3(256), 0, st, (const WT *)(W), (const u32 *)(V), \
                        (u32)(NN), w_from<WT>(plan.mask[CB]), em_, (u32)(CB), d, c->walk_max, (const u32 *)(IDOF), (u32)(IDBASE), \
                        (const u32 *)(CNTOF), mine, big, over);                                                                \
   } while (0)

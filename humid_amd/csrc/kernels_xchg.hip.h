@@ -37,7 +37,9 @@ __device__ __forceinline__ const ulonglong2 *rr_at(const RecRegs &rr, u32 r, u32
 }
 
 // k_pairs_append (kernels_cgraph.hip.h) writing RECORDS: position p of the array the walked order refers to
-// has the global id id_of ? id_of[p] : id_base + p and the count cnt_of[p]
+// has the global id id_of ? id_of[p] : id_base + p and the count cnt_of[p].  PA_PPT positions per thread as there
+// (a workgroup takes PA_PPT x 256 consecutive positions; the first two words of all a thread's walks are requested
+// together, and a launch has a quarter of the workgroups).
 template <bool PASS0, class WT>
 __global__ void __launch_bounds__(256)
 k_pairs_records(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, WT mask, EarlierMasksT<WT> em, u32 cb,
@@ -46,30 +48,42 @@ k_pairs_records(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, WT m
   HUMID_GUARD_LAST_VGPR();
   __shared__ u32 lds[8];
   __shared__ u32 s_base;
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  u32 found = 0, first_off = 0;
-  WT wi;
-  u32 jend = 0;
-  if (i < n) {
-    wi = W[i];
-    jend = (walk_max && n - i > walk_max + 1) ? i + walk_max + 1 : n;
+  const u32 i0 = blockIdx.x * (PA_PPT * 256u) + threadIdx.x;
+  u32 found[PA_PPT], first_off[PA_PPT], jend[PA_PPT];
+  WT wi[PA_PPT], w1[PA_PPT];
+#pragma unroll
+  for (u32 q = 0; q < PA_PPT; q++) {
+    const u32 i = i0 + q * 256u;
+    found[q] = 0; first_off[q] = 0; jend[q] = 0;
+    if (i < n) {
+      wi[q] = W[i];
+      w1[q] = W[i + 1 < n ? i + 1 : i];                // requested together with W[i]: most walks end at this word
+    }
+  }
+  u32 total_found = 0;
+#pragma unroll
+  for (u32 q = 0; q < PA_PPT; q++) {
+    const u32 i = i0 + q * 256u;
+    if (i >= n) continue;
+    jend[q] = (walk_max && n - i > walk_max + 1) ? i + walk_max + 1 : n;
     u32 j = i + 1;
-    for (; j < jend; j++) {
-      const WT x = w_xor(wi, W[j]);
+    for (; j < jend[q]; j++) {
+      const WT x = w_xor(wi[q], j == i + 1 ? w1[q] : W[j]);
       if (w_hits(x, mask)) break;
       if (w_mismatch(x) > distance) continue;
       bool first = true;
 #pragma unroll
-      for (u32 q = 0; q < MAX_COMBOS; q++)
-        first = first && !(q < cb && !w_hits(x, em.m[q]));
+      for (u32 t = 0; t < MAX_COMBOS; t++)
+        first = first && !(t < cb && !w_hits(x, em.m[t]));
       if (!first) continue;
-      if (!found) first_off = j - i;
-      found++;
+      if (!found[q]) first_off[q] = j - i;
+      found[q]++;
     }
-    if (big && j == jend && jend < n && !w_hits(w_xor(wi, W[jend]), mask)) atomicOr(big, 1ull << cb);
+    if (big && j == jend[q] && jend[q] < n && !w_hits(w_xor(wi[q], W[jend[q]]), mask)) atomicOr(big, 1ull << cb);
+    total_found += found[q];
   }
   const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  u32 incl = found;
+  u32 incl = total_found;
   incl = wave_incl_scan(incl);
   if (lane == 63) lds[wv] = incl;
   __syncthreads();
@@ -80,29 +94,34 @@ k_pairs_records(const WT *__restrict__ W, const u32 *__restrict__ V, u32 n, WT m
   const u32 region = blockIdx.x % ER_REGIONS;
   if (threadIdx.x == 0) s_base = atomicAdd(&rr.cur[region * ER_STRIDE], total);
   __syncthreads();
-  if (!found) return;
-  u32 at = s_base + before + incl - found;
-  if (at + found > rr.cap_r) { *overflow = 1; if (at >= rr.cap_r) return; }
+  if (!total_found) return;
+  u32 at = s_base + before + incl - total_found;
+  if (at + total_found > rr.cap_r) { *overflow = 1; if (at >= rr.cap_r) return; }
   ulonglong2 *out = rr.e + (size_t)region * rr.cap_r;
-  const u32 pi = PASS0 ? i : V[i];
-  const u32 ida = id_of ? id_of[pi] : id_base + pi, ca = cnt_of[pi];
-  auto emit = [&](u32 j) {
-    if (at >= rr.cap_r) return;
-    const u32 pj = PASS0 ? j : V[j];
-    const u32 idb = id_of ? id_of[pj] : id_base + pj, cb2 = cnt_of[pj];
-    out[at++] = ida < idb ? make_ulonglong2(((u64)ida << 32) | idb, (u64)ca | ((u64)cb2 << 32))
-                          : make_ulonglong2(((u64)idb << 32) | ida, (u64)cb2 | ((u64)ca << 32));
-  };
-  if (found == 1) { emit(i + first_off); return; }
-  for (u32 j = i + first_off; j < jend; j++) {
-    const WT x = w_xor(wi, W[j]);
-    if (w_hits(x, mask)) break;
-    if (w_mismatch(x) > distance) continue;
-    bool first = true;
 #pragma unroll
-    for (u32 q = 0; q < MAX_COMBOS; q++)
-      first = first && !(q < cb && !w_hits(x, em.m[q]));
-    if (first) emit(j);
+  for (u32 q = 0; q < PA_PPT; q++) {
+    if (!found[q]) continue;
+    const u32 i = i0 + q * 256u;
+    const u32 pi = PASS0 ? i : V[i];
+    const u32 ida = id_of ? id_of[pi] : id_base + pi, ca = cnt_of[pi];
+    auto emit = [&](u32 j) {
+      if (at >= rr.cap_r) return;
+      const u32 pj = PASS0 ? j : V[j];
+      const u32 idb = id_of ? id_of[pj] : id_base + pj, cb2 = cnt_of[pj];
+      out[at++] = ida < idb ? make_ulonglong2(((u64)ida << 32) | idb, (u64)ca | ((u64)cb2 << 32))
+                            : make_ulonglong2(((u64)idb << 32) | ida, (u64)cb2 | ((u64)ca << 32));
+    };
+    if (found[q] == 1) { emit(i + first_off[q]); continue; }
+    for (u32 j = i + first_off[q]; j < jend[q]; j++) {
+      const WT x = w_xor(wi[q], W[j]);
+      if (w_hits(x, mask)) break;
+      if (w_mismatch(x) > distance) continue;
+      bool first = true;
+#pragma unroll
+      for (u32 t = 0; t < MAX_COMBOS; t++)
+        first = first && !(t < cb && !w_hits(x, em.m[t]));
+      if (first) emit(j);
+    }
   }
 }
 
