@@ -325,8 +325,8 @@ def test_record_path_with_ten_bit_first_level():
     dq.close()
 
 
-SHAPE_SIZES = sorted({(350 << k) + e for k in range(5, 13) for e in (0, 1)} |        # the bucket bits change (PART_TARGET 350)
-                     {(1 << k) + e for k in range(14, 21) for e in (0, 1)} |           # the index bits of a record change
+SHAPE_SIZES = sorted({(350 << k) + e for k in range(5, 12) for e in (0, 1)} |        # the bucket bits change (PART_TARGET 350)
+                     {(1 << k) + e for k in range(14, 20) for e in (0, 1)} |           # the index bits of a record change
                      {(1 << 15) * 3 + e for e in (-1, 0, 1)} | {8192 * 37 + e for e in (-1, 0, 1)})   # tile edges
 
 
@@ -340,7 +340,8 @@ def test_sizes_where_the_partition_changes_shape(n, order):
     summary against the oracle."""
     dq = humid_amd.Dedup()
     dq.set_option("count_order", order)
-    for N in SHAPE_SIZES if n == 24 else SHAPE_SIZES[::3]:
+    # (the oracle runs on one core of the GPU box: all sizes for 24-nt words with the buckets forced, a third of them else)
+    for N in SHAPE_SIZES if (n == 24 and order == 1) else SHAPE_SIZES[(n + order) % 3::3]:
         words, filt = synth_words(N, 3000 + n, n, p_sub=3e-3, p_n=1e-3)
         s = check_against_oracle(dq, words, filt, n, 1, False, deep=False)
         if n == 24 and order == 1 and N > 350 << 5:       # (the default's sampler keeps a 1.5 x margin and says no at the

@@ -141,8 +141,7 @@ def test_wide_lds_buckets_overflow_goes_back_to_the_sort():
     dq.close()
 
 
-@pytest.mark.parametrize("order", [1, -1], ids=["ordered_buckets_forced", "default"])
-@pytest.mark.parametrize("n", [33, 48, 64])
+@pytest.mark.parametrize("n,order", [(33, 1), (64, 1), (48, -1)], ids=["33-ordered_buckets_forced", "64-ordered_buckets_forced", "48-default"])
 def test_wide_sizes_where_the_partition_changes_shape(n, order):
     """two-word words at the read counts where the partition changes shape (tests/test_gpu_parity.py::
     test_sizes_where_the_partition_changes_shape: bucket bits, index bits, tile edges), a third of them per length"""
