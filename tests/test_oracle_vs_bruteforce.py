@@ -159,6 +159,37 @@ def test_edit_distance_neighbours(seed, d, maximum):
     assert idx.tolist() == [x for row in det["nbrs"] for x in row]
 
 
+@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("d", [4, 5, 6, 7, 9, 12])
+def test_edit_distance_neighbours_beyond_two_indel_pairs(seed, d):
+    """-e at larger distances (the HIP path has no limit since round 3 and is checked against this oracle at d = 6 .. 30,
+    tests/test_gpu_edit.py): families whose members carry up to five deletion + insertion events and a few
+    substitutions; the trie search against the all-pairs dynamic programme, both methods; d >= n included"""
+    rng = np.random.default_rng(900 + 17 * d + seed)
+    n = int(rng.integers(6, 15))
+    n_reads = int(rng.integers(20, 120))
+    bases = rng.integers(0, 4, size=(max(2, n_reads // 10), n))
+    words = np.zeros(n_reads, dtype=np.uint64)
+    for r in range(n_reads):
+        sq = bases[rng.integers(0, len(bases))].tolist()
+        for _ in range(int(rng.integers(0, 6))):
+            del sq[int(rng.integers(0, n))]
+            sq.insert(int(rng.integers(0, n)), int(rng.integers(0, 4)))
+        for _ in range(int(rng.integers(0, 3))):
+            sq[int(rng.integers(0, n))] = int(rng.integers(0, 4))
+        words[r] = orc.pack_word(sq)
+    filt = (rng.random(n_reads) < 0.03).astype(np.uint8)
+    for maximum in (False, True):
+        cid, keep, summ, _ = orc.dedup_run(words, filt, n, d, int(maximum), edit=True)
+        bcid, bkeep, det = bf.dedup(words, filt, d, maximum, edit_nt=n)
+        assert np.array_equal(cid, bcid) and np.array_equal(keep, bkeep)
+    p = orc.Pipeline(n)
+    p.read_data(words, filt)
+    p.find_edit_neighbours(d)
+    off, idx = p.adjacency()
+    assert idx.tolist() == [x for row in det["nbrs"] for x in row]
+
+
 def test_edit_distance_one_is_hamming_distance_one():
     """equal-length words: one edit can only be a substitution"""
     words, filt = synth_words(3000, 9, 12, p_sub=0.03)
