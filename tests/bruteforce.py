@@ -66,8 +66,12 @@ def unpack(w, n):
 
 
 def edit_adjacency(uw, n, distance):
-    """ascending neighbour lists under Levenshtein distance (one-word words, small U only)"""
-    syms = [unpack(w, n) for w in uw.tolist()]
+    """ascending neighbour lists under Levenshtein distance (small U only; two-word words: rows [hi, lo], the first
+    n - 32 nucleotides in hi)"""
+    if uw.ndim == 2:
+        syms = [unpack(hi, n - 32) + unpack(lo, 32) for hi, lo in uw.tolist()]
+    else:
+        syms = [unpack(w, n) for w in uw.tolist()]
     u = len(syms)
     out = [[] for _ in range(u)]
     for i in range(u):

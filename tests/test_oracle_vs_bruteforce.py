@@ -190,6 +190,35 @@ def test_edit_distance_neighbours_beyond_two_indel_pairs(seed, d):
     assert idx.tolist() == [x for row in det["nbrs"] for x in row]
 
 
+@pytest.mark.parametrize("n,d", [(33, 2), (40, 6), (48, 7), (64, 3)])
+def test_edit_distance_neighbours_of_two_word_words(n, d):
+    """-e on words of 33 .. 64 nucleotides (insertions and deletions that cross the word boundary), the oracle's trie
+    search against the all-pairs dynamic programme"""
+    rng = np.random.default_rng(3300 + n + d)
+    n_reads = 48
+    bases = rng.integers(0, 4, size=(5, n))
+    words = np.zeros((n_reads, 2), dtype=np.uint64)
+    for r in range(n_reads):
+        sq = bases[rng.integers(0, len(bases))].tolist()
+        for _ in range(int(rng.integers(0, 4))):
+            del sq[int(rng.integers(0, n))]
+            sq.insert(int(rng.integers(0, n)), int(rng.integers(0, 4)))
+        for _ in range(int(rng.integers(0, 3))):
+            sq[int(rng.integers(0, n))] = int(rng.integers(0, 4))
+        hi = lo = 0
+        for x in sq[:n - 32]:
+            hi = (hi << 2) | x
+        for x in sq[n - 32:]:
+            lo = (lo << 2) | x
+        words[r] = (hi, lo)
+    filt = (rng.random(n_reads) < 0.03).astype(np.uint8)
+    for maximum in (False, True):
+        cid, keep, summ, _ = orc.dedup_run(words, filt, n, d, int(maximum), edit=True)
+        bcid, bkeep, det = bf.dedup(words, filt, d, maximum, edit_nt=n)
+        assert np.array_equal(cid, bcid) and np.array_equal(keep, bkeep)
+    assert summ["edges"] == sum(len(row) for row in det["nbrs"]) // 2 and summ["edges"] > 0
+
+
 def test_edit_distance_one_is_hamming_distance_one():
     """equal-length words: one edit can only be a substitution"""
     words, filt = synth_words(3000, 9, 12, p_sub=0.03)
