@@ -92,6 +92,10 @@ def _matrix():
             out.append(pytest.param(2, case, "edit", id="case%d-edit_distance-2" % ci))
         if ci in (0, 1, 3, 5):
             out.append(pytest.param(3, case, True, id="case%d-allgather_dense_return-3" % ci))
+    # one node's worth of ranks as real processes (what `bench.py --gpus 8` starts, minus the GPUs), and an odd count
+    out.append(pytest.param(8, CASES[0], "exchange", id="case0-exchange-8"))
+    out.append(pytest.param(8, CASES[1], True, id="case1-allgather_dense_return-8"))
+    out.append(pytest.param(5, CASES[3], "exchange", id="case3-exchange-5"))
     return out
 
 
